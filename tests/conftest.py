@@ -19,3 +19,24 @@ def orc():
 
     oracle.build()
     return oracle
+
+
+def _make_ctx(kind):
+    if kind == "emu":
+        from tests.emu_fixture import emu_context
+
+        return emu_context()
+    # the product library, built by hipcc, on a real MI355X -- no fallback
+    from triton_vm_amd import Context
+
+    return Context(device=0)
+
+
+@pytest.fixture(scope="module", params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def ctx(request):
+    """The C ABI behind either the TEST-ONLY CPU fiber emulation of the kernel sources ("emu", runs
+    in the GPU-less container) or the real hipcc-built libtriton_hip.so on cuda:0 ("gpu")."""
+    c = _make_ctx(request.param)
+    c.kind = request.param
+    yield c
+    c.close()

@@ -1,0 +1,56 @@
+"""csrc/hash.hip against the oracle, through the C ABI: once on the TEST-ONLY CPU fiber
+emulation of the same kernel sources (-m "not gpu") and once on the real MI355X (-m gpu)."""
+import numpy as np
+import pytest
+
+from triton_vm_amd import ArithmeticDomain, MasterTable, field
+
+
+def odom(orc, d):
+    return orc.Domain(d.offset, d.generator, d.length)
+
+
+@pytest.mark.parametrize("n_cols,fk", [(1, 1), (9, 1), (10, 1), (11, 1), (16, 1), (17, 1), (33, 1), (5, 3), (7, 3)])
+def test_row_hashes_and_merkle_tree(ctx, orc, n_cols, fk):
+    rng = np.random.default_rng(n_cols * 7 + fk)
+    n, h, expansion = 8, 3, 4
+    shape_t = (n_cols, n) + ((3,) if fk == 3 else ())
+    shape_r = (n_cols, h) + ((3,) if fk == 3 else ())
+    trace, rnd = orc.random_elements(rng, shape_t), orc.random_elements(rng, shape_r)
+    ev = ArithmeticDomain.of_length(n * expansion).with_offset(field.generator())
+    mt = MasterTable(ctx, trace, rnd, ArithmeticDomain.of_length(n), ev, ev, fk)
+    mt.maybe_low_degree_extend_all_columns()
+    table = orc.lde_table(trace, rnd, odom(orc, ev), fk)
+    want = orc.hash_rows(table.reshape(len(ev), -1))
+    assert (mt.hash_all_ldt_domain_rows() == want).all()
+    nodes = mt.merkle_tree()
+    assert (nodes == orc.merkle_tree(want)).all()
+
+
+def test_ldt_view_is_strided_subset(ctx, orc):
+    """ldt domain shorter than the evaluation domain: rows at stride (master_table.rs:792-801)."""
+    rng = np.random.default_rng(3)
+    n, h = 8, 2
+    trace, rnd = orc.random_elements(rng, (4, n)), orc.random_elements(rng, (4, h))
+    quot = ArithmeticDomain.of_length(64).with_offset(field.generator())
+    ldt = ArithmeticDomain.of_length(16).with_offset(field.generator())
+    mt = MasterTable(ctx, trace, rnd, ArithmeticDomain.of_length(n), quot, ldt, 1)
+    mt.maybe_low_degree_extend_all_columns()
+    table = orc.lde_table(trace, rnd, odom(orc, quot), 1)
+    assert (mt.hash_all_ldt_domain_rows() == orc.hash_rows(table[::4])).all()
+    assert (mt.reveal_rows([1, 15]) == table[[4, 60]]).all()
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 4, 10])
+def test_merkle_tree_sizes_and_codeword_tree(ctx, orc, log_n):
+    rng = np.random.default_rng(log_n)
+    n = 1 << log_n
+    leaves = orc.random_elements(rng, (n, 5))
+    d_nodes = ctx.alloc(10 * n)
+    d_leaves = ctx.to_device(leaves)  # keep the buffer alive across the call
+    ctx._check(ctx.lib.tvm_merkle_tree(ctx.handle, d_leaves.ptr, n, d_nodes.ptr), "merkle")
+    assert (d_nodes.download((2 * n, 5)) == orc.merkle_tree(leaves)).all()
+    cw = orc.random_elements(rng, (n, 3))
+    d_cw = ctx.to_device(cw)
+    ctx._check(ctx.lib.tvm_codeword_merkle_tree(ctx.handle, d_cw.ptr, n, d_nodes.ptr), "cw tree")
+    assert (d_nodes.download((2 * n, 5)) == orc.merkle_tree(orc.xfe_to_digest(cw))).all()

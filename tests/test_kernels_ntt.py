@@ -1,0 +1,58 @@
+"""csrc/ntt.hip against the oracle, through the C ABI: once on the TEST-ONLY CPU fiber emulation of
+the same kernel sources (-m "not gpu") and once on the real MI355X (-m gpu)."""
+import numpy as np
+import pytest
+
+from triton_vm_amd import ArithmeticDomain, MasterTable, field
+
+
+def odom(orc, d):
+    return orc.Domain(d.offset, d.generator, d.length)
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 3, 5, 6, 9])
+@pytest.mark.parametrize("fk", [1, 3])
+def test_ntt_intt_match_oracle(ctx, orc, log_n, fk):
+    rng = np.random.default_rng(log_n * 10 + fk)
+    n = 1 << log_n
+    a = orc.random_elements(rng, n * fk)
+    gen = field.primitive_root_of_unity(n)
+    d = ctx.to_device(a)
+    ctx._check(ctx.lib.tvm_ntt(ctx.handle, fk, d.ptr, n, gen), "ntt")
+    assert (d.download() == orc.ntt(a, fk)).all()
+    ctx._check(ctx.lib.tvm_intt(ctx.handle, fk, d.ptr, n, gen), "intt")
+    assert (d.download() == a).all()
+
+
+@pytest.mark.parametrize("log_len,n_coeffs", [(3, 8), (5, 20), (6, 9), (4, 40), (7, 1), (2, 3), (0, 5), (5, 0)])
+@pytest.mark.parametrize("fk", [1, 3])
+def test_evaluate_interpolate_match_oracle(ctx, orc, log_len, n_coeffs, fk):
+    rng = np.random.default_rng(log_len * 100 + n_coeffs + fk)
+    dom = ArithmeticDomain.of_length(1 << log_len).with_offset(field.generator())
+    co = orc.random_elements(rng, max(n_coeffs, 1) * fk)[: n_coeffs * fk]
+    got = dom.evaluate(ctx, ctx.to_device(co) if n_coeffs else None, n_coeffs, fk).download()
+    want = orc.coset_evaluate(co, odom(orc, dom), fk)
+    assert (got == want).all()
+    back = dom.interpolate(ctx, ctx.to_device(want), fk).download()
+    assert (back == orc.coset_interpolate(want, odom(orc, dom), fk)).all()
+
+
+@pytest.mark.parametrize("log_n,expansion,n_cols,h", [(4, 8, 3, 5), (5, 4, 18, 7), (6, 8, 33, 20), (3, 2, 1, 8), (1, 4, 2, 1)])
+@pytest.mark.parametrize("fk", [1, 3])
+def test_lde_table_matches_oracle(ctx, orc, log_n, expansion, n_cols, h, fk):
+    rng = np.random.default_rng(log_n + 31 * n_cols + fk)
+    n = 1 << log_n
+    shape_t = (n_cols, n) + ((3,) if fk == 3 else ())
+    shape_r = (n_cols, h) + ((3,) if fk == 3 else ())
+    trace, rnd = orc.random_elements(rng, shape_t), orc.random_elements(rng, shape_r)
+    trace_dom = ArithmeticDomain.of_length(n)
+    ev = ArithmeticDomain.of_length(n * expansion).with_offset(field.generator())
+    mt = MasterTable(ctx, trace, rnd, trace_dom, ev, ev, fk)
+    mt.maybe_low_degree_extend_all_columns()
+    got = mt.low_degree_extended_table()
+    want = orc.lde_table(trace, rnd, odom(orc, ev), fk)
+    assert got.shape == want.shape
+    assert (got == want).all()
+    # reveal_rows is a gather of the same table
+    idx = [0, 3, len(ev) - 1]
+    assert (mt.reveal_rows(idx) == want[idx]).all()

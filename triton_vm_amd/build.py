@@ -1,0 +1,65 @@
+"""Build libtriton_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+    python -m triton_vm_amd.build          # or: from triton_vm_amd.build import build; build()
+
+The built library is git-ignored but travels to the GPU box with the gpurun snapshot.
+"""
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libtriton_hip.so")
+ARCH = "gfx950"
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libtriton_hip.so can only be built with the ROCm toolchain")
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    """Compile every .hip translation unit for gfx950 and link the shared library."""
+    if not force and not _stale():
+        return LIB
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+             "-Wall", "-Wno-unused-function", *extra_flags]
+    procs, objs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = [_hipcc(), *flags, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        if verbose and out.strip():
+            print(out, file=sys.stderr)
+    subprocess.check_call([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,145 @@
+"""ctypes binding of the C ABI in include/triton_hip.h.
+
+This is plumbing: it adds nothing to the library and holds no algorithm.  The product library is
+``libtriton_hip.so`` next to this file, built by hipcc for gfx950 (``triton_vm_amd.build``).  There
+is no CPU fallback: loading fails loudly when the library is missing, and creating a context fails
+loudly when no GPU is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libtriton_hip.so")
+
+OK, ERR_INVALID_ARGUMENT, ERR_OUT_OF_MEMORY, ERR_DEVICE, ERR_UNSUPPORTED = range(5)
+
+u64p = C.POINTER(C.c_uint64)
+
+
+class Domain(C.Structure):
+    """(offset, generator, length) exactly as ArithmeticDomain holds them (arithmetic_domain.rs:34-47)."""
+    _fields_ = [("offset", C.c_uint64), ("generator", C.c_uint64), ("length", C.c_uint64)]
+
+    def __repr__(self):
+        return f"Domain(offset={self.offset}, generator={self.generator}, length={self.length})"
+
+
+class TritonHipError(RuntimeError):
+    def __init__(self, status, what):
+        super().__init__(f"libtriton_hip status {status}: {what}")
+        self.status = status
+
+
+_SIGNATURES = {
+    "tvm_abi_version": (C.c_int32, []),
+    "tvm_ctx_create": (C.c_int32, [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "tvm_ctx_destroy": (None, [C.c_void_p]),
+    "tvm_last_error": (C.c_char_p, [C.c_void_p]),
+    "tvm_status_string": (C.c_char_p, [C.c_int32]),
+    "tvm_sync": (C.c_int32, [C.c_void_p]),
+    "tvm_malloc": (C.c_int32, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "tvm_free": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "tvm_memcpy_h2d": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "tvm_memcpy_d2h": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "tvm_evaluate": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, Domain, C.c_void_p]),
+    "tvm_interpolate": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, Domain, C.c_void_p]),
+    "tvm_ntt": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64]),
+    "tvm_intt": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64]),
+    "tvm_lde_table": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
+                                  Domain, Domain, C.POINTER(C.c_void_p)]),
+    "tvm_table_free": (None, [C.c_void_p, C.c_void_p]),
+    "tvm_table_num_rows": (C.c_uint64, [C.c_void_p]),
+    "tvm_table_num_columns": (C.c_uint64, [C.c_void_p]),
+    "tvm_table_field_kind": (C.c_int32, [C.c_void_p]),
+    "tvm_table_export_row_major": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tvm_table_reveal_rows": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "tvm_hash_rows": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "tvm_merkle_tree": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "tvm_table_merkle_tree": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "tvm_codeword_merkle_tree": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def load_library(path=None):
+    """dlopen the C-ABI library and attach signatures.  Raises if it is missing: there is no fallback."""
+    path = path or DEFAULT_LIB
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            f"{path} not found: build it with `python -m triton_vm_amd.build` (needs hipcc, gfx950); "
+            "triton_vm_amd has no CPU fallback")
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+class DeviceBuffer:
+    """A device allocation of uint64 words owned by a Context."""
+
+    def __init__(self, ctx, n_words):
+        self.ctx = ctx
+        self.n_words = int(n_words)
+        p = C.c_void_p()
+        ctx._check(ctx.lib.tvm_malloc(ctx.handle, self.n_words * 8, C.byref(p)), "tvm_malloc")
+        self.ptr = p.value
+
+    def upload(self, array):
+        a = np.ascontiguousarray(array, dtype=np.uint64)
+        assert a.size <= self.n_words
+        self.ctx._check(self.ctx.lib.tvm_memcpy_h2d(self.ctx.handle, self.ptr, a.ctypes.data, a.size * 8), "h2d")
+        return self
+
+    def download(self, shape=None):
+        out = np.empty(self.n_words, np.uint64)
+        self.ctx._check(self.ctx.lib.tvm_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.n_words * 8), "d2h")
+        return out.reshape(shape) if shape is not None else out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.tvm_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One device context (one HIP stream); create one per proving thread."""
+
+    def __init__(self, device=0, stream=None, lib=None):
+        self.lib = lib if lib is not None else load_library()
+        h = C.c_void_p()
+        st = self.lib.tvm_ctx_create(device, stream, C.byref(h))
+        if st != OK:
+            raise TritonHipError(st, "tvm_ctx_create failed -- is an MI355X visible? "
+                                 + self.lib.tvm_status_string(st).decode())
+        self.handle = h.value
+
+    def _check(self, status, what):
+        if status != OK:
+            msg = self.lib.tvm_last_error(self.handle).decode()
+            raise TritonHipError(status, f"{what}: {self.lib.tvm_status_string(status).decode()} ({msg})")
+
+    def close(self):
+        if self.handle:
+            self.lib.tvm_ctx_destroy(self.handle)
+            self.handle = None
+
+    def sync(self):
+        self._check(self.lib.tvm_sync(self.handle), "tvm_sync")
+
+    def alloc(self, n_words):
+        return DeviceBuffer(self, n_words)
+
+    def to_device(self, array):
+        a = np.ascontiguousarray(array, dtype=np.uint64)
+        return DeviceBuffer(self, max(a.size, 1)).upload(a)

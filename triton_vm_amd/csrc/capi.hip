@@ -1,0 +1,283 @@
+// capi.hip -- the extern "C" boundary of libtriton_hip.so (declared in include/triton_hip.h).
+// Argument validation and error mapping live here; kernels live in ntt.hip / hash.hip / poly.hip.
+#include <new>
+
+#include "kernels.h"
+
+using namespace tvm;
+
+#define TVM_ABI_VERSION 1
+
+static bool valid_fk(int32_t fk) { return fk == 1 || fk == 3; }
+static bool valid_domain(const tvm_domain& d) { return is_pow2(d.length) && d.length >= 1 && d.generator < TVM_P && d.offset < TVM_P; }
+
+extern "C" {
+
+int32_t tvm_abi_version(void) { return TVM_ABI_VERSION; }
+
+const char* tvm_status_string(int32_t s) {
+    switch (s) {
+        case TVM_OK: return "ok";
+        case TVM_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case TVM_ERR_OUT_OF_MEMORY: return "device out of memory";
+        case TVM_ERR_DEVICE: return "HIP runtime error";
+        case TVM_ERR_UNSUPPORTED: return "unsupported size or configuration";
+        default: return "unknown status";
+    }
+}
+
+int32_t tvm_ctx_create(int32_t device, void* hip_stream, tvm_ctx** out) {
+    if (!out) return TVM_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return TVM_ERR_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return TVM_ERR_DEVICE;
+    tvm_ctx* c = new (std::nothrow) tvm_ctx();
+    if (!c) return TVM_ERR_OUT_OF_MEMORY;
+    c->device = device;
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+    } else {
+        if (hipStreamCreate(&c->stream) != hipSuccess) {
+            delete c;
+            return TVM_ERR_DEVICE;
+        }
+        c->owns_stream = true;
+    }
+    *out = c;
+    return TVM_OK;
+}
+
+void tvm_ctx_destroy(tvm_ctx* c) {
+    if (!c) return;
+    hipStreamSynchronize(c->stream);
+    for (auto& kv : c->tables) hipFree(kv.second);
+    for (void* p : c->scratch)
+        if (p) hipFree(p);
+    if (c->owns_stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* tvm_last_error(const tvm_ctx* c) { return c ? c->last_error.c_str() : "null context"; }
+
+int32_t tvm_sync(tvm_ctx* c) {
+    if (!c) return TVM_ERR_INVALID_ARGUMENT;
+    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return TVM_OK;
+}
+int32_t tvm_malloc(tvm_ctx* c, size_t bytes, void** d_ptr) {
+    if (!c || !d_ptr) return TVM_ERR_INVALID_ARGUMENT;
+    *d_ptr = nullptr;
+    TVM_HIP_CHECK(c, hipMalloc(d_ptr, bytes ? bytes : 1));
+    return TVM_OK;
+}
+int32_t tvm_free(tvm_ctx* c, void* d_ptr) {
+    if (!c) return TVM_ERR_INVALID_ARGUMENT;
+    if (!d_ptr) return TVM_OK;
+    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    TVM_HIP_CHECK(c, hipFree(d_ptr));
+    return TVM_OK;
+}
+int32_t tvm_memcpy_h2d(tvm_ctx* c, void* d, const void* h, size_t bytes) {
+    if (!c || (bytes && (!d || !h))) return TVM_ERR_INVALID_ARGUMENT;
+    TVM_HIP_CHECK(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return TVM_OK;
+}
+int32_t tvm_memcpy_d2h(tvm_ctx* c, void* h, const void* d, size_t bytes) {
+    if (!c || (bytes && (!d || !h))) return TVM_ERR_INVALID_ARGUMENT;
+    TVM_HIP_CHECK(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return TVM_OK;
+}
+
+// ---------------------------------------------------------------------------------- NTT family
+int32_t tvm_ntt(tvm_ctx* c, int32_t fk, uint64_t* d, uint64_t n, uint64_t gen) {
+    if (!c || !d || !valid_fk(fk) || !is_pow2(n)) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_ntt arguments");
+    if (n == 1) return TVM_OK;
+    return ntt_columns(c, d, n, fk, 0, d, fk, 0, 1, 0, fk, n, gen, TVM_ONE, TVM_ONE, TVM_ONE);
+}
+int32_t tvm_intt(tvm_ctx* c, int32_t fk, uint64_t* d, uint64_t n, uint64_t gen) {
+    if (!c || !d || !valid_fk(fk) || !is_pow2(n)) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_intt arguments");
+    if (n == 1) return TVM_OK;
+    return ntt_columns(c, d, n, fk, 0, d, fk, 0, 1, 0, fk, n, bfe_inv(gen), TVM_ONE, TVM_ONE, bfe_inv(bfe_from_u64(n)));
+}
+
+int32_t tvm_interpolate(tvm_ctx* c, int32_t fk, const uint64_t* d_values, tvm_domain dom, uint64_t* d_coeffs) {
+    if (!c || !d_values || !d_coeffs || !valid_fk(fk) || !valid_domain(dom))
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_interpolate arguments");
+    const u64 n = dom.length;
+    if (n == 1) {
+        TVM_HIP_CHECK(c, hipMemcpyAsync(d_coeffs, d_values, fk * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        return TVM_OK;
+    }
+    // fast_coset_interpolate: iNTT, then coefficient i times offset^-i
+    return ntt_columns(c, d_values, n, fk, 0, d_coeffs, fk, 0, 1, 0, fk, n, bfe_inv(dom.generator), TVM_ONE,
+                       bfe_inv(dom.offset), bfe_inv(bfe_from_u64(n)));
+}
+
+}  // extern "C"
+
+namespace tvm {
+// c'[i] = sum_k c[i + k*len] * offset^(k*len): reduction modulo X^len - offset^len, which leaves the
+// values on the coset unchanged (arithmetic_domain.rs:153-167 computes the same sum chunk-wise).
+__global__ void k_fold_chunks(const u64* __restrict__ co, u64 n_coeffs, int fk, u64 len, u64 offset_pow_len,
+                              u64* __restrict__ out) {
+    const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= len * (u64)fk) return;
+    const u64 i = e / fk;
+    const int comp = (int)(e % fk);
+    u64 acc = 0, s = TVM_ONE;
+    for (u64 j = i; j < n_coeffs; j += len) {
+        acc = bfe_add(acc, bfe_mul(co[j * fk + comp], s));
+        s = bfe_mul(s, offset_pow_len);
+    }
+    out[e] = acc;
+}
+}  // namespace tvm
+
+extern "C" {
+
+int32_t tvm_evaluate(tvm_ctx* c, int32_t fk, const uint64_t* d_coeffs, uint64_t n_coeffs, tvm_domain dom,
+                     uint64_t* d_values) {
+    if (!c || !d_values || (n_coeffs && !d_coeffs) || !valid_fk(fk) || !valid_domain(dom))
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_evaluate arguments");
+    const u64 L = dom.length;
+    if (n_coeffs == 0) {
+        TVM_HIP_CHECK(c, hipMemsetAsync(d_values, 0, L * fk * sizeof(u64), c->stream));
+        return TVM_OK;
+    }
+    const u64* co = d_coeffs;
+    if (n_coeffs > L) {
+        u64* folded = (u64*)scratch(c, 3, L * fk * sizeof(u64));
+        if (!folded) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "evaluate scratch");
+        const u64 total = L * fk;
+        TVM_LAUNCH(k_fold_chunks, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_coeffs, n_coeffs,
+                   (int)fk, L, bfe_pow(dom.offset, L), folded);
+        co = folded;
+        n_coeffs = L;
+    }
+    if (L == 1) {  // a single point: the constant term survives
+        TVM_HIP_CHECK(c, hipMemcpyAsync(d_values, co, fk * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        return TVM_OK;
+    }
+    // Evaluate on X = L/M cosets of length M >= n_coeffs instead of zero-padding to L.
+    u64 M = 2;
+    while (M < n_coeffs) M <<= 1;
+    const u64 X = L / M;
+    const u64 gen_m = bfe_pow(dom.generator, X);
+    for (u64 k = 0; k < X; k++) {
+        const u64 off = bfe_mul(dom.offset, bfe_pow(dom.generator, k));
+        TVM_TRY(ntt_columns(c, co, n_coeffs, fk, 0, d_values, fk, 0, X, k, fk, M, gen_m, off, TVM_ONE, TVM_ONE));
+    }
+    return TVM_OK;
+}
+
+// ---------------------------------------------------------------------------------- master-table LDE
+int32_t tvm_lde_table(tvm_ctx* c, int32_t fk, const uint64_t* d_trace, uint64_t n_rows, uint64_t n_cols,
+                      const uint64_t* d_rnd, uint64_t h, tvm_domain trace_dom, tvm_domain eval_dom, tvm_table** out) {
+    if (!c || !out) return TVM_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (!d_trace || (h && !d_rnd) || !valid_fk(fk) || !valid_domain(trace_dom) || !valid_domain(eval_dom) ||
+        trace_dom.length != n_rows || n_cols == 0 || n_cols * fk > (1u << 20))
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_lde_table arguments");
+    if (trace_dom.offset != TVM_ONE) return set_error(c, TVM_ERR_UNSUPPORTED, "trace domain offset must be 1");
+    tvm_table* t = new (std::nothrow) tvm_table();
+    if (!t) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "table handle");
+    t->rows = eval_dom.length;
+    t->n_cols = n_cols;
+    t->fk = fk;
+    t->W = (int)(n_cols * fk);
+    if (hipMalloc((void**)&t->data, t->bytes()) != hipSuccess) {
+        delete t;
+        return set_error(c, TVM_ERR_OUT_OF_MEMORY, "LDE table allocation");
+    }
+    if (t->W % TVM_CT) {  // unused lanes of the last tile are never written by the LDE: define them
+        const size_t tile_bytes = (size_t)t->rows * TVM_CT * sizeof(u64);
+        hipMemsetAsync((char*)t->data + t->bytes() - tile_bytes, 0, tile_bytes, c->stream);
+    }
+    int rc = lde_table(c, fk, d_trace, n_rows, n_cols, d_rnd, h, trace_dom.generator, eval_dom.offset, eval_dom.generator,
+                       eval_dom.length, t->data, 0);
+    if (rc != TVM_OK) {
+        hipStreamSynchronize(c->stream);
+        hipFree(t->data);
+        delete t;
+        return rc;
+    }
+    *out = t;
+    return TVM_OK;
+}
+
+void tvm_table_free(tvm_ctx* c, tvm_table* t) {
+    if (!t) return;
+    if (c) hipStreamSynchronize(c->stream);
+    if (t->data) hipFree(t->data);
+    delete t;
+}
+uint64_t tvm_table_num_rows(const tvm_table* t) { return t ? t->rows : 0; }
+uint64_t tvm_table_num_columns(const tvm_table* t) { return t ? t->n_cols : 0; }
+int32_t tvm_table_field_kind(const tvm_table* t) { return t ? t->fk : 0; }
+
+int32_t tvm_table_export_row_major(tvm_ctx* c, const tvm_table* t, uint64_t* d_out) {
+    if (!c || !t || !d_out) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "export arguments");
+    return table_to_row_major(c, t->data, t->rows, t->W, d_out);
+}
+
+int32_t tvm_table_reveal_rows(tvm_ctx* c, const tvm_table* t, uint64_t ldt_length, const uint64_t* h_idx, uint64_t n,
+                              uint64_t* h_out) {
+    if (!c || !t || (n && (!h_idx || !h_out)) || !is_pow2(ldt_length) || ldt_length > t->rows)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "reveal_rows arguments");
+    if (!n) return TVM_OK;
+    const u64 stride = t->rows / ldt_length;
+    std::vector<u64> idx(n);
+    for (u64 j = 0; j < n; j++) {
+        if (h_idx[j] >= ldt_length) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "reveal_rows: index out of range");
+        idx[j] = h_idx[j] * stride;
+    }
+    u64* d_idx = (u64*)scratch(c, 4, n * sizeof(u64));
+    u64* d_out = (u64*)scratch(c, 5, n * t->W * sizeof(u64));
+    if (!d_idx || !d_out) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "reveal scratch");
+    TVM_HIP_CHECK(c, hipMemcpyAsync(d_idx, idx.data(), n * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));  // idx is a local
+    TVM_TRY(gather_rows(c, t->data, t->rows, t->W, d_idx, n, d_out));
+    TVM_HIP_CHECK(c, hipMemcpyAsync(h_out, d_out, n * t->W * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return TVM_OK;
+}
+
+// ---------------------------------------------------------------------------------- hashing
+int32_t tvm_hash_rows(tvm_ctx* c, const tvm_table* t, uint64_t ldt_length, uint64_t* d_digests) {
+    if (!c || !t || !d_digests || !is_pow2(ldt_length) || ldt_length > t->rows)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "hash_rows arguments");
+    return hash_rows(c, t->data, t->rows, t->W, t->rows / ldt_length, d_digests);
+}
+int32_t tvm_merkle_tree(tvm_ctx* c, const uint64_t* d_leaves, uint64_t n, uint64_t* d_nodes) {
+    if (!c || !d_leaves || !d_nodes || !is_pow2(n)) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "merkle arguments");
+    TVM_HIP_CHECK(c, hipMemcpyAsync(d_nodes + 5 * n, d_leaves, 5 * n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+    return merkle_tree_from_leaves(c, d_nodes, n);
+}
+int32_t tvm_table_merkle_tree(tvm_ctx* c, const tvm_table* t, uint64_t ldt_length, uint64_t* d_nodes) {
+    if (!c || !t || !d_nodes || !is_pow2(ldt_length) || ldt_length > t->rows)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "table_merkle_tree arguments");
+    TVM_TRY(hash_rows(c, t->data, t->rows, t->W, t->rows / ldt_length, d_nodes + 5 * ldt_length));
+    return merkle_tree_from_leaves(c, d_nodes, ldt_length);
+}
+}  // extern "C"
+
+namespace tvm {
+__global__ void k_xfe_aos_leaves(const u64* __restrict__ cw, u64 n, u64* __restrict__ leaves) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    leaves[5 * i + 0] = cw[3 * i];
+    leaves[5 * i + 1] = cw[3 * i + 1];
+    leaves[5 * i + 2] = cw[3 * i + 2];
+    leaves[5 * i + 3] = 0;
+    leaves[5 * i + 4] = 0;
+}
+}  // namespace tvm
+
+extern "C" int32_t tvm_codeword_merkle_tree(tvm_ctx* c, const uint64_t* d_cw, uint64_t n, uint64_t* d_nodes) {
+    if (!c || !d_cw || !d_nodes || !is_pow2(n)) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "codeword tree arguments");
+    TVM_LAUNCH(tvm::k_xfe_aos_leaves, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_cw, n, d_nodes + 5 * n);
+    return merkle_tree_from_leaves(c, d_nodes, n);
+}

@@ -1,0 +1,54 @@
+// context.h -- device context shared by all entry points of libtriton_hip.so.
+//
+// One context per host thread that proves (the reference's prove() may run concurrently on several
+// threads, /root/reference/triton-vm/src/lib.rs:522-532): a context owns one HIP stream, a cache of
+// power tables (twiddles, coset scalings) and a growable scratch workspace.  Nothing here
+// synchronises with the host unless an entry point has to hand data back.
+#pragma once
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "field.h"
+#include "triton_hip.h"  // status codes and the public C ABI (include/)
+
+// Column-tile-major device tables: tiles of TVM_CT adjacent base-field columns, each tile a
+// row-major [rows][TVM_CT] array, so one row of a tile is one 128-byte line.
+#define TVM_CT 16
+
+struct tvm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    std::map<std::tuple<u64, u64, u64>, u64*> tables;  // (base, count, scale) -> device table
+    std::vector<void*> scratch;                         // named scratch slots
+    std::vector<size_t> scratch_bytes;
+    std::string last_error;
+};
+
+namespace tvm {
+// t[i] = scale * base^i, i < count (Montgomery words); cached for the life of the context
+const u64* pow_table(tvm_ctx* c, u64 base, u64 count, u64 scale = TVM_ONE);
+// scratch slot `slot` of at least `bytes` bytes (grown on demand, contents undefined)
+void* scratch(tvm_ctx* c, int slot, size_t bytes);
+int set_error(tvm_ctx* c, int code, const char* what);
+inline int ilog2(u64 n) {
+    int l = 0;
+    while ((1ull << l) < n) l++;
+    return l;
+}
+inline bool is_pow2(u64 n) { return n && !(n & (n - 1)); }
+}  // namespace tvm
+
+#define TVM_HIP_CHECK(c, expr)                                                              \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return tvm::set_error((c), e_ == hipErrorOutOfMemory ? TVM_ERR_OUT_OF_MEMORY : TVM_ERR_DEVICE, #expr); \
+    } while (0)
+#define TVM_TRY(expr)                  \
+    do {                               \
+        int rc_ = (expr);              \
+        if (rc_ != TVM_OK) return rc_; \
+    } while (0)

@@ -1,0 +1,198 @@
+// hash.hip -- Tip5 row hashing and Merkle trees on gfx950.
+//
+// Replaces, on the reference's hot path:
+//   MasterTable::hash_all_ldt_domain_rows   /root/reference/triton-vm/src/table/master_table.rs:455-468
+//   MasterTable::merkle_tree (MerkleTree::par_new, twenty-first)              master_table.rs:443-453
+//   quotient-segment row hashing + tree     /root/reference/triton-vm/src/stark.rs:425-446
+//   ProverRound::merkle_tree_from_codeword  /root/reference/triton-vm/src/low_degree_test/fri.rs:343-347
+//
+// One work-item hashes one row: the 16-word sponge state lives in VGPRs, the row is read tile by
+// tile (128-byte lines of the column-tile-major table, see ntt.hip), and the permutation is
+// instantiated exactly once inside the per-block loop so the kernel stays inside the I-cache.
+// Hashing is integer-ALU bound (38 + 28 permutations per LDT row), not HBM bound.
+#include "context.h"
+#include "tip5.h"
+
+namespace tvm {
+
+
+// w[k] for a wave-uniform k in 0..15 without dynamic register indexing
+TVM_D u64 select16(const u64 (&w)[16], int k) {
+    u64 a0 = (k & 1) ? w[1] : w[0], a1 = (k & 1) ? w[3] : w[2], a2 = (k & 1) ? w[5] : w[4], a3 = (k & 1) ? w[7] : w[6];
+    u64 a4 = (k & 1) ? w[9] : w[8], a5 = (k & 1) ? w[11] : w[10], a6 = (k & 1) ? w[13] : w[12], a7 = (k & 1) ? w[15] : w[14];
+    u64 b0 = (k & 2) ? a1 : a0, b1 = (k & 2) ? a3 : a2, b2 = (k & 2) ? a5 : a4, b3 = (k & 2) ? a7 : a6;
+    u64 c0 = (k & 4) ? b1 : b0, c1 = (k & 4) ? b3 : b2;
+    return (k & 8) ? c1 : c0;
+}
+
+// digests[r] = Tip5::hash_varlen(row r*stride of the table), table = [tiles][L][16], W words per row
+__global__ void __launch_bounds__(256) k_hash_rows(const u64* __restrict__ table, u64 L, int W, u64 stride, u64 n_out,
+                                                    u64* __restrict__ digests) {
+    __shared__ unsigned char lut[256];
+    tip5_stage_lut(lut, threadIdx.x, blockDim.x);
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_out) return;
+    const u64 row = r * stride;
+    u64 st[TIP5_STATE];
+#pragma unroll
+    for (int i = 0; i < TIP5_STATE; i++) st[i] = 0;
+    u64 w[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = 0;
+    const int n_perms = W / TIP5_RATE + 1;
+    int k = 16, t = 0, wi = 0;
+    for (int perm = 0; perm < n_perms; perm++) {
+#pragma unroll
+        for (int q = 0; q < TIP5_RATE; q++) {
+            if (k == 16 && wi < W) {
+                const u64* src = table + ((u64)t * L + row) * TVM_CT;
+#pragma unroll
+                for (int i = 0; i < 16; i++) w[i] = src[i];
+                k = 0;
+                t++;
+            }
+            u64 v = select16(w, k & 15);
+            if (wi >= W) v = (wi == W) ? TVM_ONE : 0;  // padding: 1 then 0s (tip-0005.md:83)
+            st[q] = v;
+            k++;
+            wi++;
+        }
+        tip5_permute_inline(st, lut);
+    }
+#pragma unroll
+    for (int i = 0; i < TIP5_DIGEST; i++) digests[r * 5 + i] = st[i];
+}
+
+// nodes[i] = hash_pair(nodes[2i], nodes[2i+1]) for i in [first, first + count)
+__global__ void __launch_bounds__(256) k_merkle_level(u64* __restrict__ nodes, u64 first, u64 count) {
+    __shared__ unsigned char lut[256];
+    tip5_stage_lut(lut, threadIdx.x, blockDim.x);
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const u64 i = first + j;
+    u64 st[TIP5_STATE];
+    const u64* ch = nodes + 10 * i;
+#pragma unroll
+    for (int q = 0; q < 10; q++) st[q] = ch[q];
+#pragma unroll
+    for (int q = 10; q < 16; q++) st[q] = TVM_ONE;  // fixed-length domain: capacity all ones (tip-0005.md:82)
+    tip5_permute_inline(st, lut);
+#pragma unroll
+    for (int q = 0; q < 5; q++) nodes[5 * i + q] = st[q];
+}
+
+// the last levels of a tree (<= 256 parents on the widest) inside one workgroup
+__global__ void __launch_bounds__(256) k_merkle_top(u64* __restrict__ nodes, u64 widest) {
+    __shared__ unsigned char lut[256];
+    tip5_stage_lut(lut, threadIdx.x, blockDim.x);
+    for (u64 lvl = widest; lvl >= 1; lvl >>= 1) {
+        const u64 j = threadIdx.x;
+        if (j < lvl) {
+            const u64 i = lvl + j;
+            u64 st[TIP5_STATE];
+            const u64* ch = nodes + 10 * i;
+#pragma unroll
+            for (int q = 0; q < 10; q++) st[q] = ch[q];
+#pragma unroll
+            for (int q = 10; q < 16; q++) st[q] = TVM_ONE;
+            tip5_permute_inline(st, lut);
+#pragma unroll
+            for (int q = 0; q < 5; q++) nodes[5 * i + q] = st[q];
+        }
+        __syncthreads();  // same workgroup wrote the children: workgroup-scope visibility suffices
+    }
+}
+
+// FRI leaves: Digest::from(xfe) = [c0, c1, c2, 0, 0], no hashing (fri.rs:343-347).
+// codeword planar: c0[n], c1[n], c2[n] at stride `plane`.
+__global__ void k_xfe_leaves(const u64* __restrict__ cw, u64 plane, u64 n, u64* __restrict__ leaves) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    leaves[5 * i + 0] = cw[i];
+    leaves[5 * i + 1] = cw[plane + i];
+    leaves[5 * i + 2] = cw[2 * plane + i];
+    leaves[5 * i + 3] = 0;
+    leaves[5 * i + 4] = 0;
+}
+
+// rows[j][0..W) = table row idx[j], row-major out (reveal_rows, master_table.rs:548-555)
+__global__ void k_gather_rows(const u64* __restrict__ table, u64 L, int W, const u64* __restrict__ idx, u64 n,
+                              u64* __restrict__ out) {
+    const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * (u64)W) return;
+    const u64 j = e / W;
+    const int v = (int)(e % W);
+    out[e] = table[((u64)(v / TVM_CT) * L + idx[j]) * TVM_CT + (v % TVM_CT)];
+}
+
+// whole table to the reference's row-major [L][W] layout (tests, and hosts that want the cache)
+__global__ void k_table_to_row_major(const u64* __restrict__ table, u64 L, int W, u64* __restrict__ out) {
+    const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= L * (u64)W) return;
+    const u64 row = e / W;
+    const int v = (int)(e % W);
+    out[e] = table[((u64)(v / TVM_CT) * L + row) * TVM_CT + (v % TVM_CT)];
+}
+
+// planar columns [W][L] -> column-tile-major table (used for the quotient-segment table)
+__global__ void k_columns_to_table(const u64* __restrict__ cols, u64 col_stride, u64 L, int W, u64* __restrict__ table) {
+    const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const int tiles = (W + TVM_CT - 1) / TVM_CT;
+    if (e >= (u64)tiles * L * TVM_CT) return;
+    const int b = (int)(e % TVM_CT);
+    const u64 row = (e / TVM_CT) % L;
+    const int t = (int)(e / (TVM_CT * L));
+    const int v = t * TVM_CT + b;
+    table[e] = (v < W) ? cols[(u64)v * col_stride + row] : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+int hash_rows(tvm_ctx* c, const u64* table, u64 L, int W, u64 stride, u64* digests) {
+    if (!stride || L % stride) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "hash_rows: stride must divide L");
+    const u64 n = L / stride;
+    TVM_LAUNCH(k_hash_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, table, L, W, stride, n, digests);
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+
+// nodes: [2*n_leaves][5], leaves already at nodes[n_leaves..2*n_leaves)
+int merkle_tree_from_leaves(tvm_ctx* c, u64* nodes, u64 n_leaves) {
+    if (!is_pow2(n_leaves)) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "merkle: leaf count must be a power of two");
+    TVM_HIP_CHECK(c, hipMemsetAsync(nodes, 0, 5 * sizeof(u64), c->stream));
+    u64 lvl = n_leaves >> 1;
+    for (; lvl > 256; lvl >>= 1)
+        TVM_LAUNCH(k_merkle_level, dim3((unsigned)((lvl + 255) / 256)), dim3(256), 0, c->stream, nodes, lvl, lvl);
+    if (lvl >= 1) TVM_LAUNCH(k_merkle_top, dim3(1), dim3(256), 0, c->stream, nodes, lvl);
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+
+int xfe_leaves(tvm_ctx* c, const u64* cw, u64 plane, u64 n, u64* leaves) {
+    TVM_LAUNCH(k_xfe_leaves, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, cw, plane, n, leaves);
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+
+int gather_rows(tvm_ctx* c, const u64* table, u64 L, int W, const u64* d_idx, u64 n, u64* d_out) {
+    const u64 total = n * (u64)W;
+    if (!total) return TVM_OK;
+    TVM_LAUNCH(k_gather_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, table, L, W, d_idx, n, d_out);
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+
+int table_to_row_major(tvm_ctx* c, const u64* table, u64 L, int W, u64* d_out) {
+    const u64 total = L * (u64)W;
+    TVM_LAUNCH(k_table_to_row_major, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, table, L, W, d_out);
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+
+int columns_to_table(tvm_ctx* c, const u64* cols, u64 col_stride, u64 L, int W, u64* table) {
+    const u64 total = (u64)((W + TVM_CT - 1) / TVM_CT) * L * TVM_CT;
+    TVM_LAUNCH(k_columns_to_table, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, cols, col_stride, L, W, table);
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+
+}  // namespace tvm

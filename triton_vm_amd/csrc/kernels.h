@@ -1,0 +1,28 @@
+// kernels.h -- host-callable entry points of the kernel translation units (namespace tvm).
+#pragma once
+#include "context.h"
+
+namespace tvm {
+// ntt.hip
+int ntt_columns(tvm_ctx* c, const u64* in, u64 in_len, int in_fk, u64 in_col_stride, u64* out, int out_fk,
+                u64 out_col_stride, u64 out_mul, u64 out_add, int ncols, u64 n, u64 w, u64 in_scale, u64 out_scale,
+                u64 out_mult);
+int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, const u64* rnd, u64 h, u64 trace_gen,
+              u64 eval_offset, u64 eval_gen, u64 L, u64* table, int chunk_cols);
+// hash.hip
+int hash_rows(tvm_ctx* c, const u64* table, u64 L, int W, u64 stride, u64* digests);
+int merkle_tree_from_leaves(tvm_ctx* c, u64* nodes, u64 n_leaves);
+int xfe_leaves(tvm_ctx* c, const u64* cw, u64 plane, u64 n, u64* leaves);
+int gather_rows(tvm_ctx* c, const u64* table, u64 L, int W, const u64* d_idx, u64 n, u64* d_out);
+int table_to_row_major(tvm_ctx* c, const u64* table, u64 L, int W, u64* d_out);
+int columns_to_table(tvm_ctx* c, const u64* cols, u64 col_stride, u64 L, int W, u64* table);
+}  // namespace tvm
+
+struct tvm_table {
+    u64* data = nullptr;  // [tiles][rows][TVM_CT]
+    u64 rows = 0;
+    u64 n_cols = 0;       // in elements of the table's field
+    int fk = 1;
+    int W = 0;            // base-field words per row = n_cols * fk
+    size_t bytes() const { return (size_t)((W + TVM_CT - 1) / TVM_CT) * rows * TVM_CT * sizeof(u64); }
+};

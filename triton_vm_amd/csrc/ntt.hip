@@ -1,0 +1,568 @@
+// ntt.hip -- radix-2 NTT / iNTT over F_p (p = 2^64 - 2^32 + 1) and the master-table LDE for gfx950.
+//
+// Replaces, on the reference's hot path:
+//   ArithmeticDomain::{evaluate, interpolate, low_degree_extension}
+//       /root/reference/triton-vm/src/arithmetic_domain.rs:141-212
+//   MasterTable::{randomized_column_interpolant, maybe_low_degree_extend_all_columns}
+//       /root/reference/triton-vm/src/table/master_table.rs:258-322, 392-403
+//
+// Design: a length-N transform (N up to 2^24) is split N = N1 x N2 and done in
+// two HBM passes whose tiles live in LDS: a "strided" pass (all i1 for a batch of 16 adjacent i2,
+// 128-byte coalesced runs) and a "row" pass (whole contiguous rows).  No bit-reversal pass exists
+// anywhere: inverse sub-transforms are decimation-in-frequency (natural in, bit-reversed out),
+// forward ones decimation-in-time (bit-reversed in, natural out), and the bit-reversed index is
+// absorbed into the tile <-> global index map.
+//
+// The LDE of a table column never forms the 8N-point transform.  With the evaluation domain
+// g*<w_L>, L = X*N, row X*j + k of the output is the value on coset gamma_k*<w_N>,
+// gamma_k = g*w_L^k, and on that coset X^N = gamma_k^N is constant, so the randomized interpolant
+// t(X) + (X^N - 1) r(X) folds to N coefficients: c_k[m] = (t[m] + (gamma_k^N - 1) r[m]) gamma_k^m.
+// Three kernels per column chunk:
+//   pass1  iNTT columns step (strided, DIF)                      reads trace,   writes Y   (1x)
+//   pass2  iNTT rows step (DIF) -> coefficients held in VGPRs -> for each of the X cosets:
+//          scale, forward columns step (DIT)                     reads Y,       writes Z   (Xx)
+//   pass3  forward rows step (DIT) for 16 table columns at once  reads Z,       writes the table
+// Algorithmic HBM bytes per base-field trace cell: 8 (read) + 8*X (write) = 72 at X = 8; the
+// scheme moves 8*(1+1+1+X+X+X) = 216.
+#include "context.h"
+
+namespace tvm {
+
+TVM_D u32 brev_bits(u32 x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
+
+struct Pow2 {  // t^e = lo[e & mask] * hi[e >> shift]
+    const u64* lo;
+    const u64* hi;
+    int shift;
+};
+TVM_D u64 pow2_get(const Pow2& t, u64 e) { return bfe_mul(t.lo[e & ((1ull << t.shift) - 1)], t.hi[e >> t.shift]); }
+
+__global__ void k_pow_table(u64 base, u64 count, u64 scale, u64* out) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = bfe_mul(scale, bfe_pow(base, i));
+}
+
+// In-LDS radix-2 transform of a tile: element (a, b) at s[a*SA + b*SB], a < 2^log_n the transform
+// axis, b < 2^batch_log independent transforms.  tw[e] = w^e, e < n/2, w the n-th root to use.
+// DIT = false: decimation in frequency, natural order in, bit-reversed order out.
+// DIT = true : decimation in time, bit-reversed order in, natural order out.
+// Ends with a barrier; the caller must have synchronised the tile before the call.
+template <bool DIT, bool B_FASTEST>
+TVM_D void lds_ntt(u64* s, int log_n, int batch_log, int SA, int SB, const u64* __restrict__ tw, int tid, int nt) {
+    const int half_n = (1 << log_n) >> 1;
+    const int total = half_n << batch_log;
+    for (int layer = 0; layer < log_n; layer++) {
+        const int hl = DIT ? layer : (log_n - 1 - layer);  // log2 of the butterfly span
+        const int h = 1 << hl;
+        const int tws = log_n - 1 - hl;                    // w_{2h}^j = w_n^(j << tws)
+        for (int idx = tid; idx < total; idx += nt) {
+            int bf, b;
+            if (B_FASTEST) {
+                b = idx & ((1 << batch_log) - 1);
+                bf = idx >> batch_log;
+            } else {
+                bf = idx & (half_n - 1);
+                b = idx >> (log_n - 1);
+            }
+            const int j = bf & (h - 1);
+            const int i = ((bf - j) << 1) + j;
+            u64* p0 = s + i * SA + b * SB;
+            u64* p1 = p0 + h * SA;
+            const u64 w = tw[j << tws];
+            const u64 u = *p0;
+            if (DIT) {
+                const u64 v = bfe_mul(*p1, w);
+                *p0 = bfe_add(u, v);
+                *p1 = bfe_sub(u, v);
+            } else {
+                const u64 v = *p1;
+                *p0 = bfe_add(u, v);
+                *p1 = bfe_mul(bfe_sub(u, v), w);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic two-pass transform of `ncols` columns (grid.y), natural order in and out.
+//   X[k1 + N1*k2] = sum_{i2} w_N^(i2 k1) w_N2^(i2 k2) sum_{i1} x[i1*N2 + i2] w_N1^(i1 k1)
+// Input column v starts at in + (v / fk) * in_col_stride + v % fk with element stride fk, so an
+// array-of-XFE (fk = 3) is three interleaved base-field columns; output likewise with out_fk.
+struct Ntt2Args {
+    const u64* in;
+    u64* tmp;
+    u64* out;
+    int log_n1, log_n2, batch_log;
+    u64 in_len;                  // inputs at index >= in_len are zero (zero padding)
+    int in_fk, out_fk;
+    u64 in_col_stride, tmp_col_stride, out_col_stride;
+    const u64* tw1;              // w_N1^e, e < N1/2
+    const u64* tw2;              // w_N2^e, e < N2/2
+    Pow2 tw_inter;               // w_N^e
+    const u64* pre_hi;           // optional input scaling x[i1*N2+i2] *= pre_hi[i1] * pre_lo[i2]
+    const u64* pre_lo;
+    const u64* post_lo;          // optional output scaling X[k1+N1*k2] *= post_lo[k1] * post_hi[k2]
+    const u64* post_hi;
+    u64 out_mul, out_add;        // output element k is stored at index k*out_mul + out_add
+    int col0;                    // first virtual column (in/out use col0 + blockIdx.y, tmp uses blockIdx.y)
+};
+
+#define TVM_ROW_PAD 1
+
+__global__ void __launch_bounds__(1024) k_ntt2_pass1(Ntt2Args a) {
+    TVM_DYN_SMEM(u64, s);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int n1 = 1 << a.log_n1;
+    const u64 n2 = 1ull << a.log_n2;
+    const int B = 1 << a.batch_log;
+    const int vl = blockIdx.y, v = a.col0 + vl;
+    const u64 i2_0 = (u64)blockIdx.x * B;
+    const u64* in = a.in + (u64)(v / a.in_fk) * a.in_col_stride + (v % a.in_fk);
+    const int tile = n1 << a.batch_log;
+    for (int idx = tid; idx < tile; idx += nt) {
+        const int b = idx & (B - 1), i1 = idx >> a.batch_log;
+        const u64 i2 = i2_0 + b;
+        const u64 i = (u64)i1 * n2 + i2;
+        u64 x = (i2 < n2 && i < a.in_len) ? in[i * a.in_fk] : 0;
+        if (a.pre_lo && x) x = bfe_mul(x, bfe_mul(a.pre_hi[i1], a.pre_lo[i2]));
+        s[idx] = x;
+    }
+    __syncthreads();
+    lds_ntt<false, true>(s, a.log_n1, a.batch_log, B, 1, a.tw1, tid, nt);
+    u64* tmp = a.tmp + (u64)vl * a.tmp_col_stride;
+    for (int idx = tid; idx < tile; idx += nt) {
+        const int b = idx & (B - 1), p = idx >> a.batch_log;
+        const u64 i2 = i2_0 + b;
+        if (i2 >= n2) continue;
+        const u64 k1 = brev_bits((u32)p, a.log_n1);
+        tmp[(u64)p * n2 + i2] = bfe_mul(s[idx], pow2_get(a.tw_inter, i2 * k1));
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_ntt2_pass2(Ntt2Args a) {
+    TVM_DYN_SMEM(u64, s);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const u64 n1 = 1ull << a.log_n1;
+    const int n2 = 1 << a.log_n2;
+    const int B = 1 << a.batch_log;
+    const int RS = n2 + TVM_ROW_PAD;
+    const int vl = blockIdx.y, v = a.col0 + vl;
+    const u64 k1_0 = (u64)blockIdx.x * B;
+    const u64* tmp = a.tmp + (u64)vl * a.tmp_col_stride;
+    const int tile = n2 << a.batch_log;
+    for (int idx = tid; idx < tile; idx += nt) {
+        const int i2 = idx & (n2 - 1), b = idx >> a.log_n2;
+        const u64 k1 = k1_0 + b;
+        u64 x = 0;
+        if (k1 < n1) x = tmp[(u64)brev_bits((u32)k1, a.log_n1) * n2 + i2];
+        s[b * RS + i2] = x;
+    }
+    __syncthreads();
+    lds_ntt<false, false>(s, a.log_n2, a.batch_log, 1, RS, a.tw2, tid, nt);
+    u64* out = a.out + (u64)(v / a.out_fk) * a.out_col_stride + (v % a.out_fk);
+    for (int idx = tid; idx < tile; idx += nt) {
+        const int b = idx & (B - 1), q = idx >> a.batch_log;
+        const u64 k1 = k1_0 + b;
+        if (k1 >= n1) continue;
+        const u64 k2 = brev_bits((u32)q, a.log_n2);
+        u64 x = s[b * RS + q];
+        if (a.post_lo) x = bfe_mul(x, bfe_mul(a.post_lo[k1], a.post_hi[k2]));
+        const u64 k = k1 + n1 * k2;
+        out[(k * a.out_mul + a.out_add) * a.out_fk] = x;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Master-table LDE, passes 2 and 3 (pass 1 is k_ntt2_pass1 with inverse tables).
+#define TVM_LDE_MAX_COSETS 32
+#define TVM_LDE_E 16  // coefficients a thread keeps in VGPRs across the coset loop
+
+struct LdePass2Args {
+    const u64* y;        // [cols][N1 positions p][N2]
+    u64* z;              // [cols][X][N2 (j1)][N1 positions p]
+    const u64* rnd;      // trace randomizers [n_cols][h][fk]
+    int log_n1, log_n2, batch_log;
+    int fk;
+    int col0;            // first virtual column of this chunk (y and z are chunk-local)
+    u64 h;
+    int n_cosets;
+    const u64* tw_a2;    // w_N2^-e
+    const u64* tw_b1;    // w_N2^e
+    Pow2 tw_inter;       // w_N^e
+    const u64* g_lo;     // g^m2 / N, m2 < N1
+    const u64* g_hi;     // g^(N1*m1), m1 < N2
+    const u64* wl_lo;    // w_L^m2
+    const u64* wl_hi;    // w_L^(N1*m1)
+    u64 zk[TVM_LDE_MAX_COSETS];  // N * (gamma_k^N - 1)
+};
+
+__global__ void __launch_bounds__(1024) k_lde_pass2(LdePass2Args a) {
+    TVM_DYN_SMEM(u64, s);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const u64 n1 = 1ull << a.log_n1;
+    const int n2 = 1 << a.log_n2;
+    const int B = 1 << a.batch_log;
+    const int RS = n2 + TVM_ROW_PAD;
+    const int vl = blockIdx.y;            // chunk-local virtual column
+    const int v = a.col0 + vl;
+    const u64 p0 = (u64)blockIdx.x * B;   // tile rows are positions p0..p0+B-1, k1 = brev(p)
+    const u64 n = n1 << a.log_n2;
+    const u64* y = a.y + (u64)vl * n;
+    const int tile = n2 << a.batch_log;
+
+    for (int idx = tid; idx < tile; idx += nt) {
+        const int i2 = idx & (n2 - 1), b = idx >> a.log_n2;
+        s[b * RS + i2] = (p0 + b < n1) ? y[(p0 + b) * n2 + i2] : 0;
+    }
+    __syncthreads();
+    // inverse rows step: position q of row b now holds N * t[k1 + N1*k2], k2 = brev(q)
+    lds_ntt<false, false>(s, a.log_n2, a.batch_log, 1, RS, a.tw_a2, tid, nt);
+
+    // Coefficients and their running coset factor stay in registers for the whole coset loop.
+    u64 coef[TVM_LDE_E], fac[TVM_LDE_E], wl[TVM_LDE_E], rz[TVM_LDE_E];
+    const u64* rnd = a.rnd + (u64)(v / a.fk) * a.h * a.fk + (v % a.fk);
+#pragma unroll
+    for (int e = 0; e < TVM_LDE_E; e++) {
+        const int idx = tid + e * nt;
+        coef[e] = fac[e] = wl[e] = rz[e] = 0;
+        if (idx < tile) {
+            const int q = idx & (n2 - 1), b = idx >> a.log_n2;
+            const u64 m1 = brev_bits((u32)q, a.log_n2);
+            const u64 m2 = brev_bits((u32)(p0 + b), a.log_n1);
+            const u64 m = m1 * n1 + m2;
+            coef[e] = s[b * RS + q];
+            fac[e] = bfe_mul(a.g_lo[m2], a.g_hi[m1]);
+            wl[e] = bfe_mul(a.wl_lo[m2], a.wl_hi[m1]);
+            rz[e] = (m < a.h && p0 + b < n1) ? rnd[m * a.fk] : 0;
+        }
+    }
+    for (int k = 0; k < a.n_cosets; k++) {
+        __syncthreads();
+        const u64 zk = a.zk[k];
+#pragma unroll
+        for (int e = 0; e < TVM_LDE_E; e++) {
+            const int idx = tid + e * nt;
+            if (idx < tile) {
+                const int q = idx & (n2 - 1), b = idx >> a.log_n2;
+                u64 c = coef[e];
+                if (rz[e]) c = bfe_add(c, bfe_mul(zk, rz[e]));
+                s[b * RS + q] = bfe_mul(c, fac[e]);
+                fac[e] = bfe_mul(fac[e], wl[e]);
+            }
+        }
+        __syncthreads();
+        // forward columns step over m1 (bit-reversed in position q): natural j1 out
+        lds_ntt<true, false>(s, a.log_n2, a.batch_log, 1, RS, a.tw_b1, tid, nt);
+        u64* z = a.z + ((u64)vl * a.n_cosets + k) * n;
+        for (int idx = tid; idx < tile; idx += nt) {
+            const int b = idx & (B - 1), j1 = idx >> a.batch_log;
+            if (p0 + b >= n1) continue;
+            const u64 m2 = brev_bits((u32)(p0 + b), a.log_n1);
+            z[(u64)j1 * n1 + p0 + b] = bfe_mul(s[b * RS + j1], pow2_get(a.tw_inter, m2 * (u64)j1));
+        }
+    }
+}
+
+// Output table layout ("column-tile-major"): tiles of TVM_CT adjacent virtual
+// columns, each tile a row-major [L][TVM_CT] array, so one row of a tile is one 128-byte line.
+
+struct LdePass3Args {
+    const u64* z;        // [cols][X][N2 (j1)][N1 positions p]
+    u64* table;          // [tiles][L][TVM_CT]
+    int log_n1, log_n2;
+    int n_cosets;
+    int col0;            // first virtual column of the chunk (multiple of TVM_CT)
+    int n_cols_chunk;    // valid columns in the chunk
+    u64 L;
+    const u64* tw_b2;    // w_N1^e
+    int cols_log;        // a workgroup transforms 2^cols_log (<= 16) adjacent columns of one tile
+};
+
+__global__ void __launch_bounds__(1024) k_lde_pass3(LdePass3Args a) {
+    TVM_DYN_SMEM(u64, s);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int n1 = 1 << a.log_n1;
+    const u64 n2 = 1ull << a.log_n2;
+    const int RS = n1 + TVM_ROW_PAD;
+    const u64 j1 = blockIdx.x;
+    const int k = blockIdx.y;
+    const int CB = 1 << a.cols_log;
+    const int sub_per_tile = TVM_CT >> a.cols_log;
+    const int t = blockIdx.z / sub_per_tile;            // 16-column tile within the chunk
+    const int b0 = (blockIdx.z % sub_per_tile) << a.cols_log;
+    const u64 n = (u64)n1 << a.log_n2;
+    const int tile = n1 << a.cols_log;
+    for (int idx = tid; idx < tile; idx += nt) {
+        const int p = idx & (n1 - 1), b = idx >> a.log_n1;
+        const int vl = t * TVM_CT + b0 + b;
+        s[b * RS + p] = (vl < a.n_cols_chunk) ? a.z[(((u64)vl * a.n_cosets + k) * n2 + j1) * n1 + p] : 0;
+    }
+    __syncthreads();
+    lds_ntt<true, false>(s, a.log_n1, a.cols_log, 1, RS, a.tw_b2, tid, nt);
+    u64* tab = a.table + (u64)(a.col0 / TVM_CT + t) * a.L * TVM_CT;
+    for (int idx = tid; idx < tile; idx += nt) {
+        const int b = idx & (CB - 1), j2 = idx >> a.cols_log;
+        const u64 row = (u64)a.n_cosets * (j1 + n2 * (u64)j2) + k;
+        tab[row * TVM_CT + b0 + b] = s[b * RS + j2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+const u64* pow_table(tvm_ctx* c, u64 base, u64 count, u64 scale) {
+    auto key = std::make_tuple(base, count, scale);
+    auto it = c->tables.find(key);
+    if (it != c->tables.end()) return it->second;
+    u64* d = nullptr;
+    if (hipMalloc((void**)&d, (count ? count : 1) * sizeof(u64)) != hipSuccess) return nullptr;
+    const int bs = 256;
+    TVM_LAUNCH(k_pow_table, dim3((unsigned)((count + bs - 1) / bs)), dim3(bs), 0, c->stream, base, count, scale, d);
+    c->tables[key] = d;
+    return d;
+}
+
+void* scratch(tvm_ctx* c, int slot, size_t bytes) {
+    if ((size_t)slot >= c->scratch.size()) {
+        c->scratch.resize(slot + 1, nullptr);
+        c->scratch_bytes.resize(slot + 1, 0);
+    }
+    if (c->scratch_bytes[slot] < bytes) {
+        if (c->scratch[slot]) {
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipFree(c->scratch[slot]);
+            c->scratch[slot] = nullptr;
+            c->scratch_bytes[slot] = 0;
+        }
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        c->scratch[slot] = p;
+        c->scratch_bytes[slot] = bytes;
+    }
+    return c->scratch[slot];
+}
+
+int set_error(tvm_ctx* c, int code, const char* what) {
+    if (c) c->last_error = what;
+    return code;
+}
+
+static int threads_for_tile(int tile) {
+    int t = tile / 16;
+    t = (t + 63) / 64 * 64;
+    if (t < 64) t = 64;
+    if (t > 1024) t = 1024;
+    return t;
+}
+static int batch_log_for(int log_axis) {
+    int b = 14 - log_axis;  // tile of at most 2^14 words = 128 KiB
+    return b > 4 ? 4 : b;
+}
+
+static bool g_attr_done = false;
+static void set_lds_attributes() {
+    if (g_attr_done) return;
+    g_attr_done = true;
+    const int max_lds = 160 * 1024;
+    (void)hipFuncSetAttribute((const void*)k_ntt2_pass1, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_ntt2_pass2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass3, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+}
+
+struct Split {
+    int log_n, log_n1, log_n2, shift;
+};
+static Split split_for(u64 n) {
+    Split s;
+    s.log_n = ilog2(n);
+    s.log_n1 = s.log_n / 2;
+    s.log_n2 = s.log_n - s.log_n1;
+    s.shift = (s.log_n + 1) / 2;
+    return s;
+}
+static int make_inter(tvm_ctx* c, u64 w, const Split& sp, Pow2* out) {
+    out->shift = sp.shift;
+    out->lo = pow_table(c, w, 1ull << sp.shift);
+    out->hi = pow_table(c, bfe_pow(w, 1ull << sp.shift), 1ull << (sp.log_n - sp.shift));
+    return (out->lo && out->hi) ? TVM_OK : TVM_ERR_OUT_OF_MEMORY;
+}
+
+// Transform `ncols` columns of length n with root `w` (w^n = 1; pass the inverse root for an
+// inverse transform).  in_scale/out_scale: optional x[i] *= in_scale^i and X[k] *= out_mult*out_scale^k.
+int ntt_columns(tvm_ctx* c, const u64* in, u64 in_len, int in_fk, u64 in_col_stride, u64* out, int out_fk,
+                u64 out_col_stride, u64 out_mul, u64 out_add, int ncols, u64 n, u64 w, u64 in_scale, u64 out_scale,
+                u64 out_mult) {
+    if (!is_pow2(n) || n < 2) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "ntt length must be a power of two >= 2");
+    if (n > (1ull << 24)) return set_error(c, TVM_ERR_UNSUPPORTED, "ntt length above 2^24");
+    set_lds_attributes();
+    Split sp = split_for(n);
+    const u64 n1 = 1ull << sp.log_n1, n2 = 1ull << sp.log_n2;
+    Ntt2Args a;
+    a.in = in;
+    a.out = out;
+    a.tmp = (u64*)scratch(c, 0, (size_t)ncols * n * sizeof(u64));
+    if (!a.tmp) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "ntt scratch");
+    a.log_n1 = sp.log_n1;
+    a.log_n2 = sp.log_n2;
+    a.in_len = in_len;
+    a.in_fk = in_fk;
+    a.out_fk = out_fk;
+    a.in_col_stride = in_col_stride;
+    a.tmp_col_stride = n;
+    a.out_col_stride = out_col_stride;
+    a.tw1 = pow_table(c, bfe_pow(w, n2), n1 > 1 ? n1 / 2 : 1);
+    a.tw2 = pow_table(c, bfe_pow(w, n1), n2 / 2);
+    TVM_TRY(make_inter(c, w, sp, &a.tw_inter));
+    a.pre_hi = a.pre_lo = a.post_lo = a.post_hi = nullptr;
+    if (in_scale != TVM_ONE) {
+        a.pre_lo = pow_table(c, in_scale, n2);
+        a.pre_hi = pow_table(c, bfe_pow(in_scale, n2), n1);
+        if (!a.pre_lo || !a.pre_hi) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "tables");
+    }
+    if (out_scale != TVM_ONE || out_mult != TVM_ONE) {
+        a.post_lo = pow_table(c, out_scale, n1, out_mult);
+        a.post_hi = pow_table(c, bfe_pow(out_scale, n1), n2);
+        if (!a.post_lo || !a.post_hi) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "tables");
+    }
+    if (!a.tw1 || !a.tw2) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "tables");
+    a.out_mul = out_mul;
+    a.out_add = out_add;
+    a.col0 = 0;
+    {
+        a.batch_log = batch_log_for(sp.log_n1);
+        const int B = 1 << a.batch_log;
+        const int tile = (int)n1 << a.batch_log;
+        dim3 grid((unsigned)((n2 + B - 1) / B), (unsigned)ncols);
+        TVM_LAUNCH(k_ntt2_pass1, grid, dim3(threads_for_tile(tile)), (size_t)tile * sizeof(u64), c->stream, a);
+    }
+    {
+        a.batch_log = batch_log_for(sp.log_n2);
+        const int B = 1 << a.batch_log;
+        const int tile = (int)n2 << a.batch_log;
+        dim3 grid((unsigned)((n1 + B - 1) / B), (unsigned)ncols);
+        const size_t lds = (size_t)B * (n2 + TVM_ROW_PAD) * sizeof(u64);
+        TVM_LAUNCH(k_ntt2_pass2, grid, dim3(threads_for_tile(tile)), lds, c->stream, a);
+    }
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+
+// master_table.rs:258-322.  trace: column-major [n_cols][n_rows][fk]; rnd: [n_cols][h][fk];
+// table: [ceil(n_cols*fk / 16)][L][16].
+int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, const u64* rnd, u64 h, u64 trace_gen,
+              u64 eval_offset, u64 eval_gen, u64 L, u64* table, int chunk_cols) {
+    if (!is_pow2(n_rows) || !is_pow2(L) || n_rows < 2 || L < n_rows || (fk != 1 && fk != 3))
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "lde: lengths must be powers of two, L >= n_rows >= 2");
+    const u64 X = L / n_rows;
+    if (X > TVM_LDE_MAX_COSETS) return set_error(c, TVM_ERR_UNSUPPORTED, "lde: expansion above 32");
+    if (h > n_rows) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "lde: more randomizers than rows");
+    if (n_rows > (1ull << 24)) return set_error(c, TVM_ERR_UNSUPPORTED, "lde: trace above 2^24 rows");
+    if (bfe_pow(eval_gen, X) != trace_gen)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "lde: evaluation generator ^ (L/N) must equal the trace generator");
+    set_lds_attributes();
+    const u64 N = n_rows;
+    const Split sp = split_for(N);
+    const u64 n1 = 1ull << sp.log_n1, n2 = 1ull << sp.log_n2;
+    const int W = (int)(n_cols * fk);
+    if (chunk_cols <= 0) chunk_cols = 32;
+    chunk_cols = (chunk_cols + TVM_CT - 1) / TVM_CT * TVM_CT;
+
+    const u64 w = trace_gen, wi = bfe_inv(trace_gen);
+    const u64 n_inv = bfe_inv(bfe_from_u64(N));
+    Ntt2Args p1;
+    p1.in = trace;
+    p1.out = nullptr;
+    p1.log_n1 = sp.log_n1;
+    p1.log_n2 = sp.log_n2;
+    p1.batch_log = batch_log_for(sp.log_n1);
+    p1.in_len = N;
+    p1.in_fk = fk;
+    p1.out_fk = 1;
+    p1.in_col_stride = N * fk;
+    p1.tmp_col_stride = N;
+    p1.out_col_stride = 0;
+    p1.tw1 = pow_table(c, bfe_pow(wi, n2), n1 > 1 ? n1 / 2 : 1);
+    p1.tw2 = nullptr;
+    TVM_TRY(make_inter(c, wi, sp, &p1.tw_inter));
+    p1.pre_hi = p1.pre_lo = p1.post_lo = p1.post_hi = nullptr;
+    p1.out_mul = 1;
+    p1.out_add = 0;
+    p1.col0 = 0;
+
+    LdePass2Args p2;
+    p2.rnd = rnd;
+    p2.log_n1 = sp.log_n1;
+    p2.log_n2 = sp.log_n2;
+    p2.batch_log = batch_log_for(sp.log_n2);
+    p2.fk = fk;
+    p2.h = h;
+    p2.n_cosets = (int)X;
+    p2.tw_a2 = pow_table(c, bfe_pow(wi, n1), n2 / 2);
+    p2.tw_b1 = pow_table(c, bfe_pow(w, n1), n2 / 2);
+    TVM_TRY(make_inter(c, w, sp, &p2.tw_inter));
+    p2.g_lo = pow_table(c, eval_offset, n1, n_inv);
+    p2.g_hi = pow_table(c, bfe_pow(eval_offset, n1), n2);
+    p2.wl_lo = pow_table(c, eval_gen, n1);
+    p2.wl_hi = pow_table(c, bfe_pow(eval_gen, n1), n2);
+    const u64 n_mont = bfe_from_u64(N);
+    for (u64 k = 0; k < X; k++) {
+        const u64 gamma = bfe_mul(eval_offset, bfe_pow(eval_gen, k));
+        p2.zk[k] = bfe_mul(n_mont, bfe_sub(bfe_pow(gamma, N), TVM_ONE));
+    }
+    for (u64 k = X; k < TVM_LDE_MAX_COSETS; k++) p2.zk[k] = 0;
+
+    LdePass3Args p3;
+    p3.table = table;
+    p3.log_n1 = sp.log_n1;
+    p3.log_n2 = sp.log_n2;
+    p3.n_cosets = (int)X;
+    p3.L = L;
+    p3.tw_b2 = pow_table(c, bfe_pow(w, n2), n1 > 1 ? n1 / 2 : 1);
+    if (!p1.tw1 || !p2.tw_a2 || !p2.tw_b1 || !p2.g_lo || !p2.g_hi || !p2.wl_lo || !p2.wl_hi || !p3.tw_b2)
+        return set_error(c, TVM_ERR_OUT_OF_MEMORY, "lde tables");
+
+    u64* y = (u64*)scratch(c, 1, (size_t)chunk_cols * N * sizeof(u64));
+    u64* z = (u64*)scratch(c, 2, (size_t)chunk_cols * X * N * sizeof(u64));
+    if (!y || !z) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "lde scratch");
+    p1.tmp = y;
+    p2.y = y;
+    p2.z = z;
+    p3.z = z;
+
+    for (int col0 = 0; col0 < W; col0 += chunk_cols) {
+        const int nc = (W - col0 < chunk_cols) ? (W - col0) : chunk_cols;
+        {
+            Ntt2Args a = p1;
+            a.col0 = col0;
+            const int B = 1 << a.batch_log;
+            const int tile = (int)n1 << a.batch_log;
+            dim3 grid((unsigned)((n2 + B - 1) / B), (unsigned)nc);
+            TVM_LAUNCH(k_ntt2_pass1, grid, dim3(threads_for_tile(tile)), (size_t)tile * sizeof(u64), c->stream, a);
+        }
+        {
+            LdePass2Args a = p2;
+            a.col0 = col0;
+            const int B = 1 << a.batch_log;
+            const int tile = (int)n2 << a.batch_log;
+            dim3 grid((unsigned)((n1 + B - 1) / B), (unsigned)nc);
+            const size_t lds = (size_t)B * (n2 + TVM_ROW_PAD) * sizeof(u64);
+            TVM_LAUNCH(k_lde_pass2, grid, dim3(threads_for_tile(tile)), lds, c->stream, a);
+        }
+        {
+            LdePass3Args a = p3;
+            a.col0 = col0;
+            a.n_cols_chunk = nc;
+            const int tiles = (nc + TVM_CT - 1) / TVM_CT;
+            a.cols_log = batch_log_for(sp.log_n1);
+            const int tile = (int)n1 << a.cols_log;
+            dim3 grid((unsigned)n2, (unsigned)X, (unsigned)(tiles * (TVM_CT >> a.cols_log)));
+            const size_t lds = ((size_t)(n1 + TVM_ROW_PAD) << a.cols_log) * sizeof(u64);
+            TVM_LAUNCH(k_lde_pass3, grid, dim3(threads_for_tile(tile)), lds, c->stream, a);
+        }
+    }
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+
+}  // namespace tvm

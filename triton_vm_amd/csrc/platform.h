@@ -1,0 +1,25 @@
+// platform.h -- the one place that decides how kernels are compiled.
+//
+// Product build (hipcc --offload-arch=gfx950): real HIP.  There is no CPU fallback in the product.
+// Test build (g++ -DTVM_EMU, tests/emu/): the same kernel sources run under a fiber emulator so the
+// GPU-less container can check them against the oracle.
+#pragma once
+
+#ifdef TVM_EMU
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#define TVM_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+    hipLaunchKernelGGL(kernel, (grid), (block), (shmem), (stream), __VA_ARGS__)
+#define TVM_DYN_SMEM(T, name)                                                   \
+    extern __shared__ __attribute__((aligned(16))) unsigned char tvm_dyn_smem_[]; \
+    T* name = reinterpret_cast<T*>(tvm_dyn_smem_)
+#endif
+
+#include <cstdint>
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+#define TVM_HD __host__ __device__ __forceinline__
+#define TVM_D __device__ __forceinline__

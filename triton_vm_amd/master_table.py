@@ -1,0 +1,86 @@
+"""Host mirror of the reference's MasterTable trait (/root/reference/triton-vm/src/table/master_table.rs:190-610)
+for the methods on the hot path.  The trace, the randomizers and the extended table live in HBM."""
+import ctypes as C
+
+import numpy as np
+
+
+class MasterTable:
+    """A padded master main (field_kind 1) or auxiliary (field_kind 3) table on the device.
+
+    trace:        numpy [n_cols, n_rows(, 3)] -- column-major like the reference (master_table.rs:888,1013)
+    randomizers:  numpy [n_cols, h(, 3)]      -- coefficients of trace_randomizer_for_column (:423-434),
+                  produced by the host RNG (they never come from this library)
+    """
+
+    def __init__(self, ctx, trace, randomizers, trace_domain, quotient_domain, ldt_domain, field_kind=1):
+        self.ctx, self.fk = ctx, field_kind
+        trace = np.ascontiguousarray(trace, dtype=np.uint64)
+        randomizers = np.ascontiguousarray(randomizers, dtype=np.uint64)
+        self.n_cols, self.n_rows = trace.shape[0], trace.shape[1]
+        self.num_trace_randomizers = randomizers.shape[1]
+        self.trace_domain, self.quotient_domain, self.ldt_domain = trace_domain, quotient_domain, ldt_domain
+        self.d_trace = ctx.to_device(trace)
+        self.d_randomizers = ctx.to_device(randomizers)
+        self._table = None
+
+    # master_table.rs:215-222
+    def evaluation_domain(self):
+        return self.quotient_domain if self.quotient_domain.length > self.ldt_domain.length else self.ldt_domain
+
+    # master_table.rs:258-322
+    def maybe_low_degree_extend_all_columns(self):
+        h = C.c_void_p()
+        ev = self.evaluation_domain()
+        self.ctx._check(self.ctx.lib.tvm_lde_table(self.ctx.handle, self.fk, self.d_trace.ptr, self.n_rows, self.n_cols,
+                                                   self.d_randomizers.ptr, self.num_trace_randomizers,
+                                                   self.trace_domain.c(), ev.c(), C.byref(h)), "tvm_lde_table")
+        self.clear_cache()
+        self._table = h.value
+
+    def clear_cache(self):
+        if self._table:
+            self.ctx.lib.tvm_table_free(self.ctx.handle, self._table)
+            self._table = None
+
+    def _need_table(self):
+        if not self._table:
+            raise RuntimeError("low-degree extend first (maybe_low_degree_extend_all_columns)")
+        return self._table
+
+    def low_degree_extended_table(self):
+        """The reference's row-major Array2 [rows, n_cols(, 3)] (master_table.rs:304-305), on the host."""
+        t = self._need_table()
+        rows = self.ctx.lib.tvm_table_num_rows(t)
+        buf = self.ctx.alloc(rows * self.n_cols * self.fk)
+        self.ctx._check(self.ctx.lib.tvm_table_export_row_major(self.ctx.handle, t, buf.ptr), "export")
+        shape = (rows, self.n_cols) + ((3,) if self.fk == 3 else ())
+        return buf.download(shape)
+
+    # master_table.rs:455-468
+    def hash_all_ldt_domain_rows(self):
+        n = self.ldt_domain.length
+        d = self.ctx.alloc(5 * n)
+        self.ctx._check(self.ctx.lib.tvm_hash_rows(self.ctx.handle, self._need_table(), n, d.ptr), "tvm_hash_rows")
+        return d.download((n, 5))
+
+    # master_table.rs:443-453; returns the node array [2n, 5] (node 1 = root)
+    def merkle_tree(self):
+        n = self.ldt_domain.length
+        d = self.ctx.alloc(10 * n)
+        self.ctx._check(self.ctx.lib.tvm_table_merkle_tree(self.ctx.handle, self._need_table(), n, d.ptr), "merkle")
+        return d.download((2 * n, 5))
+
+    # master_table.rs:548-555 (cached branch)
+    def reveal_rows(self, row_indices):
+        idx = np.ascontiguousarray(row_indices, dtype=np.uint64)
+        out = np.empty((idx.size, self.n_cols * self.fk), np.uint64)
+        self.ctx._check(self.ctx.lib.tvm_table_reveal_rows(self.ctx.handle, self._need_table(), self.ldt_domain.length,
+                                                           idx.ctypes.data, idx.size, out.ctypes.data), "reveal_rows")
+        return out.reshape((idx.size, self.n_cols) + ((3,) if self.fk == 3 else ()))
+
+    def __del__(self):
+        try:
+            self.clear_cache()
+        except Exception:
+            pass

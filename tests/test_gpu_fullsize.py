@@ -1,0 +1,69 @@
+"""Parity at BASELINE.json's full size (config 1: 2^20 padded rows, 379 main / 91 aux columns,
+evaluation domain 2^23) on the real MI355X.  The oracle cannot extend 652 columns of 2^23 values in
+seconds, so whole columns and whole rows are sampled: sampled columns are extended by the oracle at
+full length and compared at sampled rows; sampled rows are re-hashed by the oracle; sampled leaves
+are authenticated against the device-built Merkle root with the oracle's hash_pair."""
+import numpy as np
+import pytest
+
+from triton_vm_amd import ArithmeticDomain, MasterTable, field
+
+pytestmark = pytest.mark.gpu
+
+LOG_N = 20
+H = 198  # trace randomizers with FRI at 160-bit security
+
+
+def odom(orc, d):
+    return orc.Domain(d.offset, d.generator, d.length)
+
+
+@pytest.fixture(scope="module")
+def gctx():
+    from triton_vm_amd import Context
+
+    c = Context(device=0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("fk,n_cols,sample_cols", [(1, 379, (0, 200, 378)), (3, 91, (0, 90))])
+def test_full_size_table(gctx, orc, fk, n_cols, sample_cols):
+    ctx = gctx
+    n = 1 << LOG_N
+    trace_dom = ArithmeticDomain.of_length(n)
+    ev = ArithmeticDomain.of_length(8 * n).with_offset(field.generator())
+    mt = MasterTable.__new__(MasterTable)
+    mt.ctx, mt.fk, mt.n_cols, mt.n_rows, mt.num_trace_randomizers = ctx, fk, n_cols, n, H
+    mt.trace_domain, mt.quotient_domain, mt.ldt_domain, mt._table = trace_dom, ev, ev, None
+    mt.d_trace = ctx.synthetic(n_cols * n * fk, seed=11 + fk)
+    mt.d_randomizers = ctx.synthetic(n_cols * H * fk, seed=13 + fk)
+    mt.maybe_low_degree_extend_all_columns()
+    ctx.sync()
+
+    rng = np.random.default_rng(5)
+    rows = np.unique(np.concatenate([[0, 1, 7, 8, len(ev) - 1], rng.integers(0, len(ev), 500)])).astype(np.uint64)
+    revealed = mt.reveal_rows(rows)  # [n_rows_sampled, n_cols(, 3)]
+
+    # whole columns through the oracle
+    trace_host = mt.d_trace.download().reshape((n_cols, n) + ((3,) if fk == 3 else ()))
+    rnd_host = mt.d_randomizers.download().reshape((n_cols, H) + ((3,) if fk == 3 else ()))
+    for c in sample_cols:
+        want = orc.lde_table(trace_host[c:c + 1], rnd_host[c:c + 1], odom(orc, ev), fk)
+        assert (revealed[:, c] == want[rows.astype(np.int64), 0]).all(), f"column {c}"
+
+    # whole rows through the oracle hash
+    nodes = mt.merkle_tree()
+    L = len(ev)
+    for j, r in enumerate(rows[:64]):
+        digest = orc.hash_varlen(revealed[j].reshape(-1))
+        assert (nodes[L + int(r)] == digest).all(), f"row {r}"
+        # authentication path up to the root
+        i = L + int(r)
+        cur = digest
+        while i > 1:
+            sib = nodes[i ^ 1]
+            cur = orc.hash_pair(cur, sib) if i % 2 == 0 else orc.hash_pair(sib, cur)
+            i >>= 1
+            assert (nodes[i] == cur).all()
+    mt.clear_cache()

@@ -42,7 +42,8 @@ def build(force=False, verbose=False, extra_flags=()):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-             "-Wall", "-Wno-unused-function", *extra_flags]
+             "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-Wno-unused-variable",
+             *extra_flags]
     procs, objs = [], []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))

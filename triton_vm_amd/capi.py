@@ -43,6 +43,9 @@ _SIGNATURES = {
     "tvm_free": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "tvm_memcpy_h2d": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "tvm_memcpy_d2h": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "tvm_timer_start": (C.c_int32, [C.c_void_p]),
+    "tvm_timer_stop": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float)]),
+    "tvm_synthetic_fill": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
     "tvm_evaluate": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, Domain, C.c_void_p]),
     "tvm_interpolate": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, Domain, C.c_void_p]),
     "tvm_ntt": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64]),
@@ -136,6 +139,19 @@ class Context:
 
     def sync(self):
         self._check(self.lib.tvm_sync(self.handle), "tvm_sync")
+
+    def timer_start(self):
+        self._check(self.lib.tvm_timer_start(self.handle), "tvm_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._check(self.lib.tvm_timer_stop(self.handle, C.byref(ms)), "tvm_timer_stop")
+        return ms.value
+
+    def synthetic(self, n_words, seed):
+        buf = DeviceBuffer(self, n_words)
+        self._check(self.lib.tvm_synthetic_fill(self.handle, buf.ptr, n_words, seed), "tvm_synthetic_fill")
+        return buf
 
     def alloc(self, n_words):
         return DeviceBuffer(self, n_words)

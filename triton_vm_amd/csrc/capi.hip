@@ -54,6 +54,8 @@ void tvm_ctx_destroy(tvm_ctx* c) {
     for (auto& kv : c->tables) hipFree(kv.second);
     for (void* p : c->scratch)
         if (p) hipFree(p);
+    if (c->ev_start) hipEventDestroy(c->ev_start);
+    if (c->ev_stop) hipEventDestroy(c->ev_stop);
     if (c->owns_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -88,6 +90,46 @@ int32_t tvm_memcpy_d2h(tvm_ctx* c, void* h, const void* d, size_t bytes) {
     if (!c || (bytes && (!d || !h))) return TVM_ERR_INVALID_ARGUMENT;
     TVM_HIP_CHECK(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
     TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return TVM_OK;
+}
+
+int32_t tvm_timer_start(tvm_ctx* c) {
+    if (!c) return TVM_ERR_INVALID_ARGUMENT;
+    if (!c->ev_start) {
+        TVM_HIP_CHECK(c, hipEventCreate(&c->ev_start));
+        TVM_HIP_CHECK(c, hipEventCreate(&c->ev_stop));
+    }
+    TVM_HIP_CHECK(c, hipEventRecord(c->ev_start, c->stream));
+    return TVM_OK;
+}
+int32_t tvm_timer_stop(tvm_ctx* c, float* ms) {
+    if (!c || !ms || !c->ev_start) return TVM_ERR_INVALID_ARGUMENT;
+    TVM_HIP_CHECK(c, hipEventRecord(c->ev_stop, c->stream));
+    TVM_HIP_CHECK(c, hipEventSynchronize(c->ev_stop));
+    TVM_HIP_CHECK(c, hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+    return TVM_OK;
+}
+}  // extern "C"
+
+namespace tvm {
+// splitmix64 of (seed, index), reduced into [0, p): synthetic benchmark data only
+__global__ void k_synthetic_fill(u64* __restrict__ d, u64 n, u64 seed) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    d[i] = z >= TVM_P ? z - TVM_P : z;
+}
+}  // namespace tvm
+
+extern "C" {
+int32_t tvm_synthetic_fill(tvm_ctx* c, uint64_t* d, uint64_t n, uint64_t seed) {
+    if (!c || (n && !d)) return TVM_ERR_INVALID_ARGUMENT;
+    if (!n) return TVM_OK;
+    TVM_LAUNCH(tvm::k_synthetic_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d, n, seed);
+    TVM_HIP_CHECK(c, hipGetLastError());
     return TVM_OK;
 }
 

@@ -25,6 +25,7 @@ struct tvm_ctx {
     std::vector<void*> scratch;                         // named scratch slots
     std::vector<size_t> scratch_bytes;
     std::string last_error;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 
 namespace tvm {

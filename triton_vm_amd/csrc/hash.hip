@@ -16,45 +16,38 @@
 namespace tvm {
 
 
-// w[k] for a wave-uniform k in 0..15 without dynamic register indexing
-TVM_D u64 select16(const u64 (&w)[16], int k) {
-    u64 a0 = (k & 1) ? w[1] : w[0], a1 = (k & 1) ? w[3] : w[2], a2 = (k & 1) ? w[5] : w[4], a3 = (k & 1) ? w[7] : w[6];
-    u64 a4 = (k & 1) ? w[9] : w[8], a5 = (k & 1) ? w[11] : w[10], a6 = (k & 1) ? w[13] : w[12], a7 = (k & 1) ? w[15] : w[14];
-    u64 b0 = (k & 2) ? a1 : a0, b1 = (k & 2) ? a3 : a2, b2 = (k & 2) ? a5 : a4, b3 = (k & 2) ? a7 : a6;
-    u64 c0 = (k & 4) ? b1 : b0, c1 = (k & 4) ? b3 : b2;
-    return (k & 8) ? c1 : c0;
-}
+#define TVM_HASH_BLOCK 256
 
-// digests[r] = Tip5::hash_varlen(row r*stride of the table), table = [tiles][L][16], W words per row
-__global__ void __launch_bounds__(256) k_hash_rows(const u64* __restrict__ table, u64 L, int W, u64 stride, u64 n_out,
-                                                    u64* __restrict__ digests) {
+// digests[r] = Tip5::hash_varlen(row r*stride of the table), table = [tiles][L][16], W words per row.
+// Each work-item parks the current 16-word tile of its row in LDS, word-major ([word][lane], so
+// every access is conflict-free) and absorbs from there with a wave-uniform word index: no
+// per-lane register array, no dynamic register indexing.
+__global__ void __launch_bounds__(TVM_HASH_BLOCK) k_hash_rows(const u64* __restrict__ table, u64 L, int W, u64 stride,
+                                                               u64 n_out, u64* __restrict__ digests) {
     __shared__ unsigned char lut[256];
-    tip5_stage_lut(lut, threadIdx.x, blockDim.x);
-    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ u64 stage[16 * TVM_HASH_BLOCK];
+    const int tid = threadIdx.x;
+    tip5_stage_lut(lut, tid, blockDim.x);
+    const u64 r = (u64)blockIdx.x * blockDim.x + tid;
     if (r >= n_out) return;
     const u64 row = r * stride;
     u64 st[TIP5_STATE];
 #pragma unroll
     for (int i = 0; i < TIP5_STATE; i++) st[i] = 0;
-    u64 w[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) w[i] = 0;
     const int n_perms = W / TIP5_RATE + 1;
-    int k = 16, t = 0, wi = 0;
+    int wi = 0;
     for (int perm = 0; perm < n_perms; perm++) {
 #pragma unroll
         for (int q = 0; q < TIP5_RATE; q++) {
-            if (k == 16 && wi < W) {
-                const u64* src = table + ((u64)t * L + row) * TVM_CT;
+            const int k = wi & 15;
+            if (k == 0 && wi < W) {
+                const u64* src = table + ((u64)(wi >> 4) * L + row) * TVM_CT;
 #pragma unroll
-                for (int i = 0; i < 16; i++) w[i] = src[i];
-                k = 0;
-                t++;
+                for (int i = 0; i < 16; i++) stage[i * TVM_HASH_BLOCK + tid] = src[i];
             }
-            u64 v = select16(w, k & 15);
+            u64 v = stage[k * TVM_HASH_BLOCK + tid];
             if (wi >= W) v = (wi == W) ? TVM_ONE : 0;  // padding: 1 then 0s (tip-0005.md:83)
             st[q] = v;
-            k++;
             wi++;
         }
         tip5_permute_inline(st, lut);
@@ -150,7 +143,8 @@ __global__ void k_columns_to_table(const u64* __restrict__ cols, u64 col_stride,
 int hash_rows(tvm_ctx* c, const u64* table, u64 L, int W, u64 stride, u64* digests) {
     if (!stride || L % stride) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "hash_rows: stride must divide L");
     const u64 n = L / stride;
-    TVM_LAUNCH(k_hash_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, table, L, W, stride, n, digests);
+    TVM_LAUNCH(k_hash_rows, dim3((unsigned)((n + TVM_HASH_BLOCK - 1) / TVM_HASH_BLOCK)), dim3(TVM_HASH_BLOCK), 0, c->stream,
+               table, L, W, stride, n, digests);
     TVM_HIP_CHECK(c, hipGetLastError());
     return TVM_OK;
 }

@@ -190,10 +190,8 @@ struct LdePass2Args {
     const u64* tw_a2;    // w_N2^-e
     const u64* tw_b1;    // w_N2^e
     Pow2 tw_inter;       // w_N^e
-    const u64* g_lo;     // g^m2 / N, m2 < N1
-    const u64* g_hi;     // g^(N1*m1), m1 < N2
-    const u64* wl_lo;    // w_L^m2
-    const u64* wl_hi;    // w_L^(N1*m1)
+    const u64* g_lo;     // [X][N1]: gamma_k^m2 / N
+    const u64* g_hi;     // [X][N2]: gamma_k^(N1*m1)
     u64 zk[TVM_LDE_MAX_COSETS];  // N * (gamma_k^N - 1)
 };
 
@@ -219,36 +217,32 @@ __global__ void __launch_bounds__(1024) k_lde_pass2(LdePass2Args a) {
     // inverse rows step: position q of row b now holds N * t[k1 + N1*k2], k2 = brev(q)
     lds_ntt<false, false>(s, a.log_n2, a.batch_log, 1, RS, a.tw_a2, tid, nt);
 
-    // Coefficients and their running coset factor stay in registers for the whole coset loop.
-    u64 coef[TVM_LDE_E], fac[TVM_LDE_E], wl[TVM_LDE_E], rz[TVM_LDE_E];
+    // The N coefficients of this tile stay in VGPRs for the whole coset loop (the only per-thread
+    // state: 16 words); coset factors come from two small L2-resident tables per coset.
+    u64 coef[TVM_LDE_E];
     const u64* rnd = a.rnd + (u64)(v / a.fk) * a.h * a.fk + (v % a.fk);
 #pragma unroll
     for (int e = 0; e < TVM_LDE_E; e++) {
         const int idx = tid + e * nt;
-        coef[e] = fac[e] = wl[e] = rz[e] = 0;
-        if (idx < tile) {
-            const int q = idx & (n2 - 1), b = idx >> a.log_n2;
-            const u64 m1 = brev_bits((u32)q, a.log_n2);
-            const u64 m2 = brev_bits((u32)(p0 + b), a.log_n1);
-            const u64 m = m1 * n1 + m2;
-            coef[e] = s[b * RS + q];
-            fac[e] = bfe_mul(a.g_lo[m2], a.g_hi[m1]);
-            wl[e] = bfe_mul(a.wl_lo[m2], a.wl_hi[m1]);
-            rz[e] = (m < a.h && p0 + b < n1) ? rnd[m * a.fk] : 0;
-        }
+        coef[e] = 0;
+        if (idx < tile) coef[e] = s[(idx >> a.log_n2) * RS + (idx & (n2 - 1))];
     }
     for (int k = 0; k < a.n_cosets; k++) {
         __syncthreads();
         const u64 zk = a.zk[k];
+        const u64* g_lo = a.g_lo + (u64)k * n1;
+        const u64* g_hi = a.g_hi + (u64)k * n2;
 #pragma unroll
         for (int e = 0; e < TVM_LDE_E; e++) {
             const int idx = tid + e * nt;
             if (idx < tile) {
                 const int q = idx & (n2 - 1), b = idx >> a.log_n2;
+                const u64 m1 = brev_bits((u32)q, a.log_n2);
+                const u64 m2 = brev_bits((u32)(p0 + b), a.log_n1);
+                const u64 m = m1 * n1 + m2;
                 u64 c = coef[e];
-                if (rz[e]) c = bfe_add(c, bfe_mul(zk, rz[e]));
-                s[b * RS + q] = bfe_mul(c, fac[e]);
-                fac[e] = bfe_mul(fac[e], wl[e]);
+                if (m < a.h && p0 + b < n1) c = bfe_add(c, bfe_mul(zk, rnd[m * a.fk]));  // few lanes
+                s[b * RS + q] = bfe_mul(c, bfe_mul(g_lo[m2 & (n1 - 1)], g_hi[m1]));
             }
         }
         __syncthreads();
@@ -368,6 +362,34 @@ static void set_lds_attributes() {
     (void)hipFuncSetAttribute((const void*)k_ntt2_pass2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+}
+
+// lo[k][i] = scale * gamma_k^i (i < n1), hi[k][i] = gamma_k^(n1*i) (i < n2), gamma_k = offset * gen^k
+__global__ void k_coset_tables(u64 offset, u64 gen, u64 X, u64 n1, u64 n2, u64 scale, u64* lo, u64* hi) {
+    const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= X * (n1 + n2)) return;
+    const u64 k = e / (n1 + n2), i = e % (n1 + n2);
+    const u64 gamma = bfe_mul(offset, bfe_pow(gen, k));
+    if (i < n1) lo[k * n1 + i] = bfe_mul(scale, bfe_pow(gamma, i));
+    else hi[k * n2 + (i - n1)] = bfe_pow(bfe_pow(gamma, n1), i - n1);
+}
+static int coset_tables(tvm_ctx* c, u64 offset, u64 gen, u64 X, u64 n1, u64 n2, u64 scale, const u64** lo, const u64** hi) {
+    auto key = std::make_tuple(offset ^ 0xC05E7C05E7ull, gen, (X << 56) | (n1 << 28) | n2);
+    auto it = c->tables.find(key);
+    u64* d = nullptr;
+    if (it != c->tables.end()) {
+        d = it->second;
+    } else {
+        if (hipMalloc((void**)&d, X * (n1 + n2) * sizeof(u64)) != hipSuccess)
+            return set_error(c, TVM_ERR_OUT_OF_MEMORY, "coset tables");
+        const u64 total = X * (n1 + n2);
+        TVM_LAUNCH(k_coset_tables, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, offset, gen, X, n1, n2,
+                   scale, d, d + X * n1);
+        c->tables[key] = d;
+    }
+    *lo = d;
+    *hi = d + X * n1;
+    return TVM_OK;
 }
 
 struct Split {
@@ -501,10 +523,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     p2.tw_a2 = pow_table(c, bfe_pow(wi, n1), n2 / 2);
     p2.tw_b1 = pow_table(c, bfe_pow(w, n1), n2 / 2);
     TVM_TRY(make_inter(c, w, sp, &p2.tw_inter));
-    p2.g_lo = pow_table(c, eval_offset, n1, n_inv);
-    p2.g_hi = pow_table(c, bfe_pow(eval_offset, n1), n2);
-    p2.wl_lo = pow_table(c, eval_gen, n1);
-    p2.wl_hi = pow_table(c, bfe_pow(eval_gen, n1), n2);
+    TVM_TRY(coset_tables(c, eval_offset, eval_gen, X, n1, n2, n_inv, &p2.g_lo, &p2.g_hi));
     const u64 n_mont = bfe_from_u64(N);
     for (u64 k = 0; k < X; k++) {
         const u64 gamma = bfe_mul(eval_offset, bfe_pow(eval_gen, k));
@@ -519,7 +538,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     p3.n_cosets = (int)X;
     p3.L = L;
     p3.tw_b2 = pow_table(c, bfe_pow(w, n2), n1 > 1 ? n1 / 2 : 1);
-    if (!p1.tw1 || !p2.tw_a2 || !p2.tw_b1 || !p2.g_lo || !p2.g_hi || !p2.wl_lo || !p2.wl_hi || !p3.tw_b2)
+    if (!p1.tw1 || !p2.tw_a2 || !p2.tw_b1 || !p2.g_lo || !p2.g_hi || !p3.tw_b2)
         return set_error(c, TVM_ERR_OUT_OF_MEMORY, "lde tables");
 
     u64* y = (u64*)scratch(c, 1, (size_t)chunk_cols * N * sizeof(u64));

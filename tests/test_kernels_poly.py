@@ -1,0 +1,107 @@
+"""csrc/poly.hip against the oracle, through the C ABI: once on the TEST-ONLY CPU fiber emulation of
+the same kernel sources (-m "not gpu") and once on the real MI355X (-m gpu)."""
+import numpy as np
+import pytest
+
+from triton_vm_amd import ArithmeticDomain, MasterTable, field, stark
+
+
+def odom(orc, d):
+    return orc.Domain(d.offset, d.generator, d.length)
+
+
+def make_table(ctx, orc, rng, n, n_cols, h, fk):
+    shape = lambda k: (n_cols, k) + ((3,) if fk == 3 else ())
+    trace, rnd = orc.random_elements(rng, shape(n)), orc.random_elements(rng, shape(h))
+    ev = ArithmeticDomain.of_length(8 * n).with_offset(field.generator())
+    return MasterTable(ctx, trace, rnd, ArithmeticDomain.of_length(n), ev, ev, fk), trace, rnd
+
+
+@pytest.mark.parametrize("fk,n_cols", [(1, 7), (3, 4), (1, 20)])
+@pytest.mark.parametrize("log_n,h", [(4, 5), (6, 9)])
+def test_out_of_domain_rows(ctx, orc, fk, n_cols, log_n, h):
+    rng = np.random.default_rng(fk * 100 + n_cols + log_n)
+    mt, trace, rnd = make_table(ctx, orc, rng, 1 << log_n, n_cols, h, fk)
+    pts = orc.random_elements(rng, (2, 3))
+    got = mt.out_of_domain_rows(pts)
+    for p in range(2):
+        assert (got[p] == orc.out_of_domain_row(trace, rnd, pts[p], fk)).all()
+
+
+@pytest.mark.parametrize("fk,n_cols", [(1, 7), (3, 4)])
+@pytest.mark.parametrize("log_n,h", [(1, 1), (4, 5), (6, 9)])
+def test_weighted_sum_of_columns(ctx, orc, fk, n_cols, log_n, h):
+    rng = np.random.default_rng(fk * 10 + n_cols + log_n)
+    n = 1 << log_n
+    mt, trace, rnd = make_table(ctx, orc, rng, n, n_cols, h, fk)
+    w = orc.random_elements(rng, (n_cols, 3))
+    got = mt.weighted_sum_of_columns(w).download((2 * n, 3))
+    assert (got == orc.weighted_sum_of_columns(trace, rnd, w, fk)).all()
+
+
+@pytest.mark.parametrize("n", [1, 5, 64, 1000, 5000])
+def test_evaluate_at_points(ctx, orc, n):
+    rng = np.random.default_rng(n)
+    co = orc.random_elements(rng, (n, 3))
+    pts = orc.random_elements(rng, (3, 3))
+    d = ctx.to_device(co)
+    got = stark.evaluate_at_points(ctx, d, n, pts)
+    for p in range(3):
+        assert (got[p] == orc.poly_eval_xfe(co, pts[p])).all()
+
+
+@pytest.mark.parametrize("log_q,log_ldt,n_rand", [(4, 4, 3), (5, 5, 8), (5, 7, 5), (6, 6, 16)])
+def test_quotient_segments(ctx, orc, log_q, log_ldt, n_rand):
+    rng = np.random.default_rng(log_q * 7 + log_ldt + n_rand)
+    g = field.generator()
+    qd = ArithmeticDomain.of_length(1 << log_q).with_offset(g)
+    ldt = ArithmeticDomain.of_length(1 << log_ldt).with_offset(g)
+    cw = orc.random_elements(rng, (len(qd), 3))
+    rnd = orc.random_elements(rng, (n_rand, 3))
+    d_cw = ctx.to_device(cw)
+    qs = stark.quotient_segments(ctx, d_cw, qd, ldt, rnd)
+    seg = orc.interpolate_quotient_segments(cw, odom(orc, qd))
+    want_polys, want_cws = orc.randomize_quotient_segments(seg, rnd, odom(orc, ldt), qs.poly_len)
+    assert (qs.polys.download((5, qs.poly_len, 3)) == want_polys).all()
+    assert (qs.codewords() == want_cws).all()
+    digests = orc.hash_rows(want_cws.reshape(len(ldt), 15))
+    assert (qs.merkle_tree() == orc.merkle_tree(digests)).all()
+    w = orc.random_elements(rng, (5, 3))
+    got = qs.linear_combination(w).download((len(ldt), 3))
+    want = np.zeros((len(ldt), 3), np.uint64)
+    for i in range(len(ldt)):
+        acc = np.zeros(3, np.uint64)
+        for k in range(5):
+            acc = orc.xfe_add(acc, orc.xfe_mul(want_cws[i, k], w[k]))
+        want[i] = acc
+    assert (got == want).all()
+
+
+@pytest.mark.parametrize("log_n,k", [(3, 1), (6, 4), (8, 2)])
+def test_deep_codeword(ctx, orc, log_n, k):
+    rng = np.random.default_rng(log_n + k)
+    dom = ArithmeticDomain.of_length(1 << log_n).with_offset(field.generator())
+    cws = [orc.random_elements(rng, (len(dom), 3)) for _ in range(k)]
+    pts, vals, ws = (orc.random_elements(rng, (k, 3)) for _ in range(3))
+    bufs = [ctx.to_device(c) for c in cws]
+    got = stark.deep_codeword(ctx, bufs, dom, pts, vals, ws).download((len(dom), 3))
+    want = np.zeros((len(dom), 3), np.uint64)
+    for j in range(k):
+        comp = orc.deep_codeword(cws[j], odom(orc, dom), pts[j], vals[j])
+        for i in range(len(dom)):
+            want[i] = orc.xfe_add(want[i], orc.xfe_mul(comp[i], ws[j]))
+    assert (got == want).all()
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 5, 9])
+def test_fri_split_and_fold_and_round_tree(ctx, orc, log_n):
+    rng = np.random.default_rng(log_n)
+    dom = ArithmeticDomain.of_length(1 << log_n).with_offset(field.generator())
+    cw = orc.random_elements(rng, (len(dom), 3))
+    ch = orc.random_elements(rng, 3)
+    d = ctx.to_device(cw)
+    folded = stark.split_and_fold(ctx, d, dom, ch)
+    want = orc.fri_split_and_fold(cw, odom(orc, dom), ch)
+    assert (folded.download((len(dom) // 2, 3)) == want).all()
+    nodes = stark.merkle_tree_from_codeword(ctx, folded, len(dom) // 2).download((len(dom), 5))
+    assert (nodes == orc.merkle_tree(orc.xfe_to_digest(want))).all()

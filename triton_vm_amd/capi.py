@@ -62,6 +62,18 @@ _SIGNATURES = {
     "tvm_merkle_tree": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "tvm_table_merkle_tree": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "tvm_codeword_merkle_tree": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "tvm_out_of_domain_rows": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
+                                           C.c_uint64, Domain, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "tvm_weighted_sum_of_columns": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
+                                                C.c_uint64, Domain, C.c_void_p, C.c_void_p]),
+    "tvm_xfe_add_assign": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "tvm_evaluate_at_points": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "tvm_quotient_segments": (C.c_int32, [C.c_void_p, C.c_void_p, Domain, Domain, C.c_void_p, C.c_uint64, C.c_uint64,
+                                          C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64]),
+    "tvm_table_linear_combination": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "tvm_deep_codeword": (C.c_int32, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), Domain, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
+    "tvm_fri_split_and_fold": (C.c_int32, [C.c_void_p, C.c_void_p, Domain, C.c_void_p, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -323,3 +323,141 @@ extern "C" int32_t tvm_codeword_merkle_tree(tvm_ctx* c, const uint64_t* d_cw, ui
     TVM_LAUNCH(tvm::k_xfe_aos_leaves, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_cw, n, d_nodes + 5 * n);
     return merkle_tree_from_leaves(c, d_nodes, n);
 }
+
+// ---------------------------------------------------------------------------------- combination / DEEP / FRI
+namespace tvm {
+// small host arrays (points, weights) staged into a context scratch slot
+static const u64* stage_small(tvm_ctx* c, int slot, const u64* h, size_t words) {
+    u64* d = (u64*)scratch(c, slot, (words ? words : 1) * sizeof(u64));
+    if (!d) return nullptr;
+    if (hipMemcpyAsync(d, h, words * sizeof(u64), hipMemcpyHostToDevice, c->stream) != hipSuccess) return nullptr;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return nullptr;  // h may be a caller temporary
+    return d;
+}
+__global__ void k_xfe_add_assign(u64* __restrict__ a, const u64* __restrict__ b, u64 n_words) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) a[i] = bfe_add(a[i], b[i]);
+}
+}  // namespace tvm
+
+extern "C" {
+
+int32_t tvm_out_of_domain_rows(tvm_ctx* c, int32_t fk, const uint64_t* d_trace, uint64_t n, uint64_t n_cols,
+                               const uint64_t* d_rnd, uint64_t h, tvm_domain td, const uint64_t* h_points, uint32_t n_points,
+                               uint64_t* h_rows) {
+    if (!c || !d_trace || (h && !d_rnd) || !valid_fk(fk) || !valid_domain(td) || td.length != n || !h_points || !h_rows ||
+        !n_points || !n_cols)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "out_of_domain_rows arguments");
+    if (td.offset != TVM_ONE) return set_error(c, TVM_ERR_UNSUPPORTED, "trace domain offset must be 1");
+    const u64* d_points = stage_small(c, 9, h_points, 3 * (size_t)n_points);
+    u64* d_rows = (u64*)scratch(c, 10, (size_t)n_points * n_cols * 3 * sizeof(u64));
+    if (!d_points || !d_rows) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "ood staging");
+    TVM_TRY(out_of_domain_rows(c, fk, d_trace, n, n_cols, d_rnd, h, td.generator, d_points, (int)n_points, d_rows));
+    TVM_HIP_CHECK(c, hipMemcpyAsync(h_rows, d_rows, (size_t)n_points * n_cols * 3 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return TVM_OK;
+}
+
+int32_t tvm_weighted_sum_of_columns(tvm_ctx* c, int32_t fk, const uint64_t* d_trace, uint64_t n, uint64_t n_cols,
+                                    const uint64_t* d_rnd, uint64_t h, tvm_domain td, const uint64_t* h_weights,
+                                    uint64_t* d_poly) {
+    if (!c || !d_trace || (h && !d_rnd) || !valid_fk(fk) || !valid_domain(td) || td.length != n || !h_weights || !d_poly ||
+        !n_cols || h > n)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "weighted_sum_of_columns arguments");
+    if (td.offset != TVM_ONE) return set_error(c, TVM_ERR_UNSUPPORTED, "trace domain offset must be 1");
+    const u64* d_w = stage_small(c, 9, h_weights, 3 * (size_t)n_cols);
+    if (!d_w) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "weights staging");
+    TVM_TRY(weighted_row_sum(c, fk, d_trace, n, n_cols, d_w, 0, d_poly));
+    TVM_HIP_CHECK(c, hipMemsetAsync(d_poly + 3 * n, 0, 3 * n * sizeof(u64), c->stream));
+    if (n > 1)
+        TVM_TRY(ntt_columns(c, d_poly, n, 3, 0, d_poly, 3, 0, 1, 0, 3, n, bfe_inv(td.generator), TVM_ONE, TVM_ONE,
+                            bfe_inv(bfe_from_u64(n))));
+    return randomizer_contribution(c, fk, d_rnd, n, n_cols, h, d_w, d_poly);
+}
+
+int32_t tvm_xfe_add_assign(tvm_ctx* c, uint64_t* d_a, const uint64_t* d_b, uint64_t n) {
+    if (!c || (n && (!d_a || !d_b))) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "xfe_add_assign arguments");
+    if (!n) return TVM_OK;
+    TVM_LAUNCH(tvm::k_xfe_add_assign, dim3((unsigned)((3 * n + 255) / 256)), dim3(256), 0, c->stream, d_a, d_b, 3 * n);
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+
+int32_t tvm_evaluate_at_points(tvm_ctx* c, const uint64_t* d_coeffs, uint64_t n, const uint64_t* h_points, uint32_t n_points,
+                               uint64_t* h_out) {
+    if (!c || (n && !d_coeffs) || !h_points || !h_out || !n_points)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "evaluate_at_points arguments");
+    const u64* d_points = stage_small(c, 9, h_points, 3 * (size_t)n_points);
+    u64* d_out = (u64*)scratch(c, 10, (size_t)n_points * 3 * sizeof(u64));
+    if (!d_points || !d_out) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "points staging");
+    TVM_TRY(poly_eval(c, d_coeffs, n, d_points, (int)n_points, d_out));
+    TVM_HIP_CHECK(c, hipMemcpyAsync(h_out, d_out, (size_t)n_points * 3 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return TVM_OK;
+}
+
+int32_t tvm_quotient_segments(tvm_ctx* c, const uint64_t* d_cw, tvm_domain qd, tvm_domain ldt, const uint64_t* h_rnd,
+                              uint64_t n_rand, uint64_t zeta, tvm_table** out_table, uint64_t* d_polys, uint64_t poly_len) {
+    if (!c || !out_table) return TVM_ERR_INVALID_ARGUMENT;
+    *out_table = nullptr;
+    if (!d_cw || !d_polys || (n_rand && !h_rnd) || !valid_domain(qd) || !valid_domain(ldt) || qd.length < 4 ||
+        poly_len < qd.length / 4 || poly_len < n_rand || poly_len > ldt.length)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "quotient_segments arguments");
+    const u64 Q = qd.length, L = ldt.length;
+    u64* coeffs = (u64*)scratch(c, 11, Q * 3 * sizeof(u64));
+    const u64* d_rnd = stage_small(c, 9, h_rnd, 3 * (size_t)n_rand);
+    if (!coeffs || !d_rnd) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "segments scratch");
+    TVM_TRY(tvm_interpolate(c, 3, d_cw, qd, coeffs));
+    TVM_TRY(randomized_segments(c, coeffs, Q, d_rnd, n_rand, zeta, poly_len, d_polys));
+    tvm_table* t = new (std::nothrow) tvm_table();
+    if (!t) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "table handle");
+    t->rows = L;
+    t->n_cols = 5;
+    t->fk = 3;
+    t->W = 15;
+    if (hipMalloc((void**)&t->data, t->bytes()) != hipSuccess) {
+        delete t;
+        return set_error(c, TVM_ERR_OUT_OF_MEMORY, "segment table allocation");
+    }
+    hipMemsetAsync(t->data, 0, t->bytes(), c->stream);
+    u64 M = 2;
+    while (M < poly_len) M <<= 1;
+    const u64 X = L / M;
+    int rc = TVM_OK;
+    for (u64 k = 0; k < X && rc == TVM_OK; k++) {
+        const u64 off = bfe_mul(ldt.offset, bfe_pow(ldt.generator, k));
+        rc = ntt_columns(c, d_polys, poly_len, 3, 3 * poly_len, t->data, 1, 1, TVM_CT * X, TVM_CT * k, 15, M,
+                         bfe_pow(ldt.generator, X), off, TVM_ONE, TVM_ONE);
+    }
+    if (rc != TVM_OK) {
+        hipStreamSynchronize(c->stream);
+        hipFree(t->data);
+        delete t;
+        return rc;
+    }
+    *out_table = t;
+    return TVM_OK;
+}
+
+int32_t tvm_table_linear_combination(tvm_ctx* c, const tvm_table* t, uint64_t ldt_length, const uint64_t* h_w, uint64_t* d_out) {
+    if (!c || !t || !h_w || !d_out || !is_pow2(ldt_length) || ldt_length > t->rows)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "table_linear_combination arguments");
+    const u64* d_w = stage_small(c, 9, h_w, 3 * (size_t)t->n_cols);
+    if (!d_w) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "weights staging");
+    return table_lincomb(c, t->data, t->rows, t->fk, t->n_cols, t->rows / ldt_length, d_w, d_out);
+}
+
+int32_t tvm_deep_codeword(tvm_ctx* c, uint32_t n_comp, const uint64_t* const* d_cw, tvm_domain dom, const uint64_t* h_points,
+                          const uint64_t* h_values, const uint64_t* h_weights, uint64_t* d_out) {
+    if (!c || !d_cw || !h_points || !h_values || !h_weights || !d_out || !valid_domain(dom))
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "deep_codeword arguments");
+    return deep_sum(c, (int)n_comp, d_cw, h_points, h_values, h_weights, dom.offset, dom.generator, dom.length, d_out);
+}
+
+int32_t tvm_fri_split_and_fold(tvm_ctx* c, const uint64_t* d_cw, tvm_domain dom, const uint64_t* h_ch, uint64_t* d_out) {
+    if (!c || !d_cw || !h_ch || !d_out || !valid_domain(dom))
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "fri_split_and_fold arguments");
+    return fri_fold(c, d_cw, dom.length, dom.offset, dom.generator, h_ch, d_out);
+}
+
+}  // extern "C"

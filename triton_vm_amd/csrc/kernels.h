@@ -16,6 +16,18 @@ int xfe_leaves(tvm_ctx* c, const u64* cw, u64 plane, u64 n, u64* leaves);
 int gather_rows(tvm_ctx* c, const u64* table, u64 L, int W, const u64* d_idx, u64 n, u64* d_out);
 int table_to_row_major(tvm_ctx* c, const u64* table, u64 L, int W, u64* d_out);
 int columns_to_table(tvm_ctx* c, const u64* cols, u64 col_stride, u64 L, int W, u64* table);
+// poly.hip
+int out_of_domain_rows(tvm_ctx* c, int fk, const u64* trace, u64 n, u64 n_cols, const u64* rnd, u64 h, u64 trace_gen,
+                       const u64* d_points, int n_points, u64* d_rows);
+int weighted_row_sum(tvm_ctx* c, int fk, const u64* trace, u64 n, u64 n_cols, const u64* d_w, int accumulate, u64* d_values);
+int randomizer_contribution(tvm_ctx* c, int fk, const u64* rnd, u64 n, u64 n_cols, u64 h, const u64* d_w, u64* d_poly);
+int randomized_segments(tvm_ctx* c, const u64* d_q_coeffs, u64 q_len, const u64* d_rnd, u64 n_rand, u64 zeta, u64 poly_len,
+                        u64* d_polys);
+int table_lincomb(tvm_ctx* c, const u64* table, u64 L, int fk, u64 n_cols, u64 stride, const u64* d_w, u64* d_out);
+int poly_eval(tvm_ctx* c, const u64* d_coeffs, u64 n, const u64* d_points, int n_points, u64* d_out);
+int deep_sum(tvm_ctx* c, int n_comp, const u64* const* d_cw, const u64* h_points, const u64* h_values, const u64* h_weights,
+             u64 offset, u64 gen, u64 n, u64* d_out);
+int fri_fold(tvm_ctx* c, const u64* d_cw, u64 n, u64 offset, u64 gen, const u64* h_challenge, u64* d_out);
 }  // namespace tvm
 
 struct tvm_table {

@@ -1,0 +1,333 @@
+// poly.hip -- the element-wise / reduction kernels between the big transforms of Prover::prove:
+// out-of-domain rows, linear combinations, quotient-segment randomization, DEEP and FRI folding.
+//
+// Replaces, on the reference's hot path:
+//   MasterTable::out_of_domain_row            /root/reference/triton-vm/src/table/master_table.rs:348-390
+//   MasterTable::weighted_sum_of_columns      master_table.rs:512-542
+//   split_polynomial_into_segments + randomize_quotient_segments   stark.rs:1224-1263, 1302-1356
+//   Prover::deep_codeword / Stark::deep_update + the weighted sum   stark.rs:566-625, 1360-1379, 2096-2103
+//   ProverRound::split_and_fold               low_degree_test/fri.rs:349-366
+//
+// XFieldElement vectors are arrays of 3-word elements (c0,c1,c2), exactly the reference's layout.
+// All of these are streaming kernels: one pass over their operands, HBM bound.
+#include "context.h"
+
+namespace tvm {
+
+TVM_D xfe ld_xfe(const u64* p) { return xfe_make(p[0], p[1], p[2]); }
+TVM_D void st_xfe(u64* p, xfe v) { p[0] = v.c0; p[1] = v.c1; p[2] = v.c2; }
+// trace cell (column c, row j) of a column-major table of field kind fk, times an XFE
+TVM_D xfe cell_times(const u64* __restrict__ trace, int fk, u64 n_rows, u64 c, u64 j, xfe w) {
+    const u64* p = trace + (c * n_rows + j) * fk;
+    return fk == 1 ? xfe_mul_bfe(w, p[0]) : xfe_mul(ld_xfe(p), w);
+}
+
+#define TVM_RED_BLOCK 256
+// sum of v over the workgroup, valid in thread 0; smem: 3*TVM_RED_BLOCK words
+TVM_D xfe block_sum_xfe(xfe v, u64* smem, int tid, int nt) {
+    smem[tid] = v.c0;
+    smem[nt + tid] = v.c1;
+    smem[2 * nt + tid] = v.c2;
+    __syncthreads();
+    for (int s = nt >> 1; s > 0; s >>= 1) {
+        if (tid < s) {
+            smem[tid] = bfe_add(smem[tid], smem[tid + s]);
+            smem[nt + tid] = bfe_add(smem[nt + tid], smem[nt + tid + s]);
+            smem[2 * nt + tid] = bfe_add(smem[2 * nt + tid], smem[2 * nt + tid + s]);
+        }
+        __syncthreads();
+    }
+    return xfe_make(smem[0], smem[nt], smem[2 * nt]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Out-of-domain rows (master_table.rs:348-390), for n_points indeterminates at once.
+// u[p][j] = d_j / (alpha_p - d_j), d_j = gen^j (trace domain, offset 1)
+__global__ void k_ood_weights(u64 gen, u64 n, const u64* __restrict__ points, int n_points, u64* __restrict__ u) {
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const u64 d = bfe_pow(gen, j);
+    for (int p = 0; p < n_points; p++) {
+        xfe a = ld_xfe(points + 3 * p);
+        xfe inv = xfe_inv(xfe_sub_bfe(a, d));
+        st_xfe(u + ((u64)p * n + j) * 3, xfe_mul_bfe(inv, d));
+    }
+}
+// num[p][c] = sum_j cell(c, j) * u[p][j]; column index n_cols is the all-ones column (denominator)
+__global__ void __launch_bounds__(TVM_RED_BLOCK) k_column_dot(const u64* __restrict__ trace, int fk, u64 n, u64 n_cols,
+                                                               const u64* __restrict__ u, int n_points,
+                                                               u64* __restrict__ num) {
+    __shared__ u64 smem[3 * TVM_RED_BLOCK];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const u64 c = blockIdx.x;
+    const int p = blockIdx.y;
+    xfe acc = xfe_zero();
+    const u64* up = u + (u64)p * n * 3;
+    for (u64 j = tid; j < n; j += nt) {
+        xfe w = ld_xfe(up + 3 * j);
+        acc = xfe_add(acc, c < n_cols ? cell_times(trace, fk, n, c, j, w) : w);
+    }
+    xfe s = block_sum_xfe(acc, smem, tid, nt);
+    if (tid == 0) st_xfe(num + ((u64)p * (n_cols + 1) + c) * 3, s);
+}
+// row[p][c] = num/den + (alpha^N - 1) * r_c(alpha)
+__global__ void k_ood_finalize(const u64* __restrict__ num, const u64* __restrict__ rnd, int fk, u64 n, u64 n_cols, u64 h,
+                               const u64* __restrict__ points, int n_points, u64* __restrict__ rows) {
+    const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_cols * (u64)n_points) return;
+    const u64 c = e % n_cols;
+    const int p = (int)(e / n_cols);
+    const xfe a = ld_xfe(points + 3 * p);
+    const xfe den_inv = xfe_inv(ld_xfe(num + ((u64)p * (n_cols + 1) + n_cols) * 3));
+    const xfe zf = xfe_sub_bfe(xfe_pow(a, n), TVM_ONE);
+    xfe r = xfe_zero();
+    for (u64 j = h; j-- > 0;) {
+        r = xfe_mul(r, a);
+        const u64* q = rnd + (c * h + j) * fk;
+        r = fk == 1 ? xfe_add_bfe(r, q[0]) : xfe_add(r, ld_xfe(q));
+    }
+    xfe v = xfe_add(xfe_mul(ld_xfe(num + ((u64)p * (n_cols + 1) + c) * 3), den_inv), xfe_mul(zf, r));
+    st_xfe(rows + ((u64)p * n_cols + c) * 3, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// weighted_sum_of_columns (master_table.rs:512-542): out[j] (+)= sum_c w_c * cell(c, j)
+__global__ void k_weighted_row_sum(const u64* __restrict__ trace, int fk, u64 n, u64 n_cols, const u64* __restrict__ w,
+                                   int accumulate, u64* __restrict__ out) {
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    xfe acc = accumulate ? ld_xfe(out + 3 * j) : xfe_zero();
+    for (u64 c = 0; c < n_cols; c++) acc = xfe_add(acc, cell_times(trace, fk, n, c, j, ld_xfe(w + 3 * c)));
+    st_xfe(out + 3 * j, acc);
+}
+// R[j] = sum_c w_c r_c[j], j < h; poly[j] -= R[j]; poly[n + j] += R[j]   (mul_zerofier_with, offset 1)
+__global__ void k_randomizer_contribution(const u64* __restrict__ rnd, int fk, u64 n, u64 n_cols, u64 h,
+                                          const u64* __restrict__ w, u64* __restrict__ poly) {
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= h) return;
+    xfe acc = xfe_zero();
+    for (u64 c = 0; c < n_cols; c++) acc = xfe_add(acc, cell_times(rnd, fk, h, c, j, ld_xfe(w + 3 * c)));
+    st_xfe(poly + 3 * j, xfe_sub(ld_xfe(poly + 3 * j), acc));
+    st_xfe(poly + 3 * (n + j), xfe_add(ld_xfe(poly + 3 * (n + j)), acc));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Quotient segments (stark.rs:1224-1263) and their randomization (stark.rs:1302-1356):
+// segment k of Q has coefficients Q[4j + k]; s_4 = randomizer; s_i = q_i - zeta^i * s_{i+1}(zeta^4 X).
+// polys: [5][poly_len] XFE
+__global__ void k_randomized_segments(const u64* __restrict__ q_coeffs, u64 q_len, const u64* __restrict__ rnd, u64 n_rand,
+                                      u64 zeta, u64 poly_len, u64* __restrict__ polys) {
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= poly_len) return;
+    const u64 z4j = bfe_pow(bfe_pow(zeta, 4), j);
+    xfe s = j < n_rand ? ld_xfe(rnd + 3 * j) : xfe_zero();
+    st_xfe(polys + (4 * poly_len + j) * 3, s);
+    u64 zi = bfe_pow(zeta, 3);
+    const u64 zeta_inv = bfe_inv(zeta);
+    for (int i = 3; i >= 0; i--) {
+        const u64 idx = 4 * j + (u64)i;
+        xfe q = idx < q_len ? ld_xfe(q_coeffs + 3 * idx) : xfe_zero();
+        s = xfe_sub(q, xfe_mul_bfe(s, bfe_mul(zi, z4j)));
+        st_xfe(polys + ((u64)i * poly_len + j) * 3, s);
+        zi = bfe_mul(zi, zeta_inv);
+    }
+}
+
+// out[i] = sum_v w_v * table_cell(row i*stride, element v): linear combination of the columns of a
+// device table (used for the P and R combinations of the randomized quotient segments, stark.rs:520-540)
+__global__ void k_table_lincomb(const u64* __restrict__ table, u64 L, int fk, u64 n_cols, u64 stride, u64 n_out,
+                                const u64* __restrict__ w, u64* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    const u64 row = i * stride;
+    xfe acc = xfe_zero();
+    for (u64 c = 0; c < n_cols; c++) {
+        const xfe wc = ld_xfe(w + 3 * c);
+        u64 e[3] = {0, 0, 0};
+        for (int k = 0; k < fk; k++) {
+            const u64 v = c * fk + k;
+            e[k] = table[((v / TVM_CT) * L + row) * TVM_CT + (v % TVM_CT)];
+        }
+        acc = xfe_add(acc, fk == 1 ? xfe_mul_bfe(wc, e[0]) : xfe_mul(xfe_make(e[0], e[1], e[2]), wc));
+    }
+    st_xfe(out + 3 * i, acc);
+}
+
+// polynomial (XFE coefficients) at XFE points: partial[p][block] then a final pass
+__global__ void __launch_bounds__(TVM_RED_BLOCK) k_poly_eval_partial(const u64* __restrict__ co, u64 n,
+                                                                     const u64* __restrict__ points,
+                                                                     u64* __restrict__ partial) {
+    __shared__ u64 smem[3 * TVM_RED_BLOCK];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int p = blockIdx.y;
+    const u64 T = (u64)gridDim.x * nt;            // total work-items per point
+    const u64 t = (u64)blockIdx.x * nt + tid;
+    const xfe z = ld_xfe(points + 3 * p);
+    const xfe zT = xfe_pow(z, T);
+    // f(z) = sum_t z^t * sum_k c[t + k*T] (z^T)^k ; Horner in z^T over k descending
+    xfe acc = xfe_zero();
+    if (t < n) {
+        u64 kmax = (n - 1 - t) / T;
+        for (u64 k = kmax + 1; k-- > 0;) acc = xfe_add(xfe_mul(acc, zT), ld_xfe(co + 3 * (t + k * T)));
+        acc = xfe_mul(acc, xfe_pow(z, t));
+    }
+    xfe s = block_sum_xfe(acc, smem, tid, nt);
+    if (tid == 0) st_xfe(partial + ((u64)p * gridDim.x + blockIdx.x) * 3, s);
+}
+__global__ void __launch_bounds__(TVM_RED_BLOCK) k_sum_partials(const u64* __restrict__ partial, u64 n_partial,
+                                                                u64* __restrict__ out) {
+    __shared__ u64 smem[3 * TVM_RED_BLOCK];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int p = blockIdx.x;
+    xfe acc = xfe_zero();
+    for (u64 i = tid; i < n_partial; i += nt) acc = xfe_add(acc, ld_xfe(partial + ((u64)p * n_partial + i) * 3));
+    xfe s = block_sum_xfe(acc, smem, tid, nt);
+    if (tid == 0) st_xfe(out + 3 * p, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// DEEP (stark.rs:566-625): out[i] = sum_k weight_k * (cw_k[i] - value_k) / (x_i - point_k),
+// x_i = offset * gen^i.  One inversion per row: Montgomery's trick over the n_comp denominators.
+#define TVM_DEEP_MAX 4
+struct DeepArgs {
+    const u64* cw[TVM_DEEP_MAX];
+    u64 point[TVM_DEEP_MAX][3];
+    u64 value[TVM_DEEP_MAX][3];
+    u64 weight[TVM_DEEP_MAX][3];
+    int n_comp;
+    u64 offset, gen, n;
+    u64* out;
+};
+__global__ void k_deep(DeepArgs a) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const u64 x = bfe_mul(a.offset, bfe_pow(a.gen, i));
+    xfe den[TVM_DEEP_MAX], pre[TVM_DEEP_MAX];
+    xfe run = xfe_one();
+#pragma unroll
+    for (int k = 0; k < TVM_DEEP_MAX; k++) {
+        if (k < a.n_comp) {
+            xfe pt = xfe_make(a.point[k][0], a.point[k][1], a.point[k][2]);
+            den[k] = xfe_sub(xfe_lift(x), pt);
+            pre[k] = run;
+            run = xfe_mul(run, den[k]);
+        }
+    }
+    xfe inv = xfe_inv(run);
+    xfe acc = xfe_zero();
+#pragma unroll
+    for (int k = TVM_DEEP_MAX - 1; k >= 0; k--) {
+        if (k < a.n_comp) {
+            xfe dinv = xfe_mul(inv, pre[k]);
+            inv = xfe_mul(inv, den[k]);
+            xfe num = xfe_sub(ld_xfe(a.cw[k] + 3 * i), xfe_make(a.value[k][0], a.value[k][1], a.value[k][2]));
+            xfe w = xfe_make(a.weight[k][0], a.weight[k][1], a.weight[k][2]);
+            acc = xfe_add(acc, xfe_mul(xfe_mul(num, dinv), w));
+        }
+    }
+    st_xfe(a.out + 3 * i, acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// FRI split-and-fold (fri.rs:349-366): out[i] = ((1 + c/x_i) f[i] + (1 - c/x_i) f[i + n/2]) / 2
+__global__ void k_fri_fold(const u64* __restrict__ f, u64 n, u64 offset_inv, u64 gen_inv, u64 c0, u64 c1, u64 c2,
+                           u64 two_inv, u64* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 half = n >> 1;
+    if (i >= half) return;
+    const u64 xinv = bfe_mul(offset_inv, bfe_pow(gen_inv, i));
+    const xfe s = xfe_mul_bfe(xfe_make(c0, c1, c2), xinv);
+    const xfe l = xfe_mul(xfe_add_bfe(s, TVM_ONE), ld_xfe(f + 3 * i));
+    const xfe r = xfe_mul(xfe_sub(xfe_one(), s), ld_xfe(f + 3 * (half + i)));
+    st_xfe(out + 3 * i, xfe_mul_bfe(xfe_add(l, r), two_inv));
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+#define TVM_GRID(n, bs) dim3((unsigned)(((n) + (bs)-1) / (bs)))
+
+// h_points: n_points XFE; rows_out (device): [n_points][n_cols] XFE
+int out_of_domain_rows(tvm_ctx* c, int fk, const u64* trace, u64 n, u64 n_cols, const u64* rnd, u64 h, u64 trace_gen,
+                       const u64* d_points, int n_points, u64* d_rows) {
+    u64* u = (u64*)scratch(c, 6, (size_t)n_points * n * 3 * sizeof(u64));
+    u64* num = (u64*)scratch(c, 7, (size_t)n_points * (n_cols + 1) * 3 * sizeof(u64));
+    if (!u || !num) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "ood scratch");
+    TVM_LAUNCH(k_ood_weights, TVM_GRID(n, 256), dim3(256), 0, c->stream, trace_gen, n, d_points, n_points, u);
+    TVM_LAUNCH(k_column_dot, dim3((unsigned)(n_cols + 1), (unsigned)n_points), dim3(TVM_RED_BLOCK), 0, c->stream, trace, fk,
+               n, n_cols, u, n_points, num);
+    TVM_LAUNCH(k_ood_finalize, TVM_GRID(n_cols * n_points, 64), dim3(64), 0, c->stream, num, rnd, fk, n, n_cols, h,
+               d_points, n_points, d_rows);
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+
+// d_values: n XFE sums over the trace rows (+ accumulate); no transform here
+int weighted_row_sum(tvm_ctx* c, int fk, const u64* trace, u64 n, u64 n_cols, const u64* d_w, int accumulate, u64* d_values) {
+    TVM_LAUNCH(k_weighted_row_sum, TVM_GRID(n, 256), dim3(256), 0, c->stream, trace, fk, n, n_cols, d_w, accumulate, d_values);
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+int randomizer_contribution(tvm_ctx* c, int fk, const u64* rnd, u64 n, u64 n_cols, u64 h, const u64* d_w, u64* d_poly) {
+    if (!h) return TVM_OK;
+    TVM_LAUNCH(k_randomizer_contribution, TVM_GRID(h, 64), dim3(64), 0, c->stream, rnd, fk, n, n_cols, h, d_w, d_poly);
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+int randomized_segments(tvm_ctx* c, const u64* d_q_coeffs, u64 q_len, const u64* d_rnd, u64 n_rand, u64 zeta, u64 poly_len,
+                        u64* d_polys) {
+    TVM_LAUNCH(k_randomized_segments, TVM_GRID(poly_len, 256), dim3(256), 0, c->stream, d_q_coeffs, q_len, d_rnd, n_rand,
+               zeta, poly_len, d_polys);
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+int table_lincomb(tvm_ctx* c, const u64* table, u64 L, int fk, u64 n_cols, u64 stride, const u64* d_w, u64* d_out) {
+    const u64 n_out = L / stride;
+    TVM_LAUNCH(k_table_lincomb, TVM_GRID(n_out, 256), dim3(256), 0, c->stream, table, L, fk, n_cols, stride, n_out, d_w, d_out);
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+int poly_eval(tvm_ctx* c, const u64* d_coeffs, u64 n, const u64* d_points, int n_points, u64* d_out) {
+    if (n == 0) {
+        TVM_HIP_CHECK(c, hipMemsetAsync(d_out, 0, (size_t)n_points * 3 * sizeof(u64), c->stream));
+        return TVM_OK;
+    }
+    u64 blocks = (n + TVM_RED_BLOCK * 16 - 1) / (TVM_RED_BLOCK * 16);
+    if (blocks > 1024) blocks = 1024;
+    u64* partial = (u64*)scratch(c, 8, (size_t)n_points * blocks * 3 * sizeof(u64));
+    if (!partial) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "poly_eval scratch");
+    TVM_LAUNCH(k_poly_eval_partial, dim3((unsigned)blocks, (unsigned)n_points), dim3(TVM_RED_BLOCK), 0, c->stream, d_coeffs,
+               n, d_points, partial);
+    TVM_LAUNCH(k_sum_partials, dim3((unsigned)n_points), dim3(TVM_RED_BLOCK), 0, c->stream, partial, blocks, d_out);
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+int deep_sum(tvm_ctx* c, int n_comp, const u64* const* d_cw, const u64* h_points, const u64* h_values, const u64* h_weights,
+             u64 offset, u64 gen, u64 n, u64* d_out) {
+    if (n_comp < 1 || n_comp > TVM_DEEP_MAX) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "deep: 1..4 components");
+    DeepArgs a;
+    for (int k = 0; k < TVM_DEEP_MAX; k++) {
+        a.cw[k] = k < n_comp ? d_cw[k] : nullptr;
+        for (int j = 0; j < 3; j++) {
+            a.point[k][j] = k < n_comp ? h_points[3 * k + j] : 0;
+            a.value[k][j] = k < n_comp ? h_values[3 * k + j] : 0;
+            a.weight[k][j] = k < n_comp ? h_weights[3 * k + j] : 0;
+        }
+    }
+    a.n_comp = n_comp;
+    a.offset = offset;
+    a.gen = gen;
+    a.n = n;
+    a.out = d_out;
+    TVM_LAUNCH(k_deep, TVM_GRID(n, 256), dim3(256), 0, c->stream, a);
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+int fri_fold(tvm_ctx* c, const u64* d_cw, u64 n, u64 offset, u64 gen, const u64* h_challenge, u64* d_out) {
+    if (n < 2) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "fold: codeword of length >= 2");
+    TVM_LAUNCH(k_fri_fold, TVM_GRID(n / 2, 256), dim3(256), 0, c->stream, d_cw, n, bfe_inv(offset), bfe_inv(gen),
+               h_challenge[0], h_challenge[1], h_challenge[2], bfe_inv(bfe_from_u64(2)), d_out);
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+
+}  // namespace tvm

@@ -79,6 +79,27 @@ class MasterTable:
                                                            idx.ctypes.data, idx.size, out.ctypes.data), "reveal_rows")
         return out.reshape((idx.size, self.n_cols) + ((3,) if self.fk == 3 else ()))
 
+    # master_table.rs:348-390, for several indeterminates at once -> [n_points, n_cols, 3]
+    def out_of_domain_rows(self, points):
+        pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 3)
+        out = np.empty((pts.shape[0], self.n_cols, 3), np.uint64)
+        self.ctx._check(self.ctx.lib.tvm_out_of_domain_rows(
+            self.ctx.handle, self.fk, self.d_trace.ptr, self.n_rows, self.n_cols, self.d_randomizers.ptr,
+            self.num_trace_randomizers, self.trace_domain.c(), pts.ctypes.data, pts.shape[0], out.ctypes.data), "ood rows")
+        return out
+
+    def out_of_domain_row(self, indeterminate):
+        return self.out_of_domain_rows([indeterminate])[0]
+
+    # master_table.rs:512-542 -> DeviceBuffer of 2*n_rows XFE coefficients
+    def weighted_sum_of_columns(self, weights):
+        w = np.ascontiguousarray(weights, dtype=np.uint64).reshape(self.n_cols, 3)
+        poly = self.ctx.alloc(2 * self.n_rows * 3)
+        self.ctx._check(self.ctx.lib.tvm_weighted_sum_of_columns(
+            self.ctx.handle, self.fk, self.d_trace.ptr, self.n_rows, self.n_cols, self.d_randomizers.ptr,
+            self.num_trace_randomizers, self.trace_domain.c(), w.ctypes.data, poly.ptr), "weighted sum")
+        return poly
+
     def __del__(self):
         try:
             self.clear_cache()

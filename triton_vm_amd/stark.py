@@ -1,0 +1,98 @@
+"""Host mirror of the hot private helpers of the reference's Prover (/root/reference/triton-vm/src/stark.rs)
+and of the FRI prover round (/root/reference/triton-vm/src/low_degree_test/fri.rs), over the C ABI.
+XFE vectors are DeviceBuffers of 3-word elements."""
+import ctypes as C
+
+import numpy as np
+
+from . import field
+
+ZETA = field.to_mont(3)  # Stark::ZETA, stark.rs:1801
+NUM_QUOTIENT_SEGMENTS = 4
+NUM_RANDOMIZED_QUOTIENT_SEGMENTS = 5
+
+
+def _h(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+class QuotientSegments:
+    """Result of compute_quotient_segments' tail + randomize_quotient_segments (stark.rs:784-792,1302-1356)."""
+
+    def __init__(self, ctx, table, polys, poly_len, ldt_length):
+        self.ctx, self.table, self.polys, self.poly_len, self.ldt_length = ctx, table, polys, poly_len, ldt_length
+
+    def codewords(self):
+        """[ldt.length, 5, 3] on the host (reference layout of the randomized segment table)."""
+        buf = self.ctx.alloc(self.ldt_length * 15)
+        self.ctx._check(self.ctx.lib.tvm_table_export_row_major(self.ctx.handle, self.table, buf.ptr), "export")
+        return buf.download((self.ldt_length, 5, 3))
+
+    def merkle_tree(self):
+        d = self.ctx.alloc(10 * self.ldt_length)
+        self.ctx._check(self.ctx.lib.tvm_table_merkle_tree(self.ctx.handle, self.table, self.ldt_length, d.ptr), "merkle")
+        return d.download((2 * self.ldt_length, 5))
+
+    def linear_combination(self, weights):
+        w = _h(weights).reshape(5, 3)
+        out = self.ctx.alloc(self.ldt_length * 3)
+        self.ctx._check(self.ctx.lib.tvm_table_linear_combination(self.ctx.handle, self.table, self.ldt_length,
+                                                                  w.ctypes.data, out.ptr), "lincomb")
+        return out
+
+    def free(self):
+        if self.table:
+            self.ctx.lib.tvm_table_free(self.ctx.handle, self.table)
+            self.table = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def quotient_segments(ctx, d_quotient_codeword, quotient_domain, ldt_domain, randomizer, poly_len=None):
+    rnd = _h(randomizer).reshape(-1, 3)
+    poly_len = poly_len or max(quotient_domain.length // 4, rnd.shape[0])
+    polys = ctx.alloc(5 * poly_len * 3)
+    t = C.c_void_p()
+    ctx._check(ctx.lib.tvm_quotient_segments(ctx.handle, d_quotient_codeword.ptr, quotient_domain.c(), ldt_domain.c(),
+                                             rnd.ctypes.data, rnd.shape[0], ZETA, C.byref(t), polys.ptr, poly_len),
+               "quotient_segments")
+    return QuotientSegments(ctx, t.value, polys, poly_len, ldt_domain.length)
+
+
+def evaluate_at_points(ctx, d_coeffs, n, points):
+    pts = _h(points).reshape(-1, 3)
+    out = np.empty((pts.shape[0], 3), np.uint64)
+    ctx._check(ctx.lib.tvm_evaluate_at_points(ctx.handle, d_coeffs.ptr, n, pts.ctypes.data, pts.shape[0], out.ctypes.data),
+               "evaluate_at_points")
+    return out
+
+
+def deep_codeword(ctx, d_codewords, domain, points, values, weights):
+    """Weighted sum of the DEEP components (stark.rs:566-625); a single component with weight one is
+    Prover::deep_codeword (stark.rs:1360-1379)."""
+    k = len(d_codewords)
+    ptrs = (C.c_void_p * k)(*[b.ptr for b in d_codewords])
+    pts, vals, ws = _h(points).reshape(k, 3), _h(values).reshape(k, 3), _h(weights).reshape(k, 3)
+    out = ctx.alloc(domain.length * 3)
+    ctx._check(ctx.lib.tvm_deep_codeword(ctx.handle, k, ptrs, domain.c(), pts.ctypes.data, vals.ctypes.data,
+                                         ws.ctypes.data, out.ptr), "deep")
+    return out
+
+
+def split_and_fold(ctx, d_codeword, domain, folding_challenge):
+    """ProverRound::split_and_fold (fri.rs:349-366)."""
+    ch = _h(folding_challenge).reshape(3)
+    out = ctx.alloc(domain.length // 2 * 3)
+    ctx._check(ctx.lib.tvm_fri_split_and_fold(ctx.handle, d_codeword.ptr, domain.c(), ch.ctypes.data, out.ptr), "fold")
+    return out
+
+
+def merkle_tree_from_codeword(ctx, d_codeword, length):
+    """ProverRound::merkle_tree_from_codeword (fri.rs:343-347) -> node array [2n, 5] on the device."""
+    nodes = ctx.alloc(10 * length)
+    ctx._check(ctx.lib.tvm_codeword_merkle_tree(ctx.handle, d_codeword.ptr, length, nodes.ptr), "codeword tree")
+    return nodes

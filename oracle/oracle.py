@@ -18,7 +18,7 @@ P = 2**64 - 2**32 + 1
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("tvm_oracle.c", "tvm_oracle.h", "tip5_constants.h")]
+    src = [os.path.join(_HERE, f) for f in ("tvm_oracle.c", "tvm_oracle.h", "tip5_constants.h", "air_circuit.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
@@ -267,6 +267,17 @@ def randomize_quotient_segments(seg_polys, randomizer, ldt_domain, poly_len=None
                                           C.c_uint64(n_rand), ldt_domain, _p(polys),
                                           C.c_uint64(poly_len), _p(cws))
     return polys, cws
+
+
+def quotients_combined(main_rows, aux_rows, trace_domain, quotient_domain, challenges, weights):
+    """main_rows [Q, 379], aux_rows [Q, 91, 3] (row-major quotient-domain views) -> [Q, 3]"""
+    main_rows, aux_rows, challenges, weights = _arr(main_rows), _arr(aux_rows), _arr(challenges), _arr(weights)
+    q = quotient_domain.length
+    out = np.zeros((q, 3), np.uint64)
+    lib().orc_quotients_combined(_p(main_rows), C.c_uint64(main_rows.shape[1]), _p(aux_rows),
+                                 C.c_uint64(aux_rows.shape[1]), trace_domain, quotient_domain, _p(challenges),
+                                 _p(weights), _p(out))
+    return out
 
 
 # ---- combination / DEEP / FRI ---------------------------------------------------------------

@@ -551,3 +551,71 @@ void orc_fri_split_and_fold(const uint64_t* cw, orc_domain d, const uint64_t ch[
     }
     free(x);
 }
+
+/* ------------------------------------------------------------------ AIR / quotients
+ * master_table.rs:1264-1363 with the generated evaluate_*_constraints replaced by a literal walk of
+ * the lowered circuit DAG (air_circuit.h, exported by tools/air/export.py; every node is evaluated as
+ * an XFieldElement, base-field values lifted).  Tables are the reference's row-major quotient-domain
+ * views: main [q.length][n_main], aux [q.length][n_aux][3]. */
+#include "air_circuit.h"
+
+static void eval_section(const uint32_t (*nodes)[3], uint32_t n_nodes, const uint32_t* roots, uint32_t n_roots,
+                         const u64* consts, const u64 (*xconsts)[3], const u64* mc, const u64* mn, const u64* ac,
+                         const u64* an, const u64* challenges, const u64* weights, u64* acc /* xfe */) {
+    u64* val = (u64*)malloc((size_t)n_nodes * 24);
+    for (uint32_t i = 0; i < n_nodes; i++) {
+        u64* v = val + 3 * i;
+        uint32_t k = nodes[i][0], a = nodes[i][1], b = nodes[i][2];
+        switch (k) {
+            case 0: v[0] = consts[a]; v[1] = v[2] = 0; break;
+            case 1: memcpy(v, xconsts[a], 24); break;
+            case 2: v[0] = mc[a]; v[1] = v[2] = 0; break;
+            case 3: v[0] = mn[a]; v[1] = v[2] = 0; break;
+            case 4: memcpy(v, ac + 3 * a, 24); break;
+            case 5: memcpy(v, an + 3 * a, 24); break;
+            case 6: memcpy(v, challenges + 3 * a, 24); break;
+            case 7: orc_xfe_add(val + 3 * a, val + 3 * b, v); break;
+            default: orc_xfe_mul(val + 3 * a, val + 3 * b, v); break;
+        }
+    }
+    acc[0] = acc[1] = acc[2] = 0;
+    for (uint32_t r = 0; r < n_roots; r++) {
+        u64 t[3];
+        orc_xfe_mul(val + 3 * roots[r], weights + 3 * r, t);
+        orc_xfe_add(acc, t, acc);
+    }
+    free(val);
+}
+
+void orc_quotients_combined(const uint64_t* main_rows, uint64_t n_main, const uint64_t* aux_rows, uint64_t n_aux,
+                            orc_domain trace, orc_domain q, const uint64_t* challenges, const uint64_t* weights,
+                            uint64_t* out) {
+    u64 n = q.length, unit = q.length / trace.length;
+    u64 *zi = (u64*)malloc(n * 8), *zc = (u64*)malloc(n * 8), *zt = (u64*)malloc(n * 8), *ze = (u64*)malloc(n * 8);
+    orc_zerofier_inverses(trace, q, zi, zc, zt, ze);
+    const u64* w_init = weights;
+    const u64* w_cons = w_init + 3 * ORACLE_AIR_INIT_NUM_ROOTS;
+    const u64* w_tran = w_cons + 3 * ORACLE_AIR_CONS_NUM_ROOTS;
+    const u64* w_term = w_tran + 3 * ORACLE_AIR_TRAN_NUM_ROOTS;
+#pragma omp parallel for
+    for (u64 i = 0; i < n; i++) {
+        u64 nx = (i + unit) % n;
+        const u64 *mc = main_rows + i * n_main, *mn = main_rows + nx * n_main;
+        const u64 *ac = aux_rows + i * n_aux * 3, *an = aux_rows + nx * n_aux * 3;
+        u64 acc[3], t[3], quot[3] = {0, 0, 0};
+        eval_section(ORACLE_AIR_INIT_NODES, ORACLE_AIR_INIT_NUM_NODES, ORACLE_AIR_INIT_ROOTS, ORACLE_AIR_INIT_NUM_ROOTS,
+                     ORACLE_AIR_INIT_CONSTS, ORACLE_AIR_INIT_XCONSTS, mc, mn, ac, an, challenges, w_init, acc);
+        xfe_mul_bfe(acc, zi[i], t); orc_xfe_add(quot, t, quot);
+        eval_section(ORACLE_AIR_CONS_NODES, ORACLE_AIR_CONS_NUM_NODES, ORACLE_AIR_CONS_ROOTS, ORACLE_AIR_CONS_NUM_ROOTS,
+                     ORACLE_AIR_CONS_CONSTS, ORACLE_AIR_CONS_XCONSTS, mc, mn, ac, an, challenges, w_cons, acc);
+        xfe_mul_bfe(acc, zc[i], t); orc_xfe_add(quot, t, quot);
+        eval_section(ORACLE_AIR_TRAN_NODES, ORACLE_AIR_TRAN_NUM_NODES, ORACLE_AIR_TRAN_ROOTS, ORACLE_AIR_TRAN_NUM_ROOTS,
+                     ORACLE_AIR_TRAN_CONSTS, ORACLE_AIR_TRAN_XCONSTS, mc, mn, ac, an, challenges, w_tran, acc);
+        xfe_mul_bfe(acc, zt[i], t); orc_xfe_add(quot, t, quot);
+        eval_section(ORACLE_AIR_TERM_NODES, ORACLE_AIR_TERM_NUM_NODES, ORACLE_AIR_TERM_ROOTS, ORACLE_AIR_TERM_NUM_ROOTS,
+                     ORACLE_AIR_TERM_CONSTS, ORACLE_AIR_TERM_XCONSTS, mc, mn, ac, an, challenges, w_term, acc);
+        xfe_mul_bfe(acc, ze[i], t); orc_xfe_add(quot, t, quot);
+        memcpy(out + 3 * i, quot, 24);
+    }
+    free(zi); free(zc); free(zt); free(ze);
+}

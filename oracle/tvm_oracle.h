@@ -92,6 +92,12 @@ void orc_randomize_quotient_segments(const uint64_t* seg_polys, uint64_t seg_len
                                      const uint64_t* randomizer, uint64_t n_rand, orc_domain ldt,
                                      uint64_t* out_polys, uint64_t poly_len, uint64_t* out_codewords);
 
+/* all_quotients_combined (master_table.rs:1264-1363); row-major quotient-domain tables, 63 challenges,
+ * 604 weights, out: q.length XFE */
+void orc_quotients_combined(const uint64_t* main_rows, uint64_t n_main, const uint64_t* aux_rows, uint64_t n_aux,
+                            orc_domain trace, orc_domain q, const uint64_t* challenges, const uint64_t* weights,
+                            uint64_t* out);
+
 /* ---- combination / DEEP / FRI (master_table.rs:348-390,512-542; stark.rs:1360-1379,2096; fri.rs:349-366) ---- */
 void orc_weighted_sum_of_columns(int fk, const uint64_t* trace, uint64_t n_rows, uint64_t n_cols,
                                  const uint64_t* randomizers, uint64_t h, const uint64_t* weights /* n_cols xfe */,

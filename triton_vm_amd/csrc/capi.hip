@@ -234,10 +234,7 @@ int32_t tvm_lde_table(tvm_ctx* c, int32_t fk, const uint64_t* d_trace, uint64_t 
         delete t;
         return set_error(c, TVM_ERR_OUT_OF_MEMORY, "LDE table allocation");
     }
-    if (t->W % TVM_CT) {  // unused lanes of the last tile are never written by the LDE: define them
-        const size_t tile_bytes = (size_t)t->rows * TVM_CT * sizeof(u64);
-        hipMemsetAsync((char*)t->data + t->bytes() - tile_bytes, 0, tile_bytes, c->stream);
-    }
+    if (t->rows % TVM_RB) hipMemsetAsync(t->data, 0, t->bytes(), c->stream);  // padding rows of a tiny table
     int rc = lde_table(c, fk, d_trace, n_rows, n_cols, d_rnd, h, trace_dom.generator, eval_dom.offset, eval_dom.generator,
                        eval_dom.length, t->data, 0);
     if (rc != TVM_OK) {
@@ -419,16 +416,23 @@ int32_t tvm_quotient_segments(tvm_ctx* c, const uint64_t* d_cw, tvm_domain qd, t
         delete t;
         return set_error(c, TVM_ERR_OUT_OF_MEMORY, "segment table allocation");
     }
-    hipMemsetAsync(t->data, 0, t->bytes(), c->stream);
+    // evaluate the 5 polynomials (15 base-field columns) into planar codewords, then lay them out as a table
+    u64* planar = (u64*)scratch(c, 12, (size_t)15 * L * sizeof(u64));
+    if (!planar) {
+        hipFree(t->data);
+        delete t;
+        return set_error(c, TVM_ERR_OUT_OF_MEMORY, "segment codewords scratch");
+    }
     u64 M = 2;
     while (M < poly_len) M <<= 1;
     const u64 X = L / M;
     int rc = TVM_OK;
     for (u64 k = 0; k < X && rc == TVM_OK; k++) {
         const u64 off = bfe_mul(ldt.offset, bfe_pow(ldt.generator, k));
-        rc = ntt_columns(c, d_polys, poly_len, 3, 3 * poly_len, t->data, 1, 1, TVM_CT * X, TVM_CT * k, 15, M,
-                         bfe_pow(ldt.generator, X), off, TVM_ONE, TVM_ONE);
+        rc = ntt_columns(c, d_polys, poly_len, 3, 3 * poly_len, planar, 1, L, X, k, 15, M, bfe_pow(ldt.generator, X), off,
+                         TVM_ONE, TVM_ONE);
     }
+    if (rc == TVM_OK) rc = columns_to_table(c, planar, L, L, 15, t->data);
     if (rc != TVM_OK) {
         hipStreamSynchronize(c->stream);
         hipFree(t->data);
@@ -461,3 +465,21 @@ int32_t tvm_fri_split_and_fold(tvm_ctx* c, const uint64_t* d_cw, tvm_domain dom,
 }
 
 }  // extern "C"
+
+extern "C" int32_t tvm_all_quotients_combined(tvm_ctx* c, const tvm_table* mt, const tvm_table* at, tvm_domain td,
+                                              tvm_domain qd, const uint64_t* h_challenges, const uint64_t* h_weights,
+                                              uint64_t* d_out) {
+    if (!c || !mt || !at || !h_challenges || !h_weights || !d_out || !valid_domain(td) || !valid_domain(qd))
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "all_quotients_combined arguments");
+    if (mt->fk != 1 || mt->n_cols != TVM_NUM_MAIN_COLUMNS || at->fk != 3 || at->n_cols != TVM_NUM_AUX_COLUMNS ||
+        mt->rows != at->rows || qd.length > mt->rows)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "all_quotients_combined: tables must be 379 BFE / 91 XFE columns wide");
+    u64* staged = (u64*)scratch(c, 13, (size_t)3 * (TVM_NUM_CHALLENGES + TVM_NUM_QUOTIENT_WEIGHTS) * sizeof(u64));
+    if (!staged) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "challenge staging");
+    TVM_HIP_CHECK(c, hipMemcpyAsync(staged, h_challenges, 3 * TVM_NUM_CHALLENGES * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    TVM_HIP_CHECK(c, hipMemcpyAsync(staged + 3 * TVM_NUM_CHALLENGES, h_weights, 3 * TVM_NUM_QUOTIENT_WEIGHTS * sizeof(u64),
+                                    hipMemcpyHostToDevice, c->stream));
+    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return all_quotients_combined(c, mt->data, mt->rows, (u64)mt->W, at->data, (u64)at->W, td.length, td.generator,
+                                  qd.offset, qd.generator, qd.length, staged, staged + 3 * TVM_NUM_CHALLENGES, d_out);
+}

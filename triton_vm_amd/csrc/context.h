@@ -13,9 +13,15 @@
 #include "field.h"
 #include "triton_hip.h"  // status codes and the public C ABI (include/)
 
-// Column-tile-major device tables: tiles of TVM_CT adjacent base-field columns, each tile a
-// row-major [rows][TVM_CT] array, so one row of a tile is one 128-byte line.
-#define TVM_CT 16
+// Device tables are "row-block-major" (DESIGN.md section 2): blocks of TVM_RB = 16 consecutive rows,
+// column-major inside a block, i.e. element (row, v) of a table with W base-field words per row is at
+// ((row / 16) * W + v) * 16 + row % 16.  Sixteen consecutive rows of one column form one 128-byte line,
+// so a wavefront whose lanes are consecutive rows reads any column as four full lines (row hashing,
+// AIR evaluation, linear combinations), and the last LDE pass writes full lines.
+#define TVM_RB 16
+#define TVM_RB_LOG 4
+TVM_HD u64 tvm_tab_idx(u64 row, u64 v, u64 W) { return ((row >> TVM_RB_LOG) * W + v) * TVM_RB + (row & (TVM_RB - 1)); }
+TVM_HD u64 tvm_tab_words(u64 rows, u64 W) { return ((rows + TVM_RB - 1) / TVM_RB) * TVM_RB * W; }
 
 struct tvm_ctx {
     int device = 0;

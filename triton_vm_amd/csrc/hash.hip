@@ -18,19 +18,18 @@ namespace tvm {
 
 #define TVM_HASH_BLOCK 256
 
-// digests[r] = Tip5::hash_varlen(row r*stride of the table), table = [tiles][L][16], W words per row.
-// Each work-item parks the current 16-word tile of its row in LDS, word-major ([word][lane], so
-// every access is conflict-free) and absorbs from there with a wave-uniform word index: no
-// per-lane register array, no dynamic register indexing.
+// digests[r] = Tip5::hash_varlen(row r*stride of the table), W words per row.  Lanes are consecutive
+// rows, so word wi of 64 rows is four full 128-byte lines of the row-block-major table: every load
+// is coalesced and the ten loads of one absorb block are independent of the permutation before them.
 __global__ void __launch_bounds__(TVM_HASH_BLOCK) k_hash_rows(const u64* __restrict__ table, u64 L, int W, u64 stride,
                                                                u64 n_out, u64* __restrict__ digests) {
     __shared__ unsigned char lut[256];
-    __shared__ u64 stage[16 * TVM_HASH_BLOCK];
     const int tid = threadIdx.x;
     tip5_stage_lut(lut, tid, blockDim.x);
     const u64 r = (u64)blockIdx.x * blockDim.x + tid;
     if (r >= n_out) return;
     const u64 row = r * stride;
+    const u64* base = table + (row >> TVM_RB_LOG) * (u64)W * TVM_RB + (row & (TVM_RB - 1));
     u64 st[TIP5_STATE];
 #pragma unroll
     for (int i = 0; i < TIP5_STATE; i++) st[i] = 0;
@@ -39,14 +38,9 @@ __global__ void __launch_bounds__(TVM_HASH_BLOCK) k_hash_rows(const u64* __restr
     for (int perm = 0; perm < n_perms; perm++) {
 #pragma unroll
         for (int q = 0; q < TIP5_RATE; q++) {
-            const int k = wi & 15;
-            if (k == 0 && wi < W) {
-                const u64* src = table + ((u64)(wi >> 4) * L + row) * TVM_CT;
-#pragma unroll
-                for (int i = 0; i < 16; i++) stage[i * TVM_HASH_BLOCK + tid] = src[i];
-            }
-            u64 v = stage[k * TVM_HASH_BLOCK + tid];
-            if (wi >= W) v = (wi == W) ? TVM_ONE : 0;  // padding: 1 then 0s (tip-0005.md:83)
+            u64 v;
+            if (wi < W) v = base[(u64)wi * TVM_RB];
+            else v = (wi == W) ? TVM_ONE : 0;  // padding: 1 then 0s (tip-0005.md:83)
             st[q] = v;
             wi++;
         }
@@ -115,7 +109,7 @@ __global__ void k_gather_rows(const u64* __restrict__ table, u64 L, int W, const
     if (e >= n * (u64)W) return;
     const u64 j = e / W;
     const int v = (int)(e % W);
-    out[e] = table[((u64)(v / TVM_CT) * L + idx[j]) * TVM_CT + (v % TVM_CT)];
+    out[e] = table[tvm_tab_idx(idx[j], (u64)v, (u64)W)];
 }
 
 // whole table to the reference's row-major [L][W] layout (tests, and hosts that want the cache)
@@ -124,19 +118,18 @@ __global__ void k_table_to_row_major(const u64* __restrict__ table, u64 L, int W
     if (e >= L * (u64)W) return;
     const u64 row = e / W;
     const int v = (int)(e % W);
-    out[e] = table[((u64)(v / TVM_CT) * L + row) * TVM_CT + (v % TVM_CT)];
+    out[e] = table[tvm_tab_idx(row, (u64)v, (u64)W)];
 }
 
-// planar columns [W][L] -> column-tile-major table (used for the quotient-segment table)
+// planar columns [W][L] -> row-block-major table (used for the quotient-segment table)
 __global__ void k_columns_to_table(const u64* __restrict__ cols, u64 col_stride, u64 L, int W, u64* __restrict__ table) {
     const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const int tiles = (W + TVM_CT - 1) / TVM_CT;
-    if (e >= (u64)tiles * L * TVM_CT) return;
-    const int b = (int)(e % TVM_CT);
-    const u64 row = (e / TVM_CT) % L;
-    const int t = (int)(e / (TVM_CT * L));
-    const int v = t * TVM_CT + b;
-    table[e] = (v < W) ? cols[(u64)v * col_stride + row] : 0;
+    const u64 total = tvm_tab_words(L, (u64)W);
+    if (e >= total) return;
+    const u64 r16 = e % TVM_RB;
+    const u64 v = (e / TVM_RB) % (u64)W;
+    const u64 row = (e / (TVM_RB * (u64)W)) * TVM_RB + r16;
+    table[e] = (row < L) ? cols[v * col_stride + row] : 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -183,7 +176,7 @@ int table_to_row_major(tvm_ctx* c, const u64* table, u64 L, int W, u64* d_out) {
 }
 
 int columns_to_table(tvm_ctx* c, const u64* cols, u64 col_stride, u64 L, int W, u64* table) {
-    const u64 total = (u64)((W + TVM_CT - 1) / TVM_CT) * L * TVM_CT;
+    const u64 total = tvm_tab_words(L, (u64)W);
     TVM_LAUNCH(k_columns_to_table, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, cols, col_stride, L, W, table);
     TVM_HIP_CHECK(c, hipGetLastError());
     return TVM_OK;

@@ -28,13 +28,17 @@ int poly_eval(tvm_ctx* c, const u64* d_coeffs, u64 n, const u64* d_points, int n
 int deep_sum(tvm_ctx* c, int n_comp, const u64* const* d_cw, const u64* h_points, const u64* h_values, const u64* h_weights,
              u64 offset, u64 gen, u64 n, u64* d_out);
 int fri_fold(tvm_ctx* c, const u64* d_cw, u64 n, u64 offset, u64 gen, const u64* h_challenge, u64* d_out);
+// air.hip
+int all_quotients_combined(tvm_ctx* c, const u64* main_table, u64 main_rows, u64 main_w, const u64* aux_table, u64 aux_w,
+                           u64 trace_len, u64 trace_gen, u64 q_offset, u64 q_gen, u64 q_len, const u64* d_challenges,
+                           const u64* d_weights, u64* d_out);
 }  // namespace tvm
 
 struct tvm_table {
-    u64* data = nullptr;  // [tiles][rows][TVM_CT]
+    u64* data = nullptr;  // row-block-major, see context.h
     u64 rows = 0;
     u64 n_cols = 0;       // in elements of the table's field
     int fk = 1;
     int W = 0;            // base-field words per row = n_cols * fk
-    size_t bytes() const { return (size_t)((W + TVM_CT - 1) / TVM_CT) * rows * TVM_CT * sizeof(u64); }
+    size_t bytes() const { return (size_t)tvm_tab_words(rows, (u64)W) * sizeof(u64); }
 };

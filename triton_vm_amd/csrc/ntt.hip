@@ -258,19 +258,19 @@ __global__ void __launch_bounds__(1024) k_lde_pass2(LdePass2Args a) {
     }
 }
 
-// Output table layout ("column-tile-major"): tiles of TVM_CT adjacent virtual
-// columns, each tile a row-major [L][TVM_CT] array, so one row of a tile is one 128-byte line.
-
+// Pass 3 writes the row-block-major table (context.h).  A workgroup owns one virtual column and
+// 2^rows_log (<= 16) consecutive rows rho = X*j1 + k of every row period X*N2: it transforms the
+// corresponding (k, j1) rows of Z over m2 and stores, for each j2, one run of consecutive rows.
 struct LdePass3Args {
     const u64* z;        // [cols][X][N2 (j1)][N1 positions p]
-    u64* table;          // [tiles][L][TVM_CT]
+    u64* table;          // row-block-major [L][W]
     int log_n1, log_n2;
     int n_cosets;
-    int col0;            // first virtual column of the chunk (multiple of TVM_CT)
-    int n_cols_chunk;    // valid columns in the chunk
+    int col0;            // first virtual column of the chunk
+    int W;               // words per table row
     u64 L;
     const u64* tw_b2;    // w_N1^e
-    int cols_log;        // a workgroup transforms 2^cols_log (<= 16) adjacent columns of one tile
+    int rows_log;        // rows per workgroup tile
 };
 
 __global__ void __launch_bounds__(1024) k_lde_pass3(LdePass3Args a) {
@@ -279,26 +279,31 @@ __global__ void __launch_bounds__(1024) k_lde_pass3(LdePass3Args a) {
     const int n1 = 1 << a.log_n1;
     const u64 n2 = 1ull << a.log_n2;
     const int RS = n1 + TVM_ROW_PAD;
-    const u64 j1 = blockIdx.x;
-    const int k = blockIdx.y;
-    const int CB = 1 << a.cols_log;
-    const int sub_per_tile = TVM_CT >> a.cols_log;
-    const int t = blockIdx.z / sub_per_tile;            // 16-column tile within the chunk
-    const int b0 = (blockIdx.z % sub_per_tile) << a.cols_log;
+    const int RB = 1 << a.rows_log;
+    const u64 X = (u64)a.n_cosets;
+    const u64 period = X * n2;                 // rows per j2
+    const u64 rho0 = (u64)blockIdx.x * RB;     // first local row of the tile
+    const int vl = blockIdx.y;
     const u64 n = (u64)n1 << a.log_n2;
-    const int tile = n1 << a.cols_log;
+    const int tile = n1 << a.rows_log;
     for (int idx = tid; idx < tile; idx += nt) {
         const int p = idx & (n1 - 1), b = idx >> a.log_n1;
-        const int vl = t * TVM_CT + b0 + b;
-        s[b * RS + p] = (vl < a.n_cols_chunk) ? a.z[(((u64)vl * a.n_cosets + k) * n2 + j1) * n1 + p] : 0;
+        const u64 rho = rho0 + b;
+        u64 x = 0;
+        if (rho < period) {
+            const u64 j1 = rho / X, k = rho % X;
+            x = a.z[(((u64)vl * X + k) * n2 + j1) * n1 + p];
+        }
+        s[b * RS + p] = x;
     }
     __syncthreads();
-    lds_ntt<true, false>(s, a.log_n1, a.cols_log, 1, RS, a.tw_b2, tid, nt);
-    u64* tab = a.table + (u64)(a.col0 / TVM_CT + t) * a.L * TVM_CT;
+    lds_ntt<true, false>(s, a.log_n1, a.rows_log, 1, RS, a.tw_b2, tid, nt);
+    const u64 v = (u64)(a.col0 + vl);
     for (int idx = tid; idx < tile; idx += nt) {
-        const int b = idx & (CB - 1), j2 = idx >> a.cols_log;
-        const u64 row = (u64)a.n_cosets * (j1 + n2 * (u64)j2) + k;
-        tab[row * TVM_CT + b0 + b] = s[b * RS + j2];
+        const int b = idx & (RB - 1), j2 = idx >> a.rows_log;
+        const u64 rho = rho0 + b;
+        if (rho >= period) continue;
+        a.table[tvm_tab_idx(period * (u64)j2 + rho, v, (u64)a.W)] = s[b * RS + j2];
     }
 }
 
@@ -471,7 +476,7 @@ int ntt_columns(tvm_ctx* c, const u64* in, u64 in_len, int in_fk, u64 in_col_str
 }
 
 // master_table.rs:258-322.  trace: column-major [n_cols][n_rows][fk]; rnd: [n_cols][h][fk];
-// table: [ceil(n_cols*fk / 16)][L][16].
+// table: row-block-major [L][n_cols*fk] (context.h).
 int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, const u64* rnd, u64 h, u64 trace_gen,
               u64 eval_offset, u64 eval_gen, u64 L, u64* table, int chunk_cols) {
     if (!is_pow2(n_rows) || !is_pow2(L) || n_rows < 2 || L < n_rows || (fk != 1 && fk != 3))
@@ -488,7 +493,6 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     const u64 n1 = 1ull << sp.log_n1, n2 = 1ull << sp.log_n2;
     const int W = (int)(n_cols * fk);
     if (chunk_cols <= 0) chunk_cols = 32;
-    chunk_cols = (chunk_cols + TVM_CT - 1) / TVM_CT * TVM_CT;
 
     const u64 w = trace_gen, wi = bfe_inv(trace_gen);
     const u64 n_inv = bfe_inv(bfe_from_u64(N));
@@ -537,6 +541,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     p3.log_n2 = sp.log_n2;
     p3.n_cosets = (int)X;
     p3.L = L;
+    p3.W = W;
     p3.tw_b2 = pow_table(c, bfe_pow(w, n2), n1 > 1 ? n1 / 2 : 1);
     if (!p1.tw1 || !p2.tw_a2 || !p2.tw_b1 || !p2.g_lo || !p2.g_hi || !p3.tw_b2)
         return set_error(c, TVM_ERR_OUT_OF_MEMORY, "lde tables");
@@ -571,12 +576,11 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
         {
             LdePass3Args a = p3;
             a.col0 = col0;
-            a.n_cols_chunk = nc;
-            const int tiles = (nc + TVM_CT - 1) / TVM_CT;
-            a.cols_log = batch_log_for(sp.log_n1);
-            const int tile = (int)n1 << a.cols_log;
-            dim3 grid((unsigned)n2, (unsigned)X, (unsigned)(tiles * (TVM_CT >> a.cols_log)));
-            const size_t lds = ((size_t)(n1 + TVM_ROW_PAD) << a.cols_log) * sizeof(u64);
+            a.rows_log = batch_log_for(sp.log_n1);
+            const int RB = 1 << a.rows_log;
+            const int tile = (int)n1 << a.rows_log;
+            dim3 grid((unsigned)((X * n2 + RB - 1) / RB), (unsigned)nc);
+            const size_t lds = ((size_t)(n1 + TVM_ROW_PAD) << a.rows_log) * sizeof(u64);
             TVM_LAUNCH(k_lde_pass3, grid, dim3(threads_for_tile(tile)), lds, c->stream, a);
         }
     }

@@ -146,7 +146,7 @@ __global__ void k_table_lincomb(const u64* __restrict__ table, u64 L, int fk, u6
         u64 e[3] = {0, 0, 0};
         for (int k = 0; k < fk; k++) {
             const u64 v = c * fk + k;
-            e[k] = table[((v / TVM_CT) * L + row) * TVM_CT + (v % TVM_CT)];
+            e[k] = table[tvm_tab_idx(row, v, n_cols * (u64)fk)];
         }
         acc = xfe_add(acc, fk == 1 ? xfe_mul_bfe(wc, e[0]) : xfe_mul(xfe_make(e[0], e[1], e[2]), wc));
     }

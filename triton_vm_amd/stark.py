@@ -16,6 +16,17 @@ def _h(a):
     return np.ascontiguousarray(a, dtype=np.uint64)
 
 
+def all_quotients_combined(ctx, main_table, aux_table, trace_domain, quotient_domain, challenges, weights):
+    """all_quotients_combined (master_table.rs:1264-1363) on the two extended MasterTables -> DeviceBuffer of
+    quotient_domain.length XFE."""
+    ch, w = _h(challenges).reshape(63, 3), _h(weights).reshape(604, 3)
+    out = ctx.alloc(quotient_domain.length * 3)
+    ctx._check(ctx.lib.tvm_all_quotients_combined(ctx.handle, main_table._need_table(), aux_table._need_table(),
+                                                  trace_domain.c(), quotient_domain.c(), ch.ctypes.data, w.ctypes.data,
+                                                  out.ptr), "all_quotients_combined")
+    return out
+
+
 class QuotientSegments:
     """Result of compute_quotient_segments' tail + randomize_quotient_segments (stark.rs:784-792,1302-1356)."""
 

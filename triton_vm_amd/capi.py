@@ -76,6 +76,12 @@ _SIGNATURES = {
     "tvm_deep_codeword": (C.c_int32, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), Domain, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
     "tvm_fri_split_and_fold": (C.c_int32, [C.c_void_p, C.c_void_p, Domain, C.c_void_p, C.c_void_p]),
+    "tvm_gather_elements": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "tvm_host_tip5_permutation": (None, [C.c_void_p]),
+    "tvm_host_sponge_pad_and_absorb": (None, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "tvm_host_xfe_mul": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tvm_host_xfe_inv": (None, [C.c_void_p, C.c_void_p]),
+    "tvm_host_xfe_powers": (None, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -483,3 +483,81 @@ extern "C" int32_t tvm_all_quotients_combined(tvm_ctx* c, const tvm_table* mt, c
     return all_quotients_combined(c, mt->data, mt->rows, (u64)mt->W, at->data, (u64)at->W, td.length, td.generator,
                                   qd.offset, qd.generator, qd.length, staged, staged + 3 * TVM_NUM_CHALLENGES, d_out);
 }
+
+// ---------------------------------------------------------------------------------- small transfers, host helpers
+#include "tip5.h"
+
+namespace tvm {
+__global__ void k_gather_elements(const u64* __restrict__ src, u32 elem_words, const u64* __restrict__ idx, u64 n,
+                                  u64* __restrict__ out) {
+    const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * elem_words) return;
+    out[e] = src[idx[e / elem_words] * elem_words + e % elem_words];
+}
+}  // namespace tvm
+
+extern "C" {
+int32_t tvm_gather_elements(tvm_ctx* c, const uint64_t* d_src, uint32_t elem_words, const uint64_t* h_idx, uint64_t n,
+                            uint64_t* h_out) {
+    if (!c || !d_src || !elem_words || (n && (!h_idx || !h_out))) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "gather arguments");
+    if (!n) return TVM_OK;
+    u64* d_idx = (u64*)scratch(c, 4, n * sizeof(u64));
+    u64* d_out = (u64*)scratch(c, 5, n * elem_words * sizeof(u64));
+    if (!d_idx || !d_out) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "gather scratch");
+    TVM_HIP_CHECK(c, hipMemcpyAsync(d_idx, h_idx, n * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    const u64 total = n * elem_words;
+    TVM_LAUNCH(tvm::k_gather_elements, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_src, elem_words,
+               d_idx, n, d_out);
+    TVM_HIP_CHECK(c, hipMemcpyAsync(h_out, d_out, total * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return TVM_OK;
+}
+
+void tvm_host_tip5_permutation(uint64_t st[16]) {
+    static const u64 rc[80] = {TVM_TIP5_RC_LIST};
+    static const unsigned char lut[256] = {TVM_TIP5_LUT_LIST};
+    u64 s[16];
+    for (int i = 0; i < 16; i++) s[i] = st[i];
+    for (int r = 0; r < TIP5_ROUNDS; r++) {
+        for (int i = 0; i < 4; i++) s[i] = tip5_sbox_lookup(s[i], lut);
+        for (int i = 4; i < 16; i++) s[i] = tip5_pow7(s[i]);
+        tip5_mds(s);
+        for (int i = 0; i < 16; i++) s[i] = bfe_add(s[i], rc[16 * r + i]);
+    }
+    for (int i = 0; i < 16; i++) st[i] = s[i];
+}
+void tvm_host_sponge_pad_and_absorb(uint64_t st[16], const uint64_t* w, uint64_t n) {
+    uint64_t pos = 0;
+    for (;;) {
+        const uint64_t rem = n - pos;
+        if (rem >= 10) {
+            for (int i = 0; i < 10; i++) st[i] = w[pos + i];
+            tvm_host_tip5_permutation(st);
+            pos += 10;
+        } else {
+            for (uint64_t i = 0; i < rem; i++) st[i] = w[pos + i];
+            st[rem] = TVM_ONE;
+            for (uint64_t i = rem + 1; i < 10; i++) st[i] = 0;
+            tvm_host_tip5_permutation(st);
+            return;
+        }
+    }
+}
+void tvm_host_xfe_mul(const uint64_t a[3], const uint64_t b[3], uint64_t out[3]) {
+    xfe r = xfe_mul(xfe_make(a[0], a[1], a[2]), xfe_make(b[0], b[1], b[2]));
+    out[0] = r.c0; out[1] = r.c1; out[2] = r.c2;
+}
+void tvm_host_xfe_inv(const uint64_t a[3], uint64_t out[3]) {
+    xfe r = xfe_inv(xfe_make(a[0], a[1], a[2]));
+    out[0] = r.c0; out[1] = r.c1; out[2] = r.c2;
+}
+void tvm_host_xfe_powers(const uint64_t x[3], uint64_t first, uint64_t n, uint64_t* out) {
+    const xfe b = xfe_make(x[0], x[1], x[2]);
+    xfe p = xfe_pow(b, first);
+    for (uint64_t i = 0; i < n; i++) {
+        out[3 * i] = p.c0; out[3 * i + 1] = p.c1; out[3 * i + 2] = p.c2;
+        p = xfe_mul(p, b);
+    }
+}
+}  // extern "C"

@@ -1,0 +1,304 @@
+"""Host mirror of the hot path of ``Prover::prove`` (/root/reference/triton-vm/src/stark.rs:331-719),
+step for step, over the C ABI.  Everything bulky stays in HBM; the host only sees Merkle roots,
+out-of-domain rows, the last FRI codeword and the opened rows.
+
+The Fiat-Shamir transcript here (``ProofStream``) is a *stand-in*: the real one (BFieldCodec encoding,
+sample_scalars / sample_indices of twenty-first) stays in the Rust host and is not re-implemented.  It
+has the same data dependencies (every challenge depends on every earlier commitment), which is what
+the pipeline's timing needs; it does not produce reference-compatible proofs.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import field, stark
+from .arithmetic_domain import ArithmeticDomain
+from .master_table import MasterTable
+
+NUM_MAIN, NUM_AUX = 379, 91
+NUM_CHALLENGES, NUM_CONSTRAINTS = 63, 604
+NUM_DEEP = 4
+
+
+class ProofStream:
+    """Tip5 sponge in overwrite mode (stand-in transcript, see module docstring)."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.state = np.zeros(16, np.uint64)
+        self.items = []
+
+    def _permute(self):
+        self.lib.tvm_host_tip5_permutation(self.state.ctypes.data)
+
+    def enqueue(self, name, words):
+        w = np.ascontiguousarray(words, dtype=np.uint64).reshape(-1)
+        self.items.append((name, w.size))
+        self.lib.tvm_host_sponge_pad_and_absorb(self.state.ctypes.data, w.ctypes.data, w.size)
+
+    def _squeeze(self):
+        out = self.state[:10].copy()
+        self._permute()
+        return out
+
+    def sample_scalars(self, n):
+        words = np.concatenate([self._squeeze() for _ in range((3 * n + 9) // 10)])
+        return words[:3 * n].reshape(n, 3) % np.uint64(field.P)
+
+    def sample_indices(self, upper_bound, n):
+        out = []
+        while len(out) < n:
+            for w in self._squeeze():
+                if len(out) < n and int(w) != field.P - 1:
+                    out.append(int(w) % upper_bound)
+        return out
+
+
+def xfe_powers(lib, x, first, n):
+    x = np.ascontiguousarray(x, dtype=np.uint64)
+    out = np.empty((n, 3), np.uint64)
+    lib.tvm_host_xfe_powers(x.ctypes.data, first, n, out.ctypes.data)
+    return out
+
+
+def xfe_mul(lib, a, b):
+    a, b, o = (np.ascontiguousarray(v, dtype=np.uint64) for v in (a, b, np.zeros(3)))
+    lib.tvm_host_xfe_mul(a.ctypes.data, b.ctypes.data, o.ctypes.data)
+    return o
+
+
+def xfe_add(a, b):
+    return np.array([(int(x) + int(y)) % field.P for x, y in zip(a, b)], np.uint64)
+
+
+class StarkParameters:
+    """Domains for a padded height, as Stark::default() with LdtChoice::Fri derives them
+    (stark.rs:263-286, 1885-1916, 2083-2089; fri.rs:832-836, 907-920).  expansion = 4."""
+
+    def __init__(self, log2_padded_height, num_trace_randomizers=198, num_collinearity_checks=173, log2_expansion=2):
+        self.padded_height = 1 << log2_padded_height
+        self.h = num_trace_randomizers
+        self.num_collinearity_checks = num_collinearity_checks
+        h = self.h
+        rtl = max(self.padded_height + h, 2 * h + 1, (h + 1) * 5)
+        self.randomized_trace_len = 1 << (rtl - 1).bit_length()
+        self.trace = ArithmeticDomain.of_length(self.randomized_trace_len // 2)
+        max_degree = 4 * (self.randomized_trace_len - 1) - 1
+        quotient_len = 1 << (max_degree - 1).bit_length()
+        g = field.generator()
+        self.ldt = ArithmeticDomain.of_length(self.randomized_trace_len << log2_expansion).with_offset(g)
+        self.quotient = ArithmeticDomain.of_length(quotient_len).with_offset(g)
+        first_round_dim = self.randomized_trace_len
+        max_rounds = (first_round_dim - 1).bit_length()
+        self.fri_rounds = max(0, max_rounds - (num_collinearity_checks.bit_length() - 1) - 1)
+        self.num_quotient_randomizers = (h + 1) * 5
+
+
+class Prover:
+    """Runs the prover's hot path on synthetic (or caller-provided) padded trace tables."""
+
+    def __init__(self, ctx, params, main_trace=None, aux_trace=None, seed=1):
+        self.ctx, self.p = ctx, params
+        n, h = params.trace.length, params.h
+        rng = np.random.default_rng(seed)
+        dom = (params.trace, params.quotient, params.ldt)
+        if main_trace is None:
+            self.main = MasterTable.__new__(MasterTable)
+            self._init_synthetic(self.main, 1, NUM_MAIN, n, h, dom, seed)
+            self.aux = MasterTable.__new__(MasterTable)
+            self._init_synthetic(self.aux, 3, NUM_AUX, n, h, dom, seed + 100)
+        else:
+            rnd = lambda *s: rng.integers(0, field.P, size=s, dtype=np.uint64)
+            self.main = MasterTable(ctx, main_trace, rnd(NUM_MAIN, h), *dom, 1)
+            self.aux = MasterTable(ctx, aux_trace, rnd(NUM_AUX, h, 3), *dom, 3)
+        self.quotient_randomizer = rng.integers(0, field.P, size=(params.num_quotient_randomizers, 3), dtype=np.uint64)
+        self.timings = {}
+        self.capture = None
+
+    def _init_synthetic(self, mt, fk, n_cols, n, h, dom, seed):
+        mt.ctx, mt.fk, mt.n_cols, mt.n_rows, mt.num_trace_randomizers = self.ctx, fk, n_cols, n, h
+        mt.trace_domain, mt.quotient_domain, mt.ldt_domain, mt._table = dom[0], dom[1], dom[2], None
+        mt.d_trace = self.ctx.synthetic(n_cols * n * fk, seed)
+        mt.d_randomizers = self.ctx.synthetic(n_cols * h * fk, seed + 1)
+
+    def _timed(self, name):
+        prover = self
+
+        class T:
+            def __enter__(self):
+                if prover.profile:
+                    prover.ctx.timer_start()
+
+            def __exit__(self, *a):
+                if prover.profile:
+                    prover.timings[name] = prover.timings.get(name, 0.0) + prover.ctx.timer_stop()
+        return T()
+
+    def _root(self, d_nodes):
+        out = np.empty(5, np.uint64)
+        idx = np.array([1], np.uint64)
+        self.ctx._check(self.ctx.lib.tvm_gather_elements(self.ctx.handle, d_nodes.ptr, 5, idx.ctypes.data, 1,
+                                                         out.ctypes.data), "root")
+        return out
+
+    def _table_tree(self, table_handle, n):
+        d = self.ctx.alloc(10 * n)
+        self.ctx._check(self.ctx.lib.tvm_table_merkle_tree(self.ctx.handle, table_handle, n, d.ptr), "merkle")
+        return d
+
+    def _auth_nodes(self, d_nodes, n_leaves, indices):
+        """the sibling nodes on the paths of the opened leaves (what authentication_structure needs)"""
+        k = np.unique(np.asarray(indices, dtype=np.uint64) + np.uint64(n_leaves))
+        need = []
+        while k.size and k[0] > 1:
+            need.append(k ^ np.uint64(1))
+            k = np.unique(k >> np.uint64(1))
+        idx = np.unique(np.concatenate(need)) if need else np.zeros(0, np.uint64)
+        out = np.empty((idx.size, 5), np.uint64)
+        self.ctx._check(self.ctx.lib.tvm_gather_elements(self.ctx.handle, d_nodes.ptr, 5, idx.ctypes.data, idx.size,
+                                                         out.ctypes.data), "auth nodes")
+        return out
+
+    def prove(self, profile=False):
+        """One pass of the hot path.  Returns the (stand-in) proof stream."""
+        self.profile = profile
+        ctx, lib, p = self.ctx, self.ctx.lib, self.p
+        ps = ProofStream(lib)
+        L = p.ldt.length
+        short = p.ldt if p.ldt.length <= p.quotient.length else p.quotient
+
+        # 4-6: main table LDE, Merkle tree, challenges  (stark.rs:367-377)
+        with self._timed("main LDE"):
+            self.main.maybe_low_degree_extend_all_columns()
+        with self._timed("main Merkle"):
+            main_nodes = self._table_tree(self.main._need_table(), L)
+        ps.enqueue("main root", self._root(main_nodes))
+        challenges = ps.sample_scalars(NUM_CHALLENGES)
+
+        # 8-9: aux table (its `extend` is host work in the reference; the trace is already resident)
+        with self._timed("aux LDE"):
+            self.aux.maybe_low_degree_extend_all_columns()
+        with self._timed("aux Merkle"):
+            aux_nodes = self._table_tree(self.aux._need_table(), L)
+        ps.enqueue("aux root", self._root(aux_nodes))
+        quotient_weights = xfe_powers(lib, ps.sample_scalars(1)[0], 0, NUM_CONSTRAINTS)
+
+        # 10: quotient codeword, segments, randomization  (stark.rs:405-423)
+        with self._timed("AIR quotients"):
+            d_quot = stark.all_quotients_combined(ctx, self.main, self.aux, p.trace, p.quotient, challenges, quotient_weights)
+        with self._timed("quotient segments LDE"):
+            qs = stark.quotient_segments(ctx, d_quot, p.quotient, p.ldt, self.quotient_randomizer)
+        del d_quot
+        # 12: quotient Merkle tree  (stark.rs:425-446)
+        with self._timed("quotient Merkle"):
+            quot_nodes = self._table_tree(qs.table, L)
+        ps.enqueue("quot root", self._root(quot_nodes))
+
+        # 13: out-of-domain rows  (stark.rs:450-495)
+        alpha = ps.sample_scalars(1)[0]
+        alpha_next = np.array([field.mont_mul(int(c), p.trace.generator) for c in alpha], np.uint64)
+        with self._timed("out-of-domain rows"):
+            ood_main = self.main.out_of_domain_rows([alpha, alpha_next])
+            ood_aux = self.aux.out_of_domain_rows([alpha, alpha_next])
+            a4 = xfe_powers(lib, alpha, 4, 1)[0]
+            zeta_alpha = np.array([field.mont_mul(int(c), stark.ZETA) for c in alpha], np.uint64)
+            za4 = xfe_powers(lib, zeta_alpha, 4, 1)[0]
+            seg_ood = np.zeros((5, 2, 3), np.uint64)
+            for k in range(5):
+                view = _Slice(qs.polys, k * qs.poly_len * 3)
+                seg_ood[k] = stark.evaluate_at_points(ctx, view, qs.poly_len, [a4, za4])
+        ps.enqueue("ood main", ood_main[0]); ps.enqueue("ood aux", ood_aux[0])
+        ps.enqueue("ood main next", ood_main[1]); ps.enqueue("ood aux next", ood_aux[1])
+        ps.enqueue("ood quot p", seg_ood[:4, 0]); ps.enqueue("ood quot r", seg_ood[1:, 1])
+
+        # 14-15: combination weights, linear combinations  (stark.rs:497-543)
+        w_main_aux, w_quot, w_deep = ps.sample_scalars(3)
+        weights_ma = xfe_powers(lib, w_main_aux, 0, NUM_MAIN + NUM_AUX)
+        weights_q = xfe_powers(lib, w_quot, 0, 5)
+        weights_d = xfe_powers(lib, w_deep, 0, NUM_DEEP)
+        with self._timed("linear combination"):
+            comb = self.main.weighted_sum_of_columns(weights_ma[:NUM_MAIN])
+            comb_aux = self.aux.weighted_sum_of_columns(weights_ma[NUM_MAIN:])
+            ctx._check(lib.tvm_xfe_add_assign(ctx.handle, comb.ptr, comb_aux.ptr, 2 * p.trace.length), "add")
+            n_comb = p.trace.length + p.h
+            main_aux_codeword = short.evaluate(ctx, comb, n_comb, 3)
+            wp, wr = weights_q.copy(), weights_q.copy()
+            wp[4] = 0
+            wr[0] = 0
+            stride = L // short.length
+            cw_p, cw_r = qs.linear_combination(wp), qs.linear_combination(wr)
+            assert stride == 1, "quotient domain shorter than the LDT domain: take the strided view first"
+            ma_values = stark.evaluate_at_points(ctx, comb, n_comb, [alpha, alpha_next])
+        p_value, r_value = np.zeros(3, np.uint64), np.zeros(3, np.uint64)
+        for k in range(4):
+            p_value = xfe_add(p_value, xfe_mul(lib, weights_q[k], seg_ood[k, 0]))
+        for k in range(1, 5):
+            r_value = xfe_add(r_value, xfe_mul(lib, weights_q[k], seg_ood[k, 1]))
+
+        # 16: DEEP  (stark.rs:545-639)
+        with self._timed("DEEP"):
+            combination = stark.deep_codeword(ctx, [main_aux_codeword, main_aux_codeword, cw_p, cw_r], short,
+                                              [alpha, alpha_next, a4, za4], [ma_values[0], ma_values[1], p_value, r_value],
+                                              weights_d)
+        if self.capture is not None:
+            self.capture.update(challenges=challenges, quotient_weights=quotient_weights, alpha=alpha,
+                                weights_ma=weights_ma, weights_q=weights_q, weights_d=weights_d,
+                                main_root=self._root(main_nodes), aux_root=self._root(aux_nodes),
+                                quot_root=self._root(quot_nodes), ood_main=ood_main, ood_aux=ood_aux, seg_ood=seg_ood,
+                                combination=combination.download((short.length, 3)))
+        del main_aux_codeword, cw_p, cw_r, comb, comb_aux
+
+        # 17: FRI  (fri.rs:212-319, 754-772)
+        with self._timed("FRI"):
+            dom, cw, rounds = p.ldt, combination, []
+            for r in range(p.fri_rounds + 1):
+                nodes = stark.merkle_tree_from_codeword(ctx, cw, dom.length)
+                ps.enqueue(f"fri root {r}", self._root(nodes))
+                rounds.append((dom, cw, nodes))
+                if r == p.fri_rounds:
+                    break
+                challenge = ps.sample_scalars(1)[0]
+                cw = stark.split_and_fold(ctx, cw, dom, challenge)
+                dom = dom.pow(2)
+            last = cw.download((dom.length, 3))
+            ps.enqueue("fri last codeword", last)
+            last_poly = ArithmeticDomain.of_length(dom.length).interpolate(ctx, cw, 3).download((dom.length, 3))
+            ps.enqueue("fri last polynomial", last_poly)
+            self.last_codeword, self.last_polynomial, self.last_domain = last, last_poly, dom
+            a_indices = ps.sample_indices(p.ldt.length, p.num_collinearity_checks)
+            for r, (rdom, rcw, rnodes) in enumerate(rounds):
+                idxs = a_indices if r == 0 else []
+                b_idx = [(a + rdom.length // 2) % rdom.length for a in (i % rdom.length for i in a_indices)]
+                for which in ((idxs, b_idx) if r == 0 else (b_idx,)):
+                    if r == len(rounds) - 1 and which is b_idx:
+                        continue
+                    ix = np.array(which, np.uint64)
+                    leaves = np.empty((ix.size, 3), np.uint64)
+                    ctx._check(lib.tvm_gather_elements(ctx.handle, rcw.ptr, 3, ix.ctypes.data, ix.size, leaves.ctypes.data), "leaves")
+                    ps.enqueue(f"fri response {r}", leaves)
+                    ps.enqueue(f"fri auth {r}", self._auth_nodes(rnodes, rdom.length, which))
+            ps.sample_scalars(1)
+
+        # 19: open the trace leafs  (stark.rs:665-716)
+        with self._timed("open trace leafs"):
+            for name, mt, nodes in (("main", self.main, main_nodes), ("aux", self.aux, aux_nodes)):
+                ps.enqueue(f"{name} rows", mt.reveal_rows(a_indices))
+                ps.enqueue(f"{name} auth", self._auth_nodes(nodes, L, a_indices))
+            ix = np.array(a_indices, np.uint64)
+            qrows = np.empty((ix.size, 15), np.uint64)
+            ctx._check(lib.tvm_table_reveal_rows(ctx.handle, qs.table, L, ix.ctypes.data, ix.size, qrows.ctypes.data), "q rows")
+            ps.enqueue("quot rows", qrows)
+            ps.enqueue("quot auth", self._auth_nodes(quot_nodes, L, a_indices))
+        self.main.clear_cache()
+        self.aux.clear_cache()
+        qs.free()
+        ctx.sync()
+        return ps
+
+
+class _Slice:
+    """A view into a DeviceBuffer (word offset), enough for entry points that take `.ptr`."""
+
+    def __init__(self, buf, word_offset):
+        self.buf, self.ptr = buf, buf.ptr + 8 * word_offset

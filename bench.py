@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path of Prover::prove on MI355X, BASELINE.json's metric.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log2-rows 20]
+
+One "step" = one complete pass of the prover's hot path (triton_vm_amd/prover.py: main LDE, hashing +
+Merkle, aux LDE, hashing + Merkle, AIR/quotients, quotient segments, out-of-domain rows, linear
+combination, DEEP, FRI, openings) over synthetic padded trace tables that are already resident in
+HBM: 2^20 padded rows x (379 main + 91 aux columns = 652 base-field words), the shape of
+BASELINE.json configs[1] (`prove_fib` at 2^20 rows, Stark::default() with FRI, expansion 4,
+198 trace randomizers).  metric = padded_rows * 652 / seconds per step, summed over ranks.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); every rank proves its own
+instance (independent proofs: no data-path collective), barrier + max-over-ranks timing.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MASTER_WORDS = 652
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+LDE_ALGORITHMIC_BYTES_PER_CELL = 72   # read 8 B, write 8 * (L/N = 8) B per base-field trace cell
+
+
+def cpu_baseline(log2_rows):
+    """The oracle ("port" of the reference's algorithms, oracle/tvm_oracle.c, OpenMP over columns/rows)
+    timed on a bounded sample of the same workload: an 8-column slice of the main table at the full
+    height -- LDE onto the 8x domain, Tip5 row hashing, Merkle tree."""
+    import numpy as np
+
+    from oracle import oracle as orc
+
+    cols, h = 8, 198
+    n = 1 << log2_rows
+    rng = np.random.default_rng(1)
+    trace = orc.random_elements(rng, (cols, n))
+    rnd = orc.random_elements(rng, (cols, h))
+    ev = orc.domain_of_length(8 * n, offset=orc.lib().orc_bfe_generator())
+    t0 = time.perf_counter()
+    table = orc.lde_table(trace, rnd, ev, 1)
+    digests = orc.hash_rows(table)
+    orc.merkle_tree(digests)
+    dt = time.perf_counter() - t0
+    return {"value": round(n * cols / dt, 1), "unit": "trace-cells/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"oracle (C, OpenMP) LDE + Tip5 row hashing + Merkle tree of an {cols}-column main-table slice "
+                      f"at 2^{log2_rows} rows (8x extension), {dt:.1f} s; AIR/DEEP/FRI not included in the sample"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--log2-rows", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from triton_vm_amd import Context
+    from triton_vm_amd.prover import Prover, StarkParameters
+
+    ctx = Context(device=local_rank)
+    params = StarkParameters(args.log2_rows)
+    prover = Prover(ctx, params, seed=1000 + rank)
+    cells_per_step = params.padded_height * MASTER_WORDS
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+            import torch
+
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        prover.prove()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        prover.prove()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # live timing of the dominant HBM-bound kernel family (the main-table LDE: k_ntt2_pass1, k_lde_pass2,
+    # k_lde_pass3) with HIP events on the context's stream, and a per-stage breakdown of one more pass
+    lde_ms = []
+    if rank == 0:
+        for _ in range(3):
+            ctx.timer_start()
+            prover.main.maybe_low_degree_extend_all_columns()
+            lde_ms.append(ctx.timer_stop())
+        prover.timings = {}
+        prover.prove(profile=True)
+    barrier()
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        lde_avg_ms = sum(lde_ms) / len(lde_ms)
+        lde_cells = params.trace.length * 379
+        achieved = lde_cells * LDE_ALGORITHMIC_BYTES_PER_CELL / (lde_avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "trace-cells/sec (padded_rows x master_cols) in prove()",
+            "value": round(world * cells_per_step * args.steps / elapsed, 1),
+            "unit": "trace-cells/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64 (F_p, p = 2^64 - 2^32 + 1, Montgomery) and its cubic extension",
+            "data": "synthetic",
+            "config": {"workload": f"prove() hot path, prove_fib-shaped tables: 2^{args.log2_rows} padded rows, 379 main + "
+                                   "91 aux columns (652 words/row), Stark::default() with FRI (expansion 4, 198 trace "
+                                   "randomizers, 173 queries), traces resident in HBM; host `gen` steps (VM, pad, extend) "
+                                   "and the Rust-side transcript are not part of the path",
+                       "padded_rows": params.padded_height, "master_words": MASTER_WORDS,
+                       "ldt_domain": params.ldt.length, "parallelism": "1 proof per GPU" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "main-table LDE (k_ntt2_pass1 + k_lde_pass2 + k_lde_pass3, 12 column chunks)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "launch_ms": round(lde_avg_ms, 3),
+                         "algorithmic_bytes_per_launch": lde_cells * LDE_ALGORITHMIC_BYTES_PER_CELL},
+            "stage_ms": {k: round(v, 3) for k, v in prover.timings.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.log2_rows)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

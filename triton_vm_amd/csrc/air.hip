@@ -5,174 +5,71 @@
 // terminal}_constraints (generator: triton-constraint-builder/src/codegen.rs:141-367) and the four
 // zerofier-inverse codewords (master_table.rs:1194-1250).
 //
-// The 604 constraint polynomials (8.8k circuit nodes) arrive as a scheduled instruction stream
-// (air_program.h, generated by tools/air/export.py from a restatement of the reference's AIR and of
-// its deterministic degree lowering).  One lane evaluates one quotient-domain row; a wavefront is 64
-// consecutive rows, so every table column it reads is four full 128-byte lines of the row-block-major
-// table.  Intermediate values live in an LDS slot file laid out [slot][lane] (conflict-free); the
-// instruction stream is wave-uniform, so decoding runs on the scalar unit.  Each constraint value is
-// folded into the running sum  sum_k w_k c_k  as soon as it is produced, and each section is scaled
-// by its zerofier inverse, computed in-kernel from the row's domain point with one field inversion.
-// The kernel is integer-ALU bound (~7k modular multiplications per row), not HBM bound.
-#include "air_program.h"
+// The 604 constraint polynomials (8.8k circuit nodes) are compiled code: tools/air/export.py schedules
+// the degree-lowered circuit (a restatement of the reference's AIR and of its deterministic lowering)
+// into straight-line single-assignment HIP, one kernel per part (air_gen_<p>.hip: the initial,
+// consistency and terminal constraints together, then the transition constraints in groups of 100), and
+// hipcc allocates the registers.  Each part adds  zerofier_inverse * sum_k w_k c_k  of its constraints to
+// the quotient codeword; all arithmetic is exact, so the order of the parts does not matter.
+// The kernels are integer-ALU bound (~9k modular multiplications per row), not HBM bound (air_eval.h).
+#include "air_gen.h"
 #include "kernels.h"
 
 namespace tvm {
 
-#define AIR_LANES 64
-
-enum { OP_ADD_BB, OP_SUB_BB, OP_MUL_BB, OP_ADD_XX, OP_SUB_XX, OP_MUL_XX, OP_ADD_XB, OP_SUB_XB, OP_SUB_BX, OP_MUL_XB,
-       OP_ACC_B, OP_ACC_X, OP_END_SECTION };
-enum { T_SLOT, T_MAIN_CUR, T_MAIN_NEXT, T_AUX_CUR, T_AUX_NEXT, T_CONST, T_XCONST, T_CHALLENGE };
-
-struct QuotientArgs {
-    const u64* main_cur;   // table base; per-lane offsets are added in the kernel
-    const u64* aux_cur;
-    u64 main_w, aux_w;     // words per table row
-    u64 stride;            // table rows per quotient-domain row
-    u64 q_len, unit;       // |quotient domain|, |quotient domain| / |trace domain|
-    u64 q_offset, q_gen;
+// The four zerofier-inverse codewords over the quotient domain (master_table.rs:1194-1250):
+//   z[0] = 1/(x - 1), z[1] = 1/(x^N - 1), z[2] = (x - w^-1)/(x^N - 1), z[3] = 1/(x - w^-1),  x = offset * gen^i.
+// A thread owns ZB rows t, t + T, ... (T = number of threads) and inverts their 3*ZB factors with one
+// field inversion (Montgomery's trick).
+#define AIR_ZB 8
+struct ZerofierArgs {
+    u64 q_offset, q_gen, q_len;
     u64 trace_len, trace_gen_inv;
-    const u64* challenges; // 63 XFE
-    const u64* weights;    // 604 XFE
-    const uint32_t* program;
-    const u64* consts;
-    const u64* xconsts;
-    u64* out;              // q_len XFE
+    u64 n_threads;
+    u64 step, step_n;  // gen^T, gen^(T*N)
+    u64* zinv;         // [4][q_len]
 };
-
-struct AirLane {
-    const u64* mc;
-    const u64* mn;
-    const u64* ac;
-    const u64* an;
-    const u64* slots;
-};
-
-TVM_D u64 air_ldb(const QuotientArgs& a, const AirLane& l, uint32_t w) {
-    const uint32_t t = w & 15, idx = w >> 4;
-    switch (t) {
-        case T_SLOT: return l.slots[idx * AIR_LANES];
-        case T_MAIN_CUR: return l.mc[(u64)idx * TVM_RB];
-        case T_MAIN_NEXT: return l.mn[(u64)idx * TVM_RB];
-        default: return a.consts[idx];
-    }
-}
-TVM_D xfe air_ldx(const QuotientArgs& a, const AirLane& l, uint32_t w) {
-    const uint32_t t = w & 15, idx = w >> 4;
-    switch (t) {
-        case T_SLOT: return xfe_make(l.slots[idx * AIR_LANES], l.slots[(idx + 1) * AIR_LANES], l.slots[(idx + 2) * AIR_LANES]);
-        case T_AUX_CUR: {
-            const u64* p = l.ac + (u64)idx * 3 * TVM_RB;
-            return xfe_make(p[0], p[TVM_RB], p[2 * TVM_RB]);
-        }
-        case T_AUX_NEXT: {
-            const u64* p = l.an + (u64)idx * 3 * TVM_RB;
-            return xfe_make(p[0], p[TVM_RB], p[2 * TVM_RB]);
-        }
-        case T_XCONST: return xfe_make(a.xconsts[3 * idx], a.xconsts[3 * idx + 1], a.xconsts[3 * idx + 2]);
-        default: return xfe_make(a.challenges[3 * idx], a.challenges[3 * idx + 1], a.challenges[3 * idx + 2]);
-    }
-}
-
-__global__ void __launch_bounds__(AIR_LANES) k_quotients(QuotientArgs a) {
-    __shared__ u64 slot_file[TVM_AIR_NUM_SLOTS * AIR_LANES];
-    const int lane = threadIdx.x;
-    u64 i = (u64)blockIdx.x * AIR_LANES + lane;
-    const bool active = i < a.q_len;
-    if (!active) i = a.q_len - 1;  // keep the wave uniform; the result is discarded
-    const u64 row_cur = i * a.stride;
-    const u64 row_next = ((i + a.unit) % a.q_len) * a.stride;
-    AirLane l;
-    l.mc = a.main_cur + (row_cur >> TVM_RB_LOG) * a.main_w * TVM_RB + (row_cur & (TVM_RB - 1));
-    l.mn = a.main_cur + (row_next >> TVM_RB_LOG) * a.main_w * TVM_RB + (row_next & (TVM_RB - 1));
-    l.ac = a.aux_cur + (row_cur >> TVM_RB_LOG) * a.aux_w * TVM_RB + (row_cur & (TVM_RB - 1));
-    l.an = a.aux_cur + (row_next >> TVM_RB_LOG) * a.aux_w * TVM_RB + (row_next & (TVM_RB - 1));
-    u64* slots = slot_file + lane;
-    l.slots = slots;
-
-    // zerofier inverses at x = offset * gen^i (master_table.rs:1194-1250), one inversion for all four
-    u64 zinv[4];
-    {
-        const u64 x = bfe_mul(a.q_offset, bfe_pow(a.q_gen, i));
-        const u64 f_init = bfe_sub(x, TVM_ONE);
-        const u64 f_cons = bfe_sub(bfe_pow(x, a.trace_len), TVM_ONE);
-        const u64 f_term = bfe_sub(x, a.trace_gen_inv);
-        const u64 p01 = bfe_mul(f_init, f_cons);
-        const u64 inv_all = bfe_inv(bfe_mul(p01, f_term));
-        zinv[0] = bfe_mul(inv_all, bfe_mul(f_cons, f_term));   // 1 / (x - 1)
-        zinv[1] = bfe_mul(inv_all, bfe_mul(f_init, f_term));   // 1 / (x^N - 1)
-        zinv[2] = bfe_mul(f_term, zinv[1]);                    // (x - w^-1) / (x^N - 1)
-        zinv[3] = bfe_mul(inv_all, p01);                       // 1 / (x - w^-1)
-    }
-
-    xfe acc = xfe_zero(), quot = xfe_zero();
-    int k = 0;
-    const uint32_t* prog = a.program;
-    for (int pc = 0; pc < TVM_AIR_NUM_INSTRUCTIONS; pc++) {
-        const uint32_t w0 = prog[3 * pc], w1 = prog[3 * pc + 1], w2 = prog[3 * pc + 2];
-        const uint32_t op = w0 & 255, dst = w0 >> 8;
-        switch (op) {
-            case OP_ADD_BB: slots[dst * AIR_LANES] = bfe_add(air_ldb(a, l, w1), air_ldb(a, l, w2)); break;
-            case OP_SUB_BB: slots[dst * AIR_LANES] = bfe_sub(air_ldb(a, l, w1), air_ldb(a, l, w2)); break;
-            case OP_MUL_BB: slots[dst * AIR_LANES] = bfe_mul(air_ldb(a, l, w1), air_ldb(a, l, w2)); break;
-            case OP_ACC_B:
-                acc = xfe_add(acc, xfe_mul_bfe(xfe_make(a.weights[3 * k], a.weights[3 * k + 1], a.weights[3 * k + 2]),
-                                               air_ldb(a, l, w1)));
-                k++;
-                break;
-            case OP_ACC_X:
-                acc = xfe_add(acc, xfe_mul(xfe_make(a.weights[3 * k], a.weights[3 * k + 1], a.weights[3 * k + 2]),
-                                           air_ldx(a, l, w1)));
-                k++;
-                break;
-            case OP_END_SECTION:
-                quot = xfe_add(quot, xfe_mul_bfe(acc, zinv[dst & 3]));
-                acc = xfe_zero();
-                break;
-            default: {
-                xfe r;
-                const xfe x = air_ldx(a, l, w1);
-                if (op == OP_ADD_XX) r = xfe_add(x, air_ldx(a, l, w2));
-                else if (op == OP_SUB_XX) r = xfe_sub(x, air_ldx(a, l, w2));
-                else if (op == OP_MUL_XX) r = xfe_mul(x, air_ldx(a, l, w2));
-                else if (op == OP_ADD_XB) r = xfe_add_bfe(x, air_ldb(a, l, w2));
-                else if (op == OP_SUB_XB) r = xfe_sub_bfe(x, air_ldb(a, l, w2));
-                else if (op == OP_MUL_XB) r = xfe_mul_bfe(x, air_ldb(a, l, w2));
-                else r = xfe_zero();  // OP_SUB_BX is handled below
-                slots[dst * AIR_LANES] = r.c0;
-                slots[(dst + 1) * AIR_LANES] = r.c1;
-                slots[(dst + 2) * AIR_LANES] = r.c2;
-                break;
+__global__ void __launch_bounds__(256) k_zerofier_inverses(ZerofierArgs a) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.n_threads) return;
+    u64 x = bfe_mul(a.q_offset, bfe_pow(a.q_gen, t));
+    u64 xn = bfe_pow(x, a.trace_len);
+    u64 f[3 * AIR_ZB], pre[3 * AIR_ZB];
+    u64 run = TVM_ONE;
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < AIR_ZB; j++) {
+        if (t + (u64)j * a.n_threads < a.q_len) {
+            f[3 * j] = bfe_sub(x, TVM_ONE);
+            f[3 * j + 1] = bfe_sub(xn, TVM_ONE);
+            f[3 * j + 2] = bfe_sub(x, a.trace_gen_inv);
+#pragma unroll
+            for (int e = 0; e < 3; e++) {
+                pre[3 * j + e] = run;
+                run = bfe_mul(run, f[3 * j + e]);
             }
-            case OP_SUB_BX: {
-                const u64 bv = air_ldb(a, l, w1);
-                const xfe x = xfe_neg(air_ldx(a, l, w2));
-                slots[dst * AIR_LANES] = bfe_add(x.c0, bv);
-                slots[(dst + 1) * AIR_LANES] = x.c1;
-                slots[(dst + 2) * AIR_LANES] = x.c2;
-                break;
+            cnt = j + 1;
+        }
+        x = bfe_mul(x, a.step);
+        xn = bfe_mul(xn, a.step_n);
+    }
+    u64 inv = bfe_inv(run);
+#pragma unroll
+    for (int j = AIR_ZB - 1; j >= 0; j--) {
+        if (j < cnt) {
+            u64 r[3];
+#pragma unroll
+            for (int e = 2; e >= 0; e--) {
+                r[e] = bfe_mul(inv, pre[3 * j + e]);
+                inv = bfe_mul(inv, f[3 * j + e]);
             }
+            const u64 i = t + (u64)j * a.n_threads;
+            a.zinv[i] = r[0];
+            a.zinv[a.q_len + i] = r[1];
+            a.zinv[2 * a.q_len + i] = bfe_mul(f[3 * j + 2], r[1]);
+            a.zinv[3 * a.q_len + i] = r[2];
         }
     }
-    if (active) {
-        a.out[3 * i] = quot.c0;
-        a.out[3 * i + 1] = quot.c1;
-        a.out[3 * i + 2] = quot.c2;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-static const u64* upload_once(tvm_ctx* c, u64 key, const void* host, size_t bytes) {
-    auto k = std::make_tuple(0xA112A112ull, key, (u64)bytes);
-    auto it = c->tables.find(k);
-    if (it != c->tables.end()) return it->second;
-    u64* d = nullptr;
-    if (hipMalloc((void**)&d, bytes) != hipSuccess) return nullptr;
-    if (hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) return nullptr;
-    hipStreamSynchronize(c->stream);
-    c->tables[k] = d;
-    return d;
 }
 
 int all_quotients_combined(tvm_ctx* c, const u64* main_table, u64 main_rows, u64 main_w, const u64* aux_table, u64 aux_w,
@@ -180,26 +77,35 @@ int all_quotients_combined(tvm_ctx* c, const u64* main_table, u64 main_rows, u64
                            const u64* d_weights, u64* d_out) {
     if (!is_pow2(q_len) || !is_pow2(trace_len) || q_len < trace_len || main_rows % q_len)
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "quotients: domain lengths");
-    QuotientArgs a;
-    a.main_cur = main_table;
-    a.aux_cur = aux_table;
+    u64* zinv = (u64*)scratch(c, 14, (size_t)4 * q_len * sizeof(u64));
+    if (!zinv) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "zerofier inverses");
+    {
+        ZerofierArgs z;
+        z.q_offset = q_offset;
+        z.q_gen = q_gen;
+        z.q_len = q_len;
+        z.trace_len = trace_len;
+        z.trace_gen_inv = bfe_inv(trace_gen);
+        z.n_threads = (q_len + AIR_ZB - 1) / AIR_ZB;
+        z.step = bfe_pow(q_gen, z.n_threads);
+        z.step_n = bfe_pow(z.step, trace_len);
+        z.zinv = zinv;
+        TVM_LAUNCH(k_zerofier_inverses, dim3((unsigned)((z.n_threads + 255) / 256)), dim3(256), 0, c->stream, z);
+    }
+    AirArgs a;
+    a.main_table = main_table;
+    a.aux_table = aux_table;
     a.main_w = main_w;
     a.aux_w = aux_w;
     a.stride = main_rows / q_len;
     a.q_len = q_len;
     a.unit = q_len / trace_len;
-    a.q_offset = q_offset;
-    a.q_gen = q_gen;
-    a.trace_len = trace_len;
-    a.trace_gen_inv = bfe_inv(trace_gen);
     a.challenges = d_challenges;
     a.weights = d_weights;
-    a.program = (const uint32_t*)upload_once(c, 1, TVM_AIR_PROGRAM, sizeof(TVM_AIR_PROGRAM));
-    a.consts = upload_once(c, 2, TVM_AIR_CONSTS, sizeof(TVM_AIR_CONSTS));
-    a.xconsts = upload_once(c, 3, TVM_AIR_XCONSTS, sizeof(TVM_AIR_XCONSTS));
+    a.zinv = zinv;
     a.out = d_out;
-    if (!a.program || !a.consts || !a.xconsts) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "AIR program upload");
-    TVM_LAUNCH(k_quotients, dim3((unsigned)((q_len + AIR_LANES - 1) / AIR_LANES)), dim3(AIR_LANES), 0, c->stream, a);
+    const dim3 grid((unsigned)((q_len + AIR_BLOCK - 1) / AIR_BLOCK));
+    for (int p = 0; p < TVM_AIR_NUM_PARTS; p++) TVM_LAUNCH(TVM_AIR_PARTS[p], grid, dim3(AIR_BLOCK), 0, c->stream, a);
     TVM_HIP_CHECK(c, hipGetLastError());
     return TVM_OK;
 }

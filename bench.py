@@ -110,8 +110,10 @@ def main():
             ctx.timer_start()
             prover.main.maybe_low_degree_extend_all_columns()
             lde_ms.append(ctx.timer_stop())
-        prover.timings = {}
+        prover.timings, prover.wall = {}, {}
+        t_prof = time.perf_counter()
         prover.prove(profile=True)
+        t_prof = 1e3 * (time.perf_counter() - t_prof)
     barrier()
 
     if rank == 0:
@@ -140,6 +142,8 @@ def main():
                          "launch_ms": round(lde_avg_ms, 3),
                          "algorithmic_bytes_per_launch": lde_cells * LDE_ALGORITHMIC_BYTES_PER_CELL},
             "stage_ms": {k: round(v, 3) for k, v in prover.timings.items()},
+            "stage_wall_ms": {k: round(v, 3) for k, v in prover.wall.items()},
+            "profiled_prove_wall_ms": round(t_prof, 3),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.log2_rows)

@@ -54,8 +54,12 @@ void tvm_ctx_destroy(tvm_ctx* ctx);
 const char* tvm_last_error(const tvm_ctx* ctx);
 const char* tvm_status_string(int32_t status);
 int32_t tvm_sync(tvm_ctx* ctx);
+/* Device memory comes from a per-context caching allocator (a prove() at 2^20 rows turns over ~45 GiB of
+ * tables; the driver's allocator costs hundreds of ms at that size).  tvm_free and tvm_table_free return
+ * blocks to the cache for stream-ordered reuse; tvm_ctx_trim gives the cache back to the driver. */
 int32_t tvm_malloc(tvm_ctx* ctx, size_t bytes, void** d_ptr);
 int32_t tvm_free(tvm_ctx* ctx, void* d_ptr);
+int32_t tvm_ctx_trim(tvm_ctx* ctx);
 int32_t tvm_memcpy_h2d(tvm_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int32_t tvm_memcpy_d2h(tvm_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 
@@ -64,6 +68,11 @@ int32_t tvm_timer_start(tvm_ctx* ctx);
 int32_t tvm_timer_stop(tvm_ctx* ctx, float* h_elapsed_ms); /* synchronises the stream */
 /* Synthetic tables for benchmarks: n canonical Montgomery words < p from a counter-based generator */
 int32_t tvm_synthetic_fill(tvm_ctx* ctx, uint64_t* d_data, uint64_t n_words, uint64_t seed);
+
+/* Elementwise d_out[i] = d_a[i] op d_b[i] on Montgomery words through the device's field arithmetic
+ * (op 0: +, 1: -, 2: *, 3: a^7): the known-answer hook for the hand-scheduled carry chains in csrc/field.h
+ * (BFieldElement's Add/Sub/Mul, twenty-first; KAT triton-constraint-builder/src/codegen.rs:926-944). */
+int32_t tvm_field_op(tvm_ctx* ctx, int32_t op, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, uint64_t n);
 
 /* ---- L2 / L3: ArithmeticDomain::{evaluate, interpolate} (arithmetic_domain.rs:141-189) -------
  * d_coeffs: n_coeffs elements, d_values: domain.length elements, both arrays of field_kind-word

@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
-typedef uint64_t u64; typedef uint32_t u32;
+#include "../../triton_vm_amd/csrc/platform.h"
 #define ITER 4096
 #define CHAINS 8
 
@@ -36,6 +36,10 @@ static inline __device__ u64 mulmod(u64 a, u64 b) {
     u32 a0 = a, a1 = a >> 32, b0 = b, b1 = b >> 32; u64 p00 = (u64)a0 * b0; u64 m1 = (u64)a0 * b1 + (p00 >> 32); u64 m2 = (u64)a1 * b0 + (u32)m1;
     return montyred((m2 << 32) | (u32)p00, (u64)a1 * b1 + (m1 >> 32) + (m2 >> 32)); }
 KERNEL(k_mulmod, x[c] = mulmod(x[c], x[c] | 5);)
+#include "../../triton_vm_amd/csrc/field.h"   // the product's arithmetic (asm Montgomery reduction)
+KERNEL(k_bfe_mul, x[c] = bfe_mul(x[c], x[c] | 5);)
+KERNEL(k_bfe_add, x[c] = bfe_add(x[c], (u64)hi[c] << 20);)
+KERNEL(k_bfe_sub, x[c] = bfe_sub(x[c], (u64)hi[c] << 20);)
 
 template <class K> void run(const char* name, K k, double ops_per_iter_chain) {
     u64* out; hipMalloc(&out, 256 * 2048 * 8);
@@ -51,6 +55,6 @@ template <class K> void run(const char* name, K k, double ops_per_iter_chain) {
 int main() {
     run("mad_u64_u32", k_mad_u64_u32, 1); run("mul_lo_u32", k_mul_lo_u32, 1); run("mul_hi_u32", k_mul_hi_u32, 1);
     run("mad_u32_u24", k_mad_u32_u24, 1); run("add_u32", k_add_u32, 1); run("add_u64", k_add_u64, 1);
-    run("xor_shift", k_xor_shift, 1); run("fma_f64", k_fma_f64, 1); run("mulmod(field)", k_mulmod, 1);
+    run("xor_shift", k_xor_shift, 1); run("fma_f64", k_fma_f64, 1); run("mulmod(C, r01a)", k_mulmod, 1); run("bfe_mul(field.h)", k_bfe_mul, 1); run("bfe_add(field.h)", k_bfe_add, 1); run("bfe_sub(field.h)", k_bfe_sub, 1);
     return 0;
 }

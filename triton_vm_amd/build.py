@@ -35,11 +35,13 @@ def _stale():
     return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
 
 
-def build(force=False, verbose=False, extra_flags=()):
-    """Compile every .hip translation unit for gfx950 and link the shared library."""
-    if not force and not _stale():
+def build(force=False, verbose=False, extra_flags=(), variant=None):
+    """Compile every .hip translation unit for gfx950 and link the shared library.
+    `variant` (a name) builds an experiment library libtriton_hip_<variant>.so with extra flags."""
+    lib = LIB if variant is None else os.path.join(HERE, f"libtriton_hip_{variant}.so")
+    if variant is None and not force and not _stale():
         return LIB
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" if variant is None else f"build_{variant}")
     os.makedirs(objdir, exist_ok=True)
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
              "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-Wno-unused-variable",
@@ -58,8 +60,8 @@ def build(force=False, verbose=False, extra_flags=()):
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out, file=sys.stderr)
-    subprocess.check_call([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs])
-    return LIB
+    subprocess.check_call([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib, *objs])
+    return lib
 
 
 if __name__ == "__main__":

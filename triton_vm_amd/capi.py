@@ -41,11 +41,13 @@ _SIGNATURES = {
     "tvm_sync": (C.c_int32, [C.c_void_p]),
     "tvm_malloc": (C.c_int32, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "tvm_free": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "tvm_ctx_trim": (C.c_int32, [C.c_void_p]),
     "tvm_memcpy_h2d": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "tvm_memcpy_d2h": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "tvm_timer_start": (C.c_int32, [C.c_void_p]),
     "tvm_timer_stop": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float)]),
     "tvm_synthetic_fill": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
+    "tvm_field_op": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "tvm_evaluate": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, Domain, C.c_void_p]),
     "tvm_interpolate": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, Domain, C.c_void_p]),
     "tvm_ntt": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64]),
@@ -159,6 +161,10 @@ class Context:
 
     def sync(self):
         self._check(self.lib.tvm_sync(self.handle), "tvm_sync")
+
+    def trim(self):
+        """give the cached device blocks back to the driver"""
+        self._check(self.lib.tvm_ctx_trim(self.handle), "tvm_ctx_trim")
 
     def timer_start(self):
         self._check(self.lib.tvm_timer_start(self.handle), "tvm_timer_start")

@@ -72,11 +72,15 @@ __global__ void __launch_bounds__(256) k_zerofier_inverses(ZerofierArgs a) {
     }
 }
 
-int all_quotients_combined(tvm_ctx* c, const u64* main_table, u64 main_rows, u64 main_w, const u64* aux_table, u64 aux_w,
-                           u64 trace_len, u64 trace_gen, u64 q_offset, u64 q_gen, u64 q_len, const u64* d_challenges,
-                           const u64* d_weights, u64* d_out) {
+int all_quotients_combined(tvm_ctx* c, const u64* main_table, u64 main_rows, u64 wrap_rows, u64 main_w, const u64* aux_table,
+                           u64 aux_w, u64 trace_len, u64 trace_gen, u64 q_offset, u64 q_gen, u64 q_len,
+                           const u64* d_challenges, const u64* d_weights, u64* d_out) {
     if (!is_pow2(q_len) || !is_pow2(trace_len) || q_len < trace_len || main_rows % q_len)
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "quotients: domain lengths");
+    // the next row of quotient-domain row i is table row (i + q_len/trace_len) * (main_rows/q_len): the tables must
+    // carry that many wrap rows (tables made by tvm_lde_table do) and a workgroup's rows must fit 32-bit byte offsets
+    if (wrap_rows < main_rows / trace_len || (main_rows / q_len) * (AIR_BLOCK + q_len / trace_len) * main_w * 8 >= (1ull << 32))
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "quotients: tables lack wrap rows for this trace length");
     u64* zinv = (u64*)scratch(c, 14, (size_t)4 * q_len * sizeof(u64));
     if (!zinv) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "zerofier inverses");
     {

@@ -54,6 +54,8 @@ void tvm_ctx_destroy(tvm_ctx* c) {
     for (auto& kv : c->tables) hipFree(kv.second);
     for (void* p : c->scratch)
         if (p) hipFree(p);
+    for (auto& kv : c->pool_free) hipFree(kv.second);
+    for (auto& kv : c->pool_live) hipFree(kv.first);
     if (c->ev_start) hipEventDestroy(c->ev_start);
     if (c->ev_stop) hipEventDestroy(c->ev_stop);
     if (c->owns_stream) hipStreamDestroy(c->stream);
@@ -69,15 +71,18 @@ int32_t tvm_sync(tvm_ctx* c) {
 }
 int32_t tvm_malloc(tvm_ctx* c, size_t bytes, void** d_ptr) {
     if (!c || !d_ptr) return TVM_ERR_INVALID_ARGUMENT;
-    *d_ptr = nullptr;
-    TVM_HIP_CHECK(c, hipMalloc(d_ptr, bytes ? bytes : 1));
+    *d_ptr = pool_alloc(c, bytes);
+    if (!*d_ptr) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "tvm_malloc");
     return TVM_OK;
 }
 int32_t tvm_free(tvm_ctx* c, void* d_ptr) {
     if (!c) return TVM_ERR_INVALID_ARGUMENT;
-    if (!d_ptr) return TVM_OK;
-    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    TVM_HIP_CHECK(c, hipFree(d_ptr));
+    pool_release(c, d_ptr);
+    return TVM_OK;
+}
+int32_t tvm_ctx_trim(tvm_ctx* c) {
+    if (!c) return TVM_ERR_INVALID_ARGUMENT;
+    pool_trim(c);
     return TVM_OK;
 }
 int32_t tvm_memcpy_h2d(tvm_ctx* c, void* d, const void* h, size_t bytes) {
@@ -129,6 +134,31 @@ int32_t tvm_synthetic_fill(tvm_ctx* c, uint64_t* d, uint64_t n, uint64_t seed) {
     if (!c || (n && !d)) return TVM_ERR_INVALID_ARGUMENT;
     if (!n) return TVM_OK;
     TVM_LAUNCH(tvm::k_synthetic_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d, n, seed);
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+
+// ---------------------------------------------------------------------------------- field self-check
+}  // extern "C"
+namespace tvm {
+// out[i] = a[i] op b[i] through the device arithmetic of field.h (op: 0 add, 1 sub, 2 mul, 3 a^7)
+__global__ void k_field_op(int op, const u64* __restrict__ a, const u64* __restrict__ b, u64* __restrict__ out, u64 n) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 x = a[i], y = b[i];
+    u64 r;
+    if (op == 0) r = bfe_add(x, y);
+    else if (op == 1) r = bfe_sub(x, y);
+    else if (op == 2) r = bfe_mul(x, y);
+    else r = bfe_mul(bfe_mul(bfe_sqr(bfe_sqr(x)), bfe_sqr(x)), x);
+    out[i] = r;
+}
+}  // namespace tvm
+extern "C" {
+int32_t tvm_field_op(tvm_ctx* c, int32_t op, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, uint64_t n) {
+    if (!c || op < 0 || op > 3 || (n && (!d_a || !d_b || !d_out))) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_field_op arguments");
+    if (!n) return TVM_OK;
+    TVM_LAUNCH(tvm::k_field_op, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (int)op, d_a, d_b, d_out, n);
     TVM_HIP_CHECK(c, hipGetLastError());
     return TVM_OK;
 }
@@ -227,19 +257,21 @@ int32_t tvm_lde_table(tvm_ctx* c, int32_t fk, const uint64_t* d_trace, uint64_t 
     tvm_table* t = new (std::nothrow) tvm_table();
     if (!t) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "table handle");
     t->rows = eval_dom.length;
+    t->wrap_rows = eval_dom.length / n_rows;  // one trace-domain step in table rows
     t->n_cols = n_cols;
     t->fk = fk;
     t->W = (int)(n_cols * fk);
-    if (hipMalloc((void**)&t->data, t->bytes()) != hipSuccess) {
+    t->data = (u64*)pool_alloc(c, t->bytes());
+    if (!t->data) {
         delete t;
         return set_error(c, TVM_ERR_OUT_OF_MEMORY, "LDE table allocation");
     }
-    if (t->rows % TVM_RB) hipMemsetAsync(t->data, 0, t->bytes(), c->stream);  // padding rows of a tiny table
+    if ((t->rows + t->wrap_rows) % TVM_RB) (void)hipMemsetAsync(t->data, 0, t->bytes(), c->stream);  // padding rows
     int rc = lde_table(c, fk, d_trace, n_rows, n_cols, d_rnd, h, trace_dom.generator, eval_dom.offset, eval_dom.generator,
                        eval_dom.length, t->data, 0);
+    if (rc == TVM_OK) rc = copy_rows(c, t->data, t->W, 0, t->rows, t->wrap_rows);
     if (rc != TVM_OK) {
-        hipStreamSynchronize(c->stream);
-        hipFree(t->data);
+        pool_release(c, t->data);
         delete t;
         return rc;
     }
@@ -249,8 +281,7 @@ int32_t tvm_lde_table(tvm_ctx* c, int32_t fk, const uint64_t* d_trace, uint64_t 
 
 void tvm_table_free(tvm_ctx* c, tvm_table* t) {
     if (!t) return;
-    if (c) hipStreamSynchronize(c->stream);
-    if (t->data) hipFree(t->data);
+    if (c && t->data) pool_release(c, t->data);
     delete t;
 }
 uint64_t tvm_table_num_rows(const tvm_table* t) { return t ? t->rows : 0; }
@@ -412,14 +443,15 @@ int32_t tvm_quotient_segments(tvm_ctx* c, const uint64_t* d_cw, tvm_domain qd, t
     t->n_cols = 5;
     t->fk = 3;
     t->W = 15;
-    if (hipMalloc((void**)&t->data, t->bytes()) != hipSuccess) {
+    t->data = (u64*)pool_alloc(c, t->bytes());
+    if (!t->data) {
         delete t;
         return set_error(c, TVM_ERR_OUT_OF_MEMORY, "segment table allocation");
     }
     // evaluate the 5 polynomials (15 base-field columns) into planar codewords, then lay them out as a table
     u64* planar = (u64*)scratch(c, 12, (size_t)15 * L * sizeof(u64));
     if (!planar) {
-        hipFree(t->data);
+        pool_release(c, t->data);
         delete t;
         return set_error(c, TVM_ERR_OUT_OF_MEMORY, "segment codewords scratch");
     }
@@ -434,8 +466,7 @@ int32_t tvm_quotient_segments(tvm_ctx* c, const uint64_t* d_cw, tvm_domain qd, t
     }
     if (rc == TVM_OK) rc = columns_to_table(c, planar, L, L, 15, t->data);
     if (rc != TVM_OK) {
-        hipStreamSynchronize(c->stream);
-        hipFree(t->data);
+        pool_release(c, t->data);
         delete t;
         return rc;
     }
@@ -472,7 +503,7 @@ extern "C" int32_t tvm_all_quotients_combined(tvm_ctx* c, const tvm_table* mt, c
     if (!c || !mt || !at || !h_challenges || !h_weights || !d_out || !valid_domain(td) || !valid_domain(qd))
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "all_quotients_combined arguments");
     if (mt->fk != 1 || mt->n_cols != TVM_NUM_MAIN_COLUMNS || at->fk != 3 || at->n_cols != TVM_NUM_AUX_COLUMNS ||
-        mt->rows != at->rows || qd.length > mt->rows)
+        mt->rows != at->rows || qd.length > mt->rows || mt->wrap_rows != at->wrap_rows)
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "all_quotients_combined: tables must be 379 BFE / 91 XFE columns wide");
     u64* staged = (u64*)scratch(c, 13, (size_t)3 * (TVM_NUM_CHALLENGES + TVM_NUM_QUOTIENT_WEIGHTS) * sizeof(u64));
     if (!staged) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "challenge staging");
@@ -480,7 +511,7 @@ extern "C" int32_t tvm_all_quotients_combined(tvm_ctx* c, const tvm_table* mt, c
     TVM_HIP_CHECK(c, hipMemcpyAsync(staged + 3 * TVM_NUM_CHALLENGES, h_weights, 3 * TVM_NUM_QUOTIENT_WEIGHTS * sizeof(u64),
                                     hipMemcpyHostToDevice, c->stream));
     TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    return all_quotients_combined(c, mt->data, mt->rows, (u64)mt->W, at->data, (u64)at->W, td.length, td.generator,
+    return all_quotients_combined(c, mt->data, mt->rows, mt->wrap_rows, (u64)mt->W, at->data, (u64)at->W, td.length, td.generator,
                                   qd.offset, qd.generator, qd.length, staged, staged + 3 * TVM_NUM_CHALLENGES, d_out);
 }
 

@@ -30,6 +30,13 @@ struct tvm_ctx {
     std::map<std::tuple<u64, u64, u64>, u64*> tables;  // (base, count, scale) -> device table
     std::vector<void*> scratch;                         // named scratch slots
     std::vector<size_t> scratch_bytes;
+    // Caching device allocator: every device block handed out by the library (tvm_malloc, table handles)
+    // comes from here and returns here; a 2^20-row proof allocates ~45 GiB of tables per prove(), and
+    // hipMalloc/hipFree of that size cost hundreds of milliseconds each.  Blocks are reused in stream
+    // order (one stream per context), so handing a freed block to the next request needs no host sync.
+    std::multimap<size_t, void*> pool_free;             // capacity -> block
+    std::map<void*, size_t> pool_live;                  // block -> capacity
+    size_t pool_bytes = 0;                              // bytes held from the driver (live + cached)
     std::string last_error;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
@@ -40,6 +47,10 @@ const u64* pow_table(tvm_ctx* c, u64 base, u64 count, u64 scale = TVM_ONE);
 // scratch slot `slot` of at least `bytes` bytes (grown on demand, contents undefined)
 void* scratch(tvm_ctx* c, int slot, size_t bytes);
 int set_error(tvm_ctx* c, int code, const char* what);
+// pool: nullptr on device out-of-memory (after the cache has been given back to the driver and the request retried)
+void* pool_alloc(tvm_ctx* c, size_t bytes);
+void pool_release(tvm_ctx* c, void* p);   // back to the cache (stream-ordered reuse)
+void pool_trim(tvm_ctx* c);               // cached blocks back to the driver (synchronises the stream)
 inline int ilog2(u64 n) {
     int l = 0;
     while ((1ull << l) < n) l++;

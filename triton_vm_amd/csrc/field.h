@@ -16,14 +16,54 @@
 #define TVM_ONE 0xFFFFFFFFull          // Montgomery word of 1
 #define TVM_R2 0xFFFFFFFE00000001ull   // 2^128 mod p, to enter Montgomery form
 
+// gfx950 does not interlock a VALU instruction that reads VCC (or an SGPR) written by the VALU instruction
+// right before it: two wait states are required (LLVM: VALUWriteSGPRVALURead on gfx940+).  The compiler
+// inserts them in its own code; the asm carry chains below do it by hand.
+#define TVM_VCC_WAIT "s_nop 1\n\t"
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TVM_EMU)
+#define TVM_FIELD_ASM 1
+#endif
+
 TVM_HD u64 bfe_add(u64 a, u64 b) {
+#ifdef TVM_FIELD_ASM
+    // s = a + b (carry c1); t = s - p = s + EPS (carry c2); result = (c1 | c2) ? t : s.  32-bit full-rate
+    // ops only: the 64-bit compare/add forms the compiler picks for the C below run at a fraction of the rate.
+    u32 s0, s1, t0, t1;
+    u64 c1;
+    asm("v_add_co_u32 %[s0], vcc, %[a0], %[b0]\n\t" TVM_VCC_WAIT
+        "v_addc_co_u32_e64 %[s1], %[c1], %[a1], %[b1], vcc\n\t"
+        "v_add_co_u32 %[t0], vcc, -1, %[s0]\n\t" TVM_VCC_WAIT
+        "v_addc_co_u32 %[t1], vcc, 0, %[s1], vcc\n\t" TVM_VCC_WAIT
+        "s_or_b64 vcc, vcc, %[c1]\n\t" TVM_VCC_WAIT
+        "v_cndmask_b32 %[s0], %[s0], %[t0], vcc\n\t"
+        "v_cndmask_b32 %[s1], %[s1], %[t1], vcc"
+        : [s0] "=&v"(s0), [s1] "=&v"(s1), [t0] "=&v"(t0), [t1] "=&v"(t1), [c1] "=&s"(c1)
+        : [a0] "v"((u32)a), [a1] "v"((u32)(a >> 32)), [b0] "v"((u32)b), [b1] "v"((u32)(b >> 32))
+        : "vcc", "scc");  // s_or_b64 writes SCC
+    return ((u64)s1 << 32) | s0;
+#else
     u64 s = a + b;
     // a + b < 2p: either the 64-bit add wrapped (then +EPS == -p mod 2^64) or s may be >= p.
     return (s < a || s >= TVM_P) ? s + TVM_EPS : s;
+#endif
 }
 TVM_HD u64 bfe_sub(u64 a, u64 b) {
+#ifdef TVM_FIELD_ASM
+    // d = a - b; a borrow means d is short by p = 2^64 - EPS, i.e. subtract EPS once more
+    u32 r0, r1, m;
+    asm("v_sub_co_u32 %[r0], vcc, %[a0], %[b0]\n\t" TVM_VCC_WAIT
+        "v_subb_co_u32 %[r1], vcc, %[a1], %[b1], vcc\n\t" TVM_VCC_WAIT
+        "v_cndmask_b32_e64 %[m], 0, -1, vcc\n\t"
+        "v_sub_co_u32 %[r0], vcc, %[r0], %[m]\n\t" TVM_VCC_WAIT
+        "v_subbrev_co_u32 %[r1], vcc, 0, %[r1], vcc"
+        : [r0] "=&v"(r0), [r1] "=&v"(r1), [m] "=&v"(m)
+        : [a0] "v"((u32)a), [a1] "v"((u32)(a >> 32)), [b0] "v"((u32)b), [b1] "v"((u32)(b >> 32))
+        : "vcc");
+    return ((u64)r1 << 32) | r0;
+#else
     u64 d = a - b;
     return (a < b) ? d - TVM_EPS : d;
+#endif
 }
 TVM_HD u64 bfe_neg(u64 a) { return a ? TVM_P - a : 0; }
 TVM_HD u64 bfe_dbl(u64 a) { return bfe_add(a, a); }
@@ -44,10 +84,39 @@ TVM_HD void mul64wide(u64 a, u64 b, u64& lo, u64& hi) {
     lo = (m2 << 32) | (u32)p00;
     hi = (u64)a1 * b1 + (m1 >> 32) + (m2 >> 32);
 }
+// Device multiplication: the four 32x32 partial products are C (v_mad_u64_u32), the carry chain is asm.
+// With t = a0*b0, u = a0*b1 + t1, v = a1*b0 + u0, w = a1*b1 + u1 the 128-bit product is
+// x = (w + v1) : v0 : t0; the asm adds v1 into w and performs bfe_montyred on 32-bit limbs with the
+// carries kept in VCC -- ten VALU instructions, where the compiler's rendering of the 64-bit C form takes
+// fourteen plus re-pairing moves and a zero-extended register pair per partial sum:
+//   a1 = x1 + x0 (carry e);  b = (a1:x0) - a1 - e;  r = (x3:x2) - b;  if that borrowed, r -= 2^32 - 1.
 TVM_HD u64 bfe_mul(u64 a, u64 b) {
+#ifdef TVM_FIELD_ASM
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 t = (u64)a0 * b0;
+    const u64 u = (u64)a0 * b1 + (t >> 32);
+    const u64 v = (u64)a1 * b0 + (u32)u;
+    const u64 w = (u64)a1 * b1 + (u >> 32);
+    u32 r0, r1, s1, s0;
+    asm("v_add_co_u32 %[r0], vcc, %[w0], %[v1]\n\t" TVM_VCC_WAIT
+        "v_addc_co_u32 %[r1], vcc, 0, %[w1], vcc\n\t"
+        "v_add_co_u32 %[s1], vcc, %[x1], %[x0]\n\t" TVM_VCC_WAIT
+        "v_subb_co_u32 %[s0], vcc, %[x0], %[s1], vcc\n\t" TVM_VCC_WAIT
+        "v_subbrev_co_u32 %[s1], vcc, 0, %[s1], vcc\n\t"
+        "v_sub_co_u32 %[r0], vcc, %[r0], %[s0]\n\t" TVM_VCC_WAIT
+        "v_subb_co_u32 %[r1], vcc, %[r1], %[s1], vcc\n\t" TVM_VCC_WAIT
+        "v_cndmask_b32_e64 %[s0], 0, -1, vcc\n\t"
+        "v_sub_co_u32 %[r0], vcc, %[r0], %[s0]\n\t" TVM_VCC_WAIT
+        "v_subbrev_co_u32 %[r1], vcc, 0, %[r1], vcc"
+        : [r0] "=&v"(r0), [r1] "=&v"(r1), [s1] "=&v"(s1), [s0] "=&v"(s0)
+        : [x0] "v"((u32)t), [x1] "v"((u32)v), [w0] "v"((u32)w), [w1] "v"((u32)(w >> 32)), [v1] "v"((u32)(v >> 32))
+        : "vcc");
+    return ((u64)r1 << 32) | r0;
+#else
     u64 lo, hi;
     mul64wide(a, b, lo, hi);
     return bfe_montyred(lo, hi);
+#endif
 }
 TVM_HD u64 bfe_sqr(u64 a) { return bfe_mul(a, a); }
 // Montgomery word of a small canonical integer v

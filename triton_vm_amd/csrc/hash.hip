@@ -168,6 +168,21 @@ int gather_rows(tvm_ctx* c, const u64* table, u64 L, int W, const u64* d_idx, u6
     return TVM_OK;
 }
 
+// rows [dst_row, dst_row + n_rows) := rows [src_row, src_row + n_rows) of a row-block-major table
+__global__ void k_copy_rows(u64* __restrict__ table, int W, u64 src_row, u64 dst_row, u64 n_rows) {
+    const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_rows * (u64)W) return;
+    const u64 v = e / n_rows, r = e % n_rows;
+    table[tvm_tab_idx(dst_row + r, v, (u64)W)] = table[tvm_tab_idx(src_row + r, v, (u64)W)];
+}
+int copy_rows(tvm_ctx* c, u64* table, int W, u64 src_row, u64 dst_row, u64 n_rows) {
+    const u64 total = n_rows * (u64)W;
+    if (!total) return TVM_OK;
+    TVM_LAUNCH(k_copy_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, table, W, src_row, dst_row, n_rows);
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+
 int table_to_row_major(tvm_ctx* c, const u64* table, u64 L, int W, u64* d_out) {
     const u64 total = L * (u64)W;
     TVM_LAUNCH(k_table_to_row_major, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, table, L, W, d_out);

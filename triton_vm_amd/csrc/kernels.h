@@ -16,6 +16,7 @@ int xfe_leaves(tvm_ctx* c, const u64* cw, u64 plane, u64 n, u64* leaves);
 int gather_rows(tvm_ctx* c, const u64* table, u64 L, int W, const u64* d_idx, u64 n, u64* d_out);
 int table_to_row_major(tvm_ctx* c, const u64* table, u64 L, int W, u64* d_out);
 int columns_to_table(tvm_ctx* c, const u64* cols, u64 col_stride, u64 L, int W, u64* table);
+int copy_rows(tvm_ctx* c, u64* table, int W, u64 src_row, u64 dst_row, u64 n_rows);
 // poly.hip
 int out_of_domain_rows(tvm_ctx* c, int fk, const u64* trace, u64 n, u64 n_cols, const u64* rnd, u64 h, u64 trace_gen,
                        const u64* d_points, int n_points, u64* d_rows);
@@ -29,16 +30,18 @@ int deep_sum(tvm_ctx* c, int n_comp, const u64* const* d_cw, const u64* h_points
              u64 offset, u64 gen, u64 n, u64* d_out);
 int fri_fold(tvm_ctx* c, const u64* d_cw, u64 n, u64 offset, u64 gen, const u64* h_challenge, u64* d_out);
 // air.hip
-int all_quotients_combined(tvm_ctx* c, const u64* main_table, u64 main_rows, u64 main_w, const u64* aux_table, u64 aux_w,
-                           u64 trace_len, u64 trace_gen, u64 q_offset, u64 q_gen, u64 q_len, const u64* d_challenges,
+int all_quotients_combined(tvm_ctx* c, const u64* main_table, u64 main_rows, u64 wrap_rows, u64 main_w, const u64* aux_table,
+                           u64 aux_w, u64 trace_len, u64 trace_gen, u64 q_offset, u64 q_gen, u64 q_len, const u64* d_challenges,
                            const u64* d_weights, u64* d_out);
 }  // namespace tvm
 
 struct tvm_table {
     u64* data = nullptr;  // row-block-major, see context.h
     u64 rows = 0;
+    u64 wrap_rows = 0;    // rows [rows, rows + wrap_rows) repeat rows [0, wrap_rows): lets the AIR kernels read the
+                          // "next" row (master_table.rs:1305-1306, index + rows/|trace| mod rows) without a wrap-around
     u64 n_cols = 0;       // in elements of the table's field
     int fk = 1;
     int W = 0;            // base-field words per row = n_cols * fk
-    size_t bytes() const { return (size_t)tvm_tab_words(rows, (u64)W) * sizeof(u64); }
+    size_t bytes() const { return (size_t)tvm_tab_words(rows + wrap_rows, (u64)W) * sizeof(u64); }
 };

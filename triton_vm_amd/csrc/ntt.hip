@@ -341,6 +341,53 @@ void* scratch(tvm_ctx* c, int slot, size_t bytes) {
     return c->scratch[slot];
 }
 
+static size_t pool_round(size_t bytes) {
+    const size_t g = bytes < (1u << 20) ? 256 : (2u << 20);
+    return (bytes + g - 1) / g * g;
+}
+void* pool_alloc(tvm_ctx* c, size_t bytes) {
+    const size_t want = pool_round(bytes ? bytes : 1);
+    auto it = c->pool_free.lower_bound(want);
+    if (it != c->pool_free.end() && it->first <= want + want / 4) {  // at most 25 % slack
+        void* p = it->second;
+        c->pool_live[p] = it->first;
+        c->pool_free.erase(it);
+        return p;
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, want) != hipSuccess) {
+        (void)hipGetLastError();
+        pool_trim(c);
+        if (hipMalloc(&p, want) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+    }
+    c->pool_live[p] = want;
+    c->pool_bytes += want;
+    return p;
+}
+void pool_release(tvm_ctx* c, void* p) {
+    if (!p) return;
+    auto it = c->pool_live.find(p);
+    if (it == c->pool_live.end()) {  // not ours (should not happen): hand it to the driver
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(p);
+        return;
+    }
+    c->pool_free.emplace(it->second, p);
+    c->pool_live.erase(it);
+}
+void pool_trim(tvm_ctx* c) {
+    if (c->pool_free.empty()) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->pool_free) {
+        (void)hipFree(kv.second);
+        c->pool_bytes -= kv.first;
+    }
+    c->pool_free.clear();
+}
+
 int set_error(tvm_ctx* c, int code, const char* what) {
     if (c) c->last_error = what;
     return code;

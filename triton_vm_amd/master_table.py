@@ -32,10 +32,10 @@ class MasterTable:
     def maybe_low_degree_extend_all_columns(self):
         h = C.c_void_p()
         ev = self.evaluation_domain()
+        self.clear_cache()  # the old table's block goes back to the context's pool and is reused right away
         self.ctx._check(self.ctx.lib.tvm_lde_table(self.ctx.handle, self.fk, self.d_trace.ptr, self.n_rows, self.n_cols,
                                                    self.d_randomizers.ptr, self.num_trace_randomizers,
                                                    self.trace_domain.c(), ev.c(), C.byref(h)), "tvm_lde_table")
-        self.clear_cache()
         self._table = h.value
 
     def clear_cache(self):

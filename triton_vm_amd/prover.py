@@ -113,7 +113,7 @@ class Prover:
             self.main = MasterTable(ctx, main_trace, rnd(NUM_MAIN, h), *dom, 1)
             self.aux = MasterTable(ctx, aux_trace, rnd(NUM_AUX, h, 3), *dom, 3)
         self.quotient_randomizer = rng.integers(0, field.P, size=(params.num_quotient_randomizers, 3), dtype=np.uint64)
-        self.timings = {}
+        self.timings, self.wall = {}, {}
         self.capture = None
 
     def _init_synthetic(self, mt, fk, n_cols, n, h, dom, seed):
@@ -128,11 +128,14 @@ class Prover:
         class T:
             def __enter__(self):
                 if prover.profile:
+                    prover.ctx.sync()
+                    self.t0 = time.perf_counter()
                     prover.ctx.timer_start()
 
             def __exit__(self, *a):
                 if prover.profile:
                     prover.timings[name] = prover.timings.get(name, 0.0) + prover.ctx.timer_stop()
+                    prover.wall[name] = prover.wall.get(name, 0.0) + 1e3 * (time.perf_counter() - self.t0)
         return T()
 
     def _root(self, d_nodes):

@@ -266,7 +266,10 @@ int32_t tvm_lde_table(tvm_ctx* c, int32_t fk, const uint64_t* d_trace, uint64_t 
         delete t;
         return set_error(c, TVM_ERR_OUT_OF_MEMORY, "LDE table allocation");
     }
-    if ((t->rows + t->wrap_rows) % TVM_RB) (void)hipMemsetAsync(t->data, 0, t->bytes(), c->stream);  // padding rows
+    if ((t->rows + t->wrap_rows) % TVM_RB) {  // zero the padding rows of the last (partial) row block
+        const u64 full = (t->rows + t->wrap_rows) / TVM_RB * TVM_RB * (u64)t->W;
+        (void)hipMemsetAsync(t->data + full, 0, t->bytes() - full * sizeof(u64), c->stream);
+    }
     int rc = lde_table(c, fk, d_trace, n_rows, n_cols, d_rnd, h, trace_dom.generator, eval_dom.offset, eval_dom.generator,
                        eval_dom.length, t->data, 0);
     if (rc == TVM_OK) rc = copy_rows(c, t->data, t->W, 0, t->rows, t->wrap_rows);

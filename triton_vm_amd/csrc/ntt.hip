@@ -42,45 +42,73 @@ __global__ void k_pow_table(u64 base, u64 count, u64 scale, u64* out) {
     if (i < count) out[i] = bfe_mul(scale, bfe_pow(base, i));
 }
 
-// In-LDS radix-2 transform of a tile: element (a, b) at s[a*SA + b*SB], a < 2^log_n the transform
-// axis, b < 2^batch_log independent transforms.  tw[e] = w^e, e < n/2, w the n-th root to use.
+// In-LDS transform of a tile: element (a, b) at s[a*SA + b*SB], a < 2^log_n the transform axis,
+// b < 2^batch_log independent transforms.  tw[e] = w^e, e < n/2, w the n-th root to use.
 // DIT = false: decimation in frequency, natural order in, bit-reversed order out.
 // DIT = true : decimation in time, bit-reversed order in, natural order out.
+//
+// The log_n butterfly layers are taken four at a time: a work-item loads the 16 elements whose indices
+// differ in the four index bits of the group, runs the 32 butterflies of those layers in VGPRs and writes
+// the 16 results back in place, so a 1024-point transform makes 3 trips through LDS (4 + 4 + 2 layers)
+// instead of 10 and synchronises 3 times instead of 10.  Lanes of a wavefront are consecutive b first
+// (SB is either 1 or an odd row pitch), then consecutive groups: at most 2-way bank conflicts.
 // Ends with a barrier; the caller must have synchronised the tile before the call.
-template <bool DIT, bool B_FASTEST>
-TVM_D void lds_ntt(u64* s, int log_n, int batch_log, int SA, int SB, const u64* __restrict__ tw, int tid, int nt) {
-    const int half_n = (1 << log_n) >> 1;
-    const int total = half_n << batch_log;
-    for (int layer = 0; layer < log_n; layer++) {
-        const int hl = DIT ? layer : (log_n - 1 - layer);  // log2 of the butterfly span
-        const int h = 1 << hl;
-        const int tws = log_n - 1 - hl;                    // w_{2h}^j = w_n^(j << tws)
-        for (int idx = tid; idx < total; idx += nt) {
-            int bf, b;
-            if (B_FASTEST) {
-                b = idx & ((1 << batch_log) - 1);
-                bf = idx >> batch_log;
-            } else {
-                bf = idx & (half_n - 1);
-                b = idx >> (log_n - 1);
-            }
-            const int j = bf & (h - 1);
-            const int i = ((bf - j) << 1) + j;
-            u64* p0 = s + i * SA + b * SB;
-            u64* p1 = p0 + h * SA;
-            const u64 w = tw[j << tws];
-            const u64 u = *p0;
-            if (DIT) {
-                const u64 v = bfe_mul(*p1, w);
-                *p0 = bfe_add(u, v);
-                *p1 = bfe_sub(u, v);
-            } else {
-                const u64 v = *p1;
-                *p0 = bfe_add(u, v);
-                *p1 = bfe_mul(bfe_sub(u, v), w);
+template <bool DIT, int K>
+TVM_D void lds_ntt_group(u64* s, int log_n, int batch_log, int SA, int SB, const u64* __restrict__ tw, int l, int tid, int nt) {
+    constexpr int R = 1 << K;
+    const int n_groups = (1 << (log_n - K)) << batch_log;
+    const int bmask = (1 << batch_log) - 1, lmask = (1 << l) - 1;
+    for (int gi = tid; gi < n_groups; gi += nt) {
+        const int b = gi & bmask, g = gi >> batch_log;
+        const int j0 = g & lmask;
+        u64* p = s + ((((g >> l) << (l + K)) | j0) * SA + b * SB);
+        const int stride = SA << l;
+        u64 x[R];
+#pragma unroll
+        for (int e = 0; e < R; e++) x[e] = p[e * stride];
+#pragma unroll
+        for (int tt = 0; tt < K; tt++) {
+            const int t = DIT ? tt : (K - 1 - tt);  // layer l + t: butterfly span 2^(l+t)
+            const int h = 1 << t;
+            const int tws = log_n - 1 - (l + t);    // w_{2^(l+t+1)}^j = w_n^(j << tws)
+#pragma unroll
+            for (int m = 0; m < h; m++) {           // the 2^t distinct twiddles of this layer in the group
+                const u64 w = tw[((m << l) | j0) << tws];
+#pragma unroll
+                for (int q = 0; q < R / (2 * h); q++) {
+                    const int e = q * 2 * h + m;
+                    const u64 u = x[e];
+                    if (DIT) {
+                        const u64 v = bfe_mul(x[e + h], w);
+                        x[e] = bfe_add(u, v);
+                        x[e + h] = bfe_sub(u, v);
+                    } else {
+                        const u64 v = x[e + h];
+                        x[e] = bfe_add(u, v);
+                        x[e + h] = bfe_mul(bfe_sub(u, v), w);
+                    }
+                }
             }
         }
-        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < R; e++) p[e * stride] = x[e];
+    }
+    __syncthreads();
+}
+
+template <bool DIT, int MAXK = 4>
+TVM_D void lds_ntt(u64* s, int log_n, int batch_log, int SA, int SB, const u64* __restrict__ tw, int tid, int nt) {
+    // DIT runs the layers upwards from span 1, DIF downwards from span n/2; groups of MAXK layers (4, or 3
+    // where the caller keeps other per-thread state in VGPRs), the remainder as the last group
+    int done = 0;
+    while (done < log_n) {
+        const int k = (log_n - done) >= MAXK ? MAXK : (log_n - done);
+        const int l = DIT ? done : (log_n - done - k);
+        if (MAXK >= 4 && k == 4) lds_ntt_group<DIT, 4>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
+        else if (k == 3) lds_ntt_group<DIT, 3>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
+        else if (k == 2) lds_ntt_group<DIT, 2>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
+        else lds_ntt_group<DIT, 1>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
+        done += k;
     }
 }
 
@@ -129,7 +157,7 @@ __global__ void __launch_bounds__(1024) k_ntt2_pass1(Ntt2Args a) {
         s[idx] = x;
     }
     __syncthreads();
-    lds_ntt<false, true>(s, a.log_n1, a.batch_log, B, 1, a.tw1, tid, nt);
+    lds_ntt<false>(s, a.log_n1, a.batch_log, B, 1, a.tw1, tid, nt);
     u64* tmp = a.tmp + (u64)vl * a.tmp_col_stride;
     for (int idx = tid; idx < tile; idx += nt) {
         const int b = idx & (B - 1), p = idx >> a.batch_log;
@@ -159,7 +187,7 @@ __global__ void __launch_bounds__(1024) k_ntt2_pass2(Ntt2Args a) {
         s[b * RS + i2] = x;
     }
     __syncthreads();
-    lds_ntt<false, false>(s, a.log_n2, a.batch_log, 1, RS, a.tw2, tid, nt);
+    lds_ntt<false>(s, a.log_n2, a.batch_log, 1, RS, a.tw2, tid, nt);
     u64* out = a.out + (u64)(v / a.out_fk) * a.out_col_stride + (v % a.out_fk);
     for (int idx = tid; idx < tile; idx += nt) {
         const int b = idx & (B - 1), q = idx >> a.batch_log;
@@ -215,7 +243,7 @@ __global__ void __launch_bounds__(1024) k_lde_pass2(LdePass2Args a) {
     }
     __syncthreads();
     // inverse rows step: position q of row b now holds N * t[k1 + N1*k2], k2 = brev(q)
-    lds_ntt<false, false>(s, a.log_n2, a.batch_log, 1, RS, a.tw_a2, tid, nt);
+    lds_ntt<false>(s, a.log_n2, a.batch_log, 1, RS, a.tw_a2, tid, nt);
 
     // The N coefficients of this tile stay in VGPRs for the whole coset loop (the only per-thread
     // state: 16 words); coset factors come from two small L2-resident tables per coset.
@@ -247,7 +275,7 @@ __global__ void __launch_bounds__(1024) k_lde_pass2(LdePass2Args a) {
         }
         __syncthreads();
         // forward columns step over m1 (bit-reversed in position q): natural j1 out
-        lds_ntt<true, false>(s, a.log_n2, a.batch_log, 1, RS, a.tw_b1, tid, nt);
+        lds_ntt<true, 3>(s, a.log_n2, a.batch_log, 1, RS, a.tw_b1, tid, nt);  // coef[] stays live: 8-element groups
         u64* z = a.z + ((u64)vl * a.n_cosets + k) * n;
         for (int idx = tid; idx < tile; idx += nt) {
             const int b = idx & (B - 1), j1 = idx >> a.batch_log;
@@ -297,7 +325,7 @@ __global__ void __launch_bounds__(1024) k_lde_pass3(LdePass3Args a) {
         s[b * RS + p] = x;
     }
     __syncthreads();
-    lds_ntt<true, false>(s, a.log_n1, a.rows_log, 1, RS, a.tw_b2, tid, nt);
+    lds_ntt<true>(s, a.log_n1, a.rows_log, 1, RS, a.tw_b2, tid, nt);
     const u64 v = (u64)(a.col0 + vl);
     for (int idx = tid; idx < tile; idx += nt) {
         const int b = idx & (RB - 1), j2 = idx >> a.rows_log;

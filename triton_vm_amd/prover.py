@@ -32,10 +32,15 @@ class ProofStream:
     def _permute(self):
         self.lib.tvm_host_tip5_permutation(self.state.ctypes.data)
 
-    def enqueue(self, name, words):
+    def enqueue(self, name, words, fiat_shamir=True):
+        """ProofStream::enqueue (proof_stream.rs:36-43): the item always goes into the proof; it alters the
+        sponge only if ProofItem::include_in_fiat_shamir_heuristic says so (proof_item.rs:96-134: roots,
+        out-of-domain rows, polynomials do; authentication structures, opened rows, FRI codeword and
+        responses do not -- the prover is already committed to them through a Merkle root)."""
         w = np.ascontiguousarray(words, dtype=np.uint64).reshape(-1)
         self.items.append((name, w.size))
-        self.lib.tvm_host_sponge_pad_and_absorb(self.state.ctypes.data, w.ctypes.data, w.size)
+        if fiat_shamir:
+            self.lib.tvm_host_sponge_pad_and_absorb(self.state.ctypes.data, w.ctypes.data, w.size)
 
     def _squeeze(self):
         out = self.state[:10].copy()
@@ -265,7 +270,7 @@ class Prover:
                 cw = stark.split_and_fold(ctx, cw, dom, challenge)
                 dom = dom.pow(2)
             last = cw.download((dom.length, 3))
-            ps.enqueue("fri last codeword", last)
+            ps.enqueue("fri last codeword", last, fiat_shamir=False)
             last_poly = ArithmeticDomain.of_length(dom.length).interpolate(ctx, cw, 3).download((dom.length, 3))
             ps.enqueue("fri last polynomial", last_poly)
             self.last_codeword, self.last_polynomial, self.last_domain = last, last_poly, dom
@@ -279,20 +284,20 @@ class Prover:
                     ix = np.array(which, np.uint64)
                     leaves = np.empty((ix.size, 3), np.uint64)
                     ctx._check(lib.tvm_gather_elements(ctx.handle, rcw.ptr, 3, ix.ctypes.data, ix.size, leaves.ctypes.data), "leaves")
-                    ps.enqueue(f"fri response {r}", leaves)
-                    ps.enqueue(f"fri auth {r}", self._auth_nodes(rnodes, rdom.length, which))
+                    ps.enqueue(f"fri response {r}", leaves, fiat_shamir=False)
+                    ps.enqueue(f"fri auth {r}", self._auth_nodes(rnodes, rdom.length, which), fiat_shamir=False)
             ps.sample_scalars(1)
 
         # 19: open the trace leafs  (stark.rs:665-716)
         with self._timed("open trace leafs"):
             for name, mt, nodes in (("main", self.main, main_nodes), ("aux", self.aux, aux_nodes)):
-                ps.enqueue(f"{name} rows", mt.reveal_rows(a_indices))
-                ps.enqueue(f"{name} auth", self._auth_nodes(nodes, L, a_indices))
+                ps.enqueue(f"{name} rows", mt.reveal_rows(a_indices), fiat_shamir=False)
+                ps.enqueue(f"{name} auth", self._auth_nodes(nodes, L, a_indices), fiat_shamir=False)
             ix = np.array(a_indices, np.uint64)
             qrows = np.empty((ix.size, 15), np.uint64)
             ctx._check(lib.tvm_table_reveal_rows(ctx.handle, qs.table, L, ix.ctypes.data, ix.size, qrows.ctypes.data), "q rows")
-            ps.enqueue("quot rows", qrows)
-            ps.enqueue("quot auth", self._auth_nodes(quot_nodes, L, a_indices))
+            ps.enqueue("quot rows", qrows, fiat_shamir=False)
+            ps.enqueue("quot auth", self._auth_nodes(quot_nodes, L, a_indices), fiat_shamir=False)
         self.main.clear_cache()
         self.aux.clear_cache()
         qs.free()

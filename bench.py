@@ -10,8 +10,10 @@ HBM: 2^20 padded rows x (379 main + 91 aux columns = 652 base-field words), the 
 BASELINE.json configs[1] (`prove_fib` at 2^20 rows, Stark::default() with FRI, expansion 4,
 198 trace randomizers).  metric = padded_rows * 652 / seconds per step, summed over ranks.
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); every rank proves its own
-instance (independent proofs: no data-path collective), barrier + max-over-ranks timing.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL over xGMI).  Default: ONE proof split over
+the N GPUs by cosets of the trace domain (triton_vm_amd/sharded.py; N must divide 8): all-gather of leaf digests
+and of the quotient codeword -- total work fixed, "scaling": "strong".  --replicas: every rank proves its own
+instance instead (no data-path collective, "scaling": "weak").  Barrier + max-over-ranks timing either way.
 """
 import argparse
 import json
@@ -51,6 +53,34 @@ def cpu_baseline(log2_rows):
                       f"at 2^{log2_rows} rows (8x extension), {dt:.1f} s; AIR/DEEP/FRI not included in the sample"}
 
 
+def timed_steps(step, steps, warmup, device_sync, dist=None, device="cuda"):
+    """The driver's timing contract: `warmup` untimed steps, then exactly `steps` steps bracketed by
+    (device sync + barrier) on both sides; returns the MAX over ranks of the elapsed seconds.
+    `dist` is torch.distributed (initialised) or None; ranks run independent proofs, so the barrier and the
+    max-reduction are the only collectives of the N > 1 path (tests/test_bench_distributed.py, gloo)."""
+    def barrier():
+        device_sync()
+        if dist is not None:
+            dist.barrier()
+            device_sync()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,6 +88,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log2-rows", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--replicas", action="store_true", help="N > 1: independent proofs per GPU instead of one sharded proof")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -76,35 +107,27 @@ def main():
 
     ctx = Context(device=local_rank)
     params = StarkParameters(args.log2_rows)
-    prover = Prover(ctx, params, seed=1000 + rank)
-    cells_per_step = params.padded_height * MASTER_WORDS
-
-    def barrier():
-        ctx.sync()
-        if dist is not None:
-            dist.barrier()
-            import torch
-
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        prover.prove()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        prover.prove()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
+    sharded = world > 1 and not args.replicas
+    if sharded:
         import torch
 
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        from triton_vm_amd.sharded import ShardedProver
+
+        prover = ShardedProver(ctx, params, dist, torch.device("cuda", local_rank), seed=1000)
+    else:
+        prover = Prover(ctx, params, seed=1000 + rank)
+    cells_per_step = params.padded_height * MASTER_WORDS * (1 if sharded else world)
+
+    elapsed = timed_steps(prover.prove, args.steps, args.warmup, ctx.sync, dist)
 
     # live timing of the dominant HBM-bound kernel family (the main-table LDE: k_ntt2_pass1, k_lde_pass2,
     # k_lde_pass3) with HIP events on the context's stream, and a per-stage breakdown of one more pass
     lde_ms = []
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+
     if rank == 0:
         for _ in range(3):
             ctx.timer_start()
@@ -123,11 +146,11 @@ def main():
         achieved = lde_cells * LDE_ALGORITHMIC_BYTES_PER_CELL / (lde_avg_ms * 1e-3) / 1e9
         out = {
             "metric": "trace-cells/sec (padded_rows x master_cols) in prove()",
-            "value": round(world * cells_per_step * args.steps / elapsed, 1),
+            "value": round(cells_per_step * args.steps / elapsed, 1),
             "unit": "trace-cells/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "u64 (F_p, p = 2^64 - 2^32 + 1, Montgomery) and its cubic extension",
             "data": "synthetic",
             "config": {"workload": f"prove() hot path, prove_fib-shaped tables: 2^{args.log2_rows} padded rows, 379 main + "
@@ -135,7 +158,9 @@ def main():
                                    "randomizers, 173 queries), traces resident in HBM; host `gen` steps (VM, pad, extend) "
                                    "and the Rust-side transcript are not part of the path",
                        "padded_rows": params.padded_height, "master_words": MASTER_WORDS,
-                       "ldt_domain": params.ldt.length, "parallelism": "1 proof per GPU" if world > 1 else "single GPU"},
+                       "ldt_domain": params.ldt.length, "parallelism": (f"one proof over {world} GPUs: coset sharding of the extended tables, all-gather of digests and "
+                                       "quotient codeword" if sharded else f"{world} independent proofs, one per GPU" if world > 1
+                                       else "single GPU")},
             "roofline": {"bound": "hbm", "kernel": "main-table LDE (k_ntt2_pass1 + k_lde_pass2 + k_lde_pass3, 12 column chunks)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,

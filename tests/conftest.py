@@ -2,6 +2,9 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  -- FIRST: torch must load its bundled HIP runtime before libtriton_hip.so pulls in the
+#                system one; a process that initialises the system runtime first makes torch.cuda report
+#                "No HIP GPUs are available" (tests/test_sharded_prover.py shares a process with the other gpu tests)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -1,0 +1,61 @@
+"""The N > 1 path of bench.py on CPU: two gloo ranks run bench.timed_steps (the driver's timing contract:
+barrier on both sides, MAX over ranks) around stand-in steps of different length.  Ranks prove independent
+instances, so this harness is all of the multi-process logic."""
+import os
+import socket
+import sys
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    calls = []
+
+    def step():
+        calls.append(1)
+        time.sleep(0.02 * (rank + 1))  # rank 1 is the slow one
+
+    elapsed = bench.timed_steps(step, steps=3, warmup=1, device_sync=lambda: None, dist=dist, device="cpu")
+    out.put((rank, elapsed, len(calls)))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_report_the_slowest():
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(out.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, e0, c0), (r1, e1, c1) = got
+    assert (c0, c1) == (4, 4)                      # 1 warm-up + 3 timed steps on every rank
+    assert e0 == pytest.approx(e1)                 # both ranks hold the max
+    assert e0 >= 3 * 0.04 - 1e-3                   # ... which is the slow rank's 3 x 40 ms
+    assert e0 < 3 * 0.04 + 0.5
+
+
+def test_single_process_needs_no_collective():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    n = []
+    assert bench.timed_steps(lambda: n.append(1), steps=2, warmup=1, device_sync=lambda: None) >= 0
+    assert len(n) == 3

@@ -1,0 +1,112 @@
+"""One proof split over two ranks (triton_vm_amd/sharded.py: coset sharding, gloo on CPU, the kernels on the
+TEST-ONLY fiber emulation) must commit to the same roots, sample the same challenges and hand FRI the same
+combination codeword as the single-process prover on the same traces."""
+import os
+import socket
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LOG2_ROWS, H, QUERIES, SEED = 3, 3, 2, 5
+
+
+def _traces():
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng(77)
+    n = 1 << (LOG2_ROWS + 1)
+    return orc.random_elements(rng, (379, n)), orc.random_elements(rng, (91, n, 3))
+
+
+def _capture(prover):
+    prover.capture = {}
+    prover.prove()
+    c = prover.capture
+    keys = ("main_root", "aux_root", "quot_root", "challenges", "alpha", "ood_main", "ood_aux", "combination")
+    return {k: np.array(c[k]) for k in keys} | {"last_polynomial": prover.last_polynomial,
+                                                "main rows": prover.opened["main"], "aux rows": prover.opened["aux"]}
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from tests.emu_fixture import emu_context
+    from triton_vm_amd.prover import StarkParameters
+    from triton_vm_amd.sharded import ShardedProver
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    ctx = emu_context()
+    p = StarkParameters(LOG2_ROWS, num_trace_randomizers=H, num_collinearity_checks=QUERIES)
+    main_trace, aux_trace = _traces()
+    prover = ShardedProver(ctx, p, dist, torch.device("cpu"), main_trace, aux_trace, seed=SEED)
+    got = _capture(prover)
+    out.put((rank, got))
+    dist.destroy_process_group()
+    ctx.close()
+
+
+def test_two_rank_proof_equals_single_process_proof():
+    import torch.multiprocessing as mp
+
+    from tests.emu_fixture import emu_context
+    from triton_vm_amd.prover import Prover, StarkParameters
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mpctx = mp.get_context("spawn")
+    out = mpctx.Queue()
+    procs = [mpctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+
+    ctx = emu_context()
+    p = StarkParameters(LOG2_ROWS, num_trace_randomizers=H, num_collinearity_checks=QUERIES)
+    main_trace, aux_trace = _traces()
+    single = Prover(ctx, p, main_trace, aux_trace, seed=SEED)
+    want = _capture(single)
+    ctx.close()
+
+    results = dict(out.get(timeout=600) for _ in procs)
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    for rank in (0, 1):
+        for key, value in want.items():
+            assert (results[rank][key] == value).all(), (rank, key)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_sharded_prover_on_one_gpu_matches_plain_prover():
+    """The torch-tensor / RCCL plumbing of ShardedProver on the real device (a one-rank nccl group: the
+    collectives are identities, the data path through torch-owned device memory is not)."""
+    import torch
+    import torch.distributed as dist
+
+    from triton_vm_amd import Context
+    from triton_vm_amd.prover import Prover, StarkParameters
+    from triton_vm_amd.sharded import ShardedProver
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        ctx = Context(0)
+        p = StarkParameters(10)
+        want = _capture(Prover(ctx, p, seed=9))
+        got = _capture(ShardedProver(ctx, p, dist, torch.device("cuda", 0), seed=9))
+        for key, value in want.items():
+            assert (got[key] == value).all(), key
+        ctx.close()
+    finally:
+        dist.destroy_process_group()

@@ -24,6 +24,8 @@
 //   pass3  forward rows step (DIT) for 16 table columns at once  reads Z,       writes the table
 // Algorithmic HBM bytes per base-field trace cell: 8 (read) + 8*X (write) = 72 at X = 8; the
 // scheme moves 8*(1+1+1+X+X+X) = 216.
+#include <cstdlib>
+
 #include "context.h"
 
 namespace tvm {
@@ -428,8 +430,21 @@ static int threads_for_tile(int tile) {
     if (t > 1024) t = 1024;
     return t;
 }
+// Tile = 2^log_axis points x 2^batch transforms.  TVM_TILE_WORDS_LOG (env, experiments) caps the tile size:
+// 14 = 128 KiB (one 1024-thread workgroup per CU), 13 = 64 KiB (two 512-thread workgroups per CU, which lets
+// one workgroup's global loads/stores overlap the other's butterflies).
+static int tile_words_log() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("TVM_TILE_WORDS_LOG");
+        v = e ? atoi(e) : 14;
+        if (v < 10 || v > 14) v = 14;
+    }
+    return v;
+}
 static int batch_log_for(int log_axis) {
-    int b = 14 - log_axis;  // tile of at most 2^14 words = 128 KiB
+    int b = tile_words_log() - log_axis;
+    if (b < 0) b = 0;
     return b > 4 ? 4 : b;
 }
 

@@ -118,7 +118,7 @@ class Prover:
             self.main = MasterTable(ctx, main_trace, rnd(NUM_MAIN, h), *dom, 1)
             self.aux = MasterTable(ctx, aux_trace, rnd(NUM_AUX, h, 3), *dom, 3)
         self.quotient_randomizer = rng.integers(0, field.P, size=(params.num_quotient_randomizers, 3), dtype=np.uint64)
-        self.timings, self.wall = {}, {}
+        self.timings, self.wall, self.opened = {}, {}, {}
         self.capture = None
 
     def _init_synthetic(self, mt, fk, n_cols, n, h, dom, seed):
@@ -155,6 +155,21 @@ class Prover:
         self.ctx._check(self.ctx.lib.tvm_table_merkle_tree(self.ctx.handle, table_handle, n, d.ptr), "merkle")
         return d
 
+    # -- the three steps that touch whole extended master tables; triton_vm_amd/sharded.py overrides them to
+    #    split the extended rows across GPUs --------------------------------------------------------------
+    def _commit_master_table(self, mt):
+        """hash_all_ldt_domain_rows + merkle_tree (master_table.rs:443-468) -> device node array [2L][5]"""
+        return self._table_tree(mt._need_table(), self.p.ldt.length)
+
+    def _quotient_codeword(self, challenges, quotient_weights):
+        """all_quotients_combined over the quotient domain (master_table.rs:1264-1363) -> device XFE vector"""
+        return stark.all_quotients_combined(self.ctx, self.main, self.aux, self.p.trace, self.p.quotient, challenges,
+                                            quotient_weights)
+
+    def _reveal_master_rows(self, mt, row_indices):
+        """reveal_rows (master_table.rs:548-555) -> host array"""
+        return mt.reveal_rows(row_indices)
+
     def _auth_nodes(self, d_nodes, n_leaves, indices):
         """the sibling nodes on the paths of the opened leaves (what authentication_structure needs)"""
         k = np.unique(np.asarray(indices, dtype=np.uint64) + np.uint64(n_leaves))
@@ -180,7 +195,7 @@ class Prover:
         with self._timed("main LDE"):
             self.main.maybe_low_degree_extend_all_columns()
         with self._timed("main Merkle"):
-            main_nodes = self._table_tree(self.main._need_table(), L)
+            main_nodes = self._commit_master_table(self.main)
         ps.enqueue("main root", self._root(main_nodes))
         challenges = ps.sample_scalars(NUM_CHALLENGES)
 
@@ -188,13 +203,13 @@ class Prover:
         with self._timed("aux LDE"):
             self.aux.maybe_low_degree_extend_all_columns()
         with self._timed("aux Merkle"):
-            aux_nodes = self._table_tree(self.aux._need_table(), L)
+            aux_nodes = self._commit_master_table(self.aux)
         ps.enqueue("aux root", self._root(aux_nodes))
         quotient_weights = xfe_powers(lib, ps.sample_scalars(1)[0], 0, NUM_CONSTRAINTS)
 
         # 10: quotient codeword, segments, randomization  (stark.rs:405-423)
         with self._timed("AIR quotients"):
-            d_quot = stark.all_quotients_combined(ctx, self.main, self.aux, p.trace, p.quotient, challenges, quotient_weights)
+            d_quot = self._quotient_codeword(challenges, quotient_weights)
         with self._timed("quotient segments LDE"):
             qs = stark.quotient_segments(ctx, d_quot, p.quotient, p.ldt, self.quotient_randomizer)
         del d_quot
@@ -291,7 +306,9 @@ class Prover:
         # 19: open the trace leafs  (stark.rs:665-716)
         with self._timed("open trace leafs"):
             for name, mt, nodes in (("main", self.main, main_nodes), ("aux", self.aux, aux_nodes)):
-                ps.enqueue(f"{name} rows", mt.reveal_rows(a_indices), fiat_shamir=False)
+                rows = self._reveal_master_rows(mt, a_indices)
+                self.opened[name] = rows
+                ps.enqueue(f"{name} rows", rows, fiat_shamir=False)
                 ps.enqueue(f"{name} auth", self._auth_nodes(nodes, L, a_indices), fiat_shamir=False)
             ix = np.array(a_indices, np.uint64)
             qrows = np.empty((ix.size, 15), np.uint64)

@@ -144,6 +144,12 @@ def main():
         lde_avg_ms = sum(lde_ms) / len(lde_ms)
         lde_cells = params.trace.length * 379
         achieved = lde_cells * LDE_ALGORITHMIC_BYTES_PER_CELL / (lde_avg_ms * 1e-3) / 1e9
+        traffic = None  # fabric-side bytes per LDE launch family, from the committed PMC run (profiles/lde_traffic.json)
+        try:
+            with open(os.path.join(ROOT, "profiles", "lde_traffic.json")) as f:
+                traffic = int(json.load(f)["hbm_bytes_per_trace_cell"] * lde_cells)
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "trace-cells/sec (padded_rows x master_cols) in prove()",
             "value": round(cells_per_step * args.steps / elapsed, 1),
@@ -163,7 +169,7 @@ def main():
                                        else "single GPU")},
             "roofline": {"bound": "hbm", "kernel": "main-table LDE (k_ntt2_pass1 + k_lde_pass2 + k_lde_pass3, 12 column chunks)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "launch_ms": round(lde_avg_ms, 3),
                          "algorithmic_bytes_per_launch": lde_cells * LDE_ALGORITHMIC_BYTES_PER_CELL},
             "stage_ms": {k: round(v, 3) for k, v in prover.timings.items()},

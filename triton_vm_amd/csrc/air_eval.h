@@ -39,7 +39,79 @@ struct AirArgs {
     u64* out;                // q_len XFE
 };
 
-// sum_k w_k * c_k, kept as an XFE
+// The accumulator of  sum_k w_k * c_k  for one group of constraints.
+#ifdef TVM_FIELD_ASM
+// Device form: the 128-bit products are summed unreduced, one Montgomery reduction per coefficient and group
+// instead of one per product.  With w = (w0, w1, w2), x = (x0, x1, x2) and X^3 = X - 1:
+//   w*x = (d0 - d3) + (d1 + d3 - d4) X + (d2 + d4) X^2,   d0 = w0x0, d1 = w0x1 + w1x0, d2 = w0x2 + w1x1 + w2x0,
+//   d3 = w1x2 + w2x1, d4 = w2x2,
+// so five 160-bit sums D0..D4 (a group has <= 25 constraints: < 2^135).  A product-accumulate is 4 v_mad_u64_u32
+// + a 5-limb carry chain (13 VALU instructions; reduce-then-add is 24).
+struct Acc160 {
+    u32 l0, l1, l2, l3, l4;
+};
+TVM_D void acc160_mac(Acc160& A, u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 t = (u64)a0 * b0;
+    const u64 u = (u64)a0 * b1 + (t >> 32);
+    const u64 v = (u64)a1 * b0 + (u32)u;
+    const u64 w = (u64)a1 * b1 + ((u >> 32) + (v >> 32));  // the product is (w : v.lo : t.lo) < 2^128
+    asm("v_add_co_u32 %[l0], vcc, %[l0], %[x0]\n\t" TVM_VCC_WAIT
+        "v_addc_co_u32 %[l1], vcc, %[l1], %[x1], vcc\n\t" TVM_VCC_WAIT
+        "v_addc_co_u32 %[l2], vcc, %[l2], %[x2], vcc\n\t" TVM_VCC_WAIT
+        "v_addc_co_u32 %[l3], vcc, %[l3], %[x3], vcc\n\t" TVM_VCC_WAIT
+        "v_addc_co_u32 %[l4], vcc, 0, %[l4], vcc"
+        : [l0] "+v"(A.l0), [l1] "+v"(A.l1), [l2] "+v"(A.l2), [l3] "+v"(A.l3), [l4] "+v"(A.l4)
+        : [x0] "v"((u32)t), [x1] "v"((u32)v), [x2] "v"((u32)w), [x3] "v"((u32)(w >> 32))
+        : "vcc");
+}
+// (l4 : l3 : l2 : l1 : l0) * 2^-64 mod p, canonical: fold the top 96 bits modulo p, then one Montgomery reduction
+TVM_D u64 acc160_value(const Acc160& A) {
+    const u64 lo = ((u64)A.l1 << 32) | A.l0, mid = ((u64)A.l3 << 32) | A.l2;
+    u64 t = (u64)A.l4 * TVM_EPS;  // l4 * 2^64 mod p, l4 < 2^32
+    u64 r = mid + t;
+    if (r < t) r += TVM_EPS;
+    if (r >= TVM_P) r -= TVM_P;
+    return bfe_montyred(lo, r);
+}
+struct AirAcc {
+    Acc160 d[5];
+};
+TVM_D AirAcc air_acc_zero() {
+    AirAcc a;
+#pragma unroll
+    for (int i = 0; i < 5; i++) a.d[i].l0 = a.d[i].l1 = a.d[i].l2 = a.d[i].l3 = a.d[i].l4 = 0;
+    return a;
+}
+TVM_D void air_acc_b(AirAcc& a, xfe w, u64 c) {
+    acc160_mac(a.d[0], w.c0, c);
+    acc160_mac(a.d[1], w.c1, c);
+    acc160_mac(a.d[2], w.c2, c);
+}
+TVM_D void air_acc_x(AirAcc& a, xfe w, xfe x) {
+    acc160_mac(a.d[0], w.c0, x.c0);
+    acc160_mac(a.d[1], w.c0, x.c1);
+    acc160_mac(a.d[1], w.c1, x.c0);
+    acc160_mac(a.d[2], w.c0, x.c2);
+    acc160_mac(a.d[2], w.c1, x.c1);
+    acc160_mac(a.d[2], w.c2, x.c0);
+    acc160_mac(a.d[3], w.c1, x.c2);
+    acc160_mac(a.d[3], w.c2, x.c1);
+    acc160_mac(a.d[4], w.c2, x.c2);
+}
+TVM_D xfe air_acc_value(const AirAcc& a) {
+    const u64 d0 = acc160_value(a.d[0]), d1 = acc160_value(a.d[1]), d2 = acc160_value(a.d[2]);
+    const u64 d3 = acc160_value(a.d[3]), d4 = acc160_value(a.d[4]);
+    return xfe_make(bfe_sub(d0, d3), bfe_sub(bfe_add(d1, d3), d4), bfe_add(d2, d4));
+}
+#define AIR_PIN_ACC(acc)                                                                                           \
+    do {                                                                                                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < 5; i_++)                                                           \
+            asm volatile("" : "+v"((acc).d[i_].l0), "+v"((acc).d[i_].l1), "+v"((acc).d[i_].l2), "+v"((acc).d[i_].l3), \
+                              "+v"((acc).d[i_].l4));                                                               \
+    } while (0)
+#else
+// Emulator form: reduce every product (same value: the arithmetic is exact).
 struct AirAcc {
     xfe v;
 };
@@ -51,6 +123,8 @@ TVM_D AirAcc air_acc_zero() {
 TVM_D void air_acc_b(AirAcc& a, xfe w, u64 c) { a.v = xfe_add(a.v, xfe_mul_bfe(w, c)); }
 TVM_D void air_acc_x(AirAcc& a, xfe w, xfe c) { a.v = xfe_add(a.v, xfe_mul(w, c)); }
 TVM_D xfe air_acc_value(const AirAcc& a) { return a.v; }
+#define AIR_PIN_ACC(acc) (void)0
+#endif
 TVM_D xfe xfe_bfe_sub(u64 b, xfe x) { return xfe_make(bfe_sub(b, x.c0), bfe_neg(x.c1), bfe_neg(x.c2)); }
 
 // Addressing: a workgroup covers AIR_BLOCK consecutive quotient-domain rows, so every table cell it reads
@@ -115,7 +189,6 @@ TVM_D xfe xfe_bfe_sub(u64 b, xfe x) { return xfe_make(bfe_sub(b, x.c0), bfe_neg(
 #define AIR_PIN_B(v) asm volatile("" : "+v"(v))
 #define AIR_PIN_X(v) asm volatile("" : "+v"((v).c0), "+v"((v).c1), "+v"((v).c2))
 #endif
-#define AIR_PIN_ACC(acc) AIR_PIN_X((acc).v)
 
 #define AIR_EPILOGUE(accumulate)                                        \
     if (active_) {                                                      \

@@ -53,22 +53,76 @@ __global__ void k_ood_weights(u64 gen, u64 n, const u64* __restrict__ points, in
         st_xfe(u + ((u64)p * n + j) * 3, xfe_mul_bfe(inv, d));
     }
 }
-// num[p][c] = sum_j cell(c, j) * u[p][j]; column index n_cols is the all-ones column (denominator)
+// partial[p][c][chunk] = sum over the rows j of the chunk of cell(c, j) * u[p][j]; column index n_cols is the
+// all-ones column (the barycentric denominator).  A workgroup owns G columns and one chunk of rows: each
+// work-item reads the weights u[.][j] of its row once and the G cells next to them, so the trace is read once
+// per pass and u once per column group (the first version re-read u for every column: 19 GB at 2^20 rows).
+#define TVM_DOT_G 8        // columns per workgroup
+#define TVM_DOT_P 2        // points per pass
+TVM_D u64 wave_sum_u64(u64 v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = bfe_add(v, __shfl_xor(v, m, 64));
+    return v;
+}
 __global__ void __launch_bounds__(TVM_RED_BLOCK) k_column_dot(const u64* __restrict__ trace, int fk, u64 n, u64 n_cols,
-                                                               const u64* __restrict__ u, int n_points,
-                                                               u64* __restrict__ num) {
-    __shared__ u64 smem[3 * TVM_RED_BLOCK];
+                                                               const u64* __restrict__ u, int p0, int n_points,
+                                                               u64 rows_per_chunk, u64 n_chunks, u64* __restrict__ partial) {
+    __shared__ u64 smem[TVM_RED_BLOCK / 64][TVM_DOT_G * TVM_DOT_P * 3];
     const int tid = threadIdx.x, nt = blockDim.x;
-    const u64 c = blockIdx.x;
-    const int p = blockIdx.y;
-    xfe acc = xfe_zero();
-    const u64* up = u + (u64)p * n * 3;
-    for (u64 j = tid; j < n; j += nt) {
-        xfe w = ld_xfe(up + 3 * j);
-        acc = xfe_add(acc, c < n_cols ? cell_times(trace, fk, n, c, j, w) : w);
+    const u64 c0 = (u64)blockIdx.x * TVM_DOT_G;
+    const u64 chunk = blockIdx.y;
+    const u64 r0 = chunk * rows_per_chunk, r1 = (r0 + rows_per_chunk < n) ? r0 + rows_per_chunk : n;
+    const int np = (n_points - p0 < TVM_DOT_P) ? n_points - p0 : TVM_DOT_P;
+    xfe acc[TVM_DOT_G][TVM_DOT_P];
+#pragma unroll
+    for (int g = 0; g < TVM_DOT_G; g++)
+#pragma unroll
+        for (int q = 0; q < TVM_DOT_P; q++) acc[g][q] = xfe_zero();
+    for (u64 j = r0 + tid; j < r1; j += nt) {
+        xfe w[TVM_DOT_P];
+#pragma unroll
+        for (int q = 0; q < TVM_DOT_P; q++) w[q] = (q < np) ? ld_xfe(u + ((u64)(p0 + q) * n + j) * 3) : xfe_zero();
+#pragma unroll
+        for (int g = 0; g < TVM_DOT_G; g++) {
+            const u64 c = c0 + g;
+            if (c < n_cols) {
+                const u64* cp = trace + (c * n + j) * fk;
+                if (fk == 1) {
+                    const u64 x = cp[0];
+#pragma unroll
+                    for (int q = 0; q < TVM_DOT_P; q++) acc[g][q] = xfe_add(acc[g][q], xfe_mul_bfe(w[q], x));
+                } else {
+                    const xfe x = ld_xfe(cp);
+#pragma unroll
+                    for (int q = 0; q < TVM_DOT_P; q++) acc[g][q] = xfe_add(acc[g][q], xfe_mul(x, w[q]));
+                }
+            } else if (c == n_cols) {
+#pragma unroll
+                for (int q = 0; q < TVM_DOT_P; q++) acc[g][q] = xfe_add(acc[g][q], w[q]);
+            }
+        }
     }
-    xfe s = block_sum_xfe(acc, smem, tid, nt);
-    if (tid == 0) st_xfe(num + ((u64)p * (n_cols + 1) + c) * 3, s);
+    // wavefront sums by lane exchange, then the (<= 4) wavefronts of the workgroup through LDS
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int g = 0; g < TVM_DOT_G; g++)
+#pragma unroll
+        for (int q = 0; q < TVM_DOT_P; q++) {
+            const u64 s0 = wave_sum_u64(acc[g][q].c0), s1 = wave_sum_u64(acc[g][q].c1), s2 = wave_sum_u64(acc[g][q].c2);
+            if (lane == 0) {
+                smem[wave][(g * TVM_DOT_P + q) * 3 + 0] = s0;
+                smem[wave][(g * TVM_DOT_P + q) * 3 + 1] = s1;
+                smem[wave][(g * TVM_DOT_P + q) * 3 + 2] = s2;
+            }
+        }
+    __syncthreads();
+    if (tid < TVM_DOT_G * TVM_DOT_P * 3) {
+        u64 s = 0;
+        for (int wv = 0; wv < nt / 64; wv++) s = bfe_add(s, smem[wv][tid]);
+        const int comp = tid % 3, q = (tid / 3) % TVM_DOT_P, g = tid / (3 * TVM_DOT_P);
+        const u64 c = c0 + g;
+        if (c <= n_cols && q < np) partial[(((u64)(p0 + q) * (n_cols + 1) + c) * n_chunks + chunk) * 3 + comp] = s;
+    }
 }
 // row[p][c] = num/den + (alpha^N - 1) * r_c(alpha)
 __global__ void k_ood_finalize(const u64* __restrict__ num, const u64* __restrict__ rnd, int fk, u64 n, u64 n_cols, u64 h,
@@ -253,8 +307,16 @@ int out_of_domain_rows(tvm_ctx* c, int fk, const u64* trace, u64 n, u64 n_cols, 
     u64* num = (u64*)scratch(c, 7, (size_t)n_points * (n_cols + 1) * 3 * sizeof(u64));
     if (!u || !num) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "ood scratch");
     TVM_LAUNCH(k_ood_weights, TVM_GRID(n, 256), dim3(256), 0, c->stream, trace_gen, n, d_points, n_points, u);
-    TVM_LAUNCH(k_column_dot, dim3((unsigned)(n_cols + 1), (unsigned)n_points), dim3(TVM_RED_BLOCK), 0, c->stream, trace, fk,
-               n, n_cols, u, n_points, num);
+    // rows in chunks of 2^15 (128 rows per work-item), columns in groups of TVM_DOT_G, points two at a time
+    const u64 rows_per_chunk = n < (1ull << 15) ? n : (1ull << 15);
+    const u64 n_chunks = (n + rows_per_chunk - 1) / rows_per_chunk;
+    const u64 n_sums = (u64)n_points * (n_cols + 1);
+    u64* partial = (u64*)scratch(c, 8, (size_t)n_sums * n_chunks * 3 * sizeof(u64));
+    if (!partial) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "ood scratch");
+    for (int p0 = 0; p0 < n_points; p0 += TVM_DOT_P)
+        TVM_LAUNCH(k_column_dot, dim3((unsigned)((n_cols + 1 + TVM_DOT_G - 1) / TVM_DOT_G), (unsigned)n_chunks),
+                   dim3(TVM_RED_BLOCK), 0, c->stream, trace, fk, n, n_cols, u, p0, n_points, rows_per_chunk, n_chunks, partial);
+    TVM_LAUNCH(k_sum_partials, dim3((unsigned)n_sums), dim3(TVM_RED_BLOCK), 0, c->stream, partial, n_chunks, num);
     TVM_LAUNCH(k_ood_finalize, TVM_GRID(n_cols * n_points, 64), dim3(64), 0, c->stream, num, rnd, fk, n, n_cols, h,
                d_points, n_points, d_rows);
     TVM_HIP_CHECK(c, hipGetLastError());

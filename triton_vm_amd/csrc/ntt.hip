@@ -338,6 +338,104 @@ __global__ void __launch_bounds__(1024) k_lde_pass3(LdePass3Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Passes 2 and 3 for the production shape: tiles of 16 rows, one work-item per point of the LDS-resident
+// axis (blockDim.x == n2 resp. n1 >= 64).  Same results as k_lde_pass2 / k_lde_pass3; what changes is that
+// every index a work-item needs is either its own constant or uniform across the workgroup, so the scale
+// and store phases carry no per-element index arithmetic:
+//   * work-item tid owns position q = tid of all 16 rows: m1 = brev(tid) is its constant, m2 = brev(p0 + e)
+//     is uniform, and only work-items with m1*n1 < h ever see a randomizer coefficient;
+//   * gamma_k^m / N = gamma_k^(n1*m1) * (gamma_k^m2 / N): the first factor is applied before the column
+//     step (one load per coset, one multiplication per element), the second is a per-row constant, commutes
+//     with the column step and is merged into the inter-pass twiddle of the store phase, which itself is a
+//     running product  T(j1 + n2/16) = T(j1) * w_N^(m2*n2/16)  instead of two table loads per element.
+__global__ void __launch_bounds__(1024) k_lde_pass2_v2(LdePass2Args a) {
+    TVM_DYN_SMEM(u64, s);
+    const int tid = threadIdx.x, nt = blockDim.x;  // nt == n2
+    const u64 n1 = 1ull << a.log_n1;
+    const int n2 = 1 << a.log_n2;
+    const int RS = n2 + TVM_ROW_PAD;
+    const int vl = blockIdx.y, v = a.col0 + vl;
+    const u64 p0 = (u64)blockIdx.x * 16;
+    const u64 n = n1 << a.log_n2;
+    const u64* y = a.y + (u64)vl * n + p0 * n2;
+#pragma unroll
+    for (int e = 0; e < 16; e++) s[e * RS + tid] = y[(u64)e * n2 + tid];
+    __syncthreads();
+    lds_ntt<false>(s, a.log_n2, 4, 1, RS, a.tw_a2, tid, nt);  // position q of row e: N * t[m1*n1 + m2], m1 = brev(q)
+
+    u64 coef[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) coef[e] = s[e * RS + tid];
+    const u64 m1 = brev_bits((u32)tid, a.log_n2);
+    const bool has_rnd = m1 * n1 < a.h;  // a wavefront-uniform "no" for all but the first work-items
+    const u64* rnd = a.rnd + (u64)(v / a.fk) * a.h * a.fk + (v % a.fk);
+    // store phase: this work-item writes row b = tid % 16, columns j1 = tid / 16 + i * n2/16, i < 16
+    const int b_out = tid & 15, j1_0 = tid >> 4;
+    const u64 m2_out = brev_bits((u32)(p0 + b_out), a.log_n1);
+    const int j1_step = n2 >> 4;                                          // 16 elements per work-item
+    const u64 t_step = pow2_get(a.tw_inter, (m2_out * (u64)j1_step) & (n - 1));  // w_N^(m2 * n2/16)
+    const u64 t_first = pow2_get(a.tw_inter, m2_out * (u64)j1_0);       // w_N^(m2*j1_0)
+    for (int k = 0; k < a.n_cosets; k++) {
+        __syncthreads();
+        const u64 gh = a.g_hi[(u64)k * n2 + m1];  // gamma_k^(n1*m1)
+        if (has_rnd) {
+            const u64 zk = a.zk[k];
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const u64 m = m1 * n1 + brev_bits((u32)(p0 + e), a.log_n1);
+                u64 c = coef[e];
+                if (m < a.h) c = bfe_add(c, bfe_mul(zk, rnd[m * a.fk]));
+                s[e * RS + tid] = bfe_mul(c, gh);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; e++) s[e * RS + tid] = bfe_mul(coef[e], gh);
+        }
+        __syncthreads();
+        lds_ntt<true, 3>(s, a.log_n2, 4, 1, RS, a.tw_b1, tid, nt);  // coef[] stays live: 8-element groups
+        u64* z = a.z + ((u64)vl * a.n_cosets + k) * n + p0 + b_out;
+        u64 t = bfe_mul(t_first, a.g_lo[(u64)k * n1 + m2_out]);  // w_N^(m2*j1) * gamma_k^m2 / N at j1 = j1_0
+#pragma unroll 4
+        for (int i = 0; i < 16; i++) {
+            const int j1 = j1_0 + i * j1_step;
+            z[(u64)j1 * n1] = bfe_mul(s[b_out * RS + j1], t);
+            t = bfe_mul(t, t_step);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_lde_pass3_v2(LdePass3Args a) {
+    TVM_DYN_SMEM(u64, s);
+    const int tid = threadIdx.x, nt = blockDim.x;  // nt == n1
+    const int n1 = 1 << a.log_n1;
+    const u64 n2 = 1ull << a.log_n2;
+    const int RS = n1 + TVM_ROW_PAD;
+    const u64 X = (u64)a.n_cosets;
+    const u64 period = X * n2;                  // rows per j2, a multiple of 16
+    const u64 rho0 = (u64)blockIdx.x * 16;      // first local row of the tile
+    const int vl = blockIdx.y;
+    const u64* zc = a.z + (u64)vl * X * (n2 << a.log_n1) + tid;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const u64 rho = rho0 + e, j1 = rho / X, k = rho % X;  // uniform
+        s[e * RS + tid] = zc[(k * n2 + j1) << a.log_n1];
+    }
+    __syncthreads();
+    lds_ntt<true>(s, a.log_n1, 4, 1, RS, a.tw_b2, tid, nt);
+    const int b = tid & 15, j2_0 = tid >> 4;
+    const u64 W = (u64)a.W;
+    // row period*j2 + rho0 + b of column v: ((row / 16) * W + v) * 16 + b, row / 16 = (period / 16) * j2 + rho0 / 16
+    u64* out = a.table + (((rho0 >> TVM_RB_LOG) * W + (u64)(a.col0 + vl)) << TVM_RB_LOG) + b;
+    const u64 j2_stride = ((period >> TVM_RB_LOG) * W) << TVM_RB_LOG;
+    const int j2_step = n1 >> 4;
+#pragma unroll 4
+    for (int i = 0; i < 16; i++) {
+        const int j2 = j2_0 + i * j2_step;
+        out[(u64)j2 * j2_stride] = s[b * RS + j2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 const u64* pow_table(tvm_ctx* c, u64 base, u64 count, u64 scale) {
     auto key = std::make_tuple(base, count, scale);
@@ -457,6 +555,8 @@ static void set_lds_attributes() {
     (void)hipFuncSetAttribute((const void*)k_ntt2_pass2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass2_v2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass3_v2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
 }
 
 // lo[k][i] = scale * gamma_k^i (i < n1), hi[k][i] = gamma_k^(n1*i) (i < n2), gamma_k = offset * gen^k
@@ -661,7 +761,10 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             const int tile = (int)n2 << a.batch_log;
             dim3 grid((unsigned)((n1 + B - 1) / B), (unsigned)nc);
             const size_t lds = (size_t)B * (n2 + TVM_ROW_PAD) * sizeof(u64);
-            TVM_LAUNCH(k_lde_pass2, grid, dim3(threads_for_tile(tile)), lds, c->stream, a);
+            if (a.batch_log == 4 && n2 >= 64 && n1 >= 16)  // production shape: one work-item per column of the tile
+                TVM_LAUNCH(k_lde_pass2_v2, grid, dim3((unsigned)n2), lds, c->stream, a);
+            else
+                TVM_LAUNCH(k_lde_pass2, grid, dim3(threads_for_tile(tile)), lds, c->stream, a);
         }
         {
             LdePass3Args a = p3;
@@ -671,7 +774,10 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             const int tile = (int)n1 << a.rows_log;
             dim3 grid((unsigned)((X * n2 + RB - 1) / RB), (unsigned)nc);
             const size_t lds = ((size_t)(n1 + TVM_ROW_PAD) << a.rows_log) * sizeof(u64);
-            TVM_LAUNCH(k_lde_pass3, grid, dim3(threads_for_tile(tile)), lds, c->stream, a);
+            if (a.rows_log == 4 && n1 >= 64 && (X * n2) % 16 == 0)
+                TVM_LAUNCH(k_lde_pass3_v2, grid, dim3((unsigned)n1), lds, c->stream, a);
+            else
+                TVM_LAUNCH(k_lde_pass3, grid, dim3(threads_for_tile(tile)), lds, c->stream, a);
         }
     }
     TVM_HIP_CHECK(c, hipGetLastError());

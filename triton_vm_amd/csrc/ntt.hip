@@ -366,6 +366,10 @@ __global__ void __launch_bounds__(1024) k_lde_pass2_v2(LdePass2Args a) {
     u64 coef[16];
 #pragma unroll
     for (int e = 0; e < 16; e++) coef[e] = s[e * RS + tid];
+    // the forward twiddles w_N2^e (n2/2 words) live in LDS behind the tile for the X column steps that follow:
+    // an LDS read costs a fraction of the L1-hit latency of the same table in global memory
+    u64* tw_fwd = s + 16 * RS;
+    if (tid < (n2 >> 1)) tw_fwd[tid] = a.tw_b1[tid];
     const u64 m1 = brev_bits((u32)tid, a.log_n2);
     const bool has_rnd = m1 * n1 < a.h;  // a wavefront-uniform "no" for all but the first work-items
     const u64* rnd = a.rnd + (u64)(v / a.fk) * a.h * a.fk + (v % a.fk);
@@ -392,7 +396,7 @@ __global__ void __launch_bounds__(1024) k_lde_pass2_v2(LdePass2Args a) {
             for (int e = 0; e < 16; e++) s[e * RS + tid] = bfe_mul(coef[e], gh);
         }
         __syncthreads();
-        lds_ntt<true, 3>(s, a.log_n2, 4, 1, RS, a.tw_b1, tid, nt);  // coef[] stays live: 8-element groups
+        lds_ntt<true, 3>(s, a.log_n2, 4, 1, RS, tw_fwd, tid, nt);  // coef[] stays live: 8-element groups
         u64* z = a.z + ((u64)vl * a.n_cosets + k) * n + p0 + b_out;
         u64 t = bfe_mul(t_first, a.g_lo[(u64)k * n1 + m2_out]);  // w_N^(m2*j1) * gamma_k^m2 / N at j1 = j1_0
 #pragma unroll 4
@@ -411,17 +415,22 @@ __global__ void __launch_bounds__(1024) k_lde_pass3_v2(LdePass3Args a) {
     const u64 n2 = 1ull << a.log_n2;
     const int RS = n1 + TVM_ROW_PAD;
     const u64 X = (u64)a.n_cosets;
+    const int log_x = 31 - __builtin_clz((unsigned)a.n_cosets);
     const u64 period = X * n2;                  // rows per j2, a multiple of 16
-    const u64 rho0 = (u64)blockIdx.x * 16;      // first local row of the tile
-    const int vl = blockIdx.y;
+    // adjacent workgroups = adjacent table columns of the same 16 rows: together they write runs of
+    // chunk_cols * 128 contiguous bytes of the row-block-major table instead of lines 48 KiB apart
+    const u64 rho0 = (u64)blockIdx.y * 16;      // first local row of the tile
+    const int vl = blockIdx.x;
     const u64* zc = a.z + (u64)vl * X * (n2 << a.log_n1) + tid;
 #pragma unroll
     for (int e = 0; e < 16; e++) {
-        const u64 rho = rho0 + e, j1 = rho / X, k = rho % X;  // uniform
+        const u64 rho = rho0 + e, j1 = rho >> log_x, k = rho & (X - 1);  // uniform; X is a power of two
         s[e * RS + tid] = zc[(k * n2 + j1) << a.log_n1];
     }
+    u64* tw_fwd = s + 16 * RS;  // twiddles in LDS (see k_lde_pass2_v2)
+    if (tid < (n1 >> 1)) tw_fwd[tid] = a.tw_b2[tid];
     __syncthreads();
-    lds_ntt<true>(s, a.log_n1, 4, 1, RS, a.tw_b2, tid, nt);
+    lds_ntt<true>(s, a.log_n1, 4, 1, RS, tw_fwd, tid, nt);
     const int b = tid & 15, j2_0 = tid >> 4;
     const u64 W = (u64)a.W;
     // row period*j2 + rho0 + b of column v: ((row / 16) * W + v) * 16 + b, row / 16 = (period / 16) * j2 + rho0 / 16
@@ -682,7 +691,11 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     const Split sp = split_for(N);
     const u64 n1 = 1ull << sp.log_n1, n2 = 1ull << sp.log_n2;
     const int W = (int)(n_cols * fk);
-    if (chunk_cols <= 0) chunk_cols = 32;
+    if (chunk_cols <= 0) {
+        const char* e = getenv("TVM_LDE_CHUNK_COLS");  // experiments
+        chunk_cols = e ? atoi(e) : 32;
+        if (chunk_cols < 1 || chunk_cols > 512) chunk_cols = 32;
+    }
 
     const u64 w = trace_gen, wi = bfe_inv(trace_gen);
     const u64 n_inv = bfe_inv(bfe_from_u64(N));
@@ -762,7 +775,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             dim3 grid((unsigned)((n1 + B - 1) / B), (unsigned)nc);
             const size_t lds = (size_t)B * (n2 + TVM_ROW_PAD) * sizeof(u64);
             if (a.batch_log == 4 && n2 >= 64 && n1 >= 16)  // production shape: one work-item per column of the tile
-                TVM_LAUNCH(k_lde_pass2_v2, grid, dim3((unsigned)n2), lds, c->stream, a);
+                TVM_LAUNCH(k_lde_pass2_v2, grid, dim3((unsigned)n2), lds + (n2 / 2) * sizeof(u64), c->stream, a);
             else
                 TVM_LAUNCH(k_lde_pass2, grid, dim3(threads_for_tile(tile)), lds, c->stream, a);
         }
@@ -774,8 +787,8 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             const int tile = (int)n1 << a.rows_log;
             dim3 grid((unsigned)((X * n2 + RB - 1) / RB), (unsigned)nc);
             const size_t lds = ((size_t)(n1 + TVM_ROW_PAD) << a.rows_log) * sizeof(u64);
-            if (a.rows_log == 4 && n1 >= 64 && (X * n2) % 16 == 0)
-                TVM_LAUNCH(k_lde_pass3_v2, grid, dim3((unsigned)n1), lds, c->stream, a);
+            if (a.rows_log == 4 && n1 >= 64 && (X * n2) % 16 == 0 && X * n2 / 16 < 65536)
+                TVM_LAUNCH(k_lde_pass3_v2, dim3(grid.y, grid.x), dim3((unsigned)n1), lds + (n1 / 2) * sizeof(u64), c->stream, a);
             else
                 TVM_LAUNCH(k_lde_pass3, grid, dim3(threads_for_tile(tile)), lds, c->stream, a);
         }

@@ -41,7 +41,7 @@ def test_ldt_view_is_strided_subset(ctx, orc):
     assert (mt.reveal_rows([1, 15]) == table[[4, 60]]).all()
 
 
-@pytest.mark.parametrize("log_n", [0, 1, 4, 10])
+@pytest.mark.parametrize("log_n", [0, 1, 4, 10, 12, 15])  # 12: 16-lanes-per-parent levels, 15: all three level kernels
 def test_merkle_tree_sizes_and_codeword_tree(ctx, orc, log_n):
     rng = np.random.default_rng(log_n)
     n = 1 << log_n

@@ -68,23 +68,37 @@ __global__ void __launch_bounds__(256) k_merkle_level(u64* __restrict__ nodes, u
     for (int q = 0; q < 5; q++) nodes[5 * i + q] = st[q];
 }
 
-// the last levels of a tree (<= 256 parents on the widest) inside one workgroup
-__global__ void __launch_bounds__(256) k_merkle_top(u64* __restrict__ nodes, u64 widest) {
+// Levels too narrow to fill the chip: 16 lanes per parent (tip5_permute_lanes), nodes[i] = hash_pair(nodes[2i],
+// nodes[2i+1]) for i in [first, first + count).  Every lane of a wavefront takes part in the lane rotations,
+// so out-of-range parents are clamped and their result dropped.
+__global__ void __launch_bounds__(256) k_merkle_level_lanes(u64* __restrict__ nodes, u64 first, u64 count) {
     __shared__ unsigned char lut[256];
     tip5_stage_lut(lut, threadIdx.x, blockDim.x);
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const int pos = (int)(t & 15);
+    u64 j = t >> 4;
+    const bool live = j < count;
+    if (!live) j = count - 1;
+    const u64 i = first + j;
+    u64 x = pos < 10 ? nodes[10 * i + pos] : TVM_ONE;  // fixed-length domain: capacity all ones (tip-0005.md:82)
+    x = tip5_permute_lanes(x, pos, (int)(threadIdx.x & 63), lut);
+    if (live && pos < 5) nodes[5 * i + pos] = x;
+}
+
+// the last levels of a tree (<= 64 parents on the widest: one pass per level) inside one workgroup, 16 lanes per parent
+__global__ void __launch_bounds__(1024) k_merkle_top(u64* __restrict__ nodes, u64 widest) {
+    __shared__ unsigned char lut[256];
+    tip5_stage_lut(lut, threadIdx.x, blockDim.x);
+    const int pos = (int)(threadIdx.x & 15), lane = (int)(threadIdx.x & 63);
     for (u64 lvl = widest; lvl >= 1; lvl >>= 1) {
-        const u64 j = threadIdx.x;
-        if (j < lvl) {
+        for (u64 j0 = 0; j0 < lvl; j0 += blockDim.x / 16) {  // uniform trip count: every lane joins the rotations
+            u64 j = j0 + (threadIdx.x >> 4);
+            const bool live = j < lvl;
+            if (!live) j = lvl - 1;
             const u64 i = lvl + j;
-            u64 st[TIP5_STATE];
-            const u64* ch = nodes + 10 * i;
-#pragma unroll
-            for (int q = 0; q < 10; q++) st[q] = ch[q];
-#pragma unroll
-            for (int q = 10; q < 16; q++) st[q] = TVM_ONE;
-            tip5_permute_inline(st, lut);
-#pragma unroll
-            for (int q = 0; q < 5; q++) nodes[5 * i + q] = st[q];
+            u64 x = pos < 10 ? nodes[10 * i + pos] : TVM_ONE;
+            x = tip5_permute_lanes(x, pos, lane, lut);
+            if (live && pos < 5) nodes[5 * i + pos] = x;
         }
         __syncthreads();  // same workgroup wrote the children: workgroup-scope visibility suffices
     }
@@ -147,9 +161,11 @@ int merkle_tree_from_leaves(tvm_ctx* c, u64* nodes, u64 n_leaves) {
     if (!is_pow2(n_leaves)) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "merkle: leaf count must be a power of two");
     TVM_HIP_CHECK(c, hipMemsetAsync(nodes, 0, 5 * sizeof(u64), c->stream));
     u64 lvl = n_leaves >> 1;
-    for (; lvl > 256; lvl >>= 1)
+    for (; lvl > 32768; lvl >>= 1)  // wide levels: one lane per parent (throughput form)
         TVM_LAUNCH(k_merkle_level, dim3((unsigned)((lvl + 255) / 256)), dim3(256), 0, c->stream, nodes, lvl, lvl);
-    if (lvl >= 1) TVM_LAUNCH(k_merkle_top, dim3(1), dim3(256), 0, c->stream, nodes, lvl);
+    for (; lvl > 64; lvl >>= 1)     // narrow levels: 16 lanes per parent (latency form)
+        TVM_LAUNCH(k_merkle_level_lanes, dim3((unsigned)((lvl * 16 + 255) / 256)), dim3(256), 0, c->stream, nodes, lvl, lvl);
+    if (lvl >= 1) TVM_LAUNCH(k_merkle_top, dim3(1), dim3(1024), 0, c->stream, nodes, lvl);
     TVM_HIP_CHECK(c, hipGetLastError());
     return TVM_OK;
 }

@@ -94,3 +94,31 @@ TVM_D void tip5_permute_inline(u64 (&st)[TIP5_STATE], const unsigned char* lut) 
         for (int i = 0; i < 16; i++) st[i] = bfe_add(st[i], rc[16 * r + i]);
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Lane-parallel form: one permutation spread over 16 adjacent lanes, lane `pos` holds state word `pos`.
+// A dependent chain of permutations (the upper levels of a Merkle tree, one tree per FRI round) is bound by
+// the latency of ONE permutation, ~8.8k dependent-ish instructions when a single lane does all 16 words;
+// here a round is one S-box per lane, 16 lane rotations for the circulant MDS and one reduction: ~1k
+// instructions per permutation.  Throughput per wavefront is lower (4 permutations instead of 64), so this
+// form is used only where a level has too few nodes to fill the chip anyway.
+TVM_D u64 tip5_permute_lanes(u64 x, int pos, int lane, const unsigned char* lut) {
+    const u32 c[16] = {TVM_TIP5_MDS_LIST};
+    const int base = lane & ~15;
+    for (int r = 0; r < TIP5_ROUNDS; r++) {
+        if (pos < 4) x = tip5_sbox_lookup(x, lut);
+        else x = tip5_pow7(x);
+        // out[pos] = sum_k M[k] * x[(pos - k) mod 16], over the integers on 32-bit halves
+        u64 lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const u64 xk = k ? __shfl(x, base | ((pos - k) & 15), 64) : x;
+            lo += (u64)c[k] * (u32)xk;
+            hi += (u64)c[k] * (xk >> 32);
+        }
+        const u64 l = lo + (hi << 32);
+        const u64 h = (hi >> 32) + (l < lo ? 1 : 0);
+        x = bfe_add(bfe_reduce96(l, h), d_tip5_rc[16 * r + pos]);
+    }
+    return x;
+}

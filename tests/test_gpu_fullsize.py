@@ -67,3 +67,24 @@ def test_full_size_table(gctx, orc, fk, n_cols, sample_cols):
             i >>= 1
             assert (nodes[i] == cur).all()
     mt.clear_cache()
+
+
+@pytest.mark.parametrize("log_len", [23, 25])
+def test_large_xfe_transform_round_trip_and_point_values(gctx, log_len):
+    """Size-independent properties of the codeword transforms at the lengths of the 2^20- and 2^22-row
+    configurations (quotient domain 2^23 / 2^25): interpolate(evaluate(f)) == f, and the codeword's entry i
+    equals f(offset * generator^i) evaluated by the independent Horner kernel."""
+    from triton_vm_amd import stark
+
+    n = 1 << log_len
+    dom = ArithmeticDomain.of_length(n).with_offset(field.generator())
+    coeffs = gctx.synthetic(3 * n, 4242 + log_len)
+    want = coeffs.download()
+    cw = dom.evaluate(gctx, coeffs, n, 3)
+    back = dom.interpolate(gctx, cw, 3)
+    assert (back.download() == want).all()
+    idx = np.array([0, 1, 12345, n // 2 + 7, n - 1], np.uint64)
+    got = np.empty((idx.size, 3), np.uint64)
+    gctx._check(gctx.lib.tvm_gather_elements(gctx.handle, cw.ptr, 3, idx.ctypes.data, idx.size, got.ctypes.data), "gather")
+    points = np.array([[dom.value(int(i)), 0, 0] for i in idx], np.uint64)
+    assert (stark.evaluate_at_points(gctx, coeffs, n, points) == got).all()

@@ -620,7 +620,7 @@ int ntt_columns(tvm_ctx* c, const u64* in, u64 in_len, int in_fk, u64 in_col_str
                 u64 out_col_stride, u64 out_mul, u64 out_add, int ncols, u64 n, u64 w, u64 in_scale, u64 out_scale,
                 u64 out_mult) {
     if (!is_pow2(n) || n < 2) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "ntt length must be a power of two >= 2");
-    if (n > (1ull << 24)) return set_error(c, TVM_ERR_UNSUPPORTED, "ntt length above 2^24");
+    if (n > (1ull << 26)) return set_error(c, TVM_ERR_UNSUPPORTED, "ntt length above 2^26");  // tiles: 2^13 points x 2
     set_lds_attributes();
     Split sp = split_for(n);
     const u64 n1 = 1ull << sp.log_n1, n2 = 1ull << sp.log_n2;

@@ -53,15 +53,16 @@ TVM_HD u64 tip5_pow7(u64 x) {
     return bfe_mul(bfe_mul(x4, x2), x);
 }
 
-// y = M x for the circulant M with first column TVM_TIP5_MDS_FIRST_COLUMN, over the integers on
-// 32-bit halves: every partial sum is below 16 * 2^16 * 2^32 = 2^52.
-TVM_HD void tip5_mds(u64 (&st)[TIP5_STATE]) {
+// y = M x + rc for the circulant M with first column TVM_TIP5_MDS_FIRST_COLUMN, over the integers on 32-bit
+// halves: every partial sum is below 16 * 2^16 * 2^32 = 2^52.  The round constants (canonical words) are the
+// initial values of the integer sums, so adding them costs nothing: M x + rc < 2^69 is reduced once.
+TVM_HD void tip5_mds_add(u64 (&st)[TIP5_STATE], const u64* rc) {
     const u32 c[16] = {TVM_TIP5_MDS_LIST};
     u64 lo[16], hi[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        lo[i] = 0;
-        hi[i] = 0;
+        lo[i] = (u32)rc[i];
+        hi[i] = rc[i] >> 32;
     }
 #pragma unroll
     for (int j = 0; j < 16; j++) {
@@ -81,6 +82,10 @@ TVM_HD void tip5_mds(u64 (&st)[TIP5_STATE]) {
         st[i] = bfe_reduce96(l, h);
     }
 }
+TVM_HD void tip5_mds(u64 (&st)[TIP5_STATE]) {
+    const u64 zero[16] = {0};
+    tip5_mds_add(st, zero);
+}
 
 TVM_D void tip5_permute_inline(u64 (&st)[TIP5_STATE], const unsigned char* lut) {
     const u64* rc = d_tip5_rc;
@@ -89,9 +94,7 @@ TVM_D void tip5_permute_inline(u64 (&st)[TIP5_STATE], const unsigned char* lut) 
         for (int i = 0; i < 4; i++) st[i] = tip5_sbox_lookup(st[i], lut);
 #pragma unroll
         for (int i = 4; i < 16; i++) st[i] = tip5_pow7(st[i]);
-        tip5_mds(st);
-#pragma unroll
-        for (int i = 0; i < 16; i++) st[i] = bfe_add(st[i], rc[16 * r + i]);
+        tip5_mds_add(st, rc + 16 * r);
     }
 }
 
@@ -109,7 +112,8 @@ TVM_D u64 tip5_permute_lanes(u64 x, int pos, int lane, const unsigned char* lut)
         if (pos < 4) x = tip5_sbox_lookup(x, lut);
         else x = tip5_pow7(x);
         // out[pos] = sum_k M[k] * x[(pos - k) mod 16], over the integers on 32-bit halves
-        u64 lo = 0, hi = 0;
+        const u64 rc = d_tip5_rc[16 * r + pos];  // the round constant rides in the integer sums (tip5_mds_add)
+        u64 lo = (u32)rc, hi = rc >> 32;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const u64 xk = k ? __shfl(x, base | ((pos - k) & 15), 64) : x;
@@ -118,7 +122,7 @@ TVM_D u64 tip5_permute_lanes(u64 x, int pos, int lane, const unsigned char* lut)
         }
         const u64 l = lo + (hi << 32);
         const u64 h = (hi >> 32) + (l < lo ? 1 : 0);
-        x = bfe_add(bfe_reduce96(l, h), d_tip5_rc[16 * r + pos]);
+        x = bfe_reduce96(l, h);
     }
     return x;
 }

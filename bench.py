@@ -88,37 +88,51 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log2-rows", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--trace-randomizers", type=int, default=198, help="Stark::default() with FRI: 198 (stark.rs:2083-2089)")
+    ap.add_argument("--queries", type=int, default=173, help="FRI collinearity checks at 160 bits, expansion 4: 173")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent proofs per GPU instead of one sharded proof")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
+    # TEST-ONLY switch (tests/test_bench_distributed.py): run this very script on CPU with gloo and the fiber
+    # emulation of the kernels, to exercise the multi-process control flow without GPUs.  Never set in production.
+    test_emu = os.environ.get("TVM_BENCH_TEST_EMU") == "1"
+    dist, device = None, None
     if world > 1:
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if test_emu:
+            device = torch.device("cpu")
+            dist.init_process_group(backend="gloo")
+        else:
+            device = torch.device("cuda", local_rank)
+            torch.cuda.set_device(local_rank)  # torch first, then the Context (triton_vm_amd/sharded.py)
+            dist.init_process_group(backend="nccl", device_id=device)
 
     from triton_vm_amd import Context
     from triton_vm_amd.prover import Prover, StarkParameters
 
-    ctx = Context(device=local_rank)
-    params = StarkParameters(args.log2_rows)
+    if test_emu:
+        from tests.emu_fixture import emu_context
+
+        ctx = emu_context()
+    else:
+        ctx = Context(device=local_rank)
+    params = StarkParameters(args.log2_rows, num_trace_randomizers=args.trace_randomizers,
+                             num_collinearity_checks=args.queries)
     sharded = world > 1 and not args.replicas
     if sharded:
-        import torch
-
         from triton_vm_amd.sharded import ShardedProver
 
-        prover = ShardedProver(ctx, params, dist, torch.device("cuda", local_rank), seed=1000)
+        prover = ShardedProver(ctx, params, dist, device, seed=1000)
     else:
         prover = Prover(ctx, params, seed=1000 + rank)
     cells_per_step = params.padded_height * MASTER_WORDS * (1 if sharded else world)
 
-    elapsed = timed_steps(prover.prove, args.steps, args.warmup, ctx.sync, dist)
+    elapsed = timed_steps(prover.prove, args.steps, args.warmup, ctx.sync, dist, device="cpu" if test_emu else "cuda")
 
     # live timing of the dominant HBM-bound kernel family (the main-table LDE: k_ntt2_pass1, k_lde_pass2,
     # k_lde_pass3) with HIP events on the context's stream, and a per-stage breakdown of one more pass
@@ -133,6 +147,9 @@ def main():
             ctx.timer_start()
             prover.main.maybe_low_degree_extend_all_columns()
             lde_ms.append(ctx.timer_stop())
+    barrier()
+    t_prof = 0.0
+    if rank == 0 or sharded:  # a sharded prove() contains collectives: every rank has to take part
         prover.timings, prover.wall = {}, {}
         t_prof = time.perf_counter()
         prover.prove(profile=True)
@@ -143,11 +160,13 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         lde_avg_ms = sum(lde_ms) / len(lde_ms)
         lde_cells = params.trace.length * 379
-        achieved = lde_cells * LDE_ALGORITHMIC_BYTES_PER_CELL / (lde_avg_ms * 1e-3) / 1e9
+        # algorithmic bytes of one launch: read the trace, write this rank's share of the extended rows
+        lde_bytes_per_cell = 8 + 64 / world if sharded else LDE_ALGORITHMIC_BYTES_PER_CELL
+        achieved = lde_cells * lde_bytes_per_cell / (lde_avg_ms * 1e-3) / 1e9
         traffic = None  # fabric-side bytes per LDE launch family, from the committed PMC run (profiles/lde_traffic.json)
         try:
             with open(os.path.join(ROOT, "profiles", "lde_traffic.json")) as f:
-                traffic = int(json.load(f)["hbm_bytes_per_trace_cell"] * lde_cells)
+                traffic = int(json.load(f)["hbm_bytes_per_trace_cell"] * lde_cells) if not sharded else None
         except (OSError, KeyError, ValueError):
             pass
         out = {
@@ -160,8 +179,8 @@ def main():
             "dtype": "u64 (F_p, p = 2^64 - 2^32 + 1, Montgomery) and its cubic extension",
             "data": "synthetic",
             "config": {"workload": f"prove() hot path, prove_fib-shaped tables: 2^{args.log2_rows} padded rows, 379 main + "
-                                   "91 aux columns (652 words/row), Stark::default() with FRI (expansion 4, 198 trace "
-                                   "randomizers, 173 queries), traces resident in HBM; host `gen` steps (VM, pad, extend) "
+                                   "91 aux columns (652 words/row), Stark::default() with FRI (expansion 4, "
+                                   f"{args.trace_randomizers} trace randomizers, {args.queries} queries), traces resident in HBM; host `gen` steps (VM, pad, extend) "
                                    "and the Rust-side transcript are not part of the path",
                        "padded_rows": params.padded_height, "master_words": MASTER_WORDS,
                        "ldt_domain": params.ldt.length, "parallelism": (f"one proof over {world} GPUs: coset sharding of the extended tables, all-gather of digests and "
@@ -171,7 +190,7 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "launch_ms": round(lde_avg_ms, 3),
-                         "algorithmic_bytes_per_launch": lde_cells * LDE_ALGORITHMIC_BYTES_PER_CELL},
+                         "algorithmic_bytes_per_launch": int(lde_cells * lde_bytes_per_cell)},
             "stage_ms": {k: round(v, 3) for k, v in prover.timings.items()},
             "stage_wall_ms": {k: round(v, 3) for k, v in prover.wall.items()},
             "profiled_prove_wall_ms": round(t_prof, 3),

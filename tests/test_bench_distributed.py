@@ -59,3 +59,28 @@ def test_single_process_needs_no_collective():
     n = []
     assert bench.timed_steps(lambda: n.append(1), steps=2, warmup=1, device_sync=lambda: None) >= 0
     assert len(n) == 3
+
+
+@pytest.mark.parametrize("mode", ["sharded", "replicas"])
+def test_bench_script_runs_under_torchrun_with_two_ranks(mode):
+    """bench.py itself, launched the way the driver launches it for N = 2 (torch.distributed.run, one process per
+    rank), on CPU: gloo instead of RCCL and the test-only emulation of the kernels (TVM_BENCH_TEST_EMU=1).  The
+    sharded mode runs collectives inside prove(); a rank that skips one of them would hang this test."""
+    import json
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, TVM_BENCH_TEST_EMU="1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--log2-rows", "3", "--trace-randomizers", "3", "--queries", "2", "--no-cpu-baseline"] + (["--replicas"] if mode == "replicas" else [])
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 1 and rec["value"] > 0
+    assert rec["scaling"] == ("strong" if mode == "sharded" else "weak")
+    assert {"roofline", "stage_ms", "config"} <= set(rec)

@@ -17,7 +17,7 @@
 namespace tvm {
 
 #ifndef AIR_BLOCK
-#define AIR_BLOCK 512
+#define AIR_BLOCK 256
 #endif
 // challenges and weights are the same for every lane and never written while a part runs: reading them
 // through the constant address space makes the loads scalar (s_load) and exempt from AIR_SYNC's clobber

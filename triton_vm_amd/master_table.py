@@ -80,12 +80,18 @@ class MasterTable:
         return out.reshape((idx.size, self.n_cols) + ((3,) if self.fk == 3 else ()))
 
     # master_table.rs:348-390, for several indeterminates at once -> [n_points, n_cols, 3]
-    def out_of_domain_rows(self, points):
+    def out_of_domain_rows(self, points, first_col=0, n_cols=None):
+        """all columns, or the n_cols columns from first_col on (a rank's share when the columns are split)"""
         pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 3)
-        out = np.empty((pts.shape[0], self.n_cols, 3), np.uint64)
+        n_cols = self.n_cols - first_col if n_cols is None else n_cols
+        out = np.empty((pts.shape[0], n_cols, 3), np.uint64)
+        if n_cols == 0:
+            return out
+        word = 8 * self.fk
         self.ctx._check(self.ctx.lib.tvm_out_of_domain_rows(
-            self.ctx.handle, self.fk, self.d_trace.ptr, self.n_rows, self.n_cols, self.d_randomizers.ptr,
-            self.num_trace_randomizers, self.trace_domain.c(), pts.ctypes.data, pts.shape[0], out.ctypes.data), "ood rows")
+            self.ctx.handle, self.fk, self.d_trace.ptr + first_col * self.n_rows * word, self.n_rows, n_cols,
+            self.d_randomizers.ptr + first_col * self.num_trace_randomizers * word, self.num_trace_randomizers,
+            self.trace_domain.c(), pts.ctypes.data, pts.shape[0], out.ctypes.data), "ood rows")
         return out
 
     def out_of_domain_row(self, indeterminate):

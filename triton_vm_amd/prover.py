@@ -165,6 +165,10 @@ class Prover:
         return stark.all_quotients_combined(self.ctx, self.main, self.aux, self.p.trace, self.p.quotient, challenges,
                                             quotient_weights)
 
+    def _out_of_domain_rows(self, mt, points):
+        """out_of_domain_row at several indeterminates (master_table.rs:348-390) -> host [n_points][n_cols][3]"""
+        return mt.out_of_domain_rows(points)
+
     def _reveal_master_rows(self, mt, row_indices):
         """reveal_rows (master_table.rs:548-555) -> host array"""
         return mt.reveal_rows(row_indices)
@@ -221,8 +225,8 @@ class Prover:
         alpha = ps.sample_scalars(1)[0]
         alpha_next = np.array([field.mont_mul(int(c), p.trace.generator) for c in alpha], np.uint64)
         with self._timed("out-of-domain rows"):
-            ood_main = self.main.out_of_domain_rows([alpha, alpha_next])
-            ood_aux = self.aux.out_of_domain_rows([alpha, alpha_next])
+            ood_main = self._out_of_domain_rows(self.main, [alpha, alpha_next])
+            ood_aux = self._out_of_domain_rows(self.aux, [alpha, alpha_next])
             a4 = xfe_powers(lib, alpha, 4, 1)[0]
             zeta_alpha = np.array([field.mont_mul(int(c), stark.ZETA) for c in alpha], np.uint64)
             za4 = xfe_powers(lib, zeta_alpha, 4, 1)[0]

@@ -10,6 +10,7 @@ The trace (5 GiB at 2^20 rows) is replicated.  Exchanges (RCCL all-gather over x
     leaf digests of each master table   L x 40 B  (336 MB at 2^20), interleaved back into row order
     the quotient codeword               L x 24 B  (201 MB), likewise
     the opened rows (173 x 652 words)   summed over ranks (each row is non-zero on its owner only)
+    the out-of-domain rows              columns split over the ranks, summed likewise (2 x 470 XFE)
 
 Everything after the quotient codeword (segments, out-of-domain rows, combination, DEEP, FRI: ~55 ms of a
 411 ms proof at 2^20 rows) is computed redundantly on every rank from identical inputs, so every rank derives
@@ -101,6 +102,18 @@ class ShardedProver(Prover):
                                                       self.p.trace.c(), self.ldt_local.c(), ch.ctypes.data, w.ctypes.data,
                                                       local.data_ptr()), "all_quotients_combined")
         return _TensorBuffer(self._all_gather_rows(local, 3))
+
+    def _out_of_domain_rows(self, mt, points):
+        """columns split evenly over the ranks (the trace is replicated); the rows are tiny, so the exchange is an
+        all-reduce(sum) of a zero-padded array in which every column is non-zero on its owner only"""
+        per = -(-mt.n_cols // self.world)
+        c0 = min(self.rank * per, mt.n_cols)
+        c1 = min(c0 + per, mt.n_cols)
+        rows = np.zeros((len(points), mt.n_cols, 3), np.uint64)
+        rows[:, c0:c1] = mt.out_of_domain_rows(points, c0, c1 - c0)
+        t = self.torch.from_numpy(rows.view(np.int64)).to(self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().numpy().view(np.uint64)
 
     def _reveal_master_rows(self, mt, row_indices):
         idx = np.asarray(row_indices, dtype=np.uint64)

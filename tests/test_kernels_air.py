@@ -11,7 +11,7 @@ def odom(orc, d):
     return orc.Domain(d.offset, d.generator, d.length)
 
 
-@pytest.mark.parametrize("log_n,expansion,ldt_expansion", [(2, 8, 8), (3, 4, 4), (3, 4, 8)])
+@pytest.mark.parametrize("log_n,expansion,ldt_expansion", [(2, 8, 8), (3, 4, 4), (3, 4, 8), (4, 1, 1), (4, 2, 2)])  # 1, 2: per-rank domains of the sharded prover
 def test_all_quotients_combined(ctx, orc, log_n, expansion, ldt_expansion):
     rng = np.random.default_rng(log_n * 10 + expansion + ldt_expansion)
     n, h = 1 << log_n, 3

@@ -38,7 +38,8 @@ def test_evaluate_interpolate_match_oracle(ctx, orc, log_len, n_coeffs, fk):
 
 
 @pytest.mark.parametrize("log_n,expansion,n_cols,h", [(4, 8, 3, 5), (5, 4, 18, 7), (6, 8, 33, 20), (3, 2, 1, 8), (1, 4, 2, 1),
-                                                       (12, 8, 2, 70), (13, 4, 1, 9), (12, 2, 1, 4096)])
+                                                       (12, 8, 2, 70), (13, 4, 1, 9), (12, 2, 1, 4096),
+                                                       (4, 1, 3, 5), (12, 1, 2, 7)])  # expansion 1: a rank's share at 8 GPUs
 @pytest.mark.parametrize("fk", [1, 3])
 def test_lde_table_matches_oracle(ctx, orc, log_n, expansion, n_cols, h, fk):
     rng = np.random.default_rng(log_n + 31 * n_cols + fk)

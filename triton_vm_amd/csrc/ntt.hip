@@ -55,7 +55,7 @@ __global__ void k_pow_table(u64 base, u64 count, u64 scale, u64* out) {
 // instead of 10 and synchronises 3 times instead of 10.  Lanes of a wavefront are consecutive b first
 // (SB is either 1 or an odd row pitch), then consecutive groups: at most 2-way bank conflicts.
 // Ends with a barrier; the caller must have synchronised the tile before the call.
-template <bool DIT, int K>
+template <bool DIT, int K, bool L0>
 TVM_D void lds_ntt_group(u64* s, int log_n, int batch_log, int SA, int SB, const u64* __restrict__ tw, int l, int tid, int nt) {
     constexpr int R = 1 << K;
     const int n_groups = (1 << (log_n - K)) << batch_log;
@@ -75,19 +75,22 @@ TVM_D void lds_ntt_group(u64* s, int log_n, int batch_log, int SA, int SB, const
             const int tws = log_n - 1 - (l + t);    // w_{2^(l+t+1)}^j = w_n^(j << tws)
 #pragma unroll
             for (int m = 0; m < h; m++) {           // the 2^t distinct twiddles of this layer in the group
-                const u64 w = tw[((m << l) | j0) << tws];
+                // in the group of the lowest four layers (l == 0) the twiddle of m == 0 is w^0 = 1: 15 of its 32
+                // butterflies need no multiplication
+                const bool unit = L0 && m == 0;
+                const u64 w = unit ? TVM_ONE : tw[((m << l) | j0) << tws];
 #pragma unroll
                 for (int q = 0; q < R / (2 * h); q++) {
                     const int e = q * 2 * h + m;
                     const u64 u = x[e];
                     if (DIT) {
-                        const u64 v = bfe_mul(x[e + h], w);
+                        const u64 v = unit ? x[e + h] : bfe_mul(x[e + h], w);
                         x[e] = bfe_add(u, v);
                         x[e + h] = bfe_sub(u, v);
                     } else {
                         const u64 v = x[e + h];
                         x[e] = bfe_add(u, v);
-                        x[e + h] = bfe_mul(bfe_sub(u, v), w);
+                        x[e + h] = unit ? bfe_sub(u, v) : bfe_mul(bfe_sub(u, v), w);
                     }
                 }
             }
@@ -106,10 +109,17 @@ TVM_D void lds_ntt(u64* s, int log_n, int batch_log, int SA, int SB, const u64* 
     while (done < log_n) {
         const int k = (log_n - done) >= MAXK ? MAXK : (log_n - done);
         const int l = DIT ? done : (log_n - done - k);
-        if (MAXK >= 4 && k == 4) lds_ntt_group<DIT, 4>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
-        else if (k == 3) lds_ntt_group<DIT, 3>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
-        else if (k == 2) lds_ntt_group<DIT, 2>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
-        else lds_ntt_group<DIT, 1>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
+        if (l == 0) {
+            if (MAXK >= 4 && k == 4) lds_ntt_group<DIT, 4, true>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
+            else if (k == 3) lds_ntt_group<DIT, 3, true>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
+            else if (k == 2) lds_ntt_group<DIT, 2, true>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
+            else lds_ntt_group<DIT, 1, true>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
+        } else {
+            if (MAXK >= 4 && k == 4) lds_ntt_group<DIT, 4, false>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
+            else if (k == 3) lds_ntt_group<DIT, 3, false>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
+            else if (k == 2) lds_ntt_group<DIT, 2, false>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
+            else lds_ntt_group<DIT, 1, false>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
+        }
         done += k;
     }
 }

@@ -17,7 +17,12 @@ def main():
     n_aux = int(sys.argv[3]) if len(sys.argv) > 3 else 91
     reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
     n, h = 1 << log_n, 198
-    ctx = Context(0)
+    variant = os.environ.get('TVM_LIB_VARIANT')  # experiment libraries built with build(variant=...)
+    if variant:
+        from triton_vm_amd.capi import load_library
+        ctx = Context(0, lib=load_library(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'triton_vm_amd', f'libtriton_hip_{variant}.so')))
+    else:
+        ctx = Context(0)
     trace_dom = ArithmeticDomain.of_length(n)
     ev = ArithmeticDomain.of_length(8 * n).with_offset(field.generator())
     L = len(ev)

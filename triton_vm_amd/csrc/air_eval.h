@@ -46,23 +46,31 @@ struct AirArgs {
 //   w*x = (d0 - d3) + (d1 + d3 - d4) X + (d2 + d4) X^2,   d0 = w0x0, d1 = w0x1 + w1x0, d2 = w0x2 + w1x1 + w2x0,
 //   d3 = w1x2 + w2x1, d4 = w2x2,
 // so five 160-bit sums D0..D4 (a group has <= 25 constraints: < 2^135).  A product-accumulate is 4 v_mad_u64_u32
-// + a 5-limb carry chain (13 VALU instructions; reduce-then-add is 24).
+// + a 5-limb carry chain (13 VALU instructions; reduce-then-add is 24), three of them interleaved at a time.
 struct Acc160 {
     u32 l0, l1, l2, l3, l4;
 };
-TVM_D void acc160_mac(Acc160& A, u64 a, u64 b) {
-    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-    const u64 t = (u64)a0 * b0;
-    const u64 u = (u64)a0 * b1 + (t >> 32);
-    const u64 v = (u64)a1 * b0 + (u32)u;
-    const u64 w = (u64)a1 * b1 + ((u >> 32) + (v >> 32));  // the product is (w : v.lo : t.lo) < 2^128
-    asm("v_add_co_u32 %[l0], vcc, %[l0], %[x0]\n\t" TVM_VCC_WAIT
-        "v_addc_co_u32 %[l1], vcc, %[l1], %[x1], vcc\n\t" TVM_VCC_WAIT
-        "v_addc_co_u32 %[l2], vcc, %[l2], %[x2], vcc\n\t" TVM_VCC_WAIT
-        "v_addc_co_u32 %[l3], vcc, %[l3], %[x3], vcc\n\t" TVM_VCC_WAIT
-        "v_addc_co_u32 %[l4], vcc, 0, %[l4], vcc"
-        : [l0] "+v"(A.l0), [l1] "+v"(A.l1), [l2] "+v"(A.l2), [l3] "+v"(A.l3), [l4] "+v"(A.l4)
-        : [x0] "v"((u32)t), [x1] "v"((u32)v), [x2] "v"((u32)w), [x3] "v"((u32)(w >> 32))
+// three product-accumulates into three DIFFERENT sums, carry chains interleaved (field.h: no wait states)
+#define AIR_Q1(S, C) "v_add_co_u32_e64 %[l0" #S "], " C ", %[l0" #S "], %[x0" #S "]\n\t"
+#define AIR_Q2(S, C) "v_addc_co_u32_e64 %[l1" #S "], " C ", %[l1" #S "], %[x1" #S "], " C "\n\t"
+#define AIR_Q3(S, C) "v_addc_co_u32_e64 %[l2" #S "], " C ", %[l2" #S "], %[x2" #S "], " C "\n\t"
+#define AIR_Q4(S, C) "v_addc_co_u32_e64 %[l3" #S "], " C ", %[l3" #S "], %[x3" #S "], " C "\n\t"
+#define AIR_Q5(S, C) "v_addc_co_u32_e64 %[l4" #S "], " C ", 0, %[l4" #S "], " C "\n\t"
+#define AIR_Q_IO(S, A) [l0##S] "+v"(A.l0), [l1##S] "+v"(A.l1), [l2##S] "+v"(A.l2), [l3##S] "+v"(A.l3), [l4##S] "+v"(A.l4)
+#define AIR_Q_IN(S, t, v, w) [x0##S] "v"((u32)(t)), [x1##S] "v"((u32)(v)), [x2##S] "v"((u32)(w)), [x3##S] "v"((u32)((w) >> 32))
+#define AIR_MAC_PARTIALS(a, b, t, u, v, w)                                       \
+    const u64 t = (u64)(u32)(a) * (u32)(b);                                      \
+    const u64 u = (u64)(u32)(a) * (u32)((b) >> 32) + (t >> 32);                  \
+    const u64 v = (u64)(u32)((a) >> 32) * (u32)(b) + (u32)u;                     \
+    const u64 w = (u64)(u32)((a) >> 32) * (u32)((b) >> 32) + ((u >> 32) + (v >> 32))
+TVM_D void acc160_mac3(Acc160& A, u64 a0, u64 b0, Acc160& B, u64 a1, u64 b1, Acc160& C, u64 a2, u64 b2) {
+    AIR_MAC_PARTIALS(a0, b0, ta, ua, va, wa);
+    AIR_MAC_PARTIALS(a1, b1, tb, ub, vb, wb);
+    AIR_MAC_PARTIALS(a2, b2, tc, uc, vc, wc);
+    u64 cb, cc;
+    asm(TVM_3WAY(AIR_Q1) TVM_3WAY(AIR_Q2) TVM_3WAY(AIR_Q3) TVM_3WAY(AIR_Q4) TVM_3WAY(AIR_Q5)
+        : AIR_Q_IO(a, A), AIR_Q_IO(b, B), AIR_Q_IO(c, C), [cb] "=&s"(cb), [cc] "=&s"(cc)
+        : AIR_Q_IN(a, ta, va, wa), AIR_Q_IN(b, tb, vb, wb), AIR_Q_IN(c, tc, vc, wc)
         : "vcc");
 }
 // (l4 : l3 : l2 : l1 : l0) * 2^-64 mod p, canonical: fold the top 96 bits modulo p, then one Montgomery reduction
@@ -83,21 +91,12 @@ TVM_D AirAcc air_acc_zero() {
     for (int i = 0; i < 5; i++) a.d[i].l0 = a.d[i].l1 = a.d[i].l2 = a.d[i].l3 = a.d[i].l4 = 0;
     return a;
 }
-TVM_D void air_acc_b(AirAcc& a, xfe w, u64 c) {
-    acc160_mac(a.d[0], w.c0, c);
-    acc160_mac(a.d[1], w.c1, c);
-    acc160_mac(a.d[2], w.c2, c);
-}
+TVM_D void air_acc_b(AirAcc& a, xfe w, u64 c) { acc160_mac3(a.d[0], w.c0, c, a.d[1], w.c1, c, a.d[2], w.c2, c); }
 TVM_D void air_acc_x(AirAcc& a, xfe w, xfe x) {
-    acc160_mac(a.d[0], w.c0, x.c0);
-    acc160_mac(a.d[1], w.c0, x.c1);
-    acc160_mac(a.d[1], w.c1, x.c0);
-    acc160_mac(a.d[2], w.c0, x.c2);
-    acc160_mac(a.d[2], w.c1, x.c1);
-    acc160_mac(a.d[2], w.c2, x.c0);
-    acc160_mac(a.d[3], w.c1, x.c2);
-    acc160_mac(a.d[3], w.c2, x.c1);
-    acc160_mac(a.d[4], w.c2, x.c2);
+    // the nine products in three rounds of three different sums
+    acc160_mac3(a.d[0], w.c0, x.c0, a.d[1], w.c0, x.c1, a.d[2], w.c0, x.c2);
+    acc160_mac3(a.d[1], w.c1, x.c0, a.d[2], w.c1, x.c1, a.d[3], w.c1, x.c2);
+    acc160_mac3(a.d[2], w.c2, x.c0, a.d[3], w.c2, x.c1, a.d[4], w.c2, x.c2);
 }
 TVM_D xfe air_acc_value(const AirAcc& a) {
     const u64 d0 = acc160_value(a.d[0]), d1 = acc160_value(a.d[1]), d2 = acc160_value(a.d[2]);

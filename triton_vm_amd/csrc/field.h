@@ -19,7 +19,11 @@
 // gfx950 does not interlock a VALU instruction that reads VCC (or an SGPR) written by the VALU instruction
 // right before it: two wait states are required (LLVM: VALUWriteSGPRVALURead on gfx940+).  The compiler
 // inserts them in its own code; the asm carry chains below do it by hand.
+#ifdef TVM_EXPERIMENT_NO_WAIT  // timing experiment only: results are NOT guaranteed without the wait states
+#define TVM_VCC_WAIT ""
+#else
 #define TVM_VCC_WAIT "s_nop 1\n\t"
+#endif
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(TVM_EMU)
 #define TVM_FIELD_ASM 1
 #endif
@@ -118,6 +122,175 @@ TVM_HD u64 bfe_mul(u64 a, u64 b) {
     return bfe_montyred(lo, hi);
 #endif
 }
+// ---------------------------------------------------------------- interleaved carry chains
+// The wait states above are not free where few wavefronts share a SIMD (the AIR kernels run 2-3 per SIMD):
+// without them the AIR evaluation measured 15 % faster, the LDE 6 %.  Two or three INDEPENDENT operations
+// written as one instruction stream hide them instead: chain A carries in VCC, chains B and C in SGPR pairs
+// (VOP3 encodings), and the instructions are issued A, B, C, A, B, C ... -- with three chains every
+// carry consumer has two instructions between it and its producer, which is exactly the required distance;
+// with two chains one single-cycle s_nop per step remains.  Results are identical to the single forms.
+#ifdef TVM_FIELD_ASM
+#define TVM_CA "vcc"
+#define TVM_CB "%[cb]"
+#define TVM_CC "%[cc]"
+// steps of the multiplication tail (see bfe_mul): S = operand suffix of the chain, C = its carry register
+#define TVM_M1(S, C) "v_add_co_u32_e64 %[r0" #S "], " C ", %[w0" #S "], %[v1" #S "]\n\t"
+#define TVM_M2(S, C) "v_addc_co_u32_e64 %[r1" #S "], " C ", 0, %[w1" #S "], " C "\n\t"
+#define TVM_M3(S, C) "v_add_co_u32_e64 %[s1" #S "], " C ", %[x1" #S "], %[x0" #S "]\n\t"
+#define TVM_M4(S, C) "v_subb_co_u32_e64 %[s0" #S "], " C ", %[x0" #S "], %[s1" #S "], " C "\n\t"
+#define TVM_M5(S, C) "v_subbrev_co_u32_e64 %[s1" #S "], " C ", 0, %[s1" #S "], " C "\n\t"
+#define TVM_M6(S, C) "v_sub_co_u32_e64 %[r0" #S "], " C ", %[r0" #S "], %[s0" #S "]\n\t"
+#define TVM_M7(S, C) "v_subb_co_u32_e64 %[r1" #S "], " C ", %[r1" #S "], %[s1" #S "], " C "\n\t"
+#define TVM_M8(S, C) "v_cndmask_b32_e64 %[s0" #S "], 0, -1, " C "\n\t"
+#define TVM_M9(S, C) "v_sub_co_u32_e64 %[r0" #S "], " C ", %[r0" #S "], %[s0" #S "]\n\t"
+#define TVM_M10(S, C) "v_subbrev_co_u32_e64 %[r1" #S "], " C ", 0, %[r1" #S "], " C "\n\t"
+#define TVM_MUL_OUT(S, p, q, x, y) [r0##S] "=&v"(p), [r1##S] "=&v"(q), [s0##S] "=&v"(x), [s1##S] "=&v"(y)
+#define TVM_MUL_IN(S, t, v, w) \
+    [x0##S] "v"((u32)(t)), [x1##S] "v"((u32)(v)), [w0##S] "v"((u32)(w)), [w1##S] "v"((u32)((w) >> 32)), [v1##S] "v"((u32)((v) >> 32))
+#define TVM_MUL_PARTIALS(a, b, t, u, v, w)                                                        \
+    const u64 t = (u64)(u32)(a) * (u32)(b);                                                       \
+    const u64 u = (u64)(u32)(a) * (u32)((b) >> 32) + (t >> 32);                                   \
+    const u64 v = (u64)(u32)((a) >> 32) * (u32)(b) + (u32)u;                                      \
+    const u64 w = (u64)(u32)((a) >> 32) * (u32)((b) >> 32) + (u >> 32)
+#define TVM_3WAY(STEP) STEP(a, TVM_CA) STEP(b, TVM_CB) STEP(c, TVM_CC)
+#define TVM_2WAY(STEP) STEP(a, TVM_CA) STEP(b, TVM_CB) "s_nop 0\n\t"
+#endif
+
+// three independent products
+TVM_HD void bfe_mul3(u64 a0, u64 b0, u64 a1, u64 b1, u64 a2, u64 b2, u64& p0, u64& p1, u64& p2) {
+#ifdef TVM_FIELD_ASM
+    TVM_MUL_PARTIALS(a0, b0, ta, ua, va, wa);
+    TVM_MUL_PARTIALS(a1, b1, tb, ub, vb, wb);
+    TVM_MUL_PARTIALS(a2, b2, tc, uc, vc, wc);
+    u32 r0a, r1a, s0a, s1a, r0b, r1b, s0b, s1b, r0c, r1c, s0c, s1c;
+    u64 cb, cc;
+    asm(TVM_3WAY(TVM_M1) TVM_3WAY(TVM_M2) TVM_3WAY(TVM_M3) TVM_3WAY(TVM_M4) TVM_3WAY(TVM_M5) TVM_3WAY(TVM_M6)
+        TVM_3WAY(TVM_M7) TVM_3WAY(TVM_M8) TVM_3WAY(TVM_M9) TVM_3WAY(TVM_M10)
+        : TVM_MUL_OUT(a, r0a, r1a, s0a, s1a), TVM_MUL_OUT(b, r0b, r1b, s0b, s1b), TVM_MUL_OUT(c, r0c, r1c, s0c, s1c),
+          [cb] "=&s"(cb), [cc] "=&s"(cc)
+        : TVM_MUL_IN(a, ta, va, wa), TVM_MUL_IN(b, tb, vb, wb), TVM_MUL_IN(c, tc, vc, wc)
+        : "vcc");
+    p0 = ((u64)r1a << 32) | r0a;
+    p1 = ((u64)r1b << 32) | r0b;
+    p2 = ((u64)r1c << 32) | r0c;
+#else
+    p0 = bfe_mul(a0, b0);
+    p1 = bfe_mul(a1, b1);
+    p2 = bfe_mul(a2, b2);
+#endif
+}
+// two independent products
+TVM_HD void bfe_mul2(u64 a0, u64 b0, u64 a1, u64 b1, u64& p0, u64& p1) {
+#ifdef TVM_FIELD_ASM
+    TVM_MUL_PARTIALS(a0, b0, ta, ua, va, wa);
+    TVM_MUL_PARTIALS(a1, b1, tb, ub, vb, wb);
+    u32 r0a, r1a, s0a, s1a, r0b, r1b, s0b, s1b;
+    u64 cb;
+    asm(TVM_2WAY(TVM_M1) TVM_2WAY(TVM_M2) TVM_2WAY(TVM_M3) TVM_2WAY(TVM_M4) TVM_2WAY(TVM_M5) TVM_2WAY(TVM_M6)
+        TVM_2WAY(TVM_M7) TVM_2WAY(TVM_M8) TVM_2WAY(TVM_M9) TVM_M10(a, TVM_CA) TVM_M10(b, TVM_CB)
+        : TVM_MUL_OUT(a, r0a, r1a, s0a, s1a), TVM_MUL_OUT(b, r0b, r1b, s0b, s1b), [cb] "=&s"(cb)
+        : TVM_MUL_IN(a, ta, va, wa), TVM_MUL_IN(b, tb, vb, wb)
+        : "vcc");
+    p0 = ((u64)r1a << 32) | r0a;
+    p1 = ((u64)r1b << 32) | r0b;
+#else
+    p0 = bfe_mul(a0, b0);
+    p1 = bfe_mul(a1, b1);
+#endif
+}
+
+#ifdef TVM_FIELD_ASM
+// a - b (mod p), steps of bfe_sub
+#define TVM_S1(S, C) "v_sub_co_u32_e64 %[r0" #S "], " C ", %[a0" #S "], %[b0" #S "]\n\t"
+#define TVM_S2(S, C) "v_subb_co_u32_e64 %[r1" #S "], " C ", %[a1" #S "], %[b1" #S "], " C "\n\t"
+#define TVM_S3(S, C) "v_cndmask_b32_e64 %[m" #S "], 0, -1, " C "\n\t"
+#define TVM_S4(S, C) "v_sub_co_u32_e64 %[r0" #S "], " C ", %[r0" #S "], %[m" #S "]\n\t"
+#define TVM_S5(S, C) "v_subbrev_co_u32_e64 %[r1" #S "], " C ", 0, %[r1" #S "], " C "\n\t"
+#define TVM_SUB_OUT(S, p, q, x) [r0##S] "=&v"(p), [r1##S] "=&v"(q), [m##S] "=&v"(x)
+#define TVM_AB_IN(S, a, b) [a0##S] "v"((u32)(a)), [a1##S] "v"((u32)((a) >> 32)), [b0##S] "v"((u32)(b)), [b1##S] "v"((u32)((b) >> 32))
+// a + b (mod p), steps of bfe_add; K = the chain's saved first carry
+#define TVM_A1(S, C, K) "v_add_co_u32_e64 %[s0" #S "], " C ", %[a0" #S "], %[b0" #S "]\n\t"
+#define TVM_A2(S, C, K) "v_addc_co_u32_e64 %[s1" #S "], " K ", %[a1" #S "], %[b1" #S "], " C "\n\t"
+#define TVM_A3(S, C, K) "v_add_co_u32_e64 %[t0" #S "], " C ", -1, %[s0" #S "]\n\t"
+#define TVM_A4(S, C, K) "v_addc_co_u32_e64 %[t1" #S "], " C ", 0, %[s1" #S "], " C "\n\t"
+#define TVM_A5(S, C, K) "s_or_b64 " C ", " C ", " K "\n\t"
+#define TVM_A6(S, C, K) "v_cndmask_b32_e64 %[s0" #S "], %[s0" #S "], %[t0" #S "], " C "\n\t"
+#define TVM_A7(S, C, K) "v_cndmask_b32_e64 %[s1" #S "], %[s1" #S "], %[t1" #S "], " C "\n\t"
+#define TVM_ADD_OUT(S, p, q, x, y) [s0##S] "=&v"(p), [s1##S] "=&v"(q), [t0##S] "=&v"(x), [t1##S] "=&v"(y)
+#define TVM_3WAY_ADD(STEP) STEP(a, TVM_CA, "%[ka]") STEP(b, TVM_CB, "%[kb]") STEP(c, TVM_CC, "%[kc]")
+#define TVM_2WAY_ADD(STEP) STEP(a, TVM_CA, "%[ka]") STEP(b, TVM_CB, "%[kb]") "s_nop 0\n\t"
+#endif
+
+TVM_HD void bfe_sub3(u64 a0, u64 b0, u64 a1, u64 b1, u64 a2, u64 b2, u64& d0, u64& d1, u64& d2) {
+#ifdef TVM_FIELD_ASM
+    u32 r0a, r1a, ma, r0b, r1b, mb, r0c, r1c, mc;
+    u64 cb, cc;
+    asm(TVM_3WAY(TVM_S1) TVM_3WAY(TVM_S2) TVM_3WAY(TVM_S3) TVM_3WAY(TVM_S4) TVM_3WAY(TVM_S5)
+        : TVM_SUB_OUT(a, r0a, r1a, ma), TVM_SUB_OUT(b, r0b, r1b, mb), TVM_SUB_OUT(c, r0c, r1c, mc), [cb] "=&s"(cb),
+          [cc] "=&s"(cc)
+        : TVM_AB_IN(a, a0, b0), TVM_AB_IN(b, a1, b1), TVM_AB_IN(c, a2, b2)
+        : "vcc");
+    d0 = ((u64)r1a << 32) | r0a;
+    d1 = ((u64)r1b << 32) | r0b;
+    d2 = ((u64)r1c << 32) | r0c;
+#else
+    d0 = bfe_sub(a0, b0);
+    d1 = bfe_sub(a1, b1);
+    d2 = bfe_sub(a2, b2);
+#endif
+}
+TVM_HD void bfe_sub2(u64 a0, u64 b0, u64 a1, u64 b1, u64& d0, u64& d1) {
+#ifdef TVM_FIELD_ASM
+    u32 r0a, r1a, ma, r0b, r1b, mb;
+    u64 cb;
+    asm(TVM_2WAY(TVM_S1) TVM_2WAY(TVM_S2) TVM_2WAY(TVM_S3) TVM_2WAY(TVM_S4) TVM_S5(a, TVM_CA) TVM_S5(b, TVM_CB)
+        : TVM_SUB_OUT(a, r0a, r1a, ma), TVM_SUB_OUT(b, r0b, r1b, mb), [cb] "=&s"(cb)
+        : TVM_AB_IN(a, a0, b0), TVM_AB_IN(b, a1, b1)
+        : "vcc");
+    d0 = ((u64)r1a << 32) | r0a;
+    d1 = ((u64)r1b << 32) | r0b;
+#else
+    d0 = bfe_sub(a0, b0);
+    d1 = bfe_sub(a1, b1);
+#endif
+}
+TVM_HD void bfe_add3(u64 a0, u64 b0, u64 a1, u64 b1, u64 a2, u64 b2, u64& e0, u64& e1, u64& e2) {
+#ifdef TVM_FIELD_ASM
+    u32 s0a, s1a, t0a, t1a, s0b, s1b, t0b, t1b, s0c, s1c, t0c, t1c;
+    u64 cb, cc, ka, kb, kc;
+    asm(TVM_3WAY_ADD(TVM_A1) TVM_3WAY_ADD(TVM_A2) TVM_3WAY_ADD(TVM_A3) TVM_3WAY_ADD(TVM_A4) TVM_3WAY_ADD(TVM_A5)
+        TVM_3WAY_ADD(TVM_A6) TVM_3WAY_ADD(TVM_A7)
+        : TVM_ADD_OUT(a, s0a, s1a, t0a, t1a), TVM_ADD_OUT(b, s0b, s1b, t0b, t1b), TVM_ADD_OUT(c, s0c, s1c, t0c, t1c),
+          [cb] "=&s"(cb), [cc] "=&s"(cc), [ka] "=&s"(ka), [kb] "=&s"(kb), [kc] "=&s"(kc)
+        : TVM_AB_IN(a, a0, b0), TVM_AB_IN(b, a1, b1), TVM_AB_IN(c, a2, b2)
+        : "vcc", "scc");
+    e0 = ((u64)s1a << 32) | s0a;
+    e1 = ((u64)s1b << 32) | s0b;
+    e2 = ((u64)s1c << 32) | s0c;
+#else
+    e0 = bfe_add(a0, b0);
+    e1 = bfe_add(a1, b1);
+    e2 = bfe_add(a2, b2);
+#endif
+}
+TVM_HD void bfe_add2(u64 a0, u64 b0, u64 a1, u64 b1, u64& e0, u64& e1) {
+#ifdef TVM_FIELD_ASM
+    u32 s0a, s1a, t0a, t1a, s0b, s1b, t0b, t1b;
+    u64 cb, ka, kb;
+    asm(TVM_2WAY_ADD(TVM_A1) TVM_2WAY_ADD(TVM_A2) TVM_2WAY_ADD(TVM_A3) TVM_2WAY_ADD(TVM_A4) TVM_2WAY_ADD(TVM_A5)
+        TVM_A6(a, TVM_CA, "%[ka]") TVM_A6(b, TVM_CB, "%[kb]") TVM_A7(a, TVM_CA, "%[ka]") TVM_A7(b, TVM_CB, "%[kb]")
+        : TVM_ADD_OUT(a, s0a, s1a, t0a, t1a), TVM_ADD_OUT(b, s0b, s1b, t0b, t1b), [cb] "=&s"(cb), [ka] "=&s"(ka),
+          [kb] "=&s"(kb)
+        : TVM_AB_IN(a, a0, b0), TVM_AB_IN(b, a1, b1)
+        : "vcc", "scc");
+    e0 = ((u64)s1a << 32) | s0a;
+    e1 = ((u64)s1b << 32) | s0b;
+#else
+    e0 = bfe_add(a0, b0);
+    e1 = bfe_add(a1, b1);
+#endif
+}
+
 TVM_HD u64 bfe_sqr(u64 a) { return bfe_mul(a, a); }
 // Montgomery word of a small canonical integer v
 TVM_HD u64 bfe_from_u64(u64 v) { return bfe_mul(v >= TVM_P ? v - TVM_P : v, TVM_R2); }
@@ -140,20 +313,39 @@ TVM_HD xfe xfe_make(u64 a, u64 b, u64 c) { xfe r; r.c0 = a; r.c1 = b; r.c2 = c; 
 TVM_HD xfe xfe_zero() { return xfe_make(0, 0, 0); }
 TVM_HD xfe xfe_one() { return xfe_make(TVM_ONE, 0, 0); }
 TVM_HD xfe xfe_lift(u64 a) { return xfe_make(a, 0, 0); }
-TVM_HD xfe xfe_add(xfe a, xfe b) { return xfe_make(bfe_add(a.c0, b.c0), bfe_add(a.c1, b.c1), bfe_add(a.c2, b.c2)); }
-TVM_HD xfe xfe_sub(xfe a, xfe b) { return xfe_make(bfe_sub(a.c0, b.c0), bfe_sub(a.c1, b.c1), bfe_sub(a.c2, b.c2)); }
+TVM_HD xfe xfe_add(xfe a, xfe b) {
+    xfe r;
+    bfe_add3(a.c0, b.c0, a.c1, b.c1, a.c2, b.c2, r.c0, r.c1, r.c2);
+    return r;
+}
+TVM_HD xfe xfe_sub(xfe a, xfe b) {
+    xfe r;
+    bfe_sub3(a.c0, b.c0, a.c1, b.c1, a.c2, b.c2, r.c0, r.c1, r.c2);
+    return r;
+}
 TVM_HD xfe xfe_neg(xfe a) { return xfe_make(bfe_neg(a.c0), bfe_neg(a.c1), bfe_neg(a.c2)); }
 TVM_HD xfe xfe_add_bfe(xfe a, u64 b) { return xfe_make(bfe_add(a.c0, b), a.c1, a.c2); }
 TVM_HD xfe xfe_sub_bfe(xfe a, u64 b) { return xfe_make(bfe_sub(a.c0, b), a.c1, a.c2); }
-TVM_HD xfe xfe_mul_bfe(xfe a, u64 b) { return xfe_make(bfe_mul(a.c0, b), bfe_mul(a.c1, b), bfe_mul(a.c2, b)); }
+TVM_HD xfe xfe_mul_bfe(xfe a, u64 b) {
+    xfe r;
+    bfe_mul3(a.c0, b, a.c1, b, a.c2, b, r.c0, r.c1, r.c2);
+    return r;
+}
 // schoolbook, then X^3 = X - 1, X^4 = X^2 - X
 TVM_HD xfe xfe_mul(xfe a, xfe b) {
-    u64 d0 = bfe_mul(a.c0, b.c0);
-    u64 d1 = bfe_add(bfe_mul(a.c0, b.c1), bfe_mul(a.c1, b.c0));
-    u64 d2 = bfe_add(bfe_add(bfe_mul(a.c0, b.c2), bfe_mul(a.c1, b.c1)), bfe_mul(a.c2, b.c0));
-    u64 d3 = bfe_add(bfe_mul(a.c1, b.c2), bfe_mul(a.c2, b.c1));
-    u64 d4 = bfe_mul(a.c2, b.c2);
-    return xfe_make(bfe_sub(d0, d3), bfe_sub(bfe_add(d1, d3), d4), bfe_add(d2, d4));
+    // nine products, three independent ones at a time (interleaved carry chains)
+    u64 p00, p01, p02, p10, p11, p12, p20, p21, p22;
+    bfe_mul3(a.c0, b.c0, a.c0, b.c1, a.c0, b.c2, p00, p01, p02);
+    bfe_mul3(a.c1, b.c0, a.c1, b.c1, a.c1, b.c2, p10, p11, p12);
+    bfe_mul3(a.c2, b.c0, a.c2, b.c1, a.c2, b.c2, p20, p21, p22);
+    u64 d1, d3, t2;
+    bfe_add3(p01, p10, p12, p21, p02, p11, d1, d3, t2);  // d1, d3, and the first half of d2
+    const u64 d2 = bfe_add(t2, p20);
+    // (d0 - d3) + (d1 + d3 - d4) X + (d2 + d4) X^2 with d0 = p00, d4 = p22
+    u64 e1, c0, c1, c2;
+    bfe_add2(d1, d3, d2, p22, e1, c2);
+    bfe_sub2(p00, d3, e1, p22, c0, c1);
+    return xfe_make(c0, c1, c2);
 }
 TVM_HD xfe xfe_sqr(xfe a) { return xfe_mul(a, a); }
 TVM_HD bool xfe_eq(xfe a, xfe b) { return a.c0 == b.c0 && a.c1 == b.c1 && a.c2 == b.c2; }

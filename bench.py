@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--trace-randomizers", type=int, default=198, help="Stark::default() with FRI: 198 (stark.rs:2083-2089)")
     ap.add_argument("--queries", type=int, default=173, help="FRI collinearity checks at 160 bits, expansion 4: 173")
+    ap.add_argument("--jit-passes", type=int, default=0, help="single GPU: evaluate the extended tables coset-wise in this many "
+                    "passes (triton_vm_amd/jit.py, the reference's JIT path) instead of caching them")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent proofs per GPU instead of one sharded proof")
     args = ap.parse_args()
 
@@ -128,6 +130,10 @@ def main():
         from triton_vm_amd.sharded import ShardedProver
 
         prover = ShardedProver(ctx, params, dist, device, seed=1000)
+    elif args.jit_passes:
+        from triton_vm_amd.jit import JitProver
+
+        prover = JitProver(ctx, params, args.jit_passes, seed=1000 + rank)
     else:
         prover = Prover(ctx, params, seed=1000 + rank)
     cells_per_step = params.padded_height * MASTER_WORDS * (1 if sharded else world)
@@ -145,8 +151,9 @@ def main():
     if rank == 0:
         for _ in range(3):
             ctx.timer_start()
-            prover.main.maybe_low_degree_extend_all_columns()
+            prover.main.maybe_low_degree_extend_all_columns()  # over the domain the prover extends in one go
             lde_ms.append(ctx.timer_stop())
+        prover.main.clear_cache()
     barrier()
     t_prof = 0.0
     if rank == 0 or sharded:  # a sharded prove() contains collectives: every rank has to take part
@@ -161,12 +168,13 @@ def main():
         lde_avg_ms = sum(lde_ms) / len(lde_ms)
         lde_cells = params.trace.length * 379
         # algorithmic bytes of one launch: read the trace, write this rank's share of the extended rows
-        lde_bytes_per_cell = 8 + 64 / world if sharded else LDE_ALGORITHMIC_BYTES_PER_CELL
+        share = world if sharded else (args.jit_passes or 1)
+        lde_bytes_per_cell = 8 + 64 / share
         achieved = lde_cells * lde_bytes_per_cell / (lde_avg_ms * 1e-3) / 1e9
         traffic = None  # fabric-side bytes per LDE launch family, from the committed PMC run (profiles/lde_traffic.json)
         try:
             with open(os.path.join(ROOT, "profiles", "lde_traffic.json")) as f:
-                traffic = int(json.load(f)["hbm_bytes_per_trace_cell"] * lde_cells) if not sharded else None
+                traffic = int(json.load(f)["hbm_bytes_per_trace_cell"] * lde_cells) if share == 1 else None
         except (OSError, KeyError, ValueError):
             pass
         out = {
@@ -185,7 +193,8 @@ def main():
                        "padded_rows": params.padded_height, "master_words": MASTER_WORDS,
                        "ldt_domain": params.ldt.length, "parallelism": (f"one proof over {world} GPUs: coset sharding of the extended tables, all-gather of digests and "
                                        "quotient codeword" if sharded else f"{world} independent proofs, one per GPU" if world > 1
-                                       else "single GPU")},
+                                       else f"single GPU, tables evaluated coset-wise in {args.jit_passes} passes (nothing cached)"
+                                       if args.jit_passes else "single GPU")},
             "roofline": {"bound": "hbm", "kernel": "main-table LDE (k_ntt2_pass1 + k_lde_pass2 + k_lde_pass3, 12 column chunks)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,

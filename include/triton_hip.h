@@ -176,6 +176,16 @@ int32_t tvm_deep_codeword(tvm_ctx* ctx, uint32_t n_components, const uint64_t* c
 int32_t tvm_fri_split_and_fold(tvm_ctx* ctx, const uint64_t* d_codeword, tvm_domain domain,
                                const uint64_t* h_challenge, uint64_t* d_out);
 
+/* ---- coset-wise ("just in time") evaluation: Prover::compute_quotient_segments_with_jit_lde and the JIT branch of
+ * hash_all_ldt_domain_rows (stark.rs:805-1006, master_table.rs:470-503) -------------------------------------
+ * When the extended tables do not fit, the reference evaluates them coset by coset.  Here a coset group is an
+ * arithmetic domain of its own (offset * generator^r, generator^R, length / R), so tvm_lde_table,
+ * tvm_hash_rows and tvm_all_quotients_combined are simply called on that domain (triton_vm_amd/jit.py);
+ * the only extra primitive is putting a group's results back into row order:
+ *   d_dst[(i * stride + offset) * elem_words + w] = d_src[i * elem_words + w],  i < n. */
+int32_t tvm_scatter_strided(tvm_ctx* ctx, const uint64_t* d_src, uint32_t elem_words, uint64_t n, uint64_t stride,
+                            uint64_t offset, uint64_t* d_dst);
+
 /* ---- small transfers and host-side helpers ----------------------------------------------------
  * gather n elements of elem_words words each from a device array at the given element indices
  * (Merkle authentication-structure nodes, FRI leaves, single codeword entries) into host memory */

@@ -530,7 +530,27 @@ __global__ void k_gather_elements(const u64* __restrict__ src, u32 elem_words, c
 }
 }  // namespace tvm
 
+namespace tvm {
+__global__ void k_scatter_strided(const u64* __restrict__ src, u32 elem_words, u64 n, u64 stride, u64 offset,
+                                  u64* __restrict__ dst) {
+    const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * elem_words) return;
+    dst[((e / elem_words) * stride + offset) * elem_words + e % elem_words] = src[e];
+}
+}  // namespace tvm
+
 extern "C" {
+int32_t tvm_scatter_strided(tvm_ctx* c, const uint64_t* d_src, uint32_t elem_words, uint64_t n, uint64_t stride,
+                            uint64_t offset, uint64_t* d_dst) {
+    if (!c || !elem_words || !stride || offset >= stride || (n && (!d_src || !d_dst)))
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "scatter_strided arguments");
+    if (!n) return TVM_OK;
+    const u64 total = n * elem_words;
+    TVM_LAUNCH(tvm::k_scatter_strided, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_src, elem_words, n,
+               stride, offset, d_dst);
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
 int32_t tvm_gather_elements(tvm_ctx* c, const uint64_t* d_src, uint32_t elem_words, const uint64_t* h_idx, uint64_t n,
                             uint64_t* h_out) {
     if (!c || !d_src || !elem_words || (n && (!h_idx || !h_out))) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "gather arguments");

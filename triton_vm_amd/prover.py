@@ -154,8 +154,12 @@ class Prover:
         self.ctx._check(self.ctx.lib.tvm_table_merkle_tree(self.ctx.handle, table_handle, n, d.ptr), "merkle")
         return d
 
-    # -- the three steps that touch whole extended master tables; triton_vm_amd/sharded.py overrides them to
-    #    split the extended rows across GPUs --------------------------------------------------------------
+    # -- the steps that touch whole extended master tables; triton_vm_amd/sharded.py overrides them to split the
+    #    extended rows across GPUs, triton_vm_amd/jit.py to evaluate them coset by coset ----------------------
+    def _extend_master_table(self, mt):
+        """maybe_low_degree_extend_all_columns (master_table.rs:258-322): the cached path"""
+        mt.maybe_low_degree_extend_all_columns()
+
     def _commit_master_table(self, mt):
         """hash_all_ldt_domain_rows + merkle_tree (master_table.rs:443-468) -> device node array [2L][5]"""
         return self._table_tree(mt._need_table(), self.p.ldt.length)
@@ -196,7 +200,7 @@ class Prover:
 
         # 4-6: main table LDE, Merkle tree, challenges  (stark.rs:367-377)
         with self._timed("main LDE"):
-            self.main.maybe_low_degree_extend_all_columns()
+            self._extend_master_table(self.main)
         with self._timed("main Merkle"):
             main_nodes = self._commit_master_table(self.main)
         ps.enqueue("main root", self._root(main_nodes))
@@ -204,7 +208,7 @@ class Prover:
 
         # 8-9: aux table (its `extend` is host work in the reference; the trace is already resident)
         with self._timed("aux LDE"):
-            self.aux.maybe_low_degree_extend_all_columns()
+            self._extend_master_table(self.aux)
         with self._timed("aux Merkle"):
             aux_nodes = self._commit_master_table(self.aux)
         ps.enqueue("aux root", self._root(aux_nodes))

@@ -60,6 +60,12 @@ int32_t tvm_sync(tvm_ctx* ctx);
 int32_t tvm_malloc(tvm_ctx* ctx, size_t bytes, void** d_ptr);
 int32_t tvm_free(tvm_ctx* ctx, void* d_ptr);
 int32_t tvm_ctx_trim(tvm_ctx* ctx);
+/* Cap on the bytes this context may hold through tvm_malloc / table handles (0 = no cap).  Requests beyond it fail
+ * with TVM_ERR_OUT_OF_MEMORY exactly like a full device: the knob a host uses to share a GPU, and what the tests use to
+ * walk the reference's out-of-memory fallback (master_table.rs:268-271 -> the coset-wise path). */
+int32_t tvm_ctx_set_memory_limit(tvm_ctx* ctx, size_t bytes);
+/* bytes currently held from the driver through this context (live blocks + cached blocks) */
+int32_t tvm_ctx_memory_held(const tvm_ctx* ctx, size_t* bytes);
 int32_t tvm_memcpy_h2d(tvm_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int32_t tvm_memcpy_d2h(tvm_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 

@@ -17,7 +17,7 @@ def _capture(prover):
         "last_polynomial": prover.last_polynomial, "main rows": prover.opened["main"], "aux rows": prover.opened["aux"]}
 
 
-@pytest.mark.parametrize("passes", [1, 2, 8])
+@pytest.mark.parametrize("passes", [2, 8])
 def test_jit_prover_equals_cached_prover(ctx, orc, passes):
     rng = np.random.default_rng(5)
     p = StarkParameters(3, num_trace_randomizers=3, num_collinearity_checks=4)
@@ -33,3 +33,43 @@ def test_pass_count_must_divide_the_expansion(ctx):
     p = StarkParameters(3, num_trace_randomizers=3, num_collinearity_checks=4)
     with pytest.raises(ValueError):
         JitProver(ctx, p, 3)
+
+
+def test_out_of_memory_falls_back_to_the_coset_wise_path(ctx, orc):
+    """master_table.rs:268-271: an extension that does not fit is not an error, the prover switches to the JIT path.
+    The context's memory limit stands in for a full device; the proof must not change."""
+    from triton_vm_amd import jit
+
+    rng = np.random.default_rng(5)
+    p = StarkParameters(3, num_trace_randomizers=3, num_collinearity_checks=4)
+    n = p.trace.length
+    main_trace, aux_trace = orc.random_elements(rng, (379, n)), orc.random_elements(rng, (91, n, 3))
+    want = {}
+    prover, _ = jit.prove(ctx, p, main_trace, aux_trace, seed=11, capture=want)
+    assert type(prover) is Prover
+    del prover
+    ctx.trim()
+    traces_bytes = 8 * (main_trace.size + aux_trace.size)
+    full_tables = 8 * p.ldt.length * (379 + 273)
+    # room for what is already held, the traces, and half of the extended tables (plus allocator granularity)
+    ctx.set_memory_limit(ctx.memory_held() + traces_bytes + full_tables // 2 + (1 << 16))
+    try:
+        got = {}
+        prover, _ = jit.prove(ctx, p, main_trace, aux_trace, seed=11, capture=got)
+        assert isinstance(prover, JitProver) and prover.passes >= 2
+    finally:
+        ctx.set_memory_limit(0)
+    for key in KEYS:
+        assert (np.array(got[key]) == np.array(want[key])).all(), key
+
+
+def test_proving_does_not_mutate_the_traces(ctx, orc):
+    """stark.rs:2367-2398: computing the quotients (cached or coset-wise) leaves the trace tables as they were."""
+    rng = np.random.default_rng(6)
+    p = StarkParameters(3, num_trace_randomizers=3, num_collinearity_checks=4)
+    n = p.trace.length
+    main_trace, aux_trace = orc.random_elements(rng, (379, n)), orc.random_elements(rng, (91, n, 3))
+    for prover in (Prover(ctx, p, main_trace, aux_trace, seed=2), JitProver(ctx, p, 4, main_trace, aux_trace, seed=2)):
+        prover.prove()
+        assert (prover.main.d_trace.download(main_trace.shape) == main_trace).all()
+        assert (prover.aux.d_trace.download(aux_trace.shape) == aux_trace).all()

@@ -42,6 +42,8 @@ _SIGNATURES = {
     "tvm_malloc": (C.c_int32, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "tvm_free": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "tvm_ctx_trim": (C.c_int32, [C.c_void_p]),
+    "tvm_ctx_set_memory_limit": (C.c_int32, [C.c_void_p, C.c_size_t]),
+    "tvm_ctx_memory_held": (C.c_int32, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "tvm_memcpy_h2d": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "tvm_memcpy_d2h": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "tvm_timer_start": (C.c_int32, [C.c_void_p]),
@@ -162,6 +164,15 @@ class Context:
 
     def sync(self):
         self._check(self.lib.tvm_sync(self.handle), "tvm_sync")
+
+    def set_memory_limit(self, n_bytes):
+        """cap the device bytes this context may hold (0 = no cap); beyond it allocations raise status 2"""
+        self._check(self.lib.tvm_ctx_set_memory_limit(self.handle, n_bytes), "tvm_ctx_set_memory_limit")
+
+    def memory_held(self):
+        n = C.c_size_t()
+        self._check(self.lib.tvm_ctx_memory_held(self.handle, C.byref(n)), "tvm_ctx_memory_held")
+        return n.value
 
     def trim(self):
         """give the cached device blocks back to the driver"""

@@ -80,6 +80,16 @@ int32_t tvm_free(tvm_ctx* c, void* d_ptr) {
     pool_release(c, d_ptr);
     return TVM_OK;
 }
+int32_t tvm_ctx_set_memory_limit(tvm_ctx* c, size_t bytes) {
+    if (!c) return TVM_ERR_INVALID_ARGUMENT;
+    c->pool_limit = bytes;
+    return TVM_OK;
+}
+int32_t tvm_ctx_memory_held(const tvm_ctx* c, size_t* bytes) {
+    if (!c || !bytes) return TVM_ERR_INVALID_ARGUMENT;
+    *bytes = c->pool_bytes;
+    return TVM_OK;
+}
 int32_t tvm_ctx_trim(tvm_ctx* c) {
     if (!c) return TVM_ERR_INVALID_ARGUMENT;
     pool_trim(c);

@@ -502,6 +502,10 @@ void* pool_alloc(tvm_ctx* c, size_t bytes) {
         return p;
     }
     void* p = nullptr;
+    if (c->pool_limit && c->pool_bytes + want > c->pool_limit) {
+        pool_trim(c);  // cached blocks count against the limit: give them back first
+        if (c->pool_bytes + want > c->pool_limit) return nullptr;
+    }
     if (hipMalloc(&p, want) != hipSuccess) {
         (void)hipGetLastError();
         pool_trim(c);

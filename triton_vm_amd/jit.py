@@ -79,3 +79,30 @@ class JitProver(Prover):
                 rows[mine] = mt.reveal_rows(idx[mine] // np.uint64(self.passes)).reshape(mine.size, width)
         mt.clear_cache()
         return rows.reshape((idx.size, mt.n_cols) + ((3,) if mt.fk == 3 else ()))
+
+
+def prove(ctx, params, main_trace=None, aux_trace=None, seed=1, capture=None):
+    """The hot path with the reference's memory policy (master_table.rs:258-271, stark.rs:730-768): try the cached
+    extension; if the device (or the context's memory limit) cannot hold it, start over on the coset-wise path with as
+    few passes as fit.  The transcript is deterministic, so the restarted proof is the proof the cached path would have
+    produced.  Returns (prover, proof_stream)."""
+    from .capi import ERR_OUT_OF_MEMORY, TritonHipError
+
+    expansion = params.ldt.length // params.trace.length
+    passes = 0
+    while True:
+        prover = (JitProver(ctx, params, passes, main_trace, aux_trace, seed) if passes
+                  else Prover(ctx, params, main_trace, aux_trace, seed))
+        prover.capture = capture
+        try:
+            return prover, prover.prove()
+        except TritonHipError as e:
+            if e.status != ERR_OUT_OF_MEMORY or passes >= expansion:
+                raise
+            prover.main.clear_cache()
+            prover.aux.clear_cache()
+            del prover
+            ctx.trim()
+            passes = max(2 * passes, 2)
+            while expansion % passes:
+                passes += 1

@@ -24,8 +24,6 @@
 //   pass3  forward rows step (DIT) for 16 table columns at once  reads Z,       writes the table
 // Algorithmic HBM bytes per base-field trace cell: 8 (read) + 8*X (write) = 72 at X = 8; the
 // scheme moves 8*(1+1+1+X+X+X) = 216.
-#include <cstdlib>
-
 #include "context.h"
 
 namespace tvm {
@@ -551,18 +549,11 @@ static int threads_for_tile(int tile) {
     if (t > 1024) t = 1024;
     return t;
 }
-// Tile = 2^log_axis points x 2^batch transforms.  TVM_TILE_WORDS_LOG (env, experiments) caps the tile size:
-// 14 = 128 KiB (one 1024-thread workgroup per CU), 13 = 64 KiB (two 512-thread workgroups per CU, which lets
-// one workgroup's global loads/stores overlap the other's butterflies).
-static int tile_words_log() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("TVM_TILE_WORDS_LOG");
-        v = e ? atoi(e) : 14;
-        if (v < 10 || v > 14) v = 14;
-    }
-    return v;
-}
+// Tile = 2^log_axis points x 2^batch transforms, at most 2^14 words = 128 KiB of LDS (one 1024-thread workgroup per
+// CU).  Measured alternative: 64 KiB tiles with two 512-thread workgroups per CU, so that one workgroup's global
+// traffic overlaps the other's butterflies -- no gain (24.9 vs 25.5 ms for 128 columns): the passes are bound by
+// VALU issue, not by exposed memory latency.
+static int tile_words_log() { return 14; }
 static int batch_log_for(int log_axis) {
     int b = tile_words_log() - log_axis;
     if (b < 0) b = 0;
@@ -705,11 +696,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     const Split sp = split_for(N);
     const u64 n1 = 1ull << sp.log_n1, n2 = 1ull << sp.log_n2;
     const int W = (int)(n_cols * fk);
-    if (chunk_cols <= 0) {
-        const char* e = getenv("TVM_LDE_CHUNK_COLS");  // experiments
-        chunk_cols = e ? atoi(e) : 32;
-        if (chunk_cols < 1 || chunk_cols > 512) chunk_cols = 32;
-    }
+    if (chunk_cols <= 0) chunk_cols = 32;  // 64 / 128 columns per chunk measured the same (62.9 / 61.3 / 60.8 ms)
 
     const u64 w = trace_gen, wi = bfe_inv(trace_gen);
     const u64 n_inv = bfe_inv(bfe_from_u64(N));

@@ -20,7 +20,8 @@
  *    out-of-memory is TVM_ERR_OUT_OF_MEMORY and leaves the context usable, mirroring the
  *    reference's try_reserve_exact fallback (master_table.rs:268-271).
  *  - Work is enqueued on the context's HIP stream; functions that return host data synchronise
- *    that stream, the others do not.  One context per proving thread (lib.rs:522-532).
+ *    that stream, the others do not.  One context per proving thread (lib.rs:522-532); the calling
+ *    thread's current HIP device must be the one the context was created on.
  */
 #ifndef TRITON_HIP_H
 #define TRITON_HIP_H

@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--trace-randomizers", type=int, default=198, help="Stark::default() with FRI: 198 (stark.rs:2083-2089)")
     ap.add_argument("--queries", type=int, default=173, help="FRI collinearity checks at 160 bits, expansion 4: 173")
+    ap.add_argument("--ldt", choices=["fri", "stir"], default="fri",
+                    help="low-degree test: fri (what BASELINE.json names) or stir (the reference's default from 2^16 rows on)")
     ap.add_argument("--jit-passes", type=int, default=0, help="single GPU: evaluate the extended tables coset-wise in this many "
                     "passes (triton_vm_amd/jit.py, the reference's JIT path) instead of caching them")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent proofs per GPU instead of one sharded proof")
@@ -124,7 +126,7 @@ def main():
     else:
         ctx = Context(device=local_rank)
     params = StarkParameters(args.log2_rows, num_trace_randomizers=args.trace_randomizers,
-                             num_collinearity_checks=args.queries)
+                             num_collinearity_checks=args.queries, ldt=args.ldt)
     sharded = world > 1 and not args.replicas
     if sharded:
         from triton_vm_amd.sharded import ShardedProver
@@ -187,8 +189,10 @@ def main():
             "dtype": "u64 (F_p, p = 2^64 - 2^32 + 1, Montgomery) and its cubic extension",
             "data": "synthetic",
             "config": {"workload": f"prove() hot path, prove_fib-shaped tables: 2^{args.log2_rows} padded rows, 379 main + "
-                                   "91 aux columns (652 words/row), Stark::default() with FRI (expansion 4, "
-                                   f"{args.trace_randomizers} trace randomizers, {args.queries} queries), traces resident in HBM; host `gen` steps (VM, pad, extend) "
+                                   "91 aux columns (652 words/row), Stark::default() with "
+                                   + (f"FRI (expansion 4, {params.h} trace randomizers, {args.queries} queries)" if args.ldt == "fri"
+                                      else f"STIR (expansion 4, {params.h} trace randomizers, {len(params.stir.round_queries)} full rounds)")
+                                   + ", traces resident in HBM; host `gen` steps (VM, pad, extend) "
                                    "and the Rust-side transcript are not part of the path",
                        "padded_rows": params.padded_height, "master_words": MASTER_WORDS,
                        "ldt_domain": params.ldt.length, "parallelism": (f"one proof over {world} GPUs: coset sharding of the extended tables, all-gather of digests and "

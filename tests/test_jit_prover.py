@@ -47,6 +47,7 @@ def test_out_of_memory_falls_back_to_the_coset_wise_path(ctx, orc):
     want = {}
     prover, _ = jit.prove(ctx, p, main_trace, aux_trace, seed=11, capture=want)
     assert type(prover) is Prover
+    prover.release()
     del prover
     ctx.trim()
     traces_bytes = 8 * (main_trace.size + aux_trace.size)

@@ -80,6 +80,11 @@ _SIGNATURES = {
     "tvm_deep_codeword": (C.c_int32, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), Domain, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
     "tvm_fri_split_and_fold": (C.c_int32, [C.c_void_p, C.c_void_p, Domain, C.c_void_p, C.c_void_p]),
+    "tvm_stir_merkle_tree": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "tvm_fold_polynomial": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "tvm_stir_next_polynomial": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                                             Domain, C.c_void_p]),
+    "tvm_host_xfe_interpolate": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "tvm_scatter_strided": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
     "tvm_gather_elements": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]),
     "tvm_host_tip5_permutation": (None, [C.c_void_p]),

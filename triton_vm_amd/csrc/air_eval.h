@@ -130,7 +130,7 @@ TVM_D void air_acc_x(AirAcc& a, xfe w, xfe c) { a.v = xfe_add(a.v, xfe_mul(w, c)
 TVM_D xfe air_acc_value(const AirAcc& a) { return a.v; }
 #define AIR_PIN_ACC(acc) (void)0
 #endif
-TVM_D xfe xfe_bfe_sub(u64 b, xfe x) { return xfe_make(bfe_sub(b, x.c0), bfe_neg(x.c1), bfe_neg(x.c2)); }
+TVM_D xfe xfe_bfe_sub(u64 b, xfe x) { return xfe_bfe_minus(b, x); }
 
 // Addressing: a workgroup covers AIR_BLOCK consecutive quotient-domain rows, so every table cell it reads
 // is  (uniform block base + column offset)  +  (a 32-bit per-lane byte offset): the first term lives in

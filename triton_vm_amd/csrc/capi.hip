@@ -528,6 +528,80 @@ extern "C" int32_t tvm_all_quotients_combined(tvm_ctx* c, const tvm_table* mt, c
                                   qd.offset, qd.generator, qd.length, staged, staged + 3 * TVM_NUM_CHALLENGES, d_out);
 }
 
+// ---------------------------------------------------------------------------------- STIR
+extern "C" {
+int32_t tvm_stir_merkle_tree(tvm_ctx* c, const uint64_t* d_cw, uint64_t n, uint32_t stack_height, uint64_t* d_nodes) {
+    if (!c || !d_cw || !d_nodes || !is_pow2(n) || !stack_height || !is_pow2(stack_height) || stack_height > n ||
+        stack_height > 16)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "stir_merkle_tree arguments");
+    const u64 d = n / stack_height;
+    TVM_TRY(stir_hash_stacked(c, d_cw, n, (int)stack_height, d_nodes + 5 * d));
+    return merkle_tree_from_leaves(c, d_nodes, d);
+}
+int32_t tvm_fold_polynomial(tvm_ctx* c, const uint64_t* d_poly, uint64_t n_coeffs, uint32_t folding_factor,
+                            const uint64_t* h_randomness, uint64_t* d_out) {
+    if (!c || (n_coeffs && !d_poly) || !d_out || !h_randomness || !folding_factor || folding_factor > 64)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "fold_polynomial arguments");
+    return stir_fold_polynomial(c, d_poly, n_coeffs, (int)folding_factor, h_randomness, d_out);
+}
+int32_t tvm_stir_next_polynomial(tvm_ctx* c, const uint64_t* d_folded_poly, uint64_t n_coeffs, const uint64_t* h_quotient_set,
+                                 const uint64_t* h_answer_poly, uint32_t k, const uint64_t* h_degree_correction_randomness,
+                                 tvm_domain work_domain, uint64_t* d_out_poly) {
+    if (!c || !d_folded_poly || !d_out_poly || !h_degree_correction_randomness || (k && (!h_quotient_set || !h_answer_poly)) ||
+        !valid_domain(work_domain) || n_coeffs > work_domain.length)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "stir_next_polynomial arguments");
+    const u64 M = work_domain.length;
+    u64* vals = (u64*)scratch(c, 15, (size_t)M * 3 * sizeof(u64));
+    u64* staged = (u64*)scratch(c, 16, (size_t)(k ? k : 1) * 6 * sizeof(u64));
+    if (!vals || !staged) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "stir scratch");
+    if (k) {
+        TVM_HIP_CHECK(c, hipMemcpyAsync(staged, h_quotient_set, (size_t)k * 3 * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+        TVM_HIP_CHECK(c, hipMemcpyAsync(staged + 3 * (size_t)k, h_answer_poly, (size_t)k * 3 * sizeof(u64), hipMemcpyHostToDevice,
+                                        c->stream));
+        TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    }
+    TVM_TRY(tvm_evaluate(c, 3, d_folded_poly, n_coeffs, work_domain, vals));
+    TVM_TRY(stir_quotient(c, vals, M, work_domain.offset, work_domain.generator, staged, staged + 3 * (size_t)k, k,
+                          h_degree_correction_randomness));
+    return tvm_interpolate(c, 3, vals, work_domain, d_out_poly);
+}
+
+// Polynomial::interpolate for a handful of XFE points (the STIR "Ans" polynomial, stir.rs:954): Newton's divided
+// differences, then expansion to monomial coefficients.  Host work, O(k^2), points pairwise distinct.
+int32_t tvm_host_xfe_interpolate(const uint64_t* points, const uint64_t* values, uint32_t k, uint64_t* out_coeffs) {
+    if (k && (!points || !values || !out_coeffs)) return TVM_ERR_INVALID_ARGUMENT;
+    std::vector<xfe> p(k), d(k);
+    for (u32 i = 0; i < k; i++) {
+        p[i] = xfe_make(points[3 * i], points[3 * i + 1], points[3 * i + 2]);
+        d[i] = xfe_make(values[3 * i], values[3 * i + 1], values[3 * i + 2]);
+    }
+    for (u32 j = 1; j < k; j++)
+        for (u32 i = k - 1; i >= j; i--) {
+            const xfe den = xfe_sub(p[i], p[i - j]);
+            if (xfe_eq(den, xfe_zero())) return TVM_ERR_INVALID_ARGUMENT;  // repeated point
+            d[i] = xfe_mul(xfe_sub(d[i], d[i - 1]), xfe_inv(den));
+        }
+    // Horner over the Newton basis: c(X) = d[k-1];  c <- c * (X - p[i]) + d[i]  for i = k-2 .. 0
+    std::vector<xfe> co(k ? k : 1, xfe_zero()), nxt(k ? k : 1, xfe_zero());
+    if (k) co[0] = d[k - 1];
+    for (u32 deg = 0, i = k > 1 ? k - 1 : 0; i-- > 0; deg++) {
+        for (u32 e = 0; e <= deg + 1; e++) {
+            const xfe shifted = e ? co[e - 1] : xfe_zero();                       // X * c
+            const xfe scaled = e <= deg ? xfe_mul(p[i], co[e]) : xfe_zero();      // p_i * c
+            nxt[e] = xfe_sub(shifted, scaled);
+        }
+        nxt[0] = xfe_add(nxt[0], d[i]);
+        co.swap(nxt);
+    }
+    for (u32 i = 0; i < k; i++) {
+        out_coeffs[3 * i] = co[i].c0;
+        out_coeffs[3 * i + 1] = co[i].c1;
+        out_coeffs[3 * i + 2] = co[i].c2;
+    }
+    return TVM_OK;
+}
+}  // extern "C"
+
 // ---------------------------------------------------------------------------------- small transfers, host helpers
 #include "tip5.h"
 

@@ -326,6 +326,8 @@ TVM_HD xfe xfe_sub(xfe a, xfe b) {
 TVM_HD xfe xfe_neg(xfe a) { return xfe_make(bfe_neg(a.c0), bfe_neg(a.c1), bfe_neg(a.c2)); }
 TVM_HD xfe xfe_add_bfe(xfe a, u64 b) { return xfe_make(bfe_add(a.c0, b), a.c1, a.c2); }
 TVM_HD xfe xfe_sub_bfe(xfe a, u64 b) { return xfe_make(bfe_sub(a.c0, b), a.c1, a.c2); }
+// b - x for a base-field b (the factor (x_i - p) of a zerofier at a base-field point)
+TVM_HD xfe xfe_bfe_minus(u64 b, xfe x) { return xfe_make(bfe_sub(b, x.c0), bfe_neg(x.c1), bfe_neg(x.c2)); }
 TVM_HD xfe xfe_mul_bfe(xfe a, u64 b) {
     xfe r;
     bfe_mul3(a.c0, b, a.c1, b, a.c2, b, r.c0, r.c1, r.c2);

@@ -29,6 +29,11 @@ int poly_eval(tvm_ctx* c, const u64* d_coeffs, u64 n, const u64* d_points, int n
 int deep_sum(tvm_ctx* c, int n_comp, const u64* const* d_cw, const u64* h_points, const u64* h_values, const u64* h_weights,
              u64 offset, u64 gen, u64 n, u64* d_out);
 int fri_fold(tvm_ctx* c, const u64* d_cw, u64 n, u64 offset, u64 gen, const u64* h_challenge, u64* d_out);
+// stir.hip
+int stir_hash_stacked(tvm_ctx* c, const u64* cw, u64 n, int stack_height, u64* digests);
+int stir_fold_polynomial(tvm_ctx* c, const u64* poly, u64 n, int ff, const u64* h_r, u64* out);
+int stir_quotient(tvm_ctx* c, u64* vals, u64 n, u64 offset, u64 gen, const u64* d_points, const u64* d_answer, u32 k,
+                  const u64* h_r);
 // air.hip
 int all_quotients_combined(tvm_ctx* c, const u64* main_table, u64 main_rows, u64 wrap_rows, u64 main_w, const u64* aux_table,
                            u64 aux_w, u64 trace_len, u64 trace_gen, u64 q_offset, u64 q_gen, u64 q_len, const u64* d_challenges,

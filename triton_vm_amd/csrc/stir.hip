@@ -1,0 +1,125 @@
+// stir.hip -- the device side of the STIR prover (/root/reference/triton-vm/src/low_degree_test/stir.rs:885-993).
+//
+// Per round the reference (all on the CPU, polynomial arithmetic from twenty-first):
+//   StirMerkleTree::new      stack 4 codeword entries taken at distance n/4 into one leaf, hash_varlen, Merkle tree
+//                            (stir.rs:1380-1419)                                          -> tvm_stir_merkle_tree
+//   fold_polynomial          chunks of 4 coefficients evaluated at the folding randomness (stir.rs:1132-1147)
+//                                                                                         -> tvm_fold_polynomial
+//   next_round_domain.evaluate, out-of-domain evaluations                                 -> tvm_evaluate, tvm_evaluate_at_points
+//   quotient = (folded - Ans) / Zerofier,  next = quotient * (sum_i r^i X^i)   (stir.rs:945-966, Polynomial
+//   interpolate / zerofier / division / multiplication: O(n k) on the CPU)                -> tvm_stir_next_polynomial
+// The last step never forms Zerofier or the product as polynomials: on a coset that avoids the quotient set it
+// evaluates folded, Ans, Zerofier (as a product of linear factors) and the degree-correction series pointwise,
+// divides and multiplies pointwise and interpolates once.  The division is exact (folded - Ans vanishes on the
+// quotient set) and deg(next) = deg(folded) < |coset|, so the interpolant IS the reference's polynomial.
+#include "kernels.h"
+#include "tip5.h"
+
+namespace tvm {
+
+TVM_D xfe stir_ld(const u64* p) { return xfe_make(p[0], p[1], p[2]); }
+
+// leaf i = Tip5::hash_varlen(cw[i], cw[i + d], ..., cw[i + (sh-1) d]) with d = n / sh, XFEs flattened c0,c1,c2
+__global__ void __launch_bounds__(256) k_hash_stacked(const u64* __restrict__ cw, u64 d, int stack_height,
+                                                      u64* __restrict__ digests) {
+    __shared__ unsigned char lut[256];
+    tip5_stage_lut(lut, threadIdx.x, blockDim.x);
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d) return;
+    const int W = 3 * stack_height;
+    u64 st[TIP5_STATE];
+#pragma unroll
+    for (int q = 0; q < TIP5_STATE; q++) st[q] = 0;
+    const int n_perms = W / TIP5_RATE + 1;
+    int wi = 0;
+    for (int perm = 0; perm < n_perms; perm++) {
+#pragma unroll
+        for (int q = 0; q < TIP5_RATE; q++) {
+            u64 v;
+            if (wi < W) v = cw[(i + (u64)(wi / 3) * d) * 3 + wi % 3];
+            else v = (wi == W) ? TVM_ONE : 0;  // padding: 1 then 0s
+            st[q] = v;
+            wi++;
+        }
+        tip5_permute_inline(st, lut);
+    }
+#pragma unroll
+    for (int q = 0; q < TIP5_DIGEST; q++) digests[i * 5 + q] = st[q];
+}
+
+// out[i] = sum_j poly[ff*i + j] * r^j  (Horner from the top coefficient of the chunk; the last chunk may be short)
+__global__ void k_fold_polynomial(const u64* __restrict__ poly, u64 n, int ff, u64 r0, u64 r1, u64 r2, u64 n_out,
+                                  u64* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    const xfe r = xfe_make(r0, r1, r2);
+    const u64 base = i * (u64)ff;
+    int len = ff;
+    if (base + len > n) len = (int)(n - base);
+    xfe acc = xfe_zero();
+    for (int j = len - 1; j >= 0; j--) acc = xfe_add(xfe_mul(acc, r), stir_ld(poly + 3 * (base + j)));
+    out[3 * i] = acc.c0;
+    out[3 * i + 1] = acc.c1;
+    out[3 * i + 2] = acc.c2;
+}
+
+struct StirQuotientArgs {
+    u64* vals;          // in: folded(x_i), out: next(x_i); work_domain.length XFE
+    u64 n;
+    u64 offset, gen;
+    const u64* points;  // k XFE: the quotient set
+    const u64* answer;  // k XFE: coefficients of Ans (degree < k)
+    u32 k;
+    u64 r0, r1, r2;     // degree-correction randomness
+};
+// vals[i] = (vals[i] - Ans(x)) / prod_j (x - p_j) * sum_{e <= k} (r x)^e,  x = offset * gen^i
+__global__ void __launch_bounds__(256) k_stir_quotient(StirQuotientArgs a) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const u64 x = bfe_mul(a.offset, bfe_pow(a.gen, i));
+    xfe ans = xfe_zero(), z = xfe_one();
+    for (u32 j = a.k; j-- > 0;) ans = xfe_add(xfe_mul_bfe(ans, x), stir_ld(a.answer + 3 * j));
+    for (u32 j = 0; j < a.k; j++) z = xfe_mul(z, xfe_bfe_minus(x, stir_ld(a.points + 3 * j)));
+    const xfe t = xfe_mul_bfe(xfe_make(a.r0, a.r1, a.r2), x);
+    xfe dc = xfe_one();
+    for (u32 e = 0; e < a.k; e++) dc = xfe_add(xfe_mul(dc, t), xfe_one());  // 1 + t + ... + t^k
+    const xfe f = stir_ld(a.vals + 3 * i);
+    const xfe q = xfe_mul(xfe_mul(xfe_sub(f, ans), xfe_inv(z)), dc);
+    a.vals[3 * i] = q.c0;
+    a.vals[3 * i + 1] = q.c1;
+    a.vals[3 * i + 2] = q.c2;
+}
+
+int stir_hash_stacked(tvm_ctx* c, const u64* cw, u64 n, int stack_height, u64* digests) {
+    const u64 d = n / (u64)stack_height;
+    TVM_LAUNCH(k_hash_stacked, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, c->stream, cw, d, stack_height, digests);
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+int stir_fold_polynomial(tvm_ctx* c, const u64* poly, u64 n, int ff, const u64* h_r, u64* out) {
+    const u64 n_out = (n + ff - 1) / ff;
+    if (!n_out) return TVM_OK;
+    TVM_LAUNCH(k_fold_polynomial, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, c->stream, poly, n, ff, h_r[0], h_r[1],
+               h_r[2], n_out, out);
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+int stir_quotient(tvm_ctx* c, u64* vals, u64 n, u64 offset, u64 gen, const u64* d_points, const u64* d_answer, u32 k,
+                  const u64* h_r) {
+    StirQuotientArgs a;
+    a.vals = vals;
+    a.n = n;
+    a.offset = offset;
+    a.gen = gen;
+    a.points = d_points;
+    a.answer = d_answer;
+    a.k = k;
+    a.r0 = h_r[0];
+    a.r1 = h_r[1];
+    a.r2 = h_r[2];
+    TVM_LAUNCH(k_stir_quotient, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, a);
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+
+}  // namespace tvm

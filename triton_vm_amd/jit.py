@@ -13,6 +13,8 @@ digests / quotient values back into row order.  Peak table memory is 1/R of the 
 (41 GiB / R at 2^20 rows), which is what a proof of 2^23 rows or of expansion factor 32 needs on one GPU.
 The same decomposition, with the passes on different GPUs, is triton_vm_amd/sharded.py.
 """
+import gc
+
 import numpy as np
 
 from .prover import Prover
@@ -99,9 +101,9 @@ def prove(ctx, params, main_trace=None, aux_trace=None, seed=1, capture=None):
         except TritonHipError as e:
             if e.status != ERR_OUT_OF_MEMORY or passes >= expansion:
                 raise
-            prover.main.clear_cache()
-            prover.aux.clear_cache()
+            prover.release()
             del prover
+            gc.collect()  # buffers of the failed attempt that are still referenced from its frames
             ctx.trim()
             passes = max(2 * passes, 2)
             while expansion % passes:

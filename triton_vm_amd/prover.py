@@ -81,8 +81,20 @@ class StarkParameters:
     """Domains for a padded height, as Stark::default() with LdtChoice::Fri derives them
     (stark.rs:263-286, 1885-1916, 2083-2089; fri.rs:832-836, 907-920).  expansion = 4."""
 
-    def __init__(self, log2_padded_height, num_trace_randomizers=198, num_collinearity_checks=173, log2_expansion=2):
+    def __init__(self, log2_padded_height, num_trace_randomizers=198, num_collinearity_checks=173, log2_expansion=2,
+                 ldt="fri"):
+        """ldt = "fri" (LdtChoice::Fri, what BASELINE.json's configs name) or "stir" (the reference's automatic choice
+        from 2^16 rows on, stark.rs:1944-1951): then the STIR instance fixes the number of trace randomizers and the
+        LDT domain (Stark::stir, stark.rs:1972-2032) and the two query-count arguments are ignored."""
         self.padded_height = 1 << log2_padded_height
+        self.stir = None
+        if ldt == "stir":
+            from .low_degree_test import stark_stir
+
+            self.stir = stark_stir(self.padded_height, log2_ldt_expansion_factor=log2_expansion)
+            num_trace_randomizers = self.stir.num_trace_randomizers()
+        elif ldt != "fri":
+            raise ValueError("ldt must be 'fri' or 'stir'")
         self.h = num_trace_randomizers
         self.num_collinearity_checks = num_collinearity_checks
         h = self.h
@@ -98,6 +110,9 @@ class StarkParameters:
         max_rounds = (first_round_dim - 1).bit_length()
         self.fri_rounds = max(0, max_rounds - (num_collinearity_checks.bit_length() - 1) - 1)
         self.num_quotient_randomizers = (h + 1) * 5
+        if self.stir is not None and self.stir.initial_domain.length != self.ldt.length:
+            self.ldt = self.stir.initial_domain  # Stark::stir may have grown the domain (tiny padded heights)
+            self.quotient = ArithmeticDomain.of_length(max(quotient_len, 1)).with_offset(g)
 
 
 class Prover:
@@ -178,17 +193,49 @@ class Prover:
         return mt.reveal_rows(row_indices)
 
     def _auth_nodes(self, d_nodes, n_leaves, indices):
-        """the sibling nodes on the paths of the opened leaves (what authentication_structure needs)"""
-        k = np.unique(np.asarray(indices, dtype=np.uint64) + np.uint64(n_leaves))
-        need = []
-        while k.size and k[0] > 1:
-            need.append(k ^ np.uint64(1))
-            k = np.unique(k >> np.uint64(1))
-        idx = np.unique(np.concatenate(need)) if need else np.zeros(0, np.uint64)
-        out = np.empty((idx.size, 5), np.uint64)
-        self.ctx._check(self.ctx.lib.tvm_gather_elements(self.ctx.handle, d_nodes.ptr, 5, idx.ctypes.data, idx.size,
-                                                         out.ctypes.data), "auth nodes")
-        return out
+        return stark.auth_nodes(self.ctx, d_nodes, n_leaves, indices)
+
+    def release(self):
+        """give the device memory of both master tables (traces, randomizers, cached extensions) back to the context
+        now, without waiting for the garbage collector"""
+        for mt in (self.main, self.aux):
+            mt.clear_cache()
+            for buf in (mt.d_trace, mt.d_randomizers):
+                buf.free()
+
+    def _fri(self, combination, ps):
+        """Fri::prove (fri.rs:212-319, 754-772): commit and fold round by round, send the last codeword and
+        polynomial, answer the queries -> the first-round indices"""
+        ctx, lib, p = self.ctx, self.ctx.lib, self.p
+        dom, cw, rounds = p.ldt, combination, []
+        for r in range(p.fri_rounds + 1):
+            nodes = stark.merkle_tree_from_codeword(ctx, cw, dom.length)
+            ps.enqueue(f"fri root {r}", self._root(nodes))
+            rounds.append((dom, cw, nodes))
+            if r == p.fri_rounds:
+                break
+            challenge = ps.sample_scalars(1)[0]
+            cw = stark.split_and_fold(ctx, cw, dom, challenge)
+            dom = dom.pow(2)
+        last = cw.download((dom.length, 3))
+        ps.enqueue("fri last codeword", last, fiat_shamir=False)
+        last_poly = ArithmeticDomain.of_length(dom.length).interpolate(ctx, cw, 3).download((dom.length, 3))
+        ps.enqueue("fri last polynomial", last_poly)
+        self.last_codeword, self.last_polynomial, self.last_domain = last, last_poly, dom
+        a_indices = ps.sample_indices(p.ldt.length, p.num_collinearity_checks)
+        for r, (rdom, rcw, rnodes) in enumerate(rounds):
+            idxs = a_indices if r == 0 else []
+            b_idx = [(a + rdom.length // 2) % rdom.length for a in (i % rdom.length for i in a_indices)]
+            for which in ((idxs, b_idx) if r == 0 else (b_idx,)):
+                if r == len(rounds) - 1 and which is b_idx:
+                    continue
+                ix = np.array(which, np.uint64)
+                leaves = np.empty((ix.size, 3), np.uint64)
+                ctx._check(lib.tvm_gather_elements(ctx.handle, rcw.ptr, 3, ix.ctypes.data, ix.size, leaves.ctypes.data), "leaves")
+                ps.enqueue(f"fri response {r}", leaves, fiat_shamir=False)
+                ps.enqueue(f"fri auth {r}", self._auth_nodes(rnodes, rdom.length, which), fiat_shamir=False)
+        ps.sample_scalars(1)
+        return a_indices
 
     def prove(self, profile=False):
         """One pass of the hot path.  Returns the (stand-in) proof stream."""
@@ -279,36 +326,14 @@ class Prover:
                                 combination=combination.download((short.length, 3)))
         del main_aux_codeword, cw_p, cw_r, comb, comb_aux
 
-        # 17: FRI  (fri.rs:212-319, 754-772)
-        with self._timed("FRI"):
-            dom, cw, rounds = p.ldt, combination, []
-            for r in range(p.fri_rounds + 1):
-                nodes = stark.merkle_tree_from_codeword(ctx, cw, dom.length)
-                ps.enqueue(f"fri root {r}", self._root(nodes))
-                rounds.append((dom, cw, nodes))
-                if r == p.fri_rounds:
-                    break
-                challenge = ps.sample_scalars(1)[0]
-                cw = stark.split_and_fold(ctx, cw, dom, challenge)
-                dom = dom.pow(2)
-            last = cw.download((dom.length, 3))
-            ps.enqueue("fri last codeword", last, fiat_shamir=False)
-            last_poly = ArithmeticDomain.of_length(dom.length).interpolate(ctx, cw, 3).download((dom.length, 3))
-            ps.enqueue("fri last polynomial", last_poly)
-            self.last_codeword, self.last_polynomial, self.last_domain = last, last_poly, dom
-            a_indices = ps.sample_indices(p.ldt.length, p.num_collinearity_checks)
-            for r, (rdom, rcw, rnodes) in enumerate(rounds):
-                idxs = a_indices if r == 0 else []
-                b_idx = [(a + rdom.length // 2) % rdom.length for a in (i % rdom.length for i in a_indices)]
-                for which in ((idxs, b_idx) if r == 0 else (b_idx,)):
-                    if r == len(rounds) - 1 and which is b_idx:
-                        continue
-                    ix = np.array(which, np.uint64)
-                    leaves = np.empty((ix.size, 3), np.uint64)
-                    ctx._check(lib.tvm_gather_elements(ctx.handle, rcw.ptr, 3, ix.ctypes.data, ix.size, leaves.ctypes.data), "leaves")
-                    ps.enqueue(f"fri response {r}", leaves, fiat_shamir=False)
-                    ps.enqueue(f"fri auth {r}", self._auth_nodes(rnodes, rdom.length, which), fiat_shamir=False)
-            ps.sample_scalars(1)
+        # 17: the low-degree test  (stark.rs:641-663)
+        if p.stir is not None:
+            with self._timed("STIR"):
+                a_indices = p.stir.prove(ctx, combination, ps)
+                self.last_polynomial = p.stir.final_polynomial
+        else:
+            with self._timed("FRI"):
+                a_indices = self._fri(combination, ps)
 
         # 19: open the trace leafs  (stark.rs:665-716)
         with self._timed("open trace leafs"):

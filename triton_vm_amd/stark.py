@@ -107,3 +107,26 @@ def merkle_tree_from_codeword(ctx, d_codeword, length):
     nodes = ctx.alloc(10 * length)
     ctx._check(ctx.lib.tvm_codeword_merkle_tree(ctx.handle, d_codeword.ptr, length, nodes.ptr), "codeword tree")
     return nodes
+
+
+def auth_nodes(ctx, d_nodes, n_leaves, indices):
+    """the sibling nodes on the paths of the opened leaves of a device node array (what twenty-first's
+    authentication_structure needs from the tree), gathered to the host"""
+    k = np.unique(np.asarray(indices, dtype=np.uint64) + np.uint64(n_leaves))
+    need = []
+    while k.size and k[0] > 1:
+        need.append(k ^ np.uint64(1))
+        k = np.unique(k >> np.uint64(1))
+    idx = np.unique(np.concatenate(need)) if need else np.zeros(0, np.uint64)
+    out = np.empty((idx.size, 5), np.uint64)
+    if idx.size:
+        ctx._check(ctx.lib.tvm_gather_elements(ctx.handle, d_nodes.ptr, 5, idx.ctypes.data, idx.size, out.ctypes.data),
+                   "auth nodes")
+    return out
+
+
+def merkle_root(ctx, d_nodes):
+    """node 1 of a device node array (MerkleTree::root): one 40-byte copy, which also drains the stream"""
+    out = np.empty(5, np.uint64)
+    ctx._check(ctx.lib.tvm_memcpy_d2h(ctx.handle, out.ctypes.data, d_nodes.ptr + 40, 40), "root")
+    return out

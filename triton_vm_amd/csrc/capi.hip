@@ -561,7 +561,9 @@ int32_t tvm_stir_next_polynomial(tvm_ctx* c, const uint64_t* d_folded_poly, uint
         TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     }
     TVM_TRY(tvm_evaluate(c, 3, d_folded_poly, n_coeffs, work_domain, vals));
-    TVM_TRY(stir_quotient(c, vals, M, work_domain.offset, work_domain.generator, staged, staged + 3 * (size_t)k, k,
+    u32 kb = 0;  // leading base-field points of the quotient set
+    while (kb < k && h_quotient_set[3 * kb + 1] == 0 && h_quotient_set[3 * kb + 2] == 0) kb++;
+    TVM_TRY(stir_quotient(c, vals, M, work_domain.offset, work_domain.generator, staged, staged + 3 * (size_t)k, k, kb,
                           h_degree_correction_randomness));
     return tvm_interpolate(c, 3, vals, work_domain, d_out_poly);
 }

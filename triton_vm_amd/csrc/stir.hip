@@ -69,22 +69,34 @@ struct StirQuotientArgs {
     u64 offset, gen;
     const u64* points;  // k XFE: the quotient set
     const u64* answer;  // k XFE: coefficients of Ans (degree < k)
-    u32 k;
+    u32 k, kb;          // kb: how many leading points lie in the base field
     u64 r0, r1, r2;     // degree-correction randomness
 };
-// vals[i] = (vals[i] - Ans(x)) / prod_j (x - p_j) * sum_{e <= k} (r x)^e,  x = offset * gen^i
+// vals[i] = (vals[i] - Ans(x)) / prod_j (x - p_j) * sum_{e <= k} (r x)^e,  x = offset * gen^i.
+// The leading `kb` points of the quotient set are base-field elements (the queried domain values; only the
+// out-of-domain points are proper extension elements), so their part of the zerofier is a base-field product; the
+// degree-correction series is the geometric sum ((r x)^(k+1) - 1) / (r x - 1), and its denominator shares the one
+// inversion with the zerofier.
 __global__ void __launch_bounds__(256) k_stir_quotient(StirQuotientArgs a) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     const u64 x = bfe_mul(a.offset, bfe_pow(a.gen, i));
-    xfe ans = xfe_zero(), z = xfe_one();
+    xfe ans = xfe_zero();
     for (u32 j = a.k; j-- > 0;) ans = xfe_add(xfe_mul_bfe(ans, x), stir_ld(a.answer + 3 * j));
-    for (u32 j = 0; j < a.k; j++) z = xfe_mul(z, xfe_bfe_minus(x, stir_ld(a.points + 3 * j)));
+    u64 zb = TVM_ONE;
+    for (u32 j = 0; j < a.kb; j++) zb = bfe_mul(zb, bfe_sub(x, a.points[3 * j]));
+    xfe z = xfe_lift(zb);
+    for (u32 j = a.kb; j < a.k; j++) z = xfe_mul(z, xfe_bfe_minus(x, stir_ld(a.points + 3 * j)));
     const xfe t = xfe_mul_bfe(xfe_make(a.r0, a.r1, a.r2), x);
-    xfe dc = xfe_one();
-    for (u32 e = 0; e < a.k; e++) dc = xfe_add(xfe_mul(dc, t), xfe_one());  // 1 + t + ... + t^k
-    const xfe f = stir_ld(a.vals + 3 * i);
-    const xfe q = xfe_mul(xfe_mul(xfe_sub(f, ans), xfe_inv(z)), dc);
+    const xfe tm1 = xfe_sub_bfe(t, TVM_ONE);
+    xfe q;
+    const xfe num = xfe_sub(stir_ld(a.vals + 3 * i), ans);
+    if (xfe_eq(tm1, xfe_zero())) {  // r x = 1: the series is k + 1 ones
+        q = xfe_mul(xfe_mul_bfe(num, bfe_from_u64((u64)a.k + 1)), xfe_inv(z));
+    } else {
+        const xfe series_num = xfe_sub_bfe(xfe_pow(t, (u64)a.k + 1), TVM_ONE);
+        q = xfe_mul(xfe_mul(num, series_num), xfe_inv(xfe_mul(z, tm1)));
+    }
     a.vals[3 * i] = q.c0;
     a.vals[3 * i + 1] = q.c1;
     a.vals[3 * i + 2] = q.c2;
@@ -105,7 +117,7 @@ int stir_fold_polynomial(tvm_ctx* c, const u64* poly, u64 n, int ff, const u64* 
     return TVM_OK;
 }
 int stir_quotient(tvm_ctx* c, u64* vals, u64 n, u64 offset, u64 gen, const u64* d_points, const u64* d_answer, u32 k,
-                  const u64* h_r) {
+                  u32 kb, const u64* h_r) {
     StirQuotientArgs a;
     a.vals = vals;
     a.n = n;
@@ -114,6 +126,7 @@ int stir_quotient(tvm_ctx* c, u64* vals, u64 n, u64 offset, u64 gen, const u64* 
     a.points = d_points;
     a.answer = d_answer;
     a.k = k;
+    a.kb = kb;
     a.r0 = h_r[0];
     a.r1 = h_r[1];
     a.r2 = h_r[2];

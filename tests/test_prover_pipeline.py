@@ -68,6 +68,30 @@ def test_hot_path_matches_oracle_recomputation(ctx, orc):
     want = np.array([xsum(orc, [orc.xfe_mul(parts[k][i], wd[k]) for k in range(4)]) for i in range(128)])
     assert (c["combination"] == want).all()
 
+    # the transcript end to end, the way a verifier reads it: replay the Fiat-Shamir schedule of stark.rs:1386-1530 up to
+    # the low-degree test, let the restated FRI verifier (oracle/ldt_verifier.py) accept it, and authenticate the
+    # opened rows against the three table roots
+    from oracle import ldt_verifier as lv
+
+    view = prover.transcript.verifier_view()
+    assert (view.dequeue("main root") == c["main_root"]).all()
+    assert (view.sample_scalars(63) == c["challenges"]).all()
+    view.dequeue("aux root")
+    view.sample_scalars(1)
+    view.dequeue("quot root")
+    assert (view.sample_scalars(1)[0] == alpha).all()
+    for name in ("ood main", "ood aux", "ood main next", "ood aux next", "ood quot p", "ood quot r"):
+        view.dequeue(name)
+    view.sample_scalars(3)
+    max_degree = (p.randomized_trace_len - 1) >> p.fri_rounds
+    opened_at = lv.fri_verify(view, ldt, p.fri_rounds, p.num_collinearity_checks, max_degree)
+    for name, root, width in (("main", c["main_root"], 379), ("aux", c["aux_root"], 273), ("quot", c["quot_root"], 15)):
+        rows = np.asarray(view.dequeue(f"{name} rows"), np.uint64).reshape(len(opened_at), width)
+        auth = np.asarray(view.dequeue(f"{name} auth"), np.uint64).reshape(-1, 5)
+        lv.verify_inclusion(root, p.ldt.length, opened_at, orc.hash_rows(rows), auth)
+    assert not view.pending
+    assert (np.asarray(prover.opened["main"]).reshape(len(opened_at), 379) == main_lde[opened_at]).all()
+
     # FRI: the last polynomial respects the degree bound of a randomized_trace_len-degree input
     bound = p.randomized_trace_len >> p.fri_rounds
     assert (prover.last_polynomial[bound:] == 0).all()

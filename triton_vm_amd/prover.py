@@ -28,6 +28,7 @@ class ProofStream:
         self.lib = lib
         self.state = np.zeros(16, np.uint64)
         self.items = []
+        self.log = []      # (name, payload, fiat_shamir) in order: what a verifier dequeues
 
     def _permute(self):
         self.lib.tvm_host_tip5_permutation(self.state.ctypes.data)
@@ -39,8 +40,28 @@ class ProofStream:
         responses do not -- the prover is already committed to them through a Merkle root)."""
         w = np.ascontiguousarray(words, dtype=np.uint64).reshape(-1)
         self.items.append((name, w.size))
+        self.log.append((name, np.array(words, dtype=np.uint64), fiat_shamir))
         if fiat_shamir:
             self.lib.tvm_host_sponge_pad_and_absorb(self.state.ctypes.data, w.ctypes.data, w.size)
+
+    def verifier_view(self):
+        """a fresh transcript over the same items, for a verifier: dequeue() hands out the next item and absorbs it
+        when the prover did (ProofStream::dequeue, proof_stream.rs:56-70)"""
+        v = ProofStream(self.lib)
+        pending = list(self.log)
+
+        def dequeue(expected_prefix=None):
+            name, payload, fiat_shamir = pending.pop(0)
+            if expected_prefix is not None and not name.startswith(expected_prefix):
+                raise ValueError(f"unexpected proof item {name!r}, wanted {expected_prefix!r}")
+            if fiat_shamir:
+                w = np.ascontiguousarray(payload, dtype=np.uint64).reshape(-1)
+                v.lib.tvm_host_sponge_pad_and_absorb(v.state.ctypes.data, w.ctypes.data, w.size)
+            return payload
+
+        v.dequeue = dequeue
+        v.pending = pending
+        return v
 
     def _squeeze(self):
         out = self.state[:10].copy()
@@ -204,44 +225,16 @@ class Prover:
                 buf.free()
 
     def _fri(self, combination, ps):
-        """Fri::prove (fri.rs:212-319, 754-772): commit and fold round by round, send the last codeword and
-        polynomial, answer the queries -> the first-round indices"""
-        ctx, lib, p = self.ctx, self.ctx.lib, self.p
-        dom, cw, rounds = p.ldt, combination, []
-        for r in range(p.fri_rounds + 1):
-            nodes = stark.merkle_tree_from_codeword(ctx, cw, dom.length)
-            ps.enqueue(f"fri root {r}", self._root(nodes))
-            rounds.append((dom, cw, nodes))
-            if r == p.fri_rounds:
-                break
-            challenge = ps.sample_scalars(1)[0]
-            cw = stark.split_and_fold(ctx, cw, dom, challenge)
-            dom = dom.pow(2)
-        last = cw.download((dom.length, 3))
-        ps.enqueue("fri last codeword", last, fiat_shamir=False)
-        last_poly = ArithmeticDomain.of_length(dom.length).interpolate(ctx, cw, 3).download((dom.length, 3))
-        ps.enqueue("fri last polynomial", last_poly)
-        self.last_codeword, self.last_polynomial, self.last_domain = last, last_poly, dom
-        a_indices = ps.sample_indices(p.ldt.length, p.num_collinearity_checks)
-        for r, (rdom, rcw, rnodes) in enumerate(rounds):
-            idxs = a_indices if r == 0 else []
-            b_idx = [(a + rdom.length // 2) % rdom.length for a in (i % rdom.length for i in a_indices)]
-            for which in ((idxs, b_idx) if r == 0 else (b_idx,)):
-                if r == len(rounds) - 1 and which is b_idx:
-                    continue
-                ix = np.array(which, np.uint64)
-                leaves = np.empty((ix.size, 3), np.uint64)
-                ctx._check(lib.tvm_gather_elements(ctx.handle, rcw.ptr, 3, ix.ctypes.data, ix.size, leaves.ctypes.data), "leaves")
-                ps.enqueue(f"fri response {r}", leaves, fiat_shamir=False)
-                ps.enqueue(f"fri auth {r}", self._auth_nodes(rnodes, rdom.length, which), fiat_shamir=False)
-        ps.sample_scalars(1)
+        p = self.p
+        a_indices, self.last_codeword, self.last_polynomial, self.last_domain = stark.fri_prove(
+            self.ctx, p.ldt, p.fri_rounds, p.num_collinearity_checks, combination, ps)
         return a_indices
 
     def prove(self, profile=False):
         """One pass of the hot path.  Returns the (stand-in) proof stream."""
         self.profile = profile
         ctx, lib, p = self.ctx, self.ctx.lib, self.p
-        ps = ProofStream(lib)
+        ps = self.transcript = ProofStream(lib)
         L = p.ldt.length
         short = p.ldt if p.ldt.length <= p.quotient.length else p.quotient
 

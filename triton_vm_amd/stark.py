@@ -130,3 +130,40 @@ def merkle_root(ctx, d_nodes):
     out = np.empty(5, np.uint64)
     ctx._check(ctx.lib.tvm_memcpy_d2h(ctx.handle, out.ctypes.data, d_nodes.ptr + 40, 40), "root")
     return out
+
+
+def fri_prove(ctx, ldt_domain, num_rounds, num_collinearity_checks, d_codeword, ps):
+    """Fri::prove (fri.rs:212-319, 754-772): commit and fold round by round, send the last codeword and polynomial,
+    answer the queries.  ps: the transcript (enqueue / sample_scalars / sample_indices).
+    -> (first-round indices, last codeword, last polynomial, last domain)"""
+    from .arithmetic_domain import ArithmeticDomain
+
+    lib = ctx.lib
+    dom, cw, rounds = ldt_domain, d_codeword, []
+    for r in range(num_rounds + 1):
+        nodes = merkle_tree_from_codeword(ctx, cw, dom.length)
+        ps.enqueue(f"fri root {r}", merkle_root(ctx, nodes))
+        rounds.append((dom, cw, nodes))
+        if r == num_rounds:
+            break
+        challenge = ps.sample_scalars(1)[0]
+        cw = split_and_fold(ctx, cw, dom, challenge)
+        dom = dom.pow(2)
+    last = cw.download((dom.length, 3))
+    ps.enqueue("fri last codeword", last, fiat_shamir=False)
+    last_poly = ArithmeticDomain.of_length(dom.length).interpolate(ctx, cw, 3).download((dom.length, 3))
+    ps.enqueue("fri last polynomial", last_poly)
+    a_indices = ps.sample_indices(ldt_domain.length, num_collinearity_checks)
+    for r, (rdom, rcw, rnodes) in enumerate(rounds):
+        idxs = a_indices if r == 0 else []
+        b_idx = [(a + rdom.length // 2) % rdom.length for a in (i % rdom.length for i in a_indices)]
+        for which in ((idxs, b_idx) if r == 0 else (b_idx,)):
+            if r == len(rounds) - 1 and which is b_idx:
+                continue
+            ix = np.array(which, np.uint64)
+            leaves = np.empty((ix.size, 3), np.uint64)
+            ctx._check(lib.tvm_gather_elements(ctx.handle, rcw.ptr, 3, ix.ctypes.data, ix.size, leaves.ctypes.data), "leaves")
+            ps.enqueue(f"fri response {r}", leaves, fiat_shamir=False)
+            ps.enqueue(f"fri auth {r}", auth_nodes(ctx, rnodes, rdom.length, which), fiat_shamir=False)
+    ps.sample_scalars(1)
+    return a_indices, last, last_poly, dom

@@ -78,6 +78,7 @@ __global__ void __launch_bounds__(TVM_RED_BLOCK) k_column_dot(const u64* __restr
     for (int g = 0; g < TVM_DOT_G; g++)
 #pragma unroll
         for (int q = 0; q < TVM_DOT_P; q++) acc[g][q] = xfe_zero();
+#pragma unroll 2
     for (u64 j = r0 + tid; j < r1; j += nt) {
         xfe w[TVM_DOT_P];
 #pragma unroll
@@ -308,7 +309,9 @@ int out_of_domain_rows(tvm_ctx* c, int fk, const u64* trace, u64 n, u64 n_cols, 
     if (!u || !num) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "ood scratch");
     TVM_LAUNCH(k_ood_weights, TVM_GRID(n, 256), dim3(256), 0, c->stream, trace_gen, n, d_points, n_points, u);
     // rows in chunks of 2^15 (128 rows per work-item), columns in groups of TVM_DOT_G, points two at a time
-    const u64 rows_per_chunk = n < (1ull << 15) ? n : (1ull << 15);
+    // (2^13 for narrow tables so that the grid still fills the chip)
+    const u64 chunk_log = (n_cols + 1 + TVM_DOT_G - 1) / TVM_DOT_G >= 32 ? 15 : 13;
+    const u64 rows_per_chunk = n < (1ull << chunk_log) ? n : (1ull << chunk_log);
     const u64 n_chunks = (n + rows_per_chunk - 1) / rows_per_chunk;
     const u64 n_sums = (u64)n_points * (n_cols + 1);
     u64* partial = (u64*)scratch(c, 8, (size_t)n_sums * n_chunks * 3 * sizeof(u64));

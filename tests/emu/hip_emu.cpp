@@ -9,6 +9,7 @@ uint3_emu block_idx{0, 0, 0};
 dim3 block_dim, grid_dim;
 unsigned char* dyn_smem = nullptr;
 uint64_t xchg[4096];
+unsigned char xchg_wide[4096][64];
 
 static ucontext_t sched_ctx;
 static std::vector<Fiber> fibers;

@@ -85,6 +85,15 @@ static inline uint64_t __shfl(uint64_t v, int src, int width = 64) {
     emu::sync_wave();
     return r;
 }
+// every lane of a wave deposits `bytes` (<= 64) bytes; `all` receives the 64 deposits of the wave in lane order
+namespace emu { extern unsigned char xchg_wide[][64]; }
+static inline void emu_wave_gather(const void* mine, size_t bytes, void* all) {
+    int flat = emu::cur->tid.x + emu::block_dim.x * (emu::cur->tid.y + emu::block_dim.y * emu::cur->tid.z);
+    memcpy(emu::xchg_wide[flat], mine, bytes);
+    emu::sync_wave();
+    for (int l = 0; l < 64; l++) memcpy((unsigned char*)all + l * bytes, emu::xchg_wide[(flat & ~63) | l], bytes);
+    emu::sync_wave();
+}
 
 // ---- runtime API subset -------------------------------------------------------------------
 typedef int hipError_t;

@@ -44,6 +44,7 @@ def build(force=False, verbose=False, extra_flags=(), variant=None):
     objdir = os.path.join(HERE, "build" if variant is None else f"build_{variant}")
     os.makedirs(objdir, exist_ok=True)
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+             "-mllvm", "-amdgpu-mfma-vgpr-form",  # hash.hip: matrix-core results stay in VGPRs (no accvgpr moves)
              "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-Wno-unused-variable",
              *extra_flags]
     procs, objs = [], []

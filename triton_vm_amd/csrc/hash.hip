@@ -6,10 +6,10 @@
 //   quotient-segment row hashing + tree     /root/reference/triton-vm/src/stark.rs:425-446
 //   ProverRound::merkle_tree_from_codeword  /root/reference/triton-vm/src/low_degree_test/fri.rs:343-347
 //
-// One work-item hashes one row: the 16-word sponge state lives in VGPRs, the row is read tile by
-// tile (128-byte lines of the column-tile-major table, see ntt.hip), and the permutation is
-// instantiated exactly once inside the per-block loop so the kernel stays inside the I-cache.
-// Hashing is integer-ALU bound (38 + 28 permutations per LDT row), not HBM bound.
+// Row hashing: four lanes per row, the sponge state in VGPRs, the MDS layer of Tip5 on the matrix cores
+// (tip5.h, "matrix-core form"); Merkle levels: one lane per parent while a level fills the chip, sixteen
+// lanes per parent below that.  Hashing is integer-ALU bound (38 + 28 permutations per
+// LDT row; ~60% of a permutation's instructions are the x^7 S-boxes), not HBM bound.
 #include "context.h"
 #include "tip5.h"
 
@@ -18,36 +18,38 @@ namespace tvm {
 
 #define TVM_HASH_BLOCK 256
 
-// digests[r] = Tip5::hash_varlen(row r*stride of the table), W words per row.  Lanes are consecutive
-// rows, so word wi of 64 rows is four full 128-byte lines of the row-block-major table: every load
-// is coalesced and the ten loads of one absorb block are independent of the permutation before them.
-__global__ void __launch_bounds__(TVM_HASH_BLOCK) k_hash_rows(const u64* __restrict__ table, u64 L, int W, u64 stride,
-                                                               u64 n_out, u64* __restrict__ digests) {
+// digests[r] = Tip5::hash_varlen(row r*stride of the table), W words per row, with the permutation's MDS layer on
+// the matrix cores (tip5_permute_mfma): four lanes per row, sixteen rows per wavefront.  Lane (n, g) absorbs the
+// words g, g + 4 (and g + 8 for g < 2) of each block of ten: with consecutive rows in a wavefront (stride 1) every
+// load instruction touches four full 128-byte lines of the row-block-major table.
+__global__ void __launch_bounds__(TVM_HASH_BLOCK) k_hash_rows_mfma(const u64* __restrict__ table, u64 L, int W, u64 stride,
+                                                                    u64 n_out, u64* __restrict__ digests) {
     __shared__ unsigned char lut[256];
+    __shared__ int ctab[TIP5_ROUNDS * TIP5_MFMA_POSITIONS * 16];
     const int tid = threadIdx.x;
+    for (int i = tid; i < TIP5_ROUNDS * TIP5_MFMA_POSITIONS * 16; i += blockDim.x) ctab[i] = d_tip5_mfma_table.v[i];
     tip5_stage_lut(lut, tid, blockDim.x);
-    const u64 r = (u64)blockIdx.x * blockDim.x + tid;
-    if (r >= n_out) return;
-    const u64 row = r * stride;
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const u64 r = ((u64)blockIdx.x * (TVM_HASH_BLOCK / 64) + (tid >> 6)) * 16 + n;
+    const bool live = r < n_out;  // every lane of a wavefront takes part in the matrix instructions
+    const u64 row = (live ? r : n_out - 1) * stride;
     const u64* base = table + (row >> TVM_RB_LOG) * (u64)W * TVM_RB + (row & (TVM_RB - 1));
-    u64 st[TIP5_STATE];
-#pragma unroll
-    for (int i = 0; i < TIP5_STATE; i++) st[i] = 0;
+    const tvm_v4i a = tip5_mfma_matrix_operand(lane);
+    u64 st[4] = {0, 0, 0, 0};
     const int n_perms = W / TIP5_RATE + 1;
-    int wi = 0;
     for (int perm = 0; perm < n_perms; perm++) {
 #pragma unroll
-        for (int q = 0; q < TIP5_RATE; q++) {
-            u64 v;
-            if (wi < W) v = base[(u64)wi * TVM_RB];
-            else v = (wi == W) ? TVM_ONE : 0;  // padding: 1 then 0s (tip-0005.md:83)
-            st[q] = v;
-            wi++;
+        for (int t = 0; t < 3; t++) {
+            const int q = g + 4 * t;  // word of the state, overwritten if it is in the rate part
+            const int wi = perm * TIP5_RATE + q;
+            if (q < TIP5_RATE) st[t] = wi < W ? base[(u64)wi * TVM_RB] : (wi == W ? TVM_ONE : 0);  // padding: 1 then 0s
         }
-        tip5_permute_inline(st, lut);
+        tip5_permute_mfma(st, a, g, lut, ctab);
     }
-#pragma unroll
-    for (int i = 0; i < TIP5_DIGEST; i++) digests[r * 5 + i] = st[i];
+    if (live) {
+        digests[r * 5 + g] = st[0];
+        if (g == 0) digests[r * 5 + 4] = st[1];
+    }
 }
 
 // nodes[i] = hash_pair(nodes[2i], nodes[2i+1]) for i in [first, first + count)
@@ -150,7 +152,8 @@ __global__ void k_columns_to_table(const u64* __restrict__ cols, u64 col_stride,
 int hash_rows(tvm_ctx* c, const u64* table, u64 L, int W, u64 stride, u64* digests) {
     if (!stride || L % stride) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "hash_rows: stride must divide L");
     const u64 n = L / stride;
-    TVM_LAUNCH(k_hash_rows, dim3((unsigned)((n + TVM_HASH_BLOCK - 1) / TVM_HASH_BLOCK)), dim3(TVM_HASH_BLOCK), 0, c->stream,
+    const u64 rows_per_block = TVM_HASH_BLOCK / 4;
+    TVM_LAUNCH(k_hash_rows_mfma, dim3((unsigned)((n + rows_per_block - 1) / rows_per_block)), dim3(TVM_HASH_BLOCK), 0, c->stream,
                table, L, W, stride, n, digests);
     TVM_HIP_CHECK(c, hipGetLastError());
     return TVM_OK;

@@ -305,6 +305,7 @@ struct LdePass3Args {
     int log_n1, log_n2;
     int n_cosets;
     int col0;            // first virtual column of the chunk
+    int tiles;           // k_lde_pass3_v2: consecutive row tiles per workgroup
     int W;               // words per table row
     u64 L;
     const u64* tw_b2;    // w_N1^e
@@ -416,6 +417,9 @@ __global__ void __launch_bounds__(1024) k_lde_pass2_v2(LdePass2Args a) {
     }
 }
 
+// A workgroup walks a.tiles consecutive row tiles of its column: the 16 global loads of the next tile are issued
+// before the column step of the current one, so the read latency of a tile hides behind the arithmetic of the
+// previous tile instead of preceding it (one workgroup per CU: nobody else would cover it).
 __global__ void __launch_bounds__(1024) k_lde_pass3_v2(LdePass3Args a) {
     TVM_DYN_SMEM(u64, s);
     const int tid = threadIdx.x, nt = blockDim.x;  // nt == n1
@@ -427,28 +431,41 @@ __global__ void __launch_bounds__(1024) k_lde_pass3_v2(LdePass3Args a) {
     const u64 period = X * n2;                  // rows per j2, a multiple of 16
     // adjacent workgroups = adjacent table columns of the same 16 rows: together they write runs of
     // chunk_cols * 128 contiguous bytes of the row-block-major table instead of lines 48 KiB apart
-    const u64 rho0 = (u64)blockIdx.y * 16;      // first local row of the tile
     const int vl = blockIdx.x;
     const u64* zc = a.z + (u64)vl * X * (n2 << a.log_n1) + tid;
+    u64* tw_fwd = s + 16 * RS;  // twiddles in LDS (see k_lde_pass2_v2)
+    if (tid < (n1 >> 1)) tw_fwd[tid] = a.tw_b2[tid];
+    const int b = tid & 15, j2_0 = tid >> 4;
+    const u64 W = (u64)a.W;
+    const u64 j2_stride = ((period >> TVM_RB_LOG) * W) << TVM_RB_LOG;
+    const int j2_step = n1 >> 4;
+    u64 nxt[16];
+    u64 rho0 = (u64)blockIdx.y * a.tiles * 16;  // first local row of the tile
 #pragma unroll
     for (int e = 0; e < 16; e++) {
         const u64 rho = rho0 + e, j1 = rho >> log_x, k = rho & (X - 1);  // uniform; X is a power of two
-        s[e * RS + tid] = zc[(k * n2 + j1) << a.log_n1];
+        nxt[e] = zc[(k * n2 + j1) << a.log_n1];
     }
-    u64* tw_fwd = s + 16 * RS;  // twiddles in LDS (see k_lde_pass2_v2)
-    if (tid < (n1 >> 1)) tw_fwd[tid] = a.tw_b2[tid];
-    __syncthreads();
-    lds_ntt<true>(s, a.log_n1, 4, 1, RS, tw_fwd, tid, nt);
-    const int b = tid & 15, j2_0 = tid >> 4;
-    const u64 W = (u64)a.W;
-    // row period*j2 + rho0 + b of column v: ((row / 16) * W + v) * 16 + b, row / 16 = (period / 16) * j2 + rho0 / 16
-    u64* out = a.table + (((rho0 >> TVM_RB_LOG) * W + (u64)(a.col0 + vl)) << TVM_RB_LOG) + b;
-    const u64 j2_stride = ((period >> TVM_RB_LOG) * W) << TVM_RB_LOG;
-    const int j2_step = n1 >> 4;
+    for (int it = 0; it < a.tiles; it++, rho0 += 16) {
+        if (it) __syncthreads();  // the stores of the previous tile have read s
+#pragma unroll
+        for (int e = 0; e < 16; e++) s[e * RS + tid] = nxt[e];
+        __syncthreads();
+        if (it + 1 < a.tiles) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const u64 rho = rho0 + 16 + e, j1 = rho >> log_x, k = rho & (X - 1);
+                nxt[e] = zc[(k * n2 + j1) << a.log_n1];
+            }
+        }
+        lds_ntt<true>(s, a.log_n1, 4, 1, RS, tw_fwd, tid, nt);
+        // row period*j2 + rho0 + b of column v: ((row / 16) * W + v) * 16 + b, row / 16 = (period / 16) * j2 + rho0 / 16
+        u64* out = a.table + (((rho0 >> TVM_RB_LOG) * W + (u64)(a.col0 + vl)) << TVM_RB_LOG) + b;
 #pragma unroll 4
-    for (int i = 0; i < 16; i++) {
-        const int j2 = j2_0 + i * j2_step;
-        out[(u64)j2 * j2_stride] = s[b * RS + j2];
+        for (int i = 0; i < 16; i++) {
+            const int j2 = j2_0 + i * j2_step;
+            out[(u64)j2 * j2_stride] = s[b * RS + j2];
+        }
     }
 }
 
@@ -788,8 +805,10 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             const int tile = (int)n1 << a.rows_log;
             dim3 grid((unsigned)((X * n2 + RB - 1) / RB), (unsigned)nc);
             const size_t lds = ((size_t)(n1 + TVM_ROW_PAD) << a.rows_log) * sizeof(u64);
-            if (a.rows_log == 4 && n1 >= 64 && (X * n2) % 16 == 0 && X * n2 / 16 < 65536)
-                TVM_LAUNCH(k_lde_pass3_v2, dim3(grid.y, grid.x), dim3((unsigned)n1), lds + (n1 / 2) * sizeof(u64), c->stream, a);
+            if (a.rows_log == 4 && n1 >= 64 && (X * n2) % 16 == 0 && X * n2 / 16 < 65536) {
+                a.tiles = grid.x % 4 == 0 ? 4 : 1;
+                TVM_LAUNCH(k_lde_pass3_v2, dim3(grid.y, grid.x / a.tiles), dim3((unsigned)n1), lds + (n1 / 2) * sizeof(u64), c->stream, a);
+            }
             else
                 TVM_LAUNCH(k_lde_pass3, grid, dim3(threads_for_tile(tile)), lds, c->stream, a);
         }

@@ -19,12 +19,12 @@ namespace tvm {
 #ifndef AIR_BLOCK
 #define AIR_BLOCK 256
 #endif
-// AIR_MIN_WAVES (experiment): wavefronts per SIMD the register allocation must leave room for
-#ifdef AIR_MIN_WAVES
-#define AIR_LAUNCH_BOUNDS __launch_bounds__(AIR_BLOCK, AIR_MIN_WAVES)
-#else
-#define AIR_LAUNCH_BOUNDS __launch_bounds__(AIR_BLOCK)
+// AIR_MIN_WAVES: wavefronts per SIMD the register allocation must leave room for.  Two (256 registers per lane):
+// with the table cells of the next segment in flight some parts would otherwise take > 256 and run alone.
+#ifndef AIR_MIN_WAVES
+#define AIR_MIN_WAVES 2
 #endif
+#define AIR_LAUNCH_BOUNDS __launch_bounds__(AIR_BLOCK, AIR_MIN_WAVES)
 // challenges and weights are the same for every lane and never written while a part runs: reading them
 // through the constant address space makes the loads scalar (s_load) and exempt from AIR_SYNC's clobber
 #ifdef TVM_EMU

@@ -96,7 +96,7 @@ TVM_D void lds_ntt_group(u64* s, int log_n, int batch_log, int SA, int SB, const
 #pragma unroll
         for (int e = 0; e < R; e++) p[e * stride] = x[e];
     }
-    __syncthreads();
+    tvm_lds_barrier();
 }
 
 template <bool DIT, int MAXK = 4>
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(1024) k_ntt2_pass1(Ntt2Args a) {
         if (a.pre_lo && x) x = bfe_mul(x, bfe_mul(a.pre_hi[i1], a.pre_lo[i2]));
         s[idx] = x;
     }
-    __syncthreads();
+    tvm_lds_barrier();
     lds_ntt<false>(s, a.log_n1, a.batch_log, B, 1, a.tw1, tid, nt);
     u64* tmp = a.tmp + (u64)vl * a.tmp_col_stride;
     for (int idx = tid; idx < tile; idx += nt) {
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(1024) k_ntt2_pass2(Ntt2Args a) {
         if (k1 < n1) x = tmp[(u64)brev_bits((u32)k1, a.log_n1) * n2 + i2];
         s[b * RS + i2] = x;
     }
-    __syncthreads();
+    tvm_lds_barrier();
     lds_ntt<false>(s, a.log_n2, a.batch_log, 1, RS, a.tw2, tid, nt);
     u64* out = a.out + (u64)(v / a.out_fk) * a.out_col_stride + (v % a.out_fk);
     for (int idx = tid; idx < tile; idx += nt) {
@@ -230,6 +230,8 @@ struct LdePass2Args {
     Pow2 tw_inter;       // w_N^e
     const u64* g_lo;     // [X][N1]: gamma_k^m2 / N
     const u64* g_hi;     // [X][N2]: gamma_k^(N1*m1)
+    const u64* g_lo_step;  // [N1]: (gamma_{k+1} / gamma_k)^m2       (k_lde_pass2_v2 walks the cosets with running
+    const u64* g_hi_step;  // [N2]: (gamma_{k+1} / gamma_k)^(N1*m1)    products: no table load inside its coset loop)
     u64 zk[TVM_LDE_MAX_COSETS];  // N * (gamma_k^N - 1)
 };
 
@@ -251,7 +253,7 @@ __global__ void __launch_bounds__(1024) k_lde_pass2(LdePass2Args a) {
         const int i2 = idx & (n2 - 1), b = idx >> a.log_n2;
         s[b * RS + i2] = (p0 + b < n1) ? y[(p0 + b) * n2 + i2] : 0;
     }
-    __syncthreads();
+    tvm_lds_barrier();
     // inverse rows step: position q of row b now holds N * t[k1 + N1*k2], k2 = brev(q)
     lds_ntt<false>(s, a.log_n2, a.batch_log, 1, RS, a.tw_a2, tid, nt);
 
@@ -266,7 +268,7 @@ __global__ void __launch_bounds__(1024) k_lde_pass2(LdePass2Args a) {
         if (idx < tile) coef[e] = s[(idx >> a.log_n2) * RS + (idx & (n2 - 1))];
     }
     for (int k = 0; k < a.n_cosets; k++) {
-        __syncthreads();
+        tvm_lds_barrier();
         const u64 zk = a.zk[k];
         const u64* g_lo = a.g_lo + (u64)k * n1;
         const u64* g_hi = a.g_hi + (u64)k * n2;
@@ -283,7 +285,7 @@ __global__ void __launch_bounds__(1024) k_lde_pass2(LdePass2Args a) {
                 s[b * RS + q] = bfe_mul(c, bfe_mul(g_lo[m2 & (n1 - 1)], g_hi[m1]));
             }
         }
-        __syncthreads();
+        tvm_lds_barrier();
         // forward columns step over m1 (bit-reversed in position q): natural j1 out
         lds_ntt<true, 3>(s, a.log_n2, a.batch_log, 1, RS, a.tw_b1, tid, nt);  // coef[] stays live: 8-element groups
         u64* z = a.z + ((u64)vl * a.n_cosets + k) * n;
@@ -335,7 +337,7 @@ __global__ void __launch_bounds__(1024) k_lde_pass3(LdePass3Args a) {
         }
         s[b * RS + p] = x;
     }
-    __syncthreads();
+    tvm_lds_barrier();
     lds_ntt<true>(s, a.log_n1, a.rows_log, 1, RS, a.tw_b2, tid, nt);
     const u64 v = (u64)(a.col0 + vl);
     for (int idx = tid; idx < tile; idx += nt) {
@@ -369,7 +371,7 @@ __global__ void __launch_bounds__(1024) k_lde_pass2_v2(LdePass2Args a) {
     const u64* y = a.y + (u64)vl * n + p0 * n2;
 #pragma unroll
     for (int e = 0; e < 16; e++) s[e * RS + tid] = y[(u64)e * n2 + tid];
-    __syncthreads();
+    tvm_lds_barrier();
     lds_ntt<false>(s, a.log_n2, 4, 1, RS, a.tw_a2, tid, nt);  // position q of row e: N * t[m1*n1 + m2], m1 = brev(q)
 
     u64 coef[16];
@@ -387,10 +389,16 @@ __global__ void __launch_bounds__(1024) k_lde_pass2_v2(LdePass2Args a) {
     const u64 m2_out = brev_bits((u32)(p0 + b_out), a.log_n1);
     const int j1_step = n2 >> 4;                                          // 16 elements per work-item
     const u64 t_step = pow2_get(a.tw_inter, (m2_out * (u64)j1_step) & (n - 1));  // w_N^(m2 * n2/16)
-    const u64 t_first = pow2_get(a.tw_inter, m2_out * (u64)j1_0);       // w_N^(m2*j1_0)
+    // The coset loop below issues no global load (except the few work-items that see randomizers): a load would
+    // have to be waited for, and the counter that waits for it also waits for every older store -- the stores of
+    // coset k would drain before the arithmetic of coset k + 1 instead of under it.  So the per-coset factors are
+    // running products: gamma_k = offset * g^k.
+    u64 gh = a.g_hi[m1];                                                  // gamma_0^(n1*m1)
+    const u64 gh_step = a.g_hi_step[m1];
+    u64 t_first = bfe_mul(pow2_get(a.tw_inter, m2_out * (u64)j1_0), a.g_lo[m2_out]);  // w_N^(m2*j1_0) * gamma_0^m2 / N
+    const u64 gl_step = a.g_lo_step[m2_out];
     for (int k = 0; k < a.n_cosets; k++) {
-        __syncthreads();
-        const u64 gh = a.g_hi[(u64)k * n2 + m1];  // gamma_k^(n1*m1)
+        tvm_lds_barrier();
         if (has_rnd) {
             const u64 zk = a.zk[k];
 #pragma unroll
@@ -404,16 +412,18 @@ __global__ void __launch_bounds__(1024) k_lde_pass2_v2(LdePass2Args a) {
 #pragma unroll
             for (int e = 0; e < 16; e++) s[e * RS + tid] = bfe_mul(coef[e], gh);
         }
-        __syncthreads();
+        tvm_lds_barrier();
         lds_ntt<true, 3>(s, a.log_n2, 4, 1, RS, tw_fwd, tid, nt);  // coef[] stays live: 8-element groups
         u64* z = a.z + ((u64)vl * a.n_cosets + k) * n + p0 + b_out;
-        u64 t = bfe_mul(t_first, a.g_lo[(u64)k * n1 + m2_out]);  // w_N^(m2*j1) * gamma_k^m2 / N at j1 = j1_0
+        u64 t = t_first;  // w_N^(m2*j1) * gamma_k^m2 / N at j1 = j1_0
 #pragma unroll 4
         for (int i = 0; i < 16; i++) {
             const int j1 = j1_0 + i * j1_step;
             z[(u64)j1 * n1] = bfe_mul(s[b_out * RS + j1], t);
             t = bfe_mul(t, t_step);
         }
+        gh = bfe_mul(gh, gh_step);
+        t_first = bfe_mul(t_first, gl_step);
     }
 }
 
@@ -447,10 +457,10 @@ __global__ void __launch_bounds__(1024) k_lde_pass3_v2(LdePass3Args a) {
         nxt[e] = zc[(k * n2 + j1) << a.log_n1];
     }
     for (int it = 0; it < a.tiles; it++, rho0 += 16) {
-        if (it) __syncthreads();  // the stores of the previous tile have read s
+        if (it) tvm_lds_barrier();  // the stores of the previous tile have read s
 #pragma unroll
         for (int e = 0; e < 16; e++) s[e * RS + tid] = nxt[e];
-        __syncthreads();
+        tvm_lds_barrier();
         if (it + 1 < a.tiles) {
 #pragma unroll
             for (int e = 0; e < 16; e++) {
@@ -749,6 +759,8 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     p2.tw_b1 = pow_table(c, bfe_pow(w, n1), n2 / 2);
     TVM_TRY(make_inter(c, w, sp, &p2.tw_inter));
     TVM_TRY(coset_tables(c, eval_offset, eval_gen, X, n1, n2, n_inv, &p2.g_lo, &p2.g_hi));
+    p2.g_lo_step = pow_table(c, eval_gen, n1);
+    p2.g_hi_step = pow_table(c, bfe_pow(eval_gen, n1), n2);
     const u64 n_mont = bfe_from_u64(N);
     for (u64 k = 0; k < X; k++) {
         const u64 gamma = bfe_mul(eval_offset, bfe_pow(eval_gen, k));
@@ -764,7 +776,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     p3.L = L;
     p3.W = W;
     p3.tw_b2 = pow_table(c, bfe_pow(w, n2), n1 > 1 ? n1 / 2 : 1);
-    if (!p1.tw1 || !p2.tw_a2 || !p2.tw_b1 || !p2.g_lo || !p2.g_hi || !p3.tw_b2)
+    if (!p1.tw1 || !p2.tw_a2 || !p2.tw_b1 || !p2.g_lo || !p2.g_hi || !p2.g_lo_step || !p2.g_hi_step || !p3.tw_b2)
         return set_error(c, TVM_ERR_OUT_OF_MEMORY, "lde tables");
 
     u64* y = (u64*)scratch(c, 1, (size_t)chunk_cols * N * sizeof(u64));

@@ -16,6 +16,16 @@
     T* name = reinterpret_cast<T*>(tvm_dyn_smem_)
 #endif
 
+// tvm_lds_barrier(): a workgroup barrier that orders LDS traffic only.  __syncthreads() carries a memory fence
+// and therefore drains every outstanding GLOBAL load and store of the wavefront first (s_waitcnt vmcnt(0)).
+// Where a barrier only separates LDS phases of one tile (the NTT kernels), waiting for the LDS counter is
+// enough: loads already in flight for the next tile and stores of the previous one proceed.
+#ifdef TVM_EMU
+static inline void tvm_lds_barrier() { __syncthreads(); }
+#else
+static __device__ __forceinline__ void tvm_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
+
 #include <cstdint>
 
 typedef uint64_t u64;

@@ -91,9 +91,11 @@ TVM_HD void mul64wide(u64 a, u64 b, u64& lo, u64& hi) {
 // Device multiplication: the four 32x32 partial products are C (v_mad_u64_u32), the carry chain is asm.
 // With t = a0*b0, u = a0*b1 + t1, v = a1*b0 + u0, w = a1*b1 + u1 the 128-bit product is
 // x = (w + v1) : v0 : t0; the asm adds v1 into w and performs bfe_montyred on 32-bit limbs with the
-// carries kept in VCC -- ten VALU instructions, where the compiler's rendering of the 64-bit C form takes
-// fourteen plus re-pairing moves and a zero-extended register pair per partial sum:
-//   a1 = x1 + x0 (carry e);  b = (a1:x0) - a1 - e;  r = (x3:x2) - b;  if that borrowed, r -= 2^32 - 1.
+// carries kept in VCC -- nine VALU instructions and one scalar one, where the compiler's rendering of the 64-bit C
+// form takes fourteen plus re-pairing moves and a zero-extended register pair per partial sum:
+//   a1 = x1 + x0 (carry e);  b = (a1:x0) - a1 - e;  r = (x3:x2) - b;  if that borrowed (B), r -= 2^32 - 1.
+// The last step is r0 += B (carry c), r1 -= B & ~c: the borrow goes to an SGPR pair, the AND-NOT is an s_andn2
+// on the scalar unit, so the conditional correction costs two vector instructions instead of three.
 TVM_HD u64 bfe_mul(u64 a, u64 b) {
 #ifdef TVM_FIELD_ASM
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
@@ -102,19 +104,20 @@ TVM_HD u64 bfe_mul(u64 a, u64 b) {
     const u64 v = (u64)a1 * b0 + (u32)u;
     const u64 w = (u64)a1 * b1 + (u >> 32);
     u32 r0, r1, s1, s0;
+    u64 bw;
     asm("v_add_co_u32 %[r0], vcc, %[w0], %[v1]\n\t" TVM_VCC_WAIT
         "v_addc_co_u32 %[r1], vcc, 0, %[w1], vcc\n\t"
         "v_add_co_u32 %[s1], vcc, %[x1], %[x0]\n\t" TVM_VCC_WAIT
         "v_subb_co_u32 %[s0], vcc, %[x0], %[s1], vcc\n\t" TVM_VCC_WAIT
         "v_subbrev_co_u32 %[s1], vcc, 0, %[s1], vcc\n\t"
         "v_sub_co_u32 %[r0], vcc, %[r0], %[s0]\n\t" TVM_VCC_WAIT
-        "v_subb_co_u32 %[r1], vcc, %[r1], %[s1], vcc\n\t" TVM_VCC_WAIT
-        "v_cndmask_b32_e64 %[s0], 0, -1, vcc\n\t"
-        "v_sub_co_u32 %[r0], vcc, %[r0], %[s0]\n\t" TVM_VCC_WAIT
+        "v_subb_co_u32_e64 %[r1], %[bw], %[r1], %[s1], vcc\n\t" TVM_VCC_WAIT
+        "v_addc_co_u32_e64 %[r0], vcc, %[r0], 0, %[bw]\n\t"
+        "s_andn2_b64 vcc, %[bw], vcc\n\t"
         "v_subbrev_co_u32 %[r1], vcc, 0, %[r1], vcc"
-        : [r0] "=&v"(r0), [r1] "=&v"(r1), [s1] "=&v"(s1), [s0] "=&v"(s0)
+        : [r0] "=&v"(r0), [r1] "=&v"(r1), [s1] "=&v"(s1), [s0] "=&v"(s0), [bw] "=&s"(bw)
         : [x0] "v"((u32)t), [x1] "v"((u32)v), [w0] "v"((u32)w), [w1] "v"((u32)(w >> 32)), [v1] "v"((u32)(v >> 32))
-        : "vcc");
+        : "vcc", "scc");
     return ((u64)r1 << 32) | r0;
 #else
     u64 lo, hi;
@@ -140,11 +143,11 @@ TVM_HD u64 bfe_mul(u64 a, u64 b) {
 #define TVM_M4(S, C) "v_subb_co_u32_e64 %[s0" #S "], " C ", %[x0" #S "], %[s1" #S "], " C "\n\t"
 #define TVM_M5(S, C) "v_subbrev_co_u32_e64 %[s1" #S "], " C ", 0, %[s1" #S "], " C "\n\t"
 #define TVM_M6(S, C) "v_sub_co_u32_e64 %[r0" #S "], " C ", %[r0" #S "], %[s0" #S "]\n\t"
-#define TVM_M7(S, C) "v_subb_co_u32_e64 %[r1" #S "], " C ", %[r1" #S "], %[s1" #S "], " C "\n\t"
-#define TVM_M8(S, C) "v_cndmask_b32_e64 %[s0" #S "], 0, -1, " C "\n\t"
-#define TVM_M9(S, C) "v_sub_co_u32_e64 %[r0" #S "], " C ", %[r0" #S "], %[s0" #S "]\n\t"
+#define TVM_M7(S, C) "v_subb_co_u32_e64 %[r1" #S "], %[bw" #S "], %[r1" #S "], %[s1" #S "], " C "\n\t"
+#define TVM_M8(S, C) "v_addc_co_u32_e64 %[r0" #S "], " C ", %[r0" #S "], 0, %[bw" #S "]\n\t"
+#define TVM_M9(S, C) "s_andn2_b64 " C ", %[bw" #S "], " C "\n\t"
 #define TVM_M10(S, C) "v_subbrev_co_u32_e64 %[r1" #S "], " C ", 0, %[r1" #S "], " C "\n\t"
-#define TVM_MUL_OUT(S, p, q, x, y) [r0##S] "=&v"(p), [r1##S] "=&v"(q), [s0##S] "=&v"(x), [s1##S] "=&v"(y)
+#define TVM_MUL_OUT(S, p, q, x, y, k) [r0##S] "=&v"(p), [r1##S] "=&v"(q), [s0##S] "=&v"(x), [s1##S] "=&v"(y), [bw##S] "=&s"(k)
 #define TVM_MUL_IN(S, t, v, w) \
     [x0##S] "v"((u32)(t)), [x1##S] "v"((u32)(v)), [w0##S] "v"((u32)(w)), [w1##S] "v"((u32)((w) >> 32)), [v1##S] "v"((u32)((v) >> 32))
 #define TVM_MUL_PARTIALS(a, b, t, u, v, w)                                                        \
@@ -163,13 +166,13 @@ TVM_HD void bfe_mul3(u64 a0, u64 b0, u64 a1, u64 b1, u64 a2, u64 b2, u64& p0, u6
     TVM_MUL_PARTIALS(a1, b1, tb, ub, vb, wb);
     TVM_MUL_PARTIALS(a2, b2, tc, uc, vc, wc);
     u32 r0a, r1a, s0a, s1a, r0b, r1b, s0b, s1b, r0c, r1c, s0c, s1c;
-    u64 cb, cc;
+    u64 cb, cc, ba, bb, bc;
     asm(TVM_3WAY(TVM_M1) TVM_3WAY(TVM_M2) TVM_3WAY(TVM_M3) TVM_3WAY(TVM_M4) TVM_3WAY(TVM_M5) TVM_3WAY(TVM_M6)
         TVM_3WAY(TVM_M7) TVM_3WAY(TVM_M8) TVM_3WAY(TVM_M9) TVM_3WAY(TVM_M10)
-        : TVM_MUL_OUT(a, r0a, r1a, s0a, s1a), TVM_MUL_OUT(b, r0b, r1b, s0b, s1b), TVM_MUL_OUT(c, r0c, r1c, s0c, s1c),
+        : TVM_MUL_OUT(a, r0a, r1a, s0a, s1a, ba), TVM_MUL_OUT(b, r0b, r1b, s0b, s1b, bb), TVM_MUL_OUT(c, r0c, r1c, s0c, s1c, bc),
           [cb] "=&s"(cb), [cc] "=&s"(cc)
         : TVM_MUL_IN(a, ta, va, wa), TVM_MUL_IN(b, tb, vb, wb), TVM_MUL_IN(c, tc, vc, wc)
-        : "vcc");
+        : "vcc", "scc");
     p0 = ((u64)r1a << 32) | r0a;
     p1 = ((u64)r1b << 32) | r0b;
     p2 = ((u64)r1c << 32) | r0c;
@@ -185,12 +188,12 @@ TVM_HD void bfe_mul2(u64 a0, u64 b0, u64 a1, u64 b1, u64& p0, u64& p1) {
     TVM_MUL_PARTIALS(a0, b0, ta, ua, va, wa);
     TVM_MUL_PARTIALS(a1, b1, tb, ub, vb, wb);
     u32 r0a, r1a, s0a, s1a, r0b, r1b, s0b, s1b;
-    u64 cb;
+    u64 cb, ba, bb;
     asm(TVM_2WAY(TVM_M1) TVM_2WAY(TVM_M2) TVM_2WAY(TVM_M3) TVM_2WAY(TVM_M4) TVM_2WAY(TVM_M5) TVM_2WAY(TVM_M6)
-        TVM_2WAY(TVM_M7) TVM_2WAY(TVM_M8) TVM_2WAY(TVM_M9) TVM_M10(a, TVM_CA) TVM_M10(b, TVM_CB)
-        : TVM_MUL_OUT(a, r0a, r1a, s0a, s1a), TVM_MUL_OUT(b, r0b, r1b, s0b, s1b), [cb] "=&s"(cb)
+        TVM_2WAY(TVM_M7) TVM_2WAY(TVM_M8) TVM_M9(a, TVM_CA) TVM_M9(b, TVM_CB) TVM_M10(a, TVM_CA) TVM_M10(b, TVM_CB)
+        : TVM_MUL_OUT(a, r0a, r1a, s0a, s1a, ba), TVM_MUL_OUT(b, r0b, r1b, s0b, s1b, bb), [cb] "=&s"(cb)
         : TVM_MUL_IN(a, ta, va, wa), TVM_MUL_IN(b, tb, vb, wb)
-        : "vcc");
+        : "vcc", "scc");
     p0 = ((u64)r1a << 32) | r0a;
     p1 = ((u64)r1b << 32) | r0b;
 #else

@@ -27,6 +27,20 @@ def test_row_hashes_and_merkle_tree(ctx, orc, n_cols, fk):
     assert (nodes == orc.merkle_tree(want)).all()
 
 
+@pytest.mark.parametrize("n,expansion", [(2, 1), (2, 4), (2, 2), (4, 2), (8, 8)])
+def test_row_hashes_of_short_tables(ctx, orc, n, expansion):
+    """fewer rows than one wavefront's sixteen (the row-hashing kernel clamps and drops the idle permutations), and a
+    full tile plus change"""
+    rng = np.random.default_rng(100 * n + expansion)
+    n_cols, h = 13, 1
+    trace, rnd = orc.random_elements(rng, (n_cols, n)), orc.random_elements(rng, (n_cols, h))
+    ev = ArithmeticDomain.of_length(n * expansion).with_offset(field.generator())
+    mt = MasterTable(ctx, trace, rnd, ArithmeticDomain.of_length(n), ev, ev, 1)
+    mt.maybe_low_degree_extend_all_columns()
+    table = orc.lde_table(trace, rnd, odom(orc, ev), 1)
+    assert (mt.hash_all_ldt_domain_rows() == orc.hash_rows(table)).all()
+
+
 def test_ldt_view_is_strided_subset(ctx, orc):
     """ldt domain shorter than the evaluation domain: rows at stride (master_table.rs:792-801)."""
     rng = np.random.default_rng(3)

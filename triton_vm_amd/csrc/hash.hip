@@ -52,22 +52,31 @@ __global__ void __launch_bounds__(TVM_HASH_BLOCK) k_hash_rows_mfma(const u64* __
     }
 }
 
-// nodes[i] = hash_pair(nodes[2i], nodes[2i+1]) for i in [first, first + count)
+// nodes[i] = hash_pair(nodes[2i], nodes[2i+1]) for i in [first, first + count): the matrix-core form of the
+// permutation (four lanes per parent, sixteen parents per wavefront; tip5.h), for the levels that fill the chip.
 __global__ void __launch_bounds__(256) k_merkle_level(u64* __restrict__ nodes, u64 first, u64 count) {
     __shared__ unsigned char lut[256];
-    tip5_stage_lut(lut, threadIdx.x, blockDim.x);
-    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= count) return;
+    __shared__ int ctab[TIP5_ROUNDS * TIP5_MFMA_POSITIONS * 16];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < TIP5_ROUNDS * TIP5_MFMA_POSITIONS * 16; i += blockDim.x) ctab[i] = d_tip5_mfma_table.v[i];
+    tip5_stage_lut(lut, tid, blockDim.x);
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+    u64 j = ((u64)blockIdx.x * 4 + (tid >> 6)) * 16 + n;
+    const bool live = j < count;  // every lane of a wavefront takes part in the matrix instructions
+    if (!live) j = count - 1;
     const u64 i = first + j;
-    u64 st[TIP5_STATE];
-    const u64* ch = nodes + 10 * i;
+    const tvm_v4i a = tip5_mfma_matrix_operand(lane);
+    u64 st[4];
 #pragma unroll
-    for (int q = 0; q < 10; q++) st[q] = ch[q];
-#pragma unroll
-    for (int q = 10; q < 16; q++) st[q] = TVM_ONE;  // fixed-length domain: capacity all ones (tip-0005.md:82)
-    tip5_permute_inline(st, lut);
-#pragma unroll
-    for (int q = 0; q < 5; q++) nodes[5 * i + q] = st[q];
+    for (int t = 0; t < 4; t++) {
+        const int q = g + 4 * t;
+        st[t] = q < 10 ? nodes[10 * i + q] : TVM_ONE;  // fixed-length domain: capacity all ones (tip-0005.md:82)
+    }
+    tip5_permute_mfma(st, a, g, lut, ctab);
+    if (live) {
+        nodes[5 * i + g] = st[0];
+        if (g == 0) nodes[5 * i + 4] = st[1];
+    }
 }
 
 // Levels too narrow to fill the chip: 16 lanes per parent (tip5_permute_lanes), nodes[i] = hash_pair(nodes[2i],
@@ -165,7 +174,7 @@ int merkle_tree_from_leaves(tvm_ctx* c, u64* nodes, u64 n_leaves) {
     TVM_HIP_CHECK(c, hipMemsetAsync(nodes, 0, 5 * sizeof(u64), c->stream));
     u64 lvl = n_leaves >> 1;
     for (; lvl > 32768; lvl >>= 1)  // wide levels: one lane per parent (throughput form)
-        TVM_LAUNCH(k_merkle_level, dim3((unsigned)((lvl + 255) / 256)), dim3(256), 0, c->stream, nodes, lvl, lvl);
+        TVM_LAUNCH(k_merkle_level, dim3((unsigned)((lvl + 63) / 64)), dim3(256), 0, c->stream, nodes, lvl, lvl);
     for (; lvl > 64; lvl >>= 1)     // narrow levels: 16 lanes per parent (latency form)
         TVM_LAUNCH(k_merkle_level_lanes, dim3((unsigned)((lvl * 16 + 255) / 256)), dim3(256), 0, c->stream, nodes, lvl, lvl);
     if (lvl >= 1) TVM_LAUNCH(k_merkle_top, dim3(1), dim3(1024), 0, c->stream, nodes, lvl);

@@ -1,5 +1,6 @@
 """Build the TEST-ONLY CPU emulation of the kernels: the same csrc/*.hip sources compiled by g++
 against tests/emu/hip_emu.h.  Never loaded by the product package (see hip_emu.h)."""
+import fcntl
 import glob
 import os
 import subprocess
@@ -11,6 +12,13 @@ LIB = os.path.join(HERE, "libtriton_hip_emu.so")
 
 
 def build(force=False):
+    """Serialised by a file lock: the ranks of a multi-process test may all find the library stale at once."""
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build(force)
+
+
+def _build(force):
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + [os.path.join(HERE, "hip_emu.cpp")]
     deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h")) + \
         [os.path.join(HERE, "hip_emu.h")]
@@ -29,7 +37,8 @@ def build(force=False):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"g++ failed on {s}:\n{out}")
-    subprocess.check_call(["g++", "-shared", "-fPIC", "-o", LIB, *objs])
+    subprocess.check_call(["g++", "-shared", "-fPIC", "-o", LIB + ".tmp", *objs])
+    os.replace(LIB + ".tmp", LIB)  # never a half-written library under the final name
     return LIB
 
 

@@ -37,7 +37,16 @@ def _stale():
 
 def build(force=False, verbose=False, extra_flags=(), variant=None):
     """Compile every .hip translation unit for gfx950 and link the shared library.
-    `variant` (a name) builds an experiment library libtriton_hip_<variant>.so with extra flags."""
+    `variant` (a name) builds an experiment library libtriton_hip_<variant>.so with extra flags.
+    Serialised by a file lock: the ranks of a multi-process launch may all find the library stale at once."""
+    import fcntl
+
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build(force, verbose, extra_flags, variant)
+
+
+def _build(force, verbose, extra_flags, variant):
     lib = LIB if variant is None else os.path.join(HERE, f"libtriton_hip_{variant}.so")
     if variant is None and not force and not _stale():
         return LIB
@@ -61,7 +70,8 @@ def build(force=False, verbose=False, extra_flags=(), variant=None):
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out, file=sys.stderr)
-    subprocess.check_call([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib, *objs])
+    subprocess.check_call([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib + ".tmp", *objs])
+    os.replace(lib + ".tmp", lib)  # never a half-written library under the final name
     return lib
 
 

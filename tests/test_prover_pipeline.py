@@ -99,10 +99,13 @@ def test_hot_path_matches_oracle_recomputation(ctx, orc):
 
 
 @pytest.mark.gpu
-def test_full_size_pipeline_low_degree_invariant():
+def test_full_size_pipeline_low_degree_invariant(orc):
     """BASELINE config 1 (2^20 padded rows, 652 words per row) on the MI355X: the size-independent
     invariant -- whatever the tables hold, the codeword handed to FRI is low degree, so after all
-    folding rounds the last polynomial has at most randomized_trace_len >> rounds coefficients."""
+    folding rounds the last polynomial has at most randomized_trace_len >> rounds coefficients -- and the
+    transcript read the way a verifier reads it: the restated FRI verifier accepts it (173 queries over 13
+    rounds of the 2^23-point domain) and the 173 opened rows of each table authenticate against its root."""
+    from oracle import ldt_verifier as lv
     from triton_vm_amd import Context
 
     ctx = Context(0)
@@ -112,4 +115,22 @@ def test_full_size_pipeline_low_degree_invariant():
     bound = p.randomized_trace_len >> p.fri_rounds
     assert prover.last_codeword.shape[0] == p.ldt.length >> p.fri_rounds
     assert (prover.last_polynomial[bound:] == 0).all() and prover.last_polynomial[:bound].any()
+
+    view = prover.transcript.verifier_view()
+    roots = {"main": view.dequeue("main root")}
+    view.sample_scalars(63)
+    roots["aux"] = view.dequeue("aux root")
+    view.sample_scalars(1)
+    roots["quot"] = view.dequeue("quot root")
+    view.sample_scalars(1)
+    for name in ("ood main", "ood aux", "ood main next", "ood aux next", "ood quot p", "ood quot r"):
+        view.dequeue(name)
+    view.sample_scalars(3)
+    opened_at = lv.fri_verify(view, odom(orc, p.ldt), p.fri_rounds, p.num_collinearity_checks, bound - 1)
+    assert len(opened_at) == p.num_collinearity_checks
+    for name, width in (("main", 379), ("aux", 273), ("quot", 15)):
+        rows = np.asarray(view.dequeue(f"{name} rows"), np.uint64).reshape(len(opened_at), width)
+        auth = np.asarray(view.dequeue(f"{name} auth"), np.uint64).reshape(-1, 5)
+        lv.verify_inclusion(roots[name], p.ldt.length, opened_at, orc.hash_rows(rows), auth)
+    assert not view.pending
     ctx.close()

@@ -143,6 +143,20 @@ int32_t tvm_xfe_add_assign(tvm_ctx* ctx, uint64_t* d_a, const uint64_t* d_b, uin
 int32_t tvm_evaluate_at_points(tvm_ctx* ctx, const uint64_t* d_coeffs, uint64_t n, const uint64_t* h_points,
                                uint32_t n_points, uint64_t* h_out);
 
+/* ---- degree-lowering fill (second half) ---------------------------------------
+ * The generated DegreeLoweringTable::fill_derived_main_columns / fill_derived_aux_columns
+ * (triton-constraint-builder/src/substitutions.rs:128-205, row loops :236-400; called at the end of
+ * MasterMainTable::pad, master_table.rs:980-982, and of MasterMainTable::extend, :1066-1072): 230 of the 379
+ * main columns and 41 of the 90 non-randomizer aux columns are values of the substitution rules the degree
+ * lowering introduced.  Tables are the column-major traces tvm_lde_table takes: main [379][n_rows] words, aux
+ * [>= 90][n_rows][3] words, filled in place.  Single-row sections derive every row; the transition section
+ * derives rows 0 .. n_rows-2 from a row and its successor and leaves 0 in the last row (the reference's table is
+ * zero-initialised there).  main: columns 149..378 from columns 0..148; aux: columns 49..89 from the main
+ * table (already filled), aux columns 0..48 and the 63 challenges (host, XFE). */
+int32_t tvm_fill_derived_main_columns(tvm_ctx* ctx, uint64_t* d_main_trace, uint64_t n_rows);
+int32_t tvm_fill_derived_aux_columns(tvm_ctx* ctx, const uint64_t* d_main_trace, uint64_t* d_aux_trace, uint64_t n_rows,
+                                     const uint64_t* h_challenges);
+
 /* ---- A1-A3: all_quotients_combined (master_table.rs:1264-1363) ------------------------------
  * Evaluates the 81 + 97 + 403 + 23 = 604 AIR constraints of the (degree-lowered) Triton VM AIR on
  * every quotient-domain row of the two extended tables, including the zerofier inverses

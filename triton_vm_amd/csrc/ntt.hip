@@ -53,9 +53,16 @@ __global__ void k_pow_table(u64 base, u64 count, u64 scale, u64* out) {
 // instead of 10 and synchronises 3 times instead of 10.  Lanes of a wavefront are consecutive b first
 // (SB is either 1 or an odd row pitch), then consecutive groups: at most 2-way bank conflicts.
 // Ends with a barrier; the caller must have synchronised the tile before the call.
-template <bool DIT, int K, bool L0>
-TVM_D void lds_ntt_group(u64* s, int log_n, int batch_log, int SA, int SB, const u64* __restrict__ tw, int l, int tid, int nt) {
+#define TVM_ROW_PAD 1
+// CL / CLOGN >= 0: the group's first layer and the transform length are compile-time constants, for the
+// production tile (16 transforms side by side, element (a, b) at s[a + b * (n + TVM_ROW_PAD)]): every LDS address
+// of the group is then the work-item's base plus an immediate offset, and the twiddle indices are shifts by
+// constants -- the generic form spends ~190 of its ~1050 instructions per group on that arithmetic.
+template <bool DIT, int K, bool L0, int CL = -1, int CLOGN = -1>
+TVM_D void lds_ntt_group(u64* s, int log_n_rt, int batch_log_rt, int SA_rt, int SB_rt, const u64* __restrict__ tw, int l_rt, int tid, int nt) {
     constexpr int R = 1 << K;
+    const int log_n = CLOGN >= 0 ? CLOGN : log_n_rt, batch_log = CLOGN >= 0 ? 4 : batch_log_rt, l = CL >= 0 ? CL : l_rt;
+    const int SA = CLOGN >= 0 ? 1 : SA_rt, SB = CLOGN >= 0 ? (1 << (CLOGN >= 0 ? CLOGN : 0)) + TVM_ROW_PAD : SB_rt;
     const int n_groups = (1 << (log_n - K)) << batch_log;
     const int bmask = (1 << batch_log) - 1, lmask = (1 << l) - 1;
     for (int gi = tid; gi < n_groups; gi += nt) {
@@ -122,6 +129,17 @@ TVM_D void lds_ntt(u64* s, int log_n, int batch_log, int SA, int SB, const u64* 
     }
 }
 
+// The same sequence of groups with everything known at compile time (see lds_ntt_group).
+template <bool DIT, int MAXK, int LOGN, int DONE = 0>
+TVM_D void lds_ntt_fixed(u64* s, const u64* __restrict__ tw, int tid, int nt) {
+    if constexpr (DONE < LOGN) {
+        constexpr int k = (LOGN - DONE) >= MAXK ? MAXK : (LOGN - DONE);
+        constexpr int l = DIT ? DONE : (LOGN - DONE - k);
+        lds_ntt_group<DIT, k, l == 0, l, LOGN>(s, LOGN, 4, 1, (1 << LOGN) + TVM_ROW_PAD, tw, l, tid, nt);
+        lds_ntt_fixed<DIT, MAXK, LOGN, DONE + k>(s, tw, tid, nt);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Generic two-pass transform of `ncols` columns (grid.y), natural order in and out.
 //   X[k1 + N1*k2] = sum_{i2} w_N^(i2 k1) w_N2^(i2 k2) sum_{i1} x[i1*N2 + i2] w_N1^(i1 k1)
@@ -146,7 +164,6 @@ struct Ntt2Args {
     int col0;                    // first virtual column (in/out use col0 + blockIdx.y, tmp uses blockIdx.y)
 };
 
-#define TVM_ROW_PAD 1
 
 __global__ void __launch_bounds__(1024) k_ntt2_pass1(Ntt2Args a) {
     TVM_DYN_SMEM(u64, s);
@@ -372,7 +389,10 @@ __global__ void __launch_bounds__(1024) k_lde_pass2_v2(LdePass2Args a) {
 #pragma unroll
     for (int e = 0; e < 16; e++) s[e * RS + tid] = y[(u64)e * n2 + tid];
     tvm_lds_barrier();
-    lds_ntt<false>(s, a.log_n2, 4, 1, RS, a.tw_a2, tid, nt);  // position q of row e: N * t[m1*n1 + m2], m1 = brev(q)
+    // position q of row e: N * t[m1*n1 + m2], m1 = brev(q)
+    if (a.log_n2 == 10) lds_ntt_fixed<false, 4, 10>(s, a.tw_a2, tid, nt);
+    else if (a.log_n2 == 6) lds_ntt_fixed<false, 4, 6>(s, a.tw_a2, tid, nt);  // 2^12 rows: the size the CPU suite runs
+    else lds_ntt<false>(s, a.log_n2, 4, 1, RS, a.tw_a2, tid, nt);
 
     u64 coef[16];
 #pragma unroll
@@ -413,7 +433,10 @@ __global__ void __launch_bounds__(1024) k_lde_pass2_v2(LdePass2Args a) {
             for (int e = 0; e < 16; e++) s[e * RS + tid] = bfe_mul(coef[e], gh);
         }
         tvm_lds_barrier();
-        lds_ntt<true, 3>(s, a.log_n2, 4, 1, RS, tw_fwd, tid, nt);  // coef[] stays live: 8-element groups
+        // coef[] stays live: 8-element groups
+        if (a.log_n2 == 10) lds_ntt_fixed<true, 3, 10>(s, tw_fwd, tid, nt);
+        else if (a.log_n2 == 6) lds_ntt_fixed<true, 3, 6>(s, tw_fwd, tid, nt);
+        else lds_ntt<true, 3>(s, a.log_n2, 4, 1, RS, tw_fwd, tid, nt);
         u64* z = a.z + ((u64)vl * a.n_cosets + k) * n + p0 + b_out;
         u64 t = t_first;  // w_N^(m2*j1) * gamma_k^m2 / N at j1 = j1_0
 #pragma unroll 4
@@ -468,7 +491,9 @@ __global__ void __launch_bounds__(1024) k_lde_pass3_v2(LdePass3Args a) {
                 nxt[e] = zc[(k * n2 + j1) << a.log_n1];
             }
         }
-        lds_ntt<true>(s, a.log_n1, 4, 1, RS, tw_fwd, tid, nt);
+        if (a.log_n1 == 10) lds_ntt_fixed<true, 4, 10>(s, tw_fwd, tid, nt);
+        else if (a.log_n1 == 6) lds_ntt_fixed<true, 4, 6>(s, tw_fwd, tid, nt);
+        else lds_ntt<true>(s, a.log_n1, 4, 1, RS, tw_fwd, tid, nt);
         // row period*j2 + rho0 + b of column v: ((row / 16) * W + v) * 16 + b, row / 16 = (period / 16) * j2 + rho0 / 16
         u64* out = a.table + (((rho0 >> TVM_RB_LOG) * W + (u64)(a.col0 + vl)) << TVM_RB_LOG) + b;
 #pragma unroll 4

@@ -95,6 +95,10 @@ def main():
     ap.add_argument("--jit-passes", type=int, default=0, help="single GPU: evaluate the extended tables coset-wise in this many "
                     "passes (triton_vm_amd/jit.py, the reference's JIT path) instead of caching them")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent proofs per GPU instead of one sharded proof")
+    ap.add_argument("--host", choices=["cpp", "python"], default="cpp",
+                    help="host side that sequences the C-ABI calls of the timed step: the C++ mirror of Prover::prove "
+                         "(triton_vm_amd/host/, the default where it applies: FRI, cached tables, one proof per GPU) or the "
+                         "Python mirror (always used for --ldt stir, --jit-passes and the sharded proof)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -140,7 +144,15 @@ def main():
         prover = Prover(ctx, params, seed=1000 + rank)
     cells_per_step = params.padded_height * MASTER_WORDS * (1 if sharded else world)
 
-    elapsed = timed_steps(prover.prove, args.steps, args.warmup, ctx.sync, dist, device="cpu" if test_emu else "cuda")
+    step, host = prover.prove, "python"
+    if args.host == "cpp" and not sharded and not args.jit_passes and args.ldt == "fri" and not test_emu:
+        from triton_vm_amd import native_host
+
+        native = native_host.NativeProver(ctx, native_host.load_host_library(), params, prover.main.d_trace,
+                                          prover.main.d_randomizers, prover.aux.d_trace, prover.aux.d_randomizers,
+                                          prover.quotient_randomizer)
+        step, host = (lambda: native.prove(parse=False)), "cpp"
+    elapsed = timed_steps(step, args.steps, args.warmup, ctx.sync, dist, device="cpu" if test_emu else "cuda")
 
     # live timing of the dominant HBM-bound kernel family (the main-table LDE: k_ntt2_pass1, k_lde_pass2,
     # k_lde_pass3) with HIP events on the context's stream, and a per-stage breakdown of one more pass
@@ -194,6 +206,8 @@ def main():
                                       else f"STIR (expansion 4, {params.h} trace randomizers, {len(params.stir.round_queries)} full rounds)")
                                    + ", traces resident in HBM; host `gen` steps (VM, pad, extend) "
                                    "and the Rust-side transcript are not part of the path",
+                       "host": ("C++ mirror of Prover::prove over the C ABI (triton_vm_amd/host/triton_host.cpp)" if host == "cpp"
+                                else "Python mirror of Prover::prove over the C ABI (triton_vm_amd/prover.py)"),
                        "padded_rows": params.padded_height, "master_words": MASTER_WORDS,
                        "ldt_domain": params.ldt.length, "parallelism": (f"one proof over {world} GPUs: coset sharding of the extended tables, all-gather of digests and "
                                        "quotient codeword" if sharded else f"{world} independent proofs, one per GPU" if world > 1

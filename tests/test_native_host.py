@@ -1,0 +1,49 @@
+"""The C++ host side (triton_vm_amd/host/triton_host.cpp: ArithmeticDomain, MasterTable, ProofStream, Prover::prove over
+the C ABI) against the Python mirror of the same reference code: identical transcripts, item by item."""
+import os
+
+import numpy as np
+import pytest
+
+from triton_vm_amd import native_host
+from triton_vm_amd.prover import Prover, StarkParameters
+
+
+def _host_library(ctx):
+    backend = ctx.lib._name
+    if ctx.kind == "emu":
+        return native_host.load_host_library(backend, os.path.join(os.path.dirname(backend), "libtriton_host_emu.so"))
+    return native_host.load_host_library(backend)
+
+
+@pytest.mark.parametrize("log2_rows,h,checks", [(3, 3, 2), (4, 5, 4)])
+def test_cpp_prover_transcript_equals_python_prover_transcript(ctx, orc, log2_rows, h, checks):
+    if log2_rows > 3 and ctx.kind == "emu":
+        pytest.skip("one size on the emulation (CPU suite time); both on the GPU")
+    rng = np.random.default_rng(log2_rows)
+    p = StarkParameters(log2_rows, num_trace_randomizers=h, num_collinearity_checks=checks)
+    n = p.trace.length
+    main_trace, aux_trace = orc.random_elements(rng, (379, n)), orc.random_elements(rng, (91, n, 3))
+    py = Prover(ctx, p, main_trace, aux_trace, seed=9)
+    want = py.prove().log
+    native = native_host.NativeProver(ctx, _host_library(ctx), p, py.main.d_trace, py.main.d_randomizers, py.aux.d_trace,
+                                      py.aux.d_randomizers, py.quotient_randomizer)
+    got = native.prove()
+    assert len(got) == len(want)
+    for (k, fs, words), (name, payload, want_fs) in zip(got, want):
+        payload = np.asarray(payload, np.uint64).reshape(-1)
+        assert fs == want_fs and k == payload.size, name
+        assert (words == payload).all(), name
+    # and a second run on the same object reproduces it (nothing is left behind in the context)
+    again = native.prove()
+    assert all((a[2] == b[2]).all() for a, b in zip(got, again))
+
+
+def test_cpp_host_reports_errors(ctx):
+    p = StarkParameters(3, num_trace_randomizers=3, num_collinearity_checks=2)
+    lib = _host_library(ctx)
+    bad = native_host.NativeProver(ctx, lib, p, ctx.alloc(8), ctx.alloc(8), ctx.alloc(8), ctx.alloc(8),
+                                   np.zeros((p.num_quotient_randomizers, 3), np.uint64))
+    bad.bufs = (type("Null", (), {"ptr": None})(),) * 4   # null traces: the C ABI refuses, the C++ host reports it
+    with pytest.raises(RuntimeError, match="tvm_lde_table"):
+        bad.prove()

@@ -75,5 +75,32 @@ def _build(force, verbose, extra_flags, variant):
     return lib
 
 
+HOST_LIB = os.path.join(HERE, "libtriton_host.so")
+
+
+def build_host(backend_lib=None, out=None):
+    """The C++ host side above the C ABI (triton_vm_amd/host/): plain g++, no device code.  It is linked against the
+    backend library it is to drive (the product library by default; the test-only emulation passes its own)."""
+    backend_lib = backend_lib or build()
+    out = out or HOST_LIB
+    assert os.path.dirname(os.path.abspath(out)) == os.path.dirname(os.path.abspath(backend_lib)), "host library next to its backend"
+    srcs = [os.path.join(HERE, "host", "triton_host.cpp")]
+    deps = srcs + [os.path.join(HERE, "host", "triton_host.hpp"), os.path.join(ROOT, "include", "triton_hip.h"), backend_lib]
+    if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    import fcntl
+
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        name = os.path.basename(backend_lib)
+        assert name.startswith("lib") and name.endswith(".so")
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"),
+                               "-o", out + ".tmp", *srcs, "-L", os.path.dirname(backend_lib), "-l" + name[3:-3],
+                               "-Wl,-rpath,$ORIGIN"])  # the backend sits next to it
+        os.replace(out + ".tmp", out)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host())

@@ -1,0 +1,443 @@
+// triton_host.cpp -- see triton_host.hpp.  Step order, names and comments follow stark.rs:331-719.
+#include "triton_host.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+namespace triton_vm {
+
+typedef unsigned __int128 u128;
+static const u64 R_MOD_P = 0xFFFFFFFFull;  // 2^64 mod p
+
+u64 to_mont(u64 v) { return (u64)((u128)(v % P) * R_MOD_P % P); }
+static u64 redc(u128 t) {  // t * 2^-64 mod p for t < p * 2^64
+    const u64 lo = (u64)t, hi = (u64)(t >> 64);
+    const u64 a = lo + (lo << 32);
+    const u64 e = a < lo ? 1 : 0;
+    const u64 b = a - (a >> 32) - e;
+    const u64 r = hi - b;
+    return hi < b ? r - 0xFFFFFFFFull : r;
+}
+u64 mont_mul(u64 a, u64 b) { return redc((u128)a * b); }
+u64 mont_pow(u64 a, u64 e) {
+    u64 r = to_mont(1);
+    for (; e; e >>= 1, a = mont_mul(a, a))
+        if (e & 1) r = mont_mul(r, a);
+    return r;
+}
+u64 generator() { return to_mont(7); }
+u64 primitive_root_of_unity(u64 order) {
+    if (!order || (order & (order - 1)) || order > (1ull << 32)) throw Error(TVM_ERR_INVALID_ARGUMENT, "PrimitiveRootNotSupported");
+    return mont_pow(to_mont(7), (P - 1) / order);
+}
+static u64 bfe_add(u64 a, u64 b) { return (u64)(((u128)a + b) % P); }
+static Xfe xfe_add(const Xfe& a, const Xfe& b) { return Xfe{{bfe_add(a.c[0], b.c[0]), bfe_add(a.c[1], b.c[1]), bfe_add(a.c[2], b.c[2])}}; }
+static Xfe xfe_mul(const Xfe& a, const Xfe& b) {
+    Xfe o;
+    tvm_host_xfe_mul(a.c, b.c, o.c);
+    return o;
+}
+static Xfe xfe_scale(const Xfe& a, u64 s) { return Xfe{{mont_mul(a.c[0], s), mont_mul(a.c[1], s), mont_mul(a.c[2], s)}}; }
+static std::vector<Xfe> xfe_powers(const Xfe& x, u64 first, u64 n) {
+    std::vector<Xfe> out(n);
+    if (n) tvm_host_xfe_powers(x.c, first, n, out[0].c);
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------ Context
+void Context::check(int32_t status, const char* what) const {
+    if (status != TVM_OK) throw Error(status, std::string(what) + ": " + tvm_status_string(status) + " (" + tvm_last_error(ctx_) + ")");
+}
+u64* Context::alloc(u64 n_words) const {
+    void* p = nullptr;
+    check(tvm_malloc(ctx_, (size_t)(n_words ? n_words : 1) * sizeof(u64), &p), "tvm_malloc");
+    return (u64*)p;
+}
+DeviceBuffer& DeviceBuffer::operator=(DeviceBuffer&& o) noexcept {
+    if (this != &o) {
+        reset();
+        c_ = o.c_, p_ = o.p_, n_ = o.n_;
+        o.p_ = nullptr;
+    }
+    return *this;
+}
+void DeviceBuffer::reset() {
+    if (p_) c_->free(p_);
+    p_ = nullptr;
+}
+std::vector<u64> DeviceBuffer::download(u64 first_word, u64 n_words) const {
+    std::vector<u64> out(n_words);
+    if (n_words) c_->check(tvm_memcpy_d2h(c_->raw(), out.data(), p_ + first_word, (size_t)n_words * sizeof(u64)), "tvm_memcpy_d2h");
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------ ArithmeticDomain
+ArithmeticDomain ArithmeticDomain::of_length(u64 length) { return {to_mont(1), primitive_root_of_unity(length), length}; }
+ArithmeticDomain ArithmeticDomain::pow(u64 exponent) const {
+    if (!exponent || (exponent & (exponent - 1))) throw Error(TVM_ERR_INVALID_ARGUMENT, "IllegalExponent");
+    return {mont_pow(offset, exponent), mont_pow(generator, exponent), std::max<u64>(length / exponent, 1)};
+}
+DeviceBuffer ArithmeticDomain::evaluate(const Context& c, const u64* d_coeffs, u64 n_coeffs, int fk) const {
+    DeviceBuffer out(c, length * fk);
+    c.check(tvm_evaluate(c.raw(), fk, d_coeffs, n_coeffs, this->c(), out.ptr()), "tvm_evaluate");
+    return out;
+}
+DeviceBuffer ArithmeticDomain::interpolate(const Context& c, const u64* d_values, int fk) const {
+    DeviceBuffer out(c, length * fk);
+    c.check(tvm_interpolate(c.raw(), fk, d_values, this->c(), out.ptr()), "tvm_interpolate");
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------ ProofStream
+void ProofStream::enqueue(const std::string& name, const u64* words, u64 n, bool fiat_shamir) {
+    // the item always goes into the proof; it alters the sponge only if include_in_fiat_shamir_heuristic says so
+    // (proof_item.rs:96-134: roots, out-of-domain rows, polynomials do; authentication structures, opened rows, the FRI
+    // codeword and responses do not -- the prover is already committed to them through a Merkle root)
+    items_.push_back(Item{name, std::vector<u64>(words, words + n), fiat_shamir});
+    if (fiat_shamir) tvm_host_sponge_pad_and_absorb(state_, words, n);
+}
+void ProofStream::squeeze(u64 out[10]) {
+    std::memcpy(out, state_, 10 * sizeof(u64));
+    tvm_host_tip5_permutation(state_);
+}
+std::vector<Xfe> ProofStream::sample_scalars(u64 n) {
+    std::vector<u64> words;
+    for (u64 k = 0; k < (3 * n + 9) / 10; k++) {
+        u64 w[10];
+        squeeze(w);
+        words.insert(words.end(), w, w + 10);
+    }
+    std::vector<Xfe> out(n);
+    for (u64 i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) out[i].c[k] = words[3 * i + k] % P;
+    return out;
+}
+std::vector<u64> ProofStream::sample_indices(u64 upper_bound, u64 n) {
+    std::vector<u64> out;
+    while (out.size() < n) {
+        u64 w[10];
+        squeeze(w);
+        for (int k = 0; k < 10; k++)
+            if (out.size() < n && w[k] != P - 1) out.push_back(w[k] % upper_bound);
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------ MasterTable
+MasterTable::MasterTable(const Context& c, int field_kind, const u64* d_trace, u64 n_rows, u64 n_cols, const u64* d_randomizers,
+                         u64 num_trace_randomizers, ArithmeticDomain trace, ArithmeticDomain quotient, ArithmeticDomain ldt)
+    : c_(c), fk_(field_kind), d_trace_(d_trace), d_rnd_(d_randomizers), n_rows_(n_rows), n_cols_(n_cols),
+      h_(num_trace_randomizers), trace_(trace), quotient_(quotient), ldt_(ldt) {}
+ArithmeticDomain MasterTable::evaluation_domain() const { return quotient_.length > ldt_.length ? quotient_ : ldt_; }
+void MasterTable::maybe_low_degree_extend_all_columns() {
+    clear_cache();  // the old table's block goes back to the context's pool and is reused right away
+    c_.check(tvm_lde_table(c_.raw(), fk_, d_trace_, n_rows_, n_cols_, d_rnd_, h_, trace_.c(), evaluation_domain().c(), &table_),
+             "tvm_lde_table");
+}
+void MasterTable::clear_cache() {
+    if (table_) tvm_table_free(c_.raw(), table_);
+    table_ = nullptr;
+}
+const tvm_table* MasterTable::table() const {
+    if (!table_) throw Error(TVM_ERR_INVALID_ARGUMENT, "low-degree extend first (maybe_low_degree_extend_all_columns)");
+    return table_;
+}
+DeviceBuffer MasterTable::merkle_tree() const {
+    DeviceBuffer nodes(c_, 10 * ldt_.length);
+    c_.check(tvm_table_merkle_tree(c_.raw(), table(), ldt_.length, nodes.ptr()), "tvm_table_merkle_tree");
+    return nodes;
+}
+std::vector<u64> MasterTable::reveal_rows(const std::vector<u64>& idx) const {
+    std::vector<u64> out(idx.size() * n_cols_ * fk_);
+    c_.check(tvm_table_reveal_rows(c_.raw(), table(), ldt_.length, idx.data(), idx.size(), out.data()), "tvm_table_reveal_rows");
+    return out;
+}
+std::vector<u64> MasterTable::out_of_domain_rows(const std::vector<Xfe>& points) const {
+    std::vector<u64> out(points.size() * n_cols_ * 3);
+    c_.check(tvm_out_of_domain_rows(c_.raw(), fk_, d_trace_, n_rows_, n_cols_, d_rnd_, h_, trace_.c(), points[0].c,
+                                    (uint32_t)points.size(), out.data()), "tvm_out_of_domain_rows");
+    return out;
+}
+DeviceBuffer MasterTable::weighted_sum_of_columns(const Xfe* weights) const {
+    DeviceBuffer poly(c_, 2 * n_rows_ * 3);
+    c_.check(tvm_weighted_sum_of_columns(c_.raw(), fk_, d_trace_, n_rows_, n_cols_, d_rnd_, h_, trace_.c(), weights[0].c, poly.ptr()),
+             "tvm_weighted_sum_of_columns");
+    return poly;
+}
+
+// ------------------------------------------------------------------------------------------------ parameters
+static unsigned bit_length(u64 v) {
+    unsigned n = 0;
+    for (; v; v >>= 1) n++;
+    return n;
+}
+StarkParameters::StarkParameters(unsigned log2_padded_height, u64 num_trace_randomizers, u64 checks, unsigned log2_expansion)
+    : padded_height(1ull << log2_padded_height), h(num_trace_randomizers), num_collinearity_checks(checks) {
+    const u64 rtl = std::max({padded_height + h, 2 * h + 1, (h + 1) * 5});
+    randomized_trace_len = 1ull << bit_length(rtl - 1);
+    trace = ArithmeticDomain::of_length(randomized_trace_len / 2);
+    const u64 max_degree = 4 * (randomized_trace_len - 1) - 1;
+    const u64 quotient_len = 1ull << bit_length(max_degree - 1);
+    const u64 g = generator();
+    ldt = ArithmeticDomain::of_length(randomized_trace_len << log2_expansion).with_offset(g);
+    quotient = ArithmeticDomain::of_length(quotient_len).with_offset(g);
+    const int max_rounds = (int)bit_length(randomized_trace_len - 1);
+    const int rounds = max_rounds - ((int)bit_length(checks) - 1) - 1;
+    fri_rounds = rounds > 0 ? (unsigned)rounds : 0;
+    num_quotient_randomizers = (h + 1) * 5;
+}
+
+// ------------------------------------------------------------------------------------------------ helpers of prove
+static const u64 NUM_MAIN = TVM_NUM_MAIN_COLUMNS, NUM_AUX = TVM_NUM_AUX_COLUMNS;
+
+static std::vector<u64> merkle_root(const Context& c, const DeviceBuffer& nodes) { return nodes.download(5, 5); }  // node 1; drains the stream
+
+// the sibling nodes on the paths of the opened leaves of a device node array (what twenty-first's
+// authentication_structure needs from the tree), gathered to the host
+static std::vector<u64> auth_nodes(const Context& c, const DeviceBuffer& nodes, u64 n_leaves, const std::vector<u64>& indices) {
+    auto uniq = [](std::vector<u64> v) {
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+        return v;
+    };
+    std::vector<u64> k;
+    for (u64 i : indices) k.push_back(i + n_leaves);
+    k = uniq(k);
+    std::vector<u64> need;
+    while (!k.empty() && k[0] > 1) {
+        for (u64 x : k) need.push_back(x ^ 1);
+        for (u64& x : k) x >>= 1;
+        k = uniq(k);
+    }
+    need = uniq(need);
+    std::vector<u64> out(need.size() * 5);
+    if (!need.empty()) c.check(tvm_gather_elements(c.raw(), nodes.ptr(), 5, need.data(), need.size(), out.data()), "tvm_gather_elements");
+    return out;
+}
+
+Prover::Prover(const Context& c, const StarkParameters& p, const u64* d_main_trace, const u64* d_main_randomizers,
+               const u64* d_aux_trace, const u64* d_aux_randomizers, const std::vector<Xfe>& quotient_randomizer)
+    : c_(c), p_(p), main_(c, 1, d_main_trace, p.trace.length, NUM_MAIN, d_main_randomizers, p.h, p.trace, p.quotient, p.ldt),
+      aux_(c, 3, d_aux_trace, p.trace.length, NUM_AUX, d_aux_randomizers, p.h, p.trace, p.quotient, p.ldt),
+      quotient_randomizer_(quotient_randomizer) {
+    if (quotient_randomizer.size() != p.num_quotient_randomizers) throw Error(TVM_ERR_INVALID_ARGUMENT, "quotient randomizer length");
+}
+
+// Fri::prove (fri.rs:212-319, 754-772): commit and fold round by round, send the last codeword and polynomial,
+// answer the queries.  Returns the first-round indices.
+std::vector<u64> Prover::fri(const DeviceBuffer& combination, ProofStream& ps) {
+    struct Round {
+        ArithmeticDomain dom;
+        const u64* cw;
+        DeviceBuffer nodes;
+    };
+    std::vector<Round> rounds;
+    std::vector<DeviceBuffer> folded;  // owns the codewords of rounds 1..
+    ArithmeticDomain dom = p_.ldt;
+    const u64* cw = combination.ptr();
+    for (unsigned r = 0; r <= p_.fri_rounds; r++) {
+        DeviceBuffer nodes(c_, 10 * dom.length);
+        c_.check(tvm_codeword_merkle_tree(c_.raw(), cw, dom.length, nodes.ptr()), "tvm_codeword_merkle_tree");
+        const std::vector<u64> root = merkle_root(c_, nodes);
+        ps.enqueue("fri root " + std::to_string(r), root.data(), 5);
+        rounds.push_back(Round{dom, cw, std::move(nodes)});
+        if (r == p_.fri_rounds) break;
+        const Xfe challenge = ps.sample_scalars(1)[0];
+        DeviceBuffer next(c_, dom.length / 2 * 3);
+        c_.check(tvm_fri_split_and_fold(c_.raw(), cw, dom.c(), challenge.c, next.ptr()), "tvm_fri_split_and_fold");
+        folded.push_back(std::move(next));
+        cw = folded.back().ptr();
+        dom = dom.pow(2);
+    }
+    std::vector<u64> last(dom.length * 3);
+    c_.check(tvm_memcpy_d2h(c_.raw(), last.data(), cw, last.size() * sizeof(u64)), "last codeword");
+    ps.enqueue("fri last codeword", last.data(), last.size(), false);
+    const DeviceBuffer last_poly_d = ArithmeticDomain::of_length(dom.length).interpolate(c_, cw, 3);
+    const std::vector<u64> last_poly = last_poly_d.download(0, dom.length * 3);
+    ps.enqueue("fri last polynomial", last_poly.data(), last_poly.size());
+    last_polynomial.resize(dom.length);
+    std::memcpy(last_polynomial.data(), last_poly.data(), last_poly.size() * sizeof(u64));
+    const std::vector<u64> a_indices = ps.sample_indices(p_.ldt.length, p_.num_collinearity_checks);
+    for (size_t r = 0; r < rounds.size(); r++) {
+        const Round& round = rounds[r];
+        std::vector<u64> b_idx;
+        for (u64 i : a_indices) b_idx.push_back((i % round.dom.length + round.dom.length / 2) % round.dom.length);
+        for (int which = (r == 0 ? 0 : 1); which < 2; which++) {
+            if (which == 1 && r == rounds.size() - 1) continue;
+            const std::vector<u64>& ix = which == 0 ? a_indices : b_idx;
+            std::vector<u64> leaves(ix.size() * 3);
+            c_.check(tvm_gather_elements(c_.raw(), round.cw, 3, ix.data(), ix.size(), leaves.data()), "fri leaves");
+            ps.enqueue("fri response " + std::to_string(r), leaves.data(), leaves.size(), false);
+            const std::vector<u64> auth = auth_nodes(c_, round.nodes, round.dom.length, ix);
+            ps.enqueue("fri auth " + std::to_string(r), auth.data(), auth.size(), false);
+        }
+    }
+    (void)ps.sample_scalars(1);
+    return a_indices;
+}
+
+ProofStream Prover::prove() {
+    ProofStream ps;
+    const u64 L = p_.ldt.length;
+    const ArithmeticDomain short_dom = p_.ldt.length <= p_.quotient.length ? p_.ldt : p_.quotient;
+    const u64 zeta = to_mont(3);  // Stark::ZETA, stark.rs:1801
+    auto enqueue_xfes = [&](const char* name, const std::vector<Xfe>& v) { ps.enqueue(name, v[0].c, 3 * v.size()); };
+
+    // 4-6: main table LDE, Merkle tree, challenges  (stark.rs:367-377)
+    main_.maybe_low_degree_extend_all_columns();
+    const DeviceBuffer main_nodes = main_.merkle_tree();
+    ps.enqueue("main root", merkle_root(c_, main_nodes).data(), 5);
+    const std::vector<Xfe> challenges = ps.sample_scalars(TVM_NUM_CHALLENGES);
+
+    // 8-9: aux table (its `extend` is host work in the reference; the trace is already resident)
+    aux_.maybe_low_degree_extend_all_columns();
+    const DeviceBuffer aux_nodes = aux_.merkle_tree();
+    ps.enqueue("aux root", merkle_root(c_, aux_nodes).data(), 5);
+    const std::vector<Xfe> quotient_weights = xfe_powers(ps.sample_scalars(1)[0], 0, TVM_NUM_QUOTIENT_WEIGHTS);
+
+    // 10: quotient codeword, segments, randomization  (stark.rs:405-423)
+    DeviceBuffer quot(c_, p_.quotient.length * 3);
+    c_.check(tvm_all_quotients_combined(c_.raw(), main_.table(), aux_.table(), p_.trace.c(), p_.quotient.c(), challenges[0].c,
+                                        quotient_weights[0].c, quot.ptr()), "tvm_all_quotients_combined");
+    const u64 poly_len = std::max<u64>(p_.quotient.length / 4, quotient_randomizer_.size());
+    DeviceBuffer polys(c_, 5 * poly_len * 3);
+    tvm_table* seg_table = nullptr;
+    c_.check(tvm_quotient_segments(c_.raw(), quot.ptr(), p_.quotient.c(), p_.ldt.c(), quotient_randomizer_[0].c,
+                                   quotient_randomizer_.size(), zeta, &seg_table, polys.ptr(), poly_len), "tvm_quotient_segments");
+    struct TableGuard {
+        const Context& c;
+        tvm_table* t;
+        ~TableGuard() { tvm_table_free(c.raw(), t); }
+    } seg_guard{c_, seg_table};
+    quot.reset();
+    // 12: quotient Merkle tree  (stark.rs:425-446)
+    DeviceBuffer quot_nodes(c_, 10 * L);
+    c_.check(tvm_table_merkle_tree(c_.raw(), seg_table, L, quot_nodes.ptr()), "quotient merkle tree");
+    ps.enqueue("quot root", merkle_root(c_, quot_nodes).data(), 5);
+
+    // 13: out-of-domain rows  (stark.rs:450-495)
+    const Xfe alpha = ps.sample_scalars(1)[0];
+    const Xfe alpha_next = xfe_scale(alpha, p_.trace.generator);
+    const std::vector<u64> ood_main = main_.out_of_domain_rows({alpha, alpha_next});
+    const std::vector<u64> ood_aux = aux_.out_of_domain_rows({alpha, alpha_next});
+    const Xfe a4 = xfe_powers(alpha, 4, 1)[0];
+    const Xfe za4 = xfe_powers(xfe_scale(alpha, zeta), 4, 1)[0];
+    Xfe seg_ood[5][2];
+    for (int k = 0; k < 5; k++) {
+        const Xfe pts[2] = {a4, za4};
+        c_.check(tvm_evaluate_at_points(c_.raw(), polys.ptr() + (u64)k * poly_len * 3, poly_len, pts[0].c, 2, seg_ood[k][0].c),
+                 "tvm_evaluate_at_points");
+    }
+    ps.enqueue("ood main", ood_main.data(), NUM_MAIN * 3);
+    ps.enqueue("ood aux", ood_aux.data(), NUM_AUX * 3);
+    ps.enqueue("ood main next", ood_main.data() + NUM_MAIN * 3, NUM_MAIN * 3);
+    ps.enqueue("ood aux next", ood_aux.data() + NUM_AUX * 3, NUM_AUX * 3);
+    enqueue_xfes("ood quot p", {seg_ood[0][0], seg_ood[1][0], seg_ood[2][0], seg_ood[3][0]});
+    enqueue_xfes("ood quot r", {seg_ood[1][1], seg_ood[2][1], seg_ood[3][1], seg_ood[4][1]});
+
+    // 14-15: combination weights, linear combinations  (stark.rs:497-543)
+    const std::vector<Xfe> w3 = ps.sample_scalars(3);
+    const std::vector<Xfe> weights_ma = xfe_powers(w3[0], 0, NUM_MAIN + NUM_AUX);
+    const std::vector<Xfe> weights_q = xfe_powers(w3[1], 0, 5);
+    const std::vector<Xfe> weights_d = xfe_powers(w3[2], 0, 4);
+    DeviceBuffer comb = main_.weighted_sum_of_columns(&weights_ma[0]);
+    {
+        const DeviceBuffer comb_aux = aux_.weighted_sum_of_columns(&weights_ma[NUM_MAIN]);
+        c_.check(tvm_xfe_add_assign(c_.raw(), comb.ptr(), comb_aux.ptr(), 2 * p_.trace.length), "tvm_xfe_add_assign");
+    }
+    const u64 n_comb = p_.trace.length + p_.h;
+    const DeviceBuffer main_aux_codeword = short_dom.evaluate(c_, comb.ptr(), n_comb, 3);
+    std::vector<Xfe> wp = weights_q, wr = weights_q;
+    wp[4] = Xfe{{0, 0, 0}};
+    wr[0] = Xfe{{0, 0, 0}};
+    if (L != short_dom.length) throw Error(TVM_ERR_INVALID_ARGUMENT, "quotient domain shorter than the LDT domain: take the strided view first");
+    DeviceBuffer cw_p(c_, L * 3), cw_r(c_, L * 3);
+    c_.check(tvm_table_linear_combination(c_.raw(), seg_table, L, wp[0].c, cw_p.ptr()), "tvm_table_linear_combination");
+    c_.check(tvm_table_linear_combination(c_.raw(), seg_table, L, wr[0].c, cw_r.ptr()), "tvm_table_linear_combination");
+    Xfe ma_values[2];
+    {
+        const Xfe pts[2] = {alpha, alpha_next};
+        c_.check(tvm_evaluate_at_points(c_.raw(), comb.ptr(), n_comb, pts[0].c, 2, ma_values[0].c), "tvm_evaluate_at_points");
+    }
+    Xfe p_value{{0, 0, 0}}, r_value{{0, 0, 0}};
+    for (int k = 0; k < 4; k++) p_value = xfe_add(p_value, xfe_mul(weights_q[k], seg_ood[k][0]));
+    for (int k = 1; k < 5; k++) r_value = xfe_add(r_value, xfe_mul(weights_q[k], seg_ood[k][1]));
+
+    // 16: DEEP  (stark.rs:545-639)
+    DeviceBuffer combination(c_, short_dom.length * 3);
+    {
+        const u64* cws[4] = {main_aux_codeword.ptr(), main_aux_codeword.ptr(), cw_p.ptr(), cw_r.ptr()};
+        const Xfe points[4] = {alpha, alpha_next, a4, za4}, values[4] = {ma_values[0], ma_values[1], p_value, r_value};
+        c_.check(tvm_deep_codeword(c_.raw(), 4, cws, short_dom.c(), points[0].c, values[0].c, weights_d[0].c, combination.ptr()),
+                 "tvm_deep_codeword");
+    }
+    cw_p.reset();
+    cw_r.reset();
+    comb.reset();
+
+    // 17: the low-degree test  (stark.rs:641-663)
+    const std::vector<u64> a_indices = fri(combination, ps);
+
+    // 19: open the trace leafs  (stark.rs:665-716)
+    {
+        const std::vector<u64> rows = main_.reveal_rows(a_indices), auth = auth_nodes(c_, main_nodes, L, a_indices);
+        ps.enqueue("main rows", rows.data(), rows.size(), false);
+        ps.enqueue("main auth", auth.data(), auth.size(), false);
+    }
+    {
+        const std::vector<u64> rows = aux_.reveal_rows(a_indices), auth = auth_nodes(c_, aux_nodes, L, a_indices);
+        ps.enqueue("aux rows", rows.data(), rows.size(), false);
+        ps.enqueue("aux auth", auth.data(), auth.size(), false);
+    }
+    {
+        std::vector<u64> qrows(a_indices.size() * 15);
+        c_.check(tvm_table_reveal_rows(c_.raw(), seg_table, L, a_indices.data(), a_indices.size(), qrows.data()), "quotient rows");
+        const std::vector<u64> auth = auth_nodes(c_, quot_nodes, L, a_indices);
+        ps.enqueue("quot rows", qrows.data(), qrows.size(), false);
+        ps.enqueue("quot auth", auth.data(), auth.size(), false);
+    }
+    main_.clear_cache();
+    aux_.clear_cache();
+    c_.check(tvm_sync(c_.raw()), "tvm_sync");
+    return ps;
+}
+
+}  // namespace triton_vm
+
+extern "C" int32_t tvmh_prove(tvm_ctx* ctx, uint32_t log2_padded_height, uint64_t num_trace_randomizers,
+                              uint64_t num_collinearity_checks, const uint64_t* d_main_trace,
+                              const uint64_t* d_main_randomizers, const uint64_t* d_aux_trace,
+                              const uint64_t* d_aux_randomizers, const uint64_t* h_quotient_randomizer,
+                              uint64_t* h_transcript, uint64_t capacity, uint64_t* transcript_words, char* error,
+                              uint64_t error_capacity) {
+    using namespace triton_vm;
+    try {
+        const Context c(ctx);
+        const StarkParameters p(log2_padded_height, num_trace_randomizers, num_collinearity_checks);
+        std::vector<Xfe> qr(p.num_quotient_randomizers);
+        std::memcpy(qr.data(), h_quotient_randomizer, qr.size() * sizeof(Xfe));
+        Prover prover(c, p, d_main_trace, d_main_randomizers, d_aux_trace, d_aux_randomizers, qr);
+        const ProofStream ps = prover.prove();
+        u64 need = 1;
+        for (const auto& it : ps.items()) need += 2 + it.words.size();
+        if (transcript_words) *transcript_words = need;
+        if (h_transcript && capacity >= need) {
+            u64* o = h_transcript;
+            *o++ = ps.items().size();
+            for (const auto& it : ps.items()) {
+                *o++ = it.words.size();
+                *o++ = it.fiat_shamir ? 1 : 0;
+                std::memcpy(o, it.words.data(), it.words.size() * sizeof(u64));
+                o += it.words.size();
+            }
+        }
+        return TVM_OK;
+    } catch (const Error& e) {
+        if (error && error_capacity) std::snprintf(error, error_capacity, "%s", e.what());
+        return e.status ? e.status : TVM_ERR_INVALID_ARGUMENT;
+    } catch (const std::exception& e) {
+        if (error && error_capacity) std::snprintf(error, error_capacity, "%s", e.what());
+        return TVM_ERR_DEVICE;
+    }
+}

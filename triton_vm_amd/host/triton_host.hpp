@@ -1,0 +1,163 @@
+// triton_host.hpp -- C++ host side above the C ABI of libtriton_hip.so: the reference's interface for the hot
+// path of Prover::prove, same names, argument meaning and step order (the reference is Rust; its toolchain is
+// not in the build image, so the host mirror is C++ -- INTEGRATION.md has the Rust binding a maintainer would add).
+//
+//   ArithmeticDomain   /root/reference/triton-vm/src/arithmetic_domain.rs:34-92, 227-229, 280-296
+//   MasterTable        /root/reference/triton-vm/src/table/master_table.rs:190-610 (the methods on the hot path)
+//   ProofStream        /root/reference/triton-vm/src/proof_stream.rs:36-70 (a STAND-IN transcript: same data
+//                      dependencies and Fiat-Shamir inclusion rules, proof_item.rs:96-134; not the reference's encoding)
+//   Stark / Prover     /root/reference/triton-vm/src/stark.rs:263-286 (domains), 331-719 (prove), fri.rs:212-366
+//
+// Everything bulky stays in HBM behind the C ABI; this file only sequences calls and keeps the transcript.
+// No device code, no HIP headers: it compiles with g++ and binds to whichever library exports the tvm_* symbols.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "triton_hip.h"
+
+namespace triton_vm {
+
+typedef uint64_t u64;
+constexpr u64 P = 0xFFFFFFFF00000001ull;
+struct Xfe {
+    u64 c[3];
+};
+
+// ---- scalar helpers over F_p on Montgomery words (twenty-first's BFieldElement; host plumbing only) ---------
+u64 to_mont(u64 v);
+u64 mont_mul(u64 a, u64 b);
+u64 mont_pow(u64 a, u64 e);
+u64 generator();                          // BFieldElement::generator() = 7
+u64 primitive_root_of_unity(u64 order);   // 7^((p-1)/order)
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int s, const std::string& what) : std::runtime_error(what), status(s) {}
+};
+
+class Context {  // one per proving thread (lib.rs:522-532)
+public:
+    explicit Context(tvm_ctx* borrowed) : ctx_(borrowed) {}
+    tvm_ctx* raw() const { return ctx_; }
+    void check(int32_t status, const char* what) const;
+    u64* alloc(u64 n_words) const;
+    void free(u64* p) const { (void)tvm_free(ctx_, p); }
+
+private:
+    tvm_ctx* ctx_;
+};
+
+class DeviceBuffer {  // owning device array of 64-bit words
+public:
+    DeviceBuffer() = default;
+    DeviceBuffer(const Context& c, u64 n_words) : c_(&c), p_(c.alloc(n_words)), n_(n_words) {}
+    DeviceBuffer(DeviceBuffer&& o) noexcept : c_(o.c_), p_(o.p_), n_(o.n_) { o.p_ = nullptr; }
+    DeviceBuffer& operator=(DeviceBuffer&& o) noexcept;
+    DeviceBuffer(const DeviceBuffer&) = delete;
+    ~DeviceBuffer() { reset(); }
+    void reset();
+    u64* ptr() const { return p_; }
+    u64 words() const { return n_; }
+    std::vector<u64> download(u64 first_word, u64 n_words) const;
+
+private:
+    const Context* c_ = nullptr;
+    u64* p_ = nullptr;
+    u64 n_ = 0;
+};
+
+struct ArithmeticDomain {
+    u64 offset, generator, length;
+    static ArithmeticDomain of_length(u64 length);                       // arithmetic_domain.rs:78-85
+    ArithmeticDomain with_offset(u64 o) const { return {o, generator, length}; }  // :89-92
+    ArithmeticDomain pow(u64 exponent) const;                            // :280-296
+    u64 value(u64 n) const { return mont_mul(mont_pow(generator, n), offset); }   // :227-229
+    tvm_domain c() const { return tvm_domain{offset, generator, length}; }
+    DeviceBuffer evaluate(const Context& c, const u64* d_coeffs, u64 n_coeffs, int field_kind) const;  // :141-170
+    DeviceBuffer interpolate(const Context& c, const u64* d_values, int field_kind) const;             // :182-189
+};
+
+// Stand-in Fiat-Shamir transcript: a Tip5 sponge in overwrite mode over the items the prover sends.
+class ProofStream {
+public:
+    struct Item {
+        std::string name;
+        std::vector<u64> words;
+        bool fiat_shamir;
+    };
+    void enqueue(const std::string& name, const u64* words, u64 n, bool fiat_shamir = true);  // proof_stream.rs:36-43
+    std::vector<Xfe> sample_scalars(u64 n);
+    std::vector<u64> sample_indices(u64 upper_bound, u64 n);
+    const std::vector<Item>& items() const { return items_; }
+
+private:
+    void squeeze(u64 out[10]);
+    u64 state_[16] = {0};
+    std::vector<Item> items_;
+};
+
+// A padded master main (field_kind 1) or auxiliary (field_kind 3) table on the device.  The trace
+// [n_cols][n_rows](x3) and the trace-randomizer coefficients [n_cols][h](x3) are device arrays owned by the caller.
+class MasterTable {
+public:
+    MasterTable(const Context& c, int field_kind, const u64* d_trace, u64 n_rows, u64 n_cols, const u64* d_randomizers,
+                u64 num_trace_randomizers, ArithmeticDomain trace, ArithmeticDomain quotient, ArithmeticDomain ldt);
+    ~MasterTable() { clear_cache(); }
+    ArithmeticDomain evaluation_domain() const;                           // master_table.rs:215-222
+    void maybe_low_degree_extend_all_columns();                           // :258-322
+    void clear_cache();
+    const tvm_table* table() const;
+    DeviceBuffer merkle_tree() const;                                     // :443-468 -> node array [2L][5]
+    std::vector<u64> reveal_rows(const std::vector<u64>& row_indices) const;          // :548-555
+    std::vector<u64> out_of_domain_rows(const std::vector<Xfe>& points) const;        // :348-390, [n_points][n_cols][3]
+    DeviceBuffer weighted_sum_of_columns(const Xfe* weights) const;       // :512-542 -> 2 * n_rows XFE coefficients
+    int field_kind() const { return fk_; }
+    u64 n_cols() const { return n_cols_; }
+
+private:
+    const Context& c_;
+    int fk_;
+    const u64 *d_trace_, *d_rnd_;
+    u64 n_rows_, n_cols_, h_;
+    ArithmeticDomain trace_, quotient_, ldt_;
+    tvm_table* table_ = nullptr;
+};
+
+// Domains for a padded height as Stark::default() with LdtChoice::Fri derives them
+// (stark.rs:263-286, 1885-1916, 2083-2089; fri.rs:832-836, 907-920).
+struct StarkParameters {
+    StarkParameters(unsigned log2_padded_height, u64 num_trace_randomizers = 198, u64 num_collinearity_checks = 173,
+                    unsigned log2_expansion = 2);
+    u64 padded_height, h, num_collinearity_checks, randomized_trace_len, num_quotient_randomizers;
+    unsigned fri_rounds;
+    ArithmeticDomain trace, quotient, ldt;
+};
+
+class Prover {
+public:
+    Prover(const Context& c, const StarkParameters& p, const u64* d_main_trace, const u64* d_main_randomizers,
+           const u64* d_aux_trace, const u64* d_aux_randomizers, const std::vector<Xfe>& quotient_randomizer);
+    ProofStream prove();  // the hot path of Prover::prove, stark.rs:331-719
+    std::vector<Xfe> last_polynomial;
+
+private:
+    std::vector<u64> fri(const DeviceBuffer& combination, ProofStream& ps);  // Fri::prove, fri.rs:212-319
+    const Context& c_;
+    StarkParameters p_;
+    MasterTable main_, aux_;
+    std::vector<Xfe> quotient_randomizer_;
+};
+
+}  // namespace triton_vm
+
+// C entry for hosts without a C++ ABI (the Python tests and bench.py): runs Prover::prove on device-resident traces
+// and returns the transcript, flattened as  n_items, then per item: n_words, fiat_shamir flag, the words.
+extern "C" int32_t tvmh_prove(tvm_ctx* ctx, uint32_t log2_padded_height, uint64_t num_trace_randomizers,
+                              uint64_t num_collinearity_checks, const uint64_t* d_main_trace,
+                              const uint64_t* d_main_randomizers, const uint64_t* d_aux_trace,
+                              const uint64_t* d_aux_randomizers, const uint64_t* h_quotient_randomizer,
+                              uint64_t* h_transcript, uint64_t transcript_capacity_words, uint64_t* transcript_words,
+                              char* error, uint64_t error_capacity);

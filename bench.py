@@ -148,10 +148,15 @@ def main():
     if args.host == "cpp" and not sharded and not args.jit_passes and args.ldt == "fri" and not test_emu:
         from triton_vm_amd import native_host
 
-        native = native_host.NativeProver(ctx, native_host.load_host_library(), params, prover.main.d_trace,
-                                          prover.main.d_randomizers, prover.aux.d_trace, prover.aux.d_randomizers,
-                                          prover.quotient_randomizer)
-        step, host = (lambda: native.prove(parse=False)), "cpp"
+        try:
+            host_lib = native_host.load_host_library()
+        except Exception as e:  # no g++ on this machine: the Python mirror sequences the same C-ABI calls
+            print(f"bench.py: C++ host library unavailable ({e}); timing the Python host", file=sys.stderr)
+            host_lib = None
+        if host_lib is not None:
+            native = native_host.NativeProver(ctx, host_lib, params, prover.main.d_trace, prover.main.d_randomizers,
+                                              prover.aux.d_trace, prover.aux.d_randomizers, prover.quotient_randomizer)
+            step, host = (lambda: native.prove(parse=False)), "cpp"
     elapsed = timed_steps(step, args.steps, args.warmup, ctx.sync, dist, device="cpu" if test_emu else "cuda")
 
     # live timing of the dominant HBM-bound kernel family (the main-table LDE: k_ntt2_pass1, k_lde_pass2,

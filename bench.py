@@ -3,7 +3,8 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--log2-rows 20]
 
-One "step" = one complete pass of the prover's hot path (triton_vm_amd/prover.py: main LDE, hashing +
+One "step" = one complete pass of the prover's hot path (the C++ host triton_vm_amd/host/triton_host.cpp, or the
+Python mirror triton_vm_amd/prover.py with --host python; both sequence the same C-ABI calls: main LDE, hashing +
 Merkle, aux LDE, hashing + Merkle, AIR/quotients, quotient segments, out-of-domain rows, linear
 combination, DEEP, FRI, openings) over synthetic padded trace tables that are already resident in
 HBM: 2^20 padded rows x (379 main + 91 aux columns = 652 base-field words), the shape of

@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 MASTER_WORDS = 652
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
-LDE_ALGORITHMIC_BYTES_PER_CELL = 72   # read 8 B, write 8 * (L/N = 8) B per base-field trace cell
+LDE_ALGORITHMIC_BYTES_PER_CELL = 72   # read 8 B, write 8 * (L/N = 8) B per base-field trace cell (default expansion)
 
 
 def cpu_baseline(log2_rows):
@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--trace-randomizers", type=int, default=198, help="Stark::default() with FRI: 198 (stark.rs:2083-2089)")
     ap.add_argument("--queries", type=int, default=173, help="FRI collinearity checks at 160 bits, expansion 4: 173")
+    ap.add_argument("--log2-expansion", type=int, default=2, help="log2 of the LDT expansion factor: 2 (Stark::default()); 4 is "
+                    "BASELINE config 5's FRI log-blowup (the quotient domain is then the short domain)")
     ap.add_argument("--ldt", choices=["fri", "stir"], default="fri",
                     help="low-degree test: fri (what BASELINE.json names) or stir (the reference's default from 2^16 rows on)")
     ap.add_argument("--jit-passes", type=int, default=0, help="single GPU: evaluate the extended tables coset-wise in this many "
@@ -131,7 +133,7 @@ def main():
     else:
         ctx = Context(device=local_rank)
     params = StarkParameters(args.log2_rows, num_trace_randomizers=args.trace_randomizers,
-                             num_collinearity_checks=args.queries, ldt=args.ldt)
+                             num_collinearity_checks=args.queries, ldt=args.ldt, log2_expansion=args.log2_expansion)
     sharded = world > 1 and not args.replicas
     if sharded:
         from triton_vm_amd.sharded import ShardedProver
@@ -189,12 +191,13 @@ def main():
         lde_cells = params.trace.length * 379
         # algorithmic bytes of one launch: read the trace, write this rank's share of the extended rows
         share = world if sharded else (args.jit_passes or 1)
-        lde_bytes_per_cell = 8 + 64 / share
+        lde_bytes_per_cell = 8 + 8 * (params.ldt.length // params.trace.length) / share  # read once, write L/N values
         achieved = lde_cells * lde_bytes_per_cell / (lde_avg_ms * 1e-3) / 1e9
         traffic = None  # fabric-side bytes per LDE launch family, from the committed PMC run (profiles/lde_traffic.json)
         try:
             with open(os.path.join(ROOT, "profiles", "lde_traffic.json")) as f:
-                traffic = int(json.load(f)["hbm_bytes_per_trace_cell"] * lde_cells) if share == 1 else None
+                # (measured for the default expansion only)
+                traffic = int(json.load(f)["hbm_bytes_per_trace_cell"] * lde_cells) if share == 1 and args.log2_expansion == 2 else None
         except (OSError, KeyError, ValueError):
             pass
         out = {
@@ -208,8 +211,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"prove() hot path, prove_fib-shaped tables: 2^{args.log2_rows} padded rows, 379 main + "
                                    "91 aux columns (652 words/row), Stark::default() with "
-                                   + (f"FRI (expansion 4, {params.h} trace randomizers, {args.queries} queries)" if args.ldt == "fri"
-                                      else f"STIR (expansion 4, {params.h} trace randomizers, {len(params.stir.round_queries)} full rounds)")
+                                   + (f"FRI (expansion {1 << args.log2_expansion}, {params.h} trace randomizers, {args.queries} queries)" if args.ldt == "fri"
+                                      else f"STIR (expansion {1 << args.log2_expansion}, {params.h} trace randomizers, {len(params.stir.round_queries)} full rounds)")
                                    + ", traces resident in HBM; host `gen` steps (VM, pad, extend) "
                                    "and the Rust-side transcript are not part of the path",
                        "host": ("C++ mirror of Prover::prove over the C ABI (triton_vm_amd/host/triton_host.cpp)" if host == "cpp"

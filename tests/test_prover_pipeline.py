@@ -98,6 +98,50 @@ def test_hot_path_matches_oracle_recomputation(ctx, orc):
     assert prover.last_polynomial[:bound].any()
 
 
+def test_log_blowup_4_quotient_domain_is_the_short_domain(ctx, orc):
+    """BASELINE config 5's shape (FRI expansion factor 16): the quotient domain is then shorter than the LDT domain, the
+    tables are evaluated on the LDT domain and the AIR reads a stride view of them, the DEEP codeword is built on the
+    quotient domain and low-degree-extended to the LDT domain (stark.rs:501-506, 629-639).  The transcript must pass
+    the restated FRI verifier and the opened rows must authenticate against the roots."""
+    from oracle import ldt_verifier as lv
+
+    rng = np.random.default_rng(16)
+    p = StarkParameters(3, num_trace_randomizers=3, num_collinearity_checks=3, log2_expansion=4)
+    assert p.quotient.length == 128 and p.ldt.length == 512
+    main_trace, aux_trace = orc.random_elements(rng, (379, p.trace.length)), orc.random_elements(rng, (91, p.trace.length, 3))
+    prover = Prover(ctx, p, main_trace, aux_trace, seed=6)
+    prover.capture = {}
+    prover.prove()
+    c = prover.capture
+    # the quotient codeword is the oracle's, evaluated on the quotient domain from tables extended onto the LDT domain
+    main_rnd, aux_rnd = prover.main.d_randomizers.download((379, p.h)), prover.aux.d_randomizers.download((91, p.h, 3))
+    quot, trace = odom(orc, p.quotient), odom(orc, p.trace)
+    main_q, aux_q = orc.lde_table(main_trace, main_rnd, quot, 1), orc.lde_table(aux_trace, aux_rnd, quot, 3)
+    q = orc.quotients_combined(main_q, aux_q, trace, quot, c["challenges"], c["quotient_weights"])
+    seg = orc.interpolate_quotient_segments(q, quot)
+    _polys, seg_cws = orc.randomize_quotient_segments(seg, prover.quotient_randomizer, odom(orc, p.ldt))
+    assert (orc.merkle_tree(orc.hash_rows(seg_cws.reshape(512, 15)))[1] == c["quot_root"]).all()
+    # low degree after folding, verifier replay
+    bound = p.randomized_trace_len >> p.fri_rounds
+    assert (prover.last_polynomial[bound:] == 0).all() and prover.last_polynomial[:bound].any()
+    view = prover.transcript.verifier_view()
+    roots = {"main": view.dequeue("main root")}
+    view.sample_scalars(63)
+    roots["aux"] = view.dequeue("aux root")
+    view.sample_scalars(1)
+    roots["quot"] = view.dequeue("quot root")
+    view.sample_scalars(1)
+    for name in ("ood main", "ood aux", "ood main next", "ood aux next", "ood quot p", "ood quot r"):
+        view.dequeue(name)
+    view.sample_scalars(3)
+    opened_at = lv.fri_verify(view, odom(orc, p.ldt), p.fri_rounds, p.num_collinearity_checks, bound - 1)
+    for name, width in (("main", 379), ("aux", 273), ("quot", 15)):
+        rows = np.asarray(view.dequeue(f"{name} rows"), np.uint64).reshape(len(opened_at), width)
+        auth = np.asarray(view.dequeue(f"{name} auth"), np.uint64).reshape(-1, 5)
+        lv.verify_inclusion(roots[name], p.ldt.length, opened_at, orc.hash_rows(rows), auth)
+    assert not view.pending
+
+
 @pytest.mark.gpu
 def test_full_size_pipeline_low_degree_invariant(orc):
     """BASELINE config 1 (2^20 padded rows, 652 words per row) on the MI355X: the size-independent

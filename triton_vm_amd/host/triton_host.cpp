@@ -351,10 +351,11 @@ ProofStream Prover::prove() {
     std::vector<Xfe> wp = weights_q, wr = weights_q;
     wp[4] = Xfe{{0, 0, 0}};
     wr[0] = Xfe{{0, 0, 0}};
-    if (L != short_dom.length) throw Error(TVM_ERR_INVALID_ARGUMENT, "quotient domain shorter than the LDT domain: take the strided view first");
-    DeviceBuffer cw_p(c_, L * 3), cw_r(c_, L * 3);
-    c_.check(tvm_table_linear_combination(c_.raw(), seg_table, L, wp[0].c, cw_p.ptr()), "tvm_table_linear_combination");
-    c_.check(tvm_table_linear_combination(c_.raw(), seg_table, L, wr[0].c, cw_r.ptr()), "tvm_table_linear_combination");
+    // values of the P and R polynomials on the short domain (stark.rs:536-539): its points are the rows i * L/|short| of
+    // the segment table, which was evaluated on the LDT domain
+    DeviceBuffer cw_p(c_, short_dom.length * 3), cw_r(c_, short_dom.length * 3);
+    c_.check(tvm_table_linear_combination(c_.raw(), seg_table, short_dom.length, wp[0].c, cw_p.ptr()), "tvm_table_linear_combination");
+    c_.check(tvm_table_linear_combination(c_.raw(), seg_table, short_dom.length, wr[0].c, cw_r.ptr()), "tvm_table_linear_combination");
     Xfe ma_values[2];
     {
         const Xfe pts[2] = {alpha, alpha_next};
@@ -375,6 +376,10 @@ ProofStream Prover::prove() {
     cw_p.reset();
     cw_r.reset();
     comb.reset();
+    if (short_dom.length != L) {  // stark.rs:629-639: the quotient domain was the short one -- extend to the LDT domain
+        const DeviceBuffer coeffs = p_.quotient.interpolate(c_, combination.ptr(), 3);
+        combination = p_.ldt.evaluate(c_, coeffs.ptr(), p_.quotient.length, 3);
+    }
 
     // 17: the low-degree test  (stark.rs:641-663)
     const std::vector<u64> a_indices = fri(combination, ps);
@@ -406,7 +411,7 @@ ProofStream Prover::prove() {
 }  // namespace triton_vm
 
 extern "C" int32_t tvmh_prove(tvm_ctx* ctx, uint32_t log2_padded_height, uint64_t num_trace_randomizers,
-                              uint64_t num_collinearity_checks, const uint64_t* d_main_trace,
+                              uint64_t num_collinearity_checks, uint32_t log2_expansion, const uint64_t* d_main_trace,
                               const uint64_t* d_main_randomizers, const uint64_t* d_aux_trace,
                               const uint64_t* d_aux_randomizers, const uint64_t* h_quotient_randomizer,
                               uint64_t* h_transcript, uint64_t capacity, uint64_t* transcript_words, char* error,
@@ -414,7 +419,7 @@ extern "C" int32_t tvmh_prove(tvm_ctx* ctx, uint32_t log2_padded_height, uint64_
     using namespace triton_vm;
     try {
         const Context c(ctx);
-        const StarkParameters p(log2_padded_height, num_trace_randomizers, num_collinearity_checks);
+        const StarkParameters p(log2_padded_height, num_trace_randomizers, num_collinearity_checks, log2_expansion);
         std::vector<Xfe> qr(p.num_quotient_randomizers);
         std::memcpy(qr.data(), h_quotient_randomizer, qr.size() * sizeof(Xfe));
         Prover prover(c, p, d_main_trace, d_main_randomizers, d_aux_trace, d_aux_randomizers, qr);

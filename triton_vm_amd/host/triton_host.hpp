@@ -156,7 +156,7 @@ private:
 // C entry for hosts without a C++ ABI (the Python tests and bench.py): runs Prover::prove on device-resident traces
 // and returns the transcript, flattened as  n_items, then per item: n_words, fiat_shamir flag, the words.
 extern "C" int32_t tvmh_prove(tvm_ctx* ctx, uint32_t log2_padded_height, uint64_t num_trace_randomizers,
-                              uint64_t num_collinearity_checks, const uint64_t* d_main_trace,
+                              uint64_t num_collinearity_checks, uint32_t log2_expansion, const uint64_t* d_main_trace,
                               const uint64_t* d_main_randomizers, const uint64_t* d_aux_trace,
                               const uint64_t* d_aux_randomizers, const uint64_t* h_quotient_randomizer,
                               uint64_t* h_transcript, uint64_t transcript_capacity_words, uint64_t* transcript_words,

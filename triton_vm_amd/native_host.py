@@ -11,7 +11,7 @@ from .build import build_host
 def load_host_library(backend_path=None, out=None):
     lib = C.CDLL(build_host(backend_path, out))
     lib.tvmh_prove.restype = C.c_int32
-    lib.tvmh_prove.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+    lib.tvmh_prove.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64]
     return lib
 
@@ -35,7 +35,7 @@ class NativeProver:
         err = C.create_string_buffer(512)
         n = C.c_uint64(0)
         while True:
-            rc = self.lib.tvmh_prove(self.ctx.handle, log2, p.h, p.num_collinearity_checks, self.bufs[0].ptr, self.bufs[1].ptr,
+            rc = self.lib.tvmh_prove(self.ctx.handle, log2, p.h, p.num_collinearity_checks, p.log2_expansion, self.bufs[0].ptr, self.bufs[1].ptr,
                                      self.bufs[2].ptr, self.bufs[3].ptr, self.qr.ctypes.data, self.out.ctypes.data, self.capacity,
                                      C.byref(n), err, len(err))
             if rc != 0:

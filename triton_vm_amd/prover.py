@@ -108,6 +108,7 @@ class StarkParameters:
         from 2^16 rows on, stark.rs:1944-1951): then the STIR instance fixes the number of trace randomizers and the
         LDT domain (Stark::stir, stark.rs:1972-2032) and the two query-count arguments are ignored."""
         self.padded_height = 1 << log2_padded_height
+        self.log2_expansion = log2_expansion
         self.stir = None
         if ldt == "stir":
             from .low_degree_test import stark_stir
@@ -296,9 +297,9 @@ class Prover:
             wp, wr = weights_q.copy(), weights_q.copy()
             wp[4] = 0
             wr[0] = 0
-            stride = L // short.length
-            cw_p, cw_r = qs.linear_combination(wp), qs.linear_combination(wr)
-            assert stride == 1, "quotient domain shorter than the LDT domain: take the strided view first"
+            # values of the P and R polynomials on the short domain (stark.rs:536-539): its points are the rows
+            # i * L/|short| of the segment table, which was evaluated on the LDT domain
+            cw_p, cw_r = qs.linear_combination(wp, short.length), qs.linear_combination(wr, short.length)
             ma_values = stark.evaluate_at_points(ctx, comb, n_comb, [alpha, alpha_next])
         p_value, r_value = np.zeros(3, np.uint64), np.zeros(3, np.uint64)
         for k in range(4):
@@ -318,6 +319,9 @@ class Prover:
                                 quot_root=self._root(quot_nodes), ood_main=ood_main, ood_aux=ood_aux, seg_ood=seg_ood,
                                 combination=combination.download((short.length, 3)))
         del main_aux_codeword, cw_p, cw_r, comb, comb_aux
+        if short.length != L:  # stark.rs:629-639: the quotient domain was the short one -- extend to the LDT domain
+            with self._timed("DEEP"):
+                combination = p.quotient.low_degree_extension(ctx, combination, p.ldt, 3)
 
         # 17: the low-degree test  (stark.rs:641-663)
         if p.stir is not None:

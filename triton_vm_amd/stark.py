@@ -44,11 +44,14 @@ class QuotientSegments:
         self.ctx._check(self.ctx.lib.tvm_table_merkle_tree(self.ctx.handle, self.table, self.ldt_length, d.ptr), "merkle")
         return d.download((2 * self.ldt_length, 5))
 
-    def linear_combination(self, weights):
+    def linear_combination(self, weights, view_length=None):
+        """over the LDT-domain rows, or over the stride view of `view_length` rows (the quotient domain when it is the
+        shorter one: the same points, stark.rs:501-506)"""
         w = _h(weights).reshape(5, 3)
-        out = self.ctx.alloc(self.ldt_length * 3)
-        self.ctx._check(self.ctx.lib.tvm_table_linear_combination(self.ctx.handle, self.table, self.ldt_length,
-                                                                  w.ctypes.data, out.ptr), "lincomb")
+        n = view_length or self.ldt_length
+        out = self.ctx.alloc(n * 3)
+        self.ctx._check(self.ctx.lib.tvm_table_linear_combination(self.ctx.handle, self.table, n, w.ctypes.data, out.ptr),
+                        "lincomb")
         return out
 
     def free(self):

@@ -91,6 +91,9 @@ def test_hot_path_matches_oracle_recomputation(ctx, orc):
         lv.verify_inclusion(root, p.ldt.length, opened_at, orc.hash_rows(rows), auth)
     assert not view.pending
     assert (np.asarray(prover.opened["main"]).reshape(len(opened_at), 379) == main_lde[opened_at]).all()
+    # stark.rs:2367-2398: proving leaves the trace tables as they were
+    assert (prover.main.d_trace.download(main_trace.shape) == main_trace).all()
+    assert (prover.aux.d_trace.download(aux_trace.shape) == aux_trace).all()
 
     # FRI: the last polynomial respects the degree bound of a randomized_trace_len-degree input
     bound = p.randomized_trace_len >> p.fri_rounds

@@ -26,7 +26,7 @@ class NativeProver:
         self.bufs = (d_main_trace, d_main_randomizers, d_aux_trace, d_aux_randomizers)  # keep them alive
         self.qr = np.ascontiguousarray(quotient_randomizer, dtype=np.uint64).reshape(-1, 3)
         assert self.qr.shape[0] == params.num_quotient_randomizers
-        self.capacity = 1 << 16
+        self.capacity = 1 << 21   # words; a 2^20-row transcript (173 opened rows of 3 tables + authentication nodes) is ~0.4 M words
         self.out = np.empty(self.capacity, np.uint64)
 
     def prove(self, parse=True):

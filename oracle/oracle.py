@@ -280,6 +280,16 @@ def quotients_combined(main_rows, aux_rows, trace_domain, quotient_domain, chall
     return out
 
 
+def air_constraint_values(main_cur, main_next, aux_cur, aux_next, challenges):
+    """All 604 constraint values on one row pair -> [604, 3]; main rows [379] (base field) or [379, 3]."""
+    main_cur, main_next, aux_cur, aux_next, challenges = map(_arr, (main_cur, main_next, aux_cur, aux_next, challenges))
+    words = 3 if main_cur.ndim == 2 else 1
+    out = np.zeros((604, 3), np.uint64)
+    lib().orc_air_constraint_values(_p(main_cur), _p(main_next), _p(aux_cur), _p(aux_next), _p(challenges),
+                                    C.c_int(words), _p(out))
+    return out
+
+
 # ---- combination / DEEP / FRI ---------------------------------------------------------------
 def weighted_sum_of_columns(trace, randomizers, weights, fk=1):
     trace, randomizers, weights = _arr(trace), _arr(randomizers), _arr(weights)

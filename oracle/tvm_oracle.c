@@ -587,6 +587,53 @@ static void eval_section(const uint32_t (*nodes)[3], uint32_t n_nodes, const uin
     free(val);
 }
 
+/* All 604 constraint values on one (current, next) row pair, in the evaluator's order (per section: base-field
+ * constraints first, then extension-field ones; sections init, cons, tran, term) -- what the reference's
+ * MasterAuxTable::evaluate_{initial,consistency,transition,terminal}_constraints return
+ * (master_table.rs:2349-2392 calls them with BFieldElement and with XFieldElement main rows).
+ * main_words = 1: main rows are base-field words; 3: main rows are XFieldElements. out: [604][3]. */
+static void eval_section_values(const uint32_t (*nodes)[3], uint32_t n_nodes, const uint32_t* roots, uint32_t n_roots,
+                                const u64* consts, const u64 (*xconsts)[3], const u64* mc, const u64* mn, const u64* ac,
+                                const u64* an, const u64* challenges, int main_words, u64* out) {
+    u64* val = (u64*)malloc((size_t)n_nodes * 24);
+    for (uint32_t i = 0; i < n_nodes; i++) {
+        u64* v = val + 3 * i;
+        uint32_t k = nodes[i][0], a = nodes[i][1], b = nodes[i][2];
+        switch (k) {
+            case 0: v[0] = consts[a]; v[1] = v[2] = 0; break;
+            case 1: memcpy(v, xconsts[a], 24); break;
+            case 2: case 3: {
+                const u64* m = (k == 2 ? mc : mn) + (size_t)main_words * a;
+                v[0] = m[0]; v[1] = main_words == 3 ? m[1] : 0; v[2] = main_words == 3 ? m[2] : 0;
+                break;
+            }
+            case 4: memcpy(v, ac + 3 * a, 24); break;
+            case 5: memcpy(v, an + 3 * a, 24); break;
+            case 6: memcpy(v, challenges + 3 * a, 24); break;
+            case 7: orc_xfe_add(val + 3 * a, val + 3 * b, v); break;
+            default: orc_xfe_mul(val + 3 * a, val + 3 * b, v); break;
+        }
+    }
+    for (uint32_t r = 0; r < n_roots; r++) memcpy(out + 3 * r, val + 3 * roots[r], 24);
+    free(val);
+}
+
+void orc_air_constraint_values(const uint64_t* mc, const uint64_t* mn, const uint64_t* ac, const uint64_t* an,
+                               const uint64_t* challenges, int main_words, uint64_t* out) {
+    u64* o = out;
+    eval_section_values(ORACLE_AIR_INIT_NODES, ORACLE_AIR_INIT_NUM_NODES, ORACLE_AIR_INIT_ROOTS, ORACLE_AIR_INIT_NUM_ROOTS,
+                        ORACLE_AIR_INIT_CONSTS, ORACLE_AIR_INIT_XCONSTS, mc, mn, ac, an, challenges, main_words, o);
+    o += 3 * ORACLE_AIR_INIT_NUM_ROOTS;
+    eval_section_values(ORACLE_AIR_CONS_NODES, ORACLE_AIR_CONS_NUM_NODES, ORACLE_AIR_CONS_ROOTS, ORACLE_AIR_CONS_NUM_ROOTS,
+                        ORACLE_AIR_CONS_CONSTS, ORACLE_AIR_CONS_XCONSTS, mc, mn, ac, an, challenges, main_words, o);
+    o += 3 * ORACLE_AIR_CONS_NUM_ROOTS;
+    eval_section_values(ORACLE_AIR_TRAN_NODES, ORACLE_AIR_TRAN_NUM_NODES, ORACLE_AIR_TRAN_ROOTS, ORACLE_AIR_TRAN_NUM_ROOTS,
+                        ORACLE_AIR_TRAN_CONSTS, ORACLE_AIR_TRAN_XCONSTS, mc, mn, ac, an, challenges, main_words, o);
+    o += 3 * ORACLE_AIR_TRAN_NUM_ROOTS;
+    eval_section_values(ORACLE_AIR_TERM_NODES, ORACLE_AIR_TERM_NUM_NODES, ORACLE_AIR_TERM_ROOTS, ORACLE_AIR_TERM_NUM_ROOTS,
+                        ORACLE_AIR_TERM_CONSTS, ORACLE_AIR_TERM_XCONSTS, mc, mn, ac, an, challenges, main_words, o);
+}
+
 void orc_quotients_combined(const uint64_t* main_rows, uint64_t n_main, const uint64_t* aux_rows, uint64_t n_aux,
                             orc_domain trace, orc_domain q, const uint64_t* challenges, const uint64_t* weights,
                             uint64_t* out) {

@@ -98,6 +98,12 @@ void orc_quotients_combined(const uint64_t* main_rows, uint64_t n_main, const ui
                             orc_domain trace, orc_domain q, const uint64_t* challenges, const uint64_t* weights,
                             uint64_t* out);
 
+/* the 604 constraint values on one (current, next) row pair in the generated evaluators' order
+ * (evaluate_{initial,consistency,transition,terminal}_constraints; per section base-field constraints first);
+ * main_words 1 = BFieldElement main rows, 3 = XFieldElement main rows; aux rows 91 xfe; out [604][3] */
+void orc_air_constraint_values(const uint64_t* main_cur, const uint64_t* main_next, const uint64_t* aux_cur,
+                               const uint64_t* aux_next, const uint64_t* challenges, int main_words, uint64_t* out);
+
 /* ---- combination / DEEP / FRI (master_table.rs:348-390,512-542; stark.rs:1360-1379,2096; fri.rs:349-366) ---- */
 void orc_weighted_sum_of_columns(int fk, const uint64_t* trace, uint64_t n_rows, uint64_t n_cols,
                                  const uint64_t* randomizers, uint64_t h, const uint64_t* weights /* n_cols xfe */,

@@ -27,6 +27,8 @@ sys.path.insert(0, ROOT)
 
 MASTER_WORDS = 652
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4   # wave64 VALU instructions per ns: 256 CUs x 4 SIMDs, one instruction per 4 cycles
+#                                        per SIMD at 2.4 GHz (profiles/r01_valu_rates_microbench.txt: 64 lane-ops/clk/CU) = 614.4 G/s
 LDE_ALGORITHMIC_BYTES_PER_CELL = 72   # read 8 B, write 8 * (L/N = 8) B per base-field trace cell (default expansion)
 
 
@@ -51,7 +53,48 @@ def cpu_baseline(log2_rows):
     dt = time.perf_counter() - t0
     return {"value": round(n * cols / dt, 1), "unit": "trace-cells/s", "cores": os.cpu_count(), "kind": "port",
             "sample": f"oracle (C, OpenMP) LDE + Tip5 row hashing + Merkle tree of an {cols}-column main-table slice "
-                      f"at 2^{log2_rows} rows (8x extension), {dt:.1f} s; AIR/DEEP/FRI not included in the sample"}
+                      f"at 2^{log2_rows} rows (8x extension), {dt:.1f} s; AIR/DEEP/FRI not included in the sample; a textbook "
+                      "restatement, NOT the Rust prover (no cargo in this image): do not use as a speed-up ratio"}
+
+
+def valu_roofline(launch_ms, rows, n_words):
+    """VALU-issue roofline of the row-hashing kernel: wave64 VALU instructions per launch (dynamic count,
+    SQ_INSTS_VALU of the committed PMC run, profiles/valu_counts.json: per extended row and permutation) over the
+    live launch time, against 256 CUs x 4 SIMDs x one instruction per 4 cycles."""
+    perms = n_words // 10 + 1            # absorb blocks of 10 words incl. the padding block (master_table.rs:667-716)
+    try:
+        with open(os.path.join(ROOT, "profiles", "valu_counts.json")) as f:
+            per_row_perm = json.load(f)["k_hash_rows_mfma"]["wave_valu_instructions_per_row_permutation"]
+    except (OSError, KeyError, ValueError):
+        return None
+    instr = per_row_perm * rows * perms
+    achieved = instr / (launch_ms * 1e-3) / 1e9
+    return {"bound": "valu", "kernel": "k_hash_rows_mfma (main-table row hashing)", "achieved": round(achieved, 1),
+            "peak": round(VALU_PEAK_GINSTR, 1), "unit": "G wave-instr/s", "frac": round(achieved / VALU_PEAK_GINSTR, 4),
+            "launch_ms": round(launch_ms, 3), "permutations_per_row": perms,
+            "wave_valu_instructions_per_launch": int(instr),
+            "hbm_frac": round(rows * n_words * 8 / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+
+
+def spawn_ranks(n):
+    """Re-launch this script as n ranks under torch.distributed.run (rendezvous on 127.0.0.1)."""
+    import socket
+    import subprocess
+
+    if os.environ.get("TVM_BENCH_TEST_EMU") != "1":
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible", file=sys.stderr)
+            return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def timed_steps(step, steps, warmup, device_sync, dist=None, device="cuda"):
@@ -89,6 +132,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log2-rows", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-default-ldt", action="store_true", help="skip the extra measurement of the reference-default LDT (STIR)")
     ap.add_argument("--trace-randomizers", type=int, default=198, help="Stark::default() with FRI: 198 (stark.rs:2083-2089)")
     ap.add_argument("--queries", type=int, default=173, help="FRI collinearity checks at 160 bits, expansion 4: 173")
     ap.add_argument("--log2-expansion", type=int, default=2, help="log2 of the LDT expansion factor: 2 (Stark::default()); 4 is "
@@ -103,6 +147,13 @@ def main():
                          "(triton_vm_amd/host/, the default where it applies: FRI, cached tables, one proof per GPU) or the "
                          "Python mirror (always used for --ldt stir, --jit-passes and the sharded proof)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the same
+        # command the driver's torch.distributed.run form uses) -- and fail loudly when the node has fewer GPUs.
+        sys.exit(spawn_ranks(args.gpus))
+    if args.gpus > 1 and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -175,6 +226,15 @@ def main():
             ctx.timer_start()
             prover.main.maybe_low_degree_extend_all_columns()  # over the domain the prover extends in one go
             lde_ms.append(ctx.timer_stop())
+        # the kernel furthest from the HBM roofline by time: main-table row hashing (k_hash_rows_mfma), VALU-issue bound
+        hash_ms = []
+        d_digests = ctx.alloc(5 * params.ldt.length)
+        for _ in range(3):
+            ctx.timer_start()
+            ctx._check(ctx.lib.tvm_hash_rows(ctx.handle, prover.main._need_table(), prover.main.ldt_domain.length, d_digests.ptr),
+                       "tvm_hash_rows")
+            hash_ms.append(ctx.timer_stop())
+        del d_digests
         prover.main.clear_cache()
     barrier()
     t_prof = 0.0
@@ -227,10 +287,22 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "launch_ms": round(lde_avg_ms, 3),
                          "algorithmic_bytes_per_launch": int(lde_cells * lde_bytes_per_cell)},
+            "roofline_valu": valu_roofline(sum(hash_ms) / len(hash_ms), prover.main.ldt_domain.length, 379),
             "stage_ms": {k: round(v, 3) for k, v in prover.timings.items()},
             "stage_wall_ms": {k: round(v, 3) for k, v in prover.wall.items()},
             "profiled_prove_wall_ms": round(t_prof, 3),
         }
+        if world == 1 and args.ldt == "fri" and not args.jit_passes and not args.no_default_ldt and args.log2_rows >= 16:
+            # Stark::default() selects STIR from 2^16 padded rows on (stark.rs:1944-1951); BASELINE.json's configs name
+            # FRI, which is what `value` is quoted on.  The reference-default variant is measured beside it.
+            prover.release()
+            sp = StarkParameters(args.log2_rows, ldt="stir", log2_expansion=args.log2_expansion)
+            stir = Prover(ctx, sp, seed=1000)
+            t = timed_steps(stir.prove, 2, 1, ctx.sync)
+            out["reference_default_ldt"] = {"ldt": "stir", "trace_randomizers": sp.h, "ms_per_step": round(1e3 * t / 2, 3),
+                                            "value": round(sp.padded_height * MASTER_WORDS * 2 / t, 1), "unit": "trace-cells/s",
+                                            "host": "python"}
+            stir.release()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.log2_rows)
         print(json.dumps(out), flush=True)

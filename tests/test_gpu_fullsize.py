@@ -88,3 +88,16 @@ def test_large_xfe_transform_round_trip_and_point_values(gctx, log_len):
     gctx._check(gctx.lib.tvm_gather_elements(gctx.handle, cw.ptr, 3, idx.ctypes.data, idx.size, got.ctypes.data), "gather")
     points = np.array([[dom.value(int(i)), 0, 0] for i in idx], np.uint64)
     assert (stark.evaluate_at_points(gctx, coeffs, n, points) == got).all()
+
+
+
+@pytest.mark.parametrize("log_n,log_ldt_expansion", [(20, 3), (18, 5)])
+def test_full_size_air_sampled_rows(gctx, orc, log_n, log_ldt_expansion):
+    """all_quotients_combined at BASELINE config 1's size (2^20 rows: quotient = LDT domain 2^23, tables of 23.7 +
+    17.1 GiB, i.e. cell offsets far beyond 4 GiB and 32768 AIR workgroups) and on the stride-4 view of a log-blowup-4-
+    shaped instance (2^18 rows, LDT domain 2^23, quotient domain 2^21): for sampled quotient-domain rows i -- the first
+    and last blocks, the rows whose successor is a wrap row (i >= |Q| - |Q|/N), rows in the upper half of the table --
+    rows i and i + |Q|/N of both extended tables are revealed and pushed through the oracle's constraint DAG."""
+    from tests.test_kernels_air import check_sampled_quotient_rows
+
+    check_sampled_quotient_rows(gctx, orc, log_n, log_ldt_expansion, H, synthetic=True)

@@ -11,8 +11,13 @@ def odom(orc, d):
     return orc.Domain(d.offset, d.generator, d.length)
 
 
-@pytest.mark.parametrize("log_n,expansion,ldt_expansion", [(2, 8, 8), (3, 4, 4), (3, 4, 8), (4, 1, 1), (4, 2, 2)])  # 1, 2: per-rank domains of the sharded prover
+@pytest.mark.parametrize("log_n,expansion,ldt_expansion", [
+    (2, 8, 8), (3, 4, 4), (3, 4, 8), (4, 1, 1), (4, 2, 2),  # 1, 2: per-rank domains of the sharded prover
+    # several 256-row workgroups (block-base addressing, wrap rows of the last block); GPU only: the emulation needs minutes
+    pytest.param(8, 8, 8, marks=pytest.mark.gpu), pytest.param(9, 4, 16, marks=pytest.mark.gpu)])
 def test_all_quotients_combined(ctx, orc, log_n, expansion, ldt_expansion):
+    if log_n >= 8 and ctx.kind != "gpu":
+        pytest.skip("multi-workgroup case runs on the MI355X")
     rng = np.random.default_rng(log_n * 10 + expansion + ldt_expansion)
     n, h = 1 << log_n, 3
     g = field.generator()
@@ -32,3 +37,92 @@ def test_all_quotients_combined(ctx, orc, log_n, expansion, ldt_expansion):
     aux_rows = np.ascontiguousarray(aux.low_degree_extended_table()[::stride])
     want = orc.quotients_combined(main_rows, aux_rows, odom(orc, trace_dom), odom(orc, quot), challenges, weights)
     assert (got == want).all()
+
+
+def _python_quotient(orc, main_cur, main_next, aux_cur, aux_next, challenges, weights, x, n_trace, omega_inv):
+    """all_quotients_combined for ONE row (master_table.rs:1302-1359) in python integers: constraint values from the
+    oracle's DAG walk, zerofier inverses (master_table.rs:1194-1250) and the weighted sums recomputed here."""
+    P = orc.P
+    vals = orc.from_mont(orc.air_constraint_values(main_cur, main_next, aux_cur, aux_next, challenges)).astype(object)
+    w = orc.from_mont(weights).astype(object)
+
+    def xmul(a, b):
+        c0, c1, c2 = a[0] * b[0], a[0] * b[1] + a[1] * b[0], a[0] * b[2] + a[1] * b[1] + a[2] * b[0]
+        c3, c4 = a[1] * b[2] + a[2] * b[1], a[2] * b[2]
+        return [(c0 - c3) % P, (c1 + c3 - c4) % P, (c2 + c4) % P]
+
+    xn = pow(x, n_trace, P)
+    z_init = pow(x - 1, -1, P)
+    z_cons = pow(xn - 1, -1, P)
+    z_tran = (x - omega_inv) * z_cons % P
+    z_term = pow(x - omega_inv, -1, P)
+    ends = [0, 81, 178, 581, 604]
+    q = [0, 0, 0]
+    for s, z in enumerate((z_init, z_cons, z_tran, z_term)):
+        acc = [0, 0, 0]
+        for k in range(ends[s], ends[s + 1]):
+            t = xmul(vals[k], w[k])
+            acc = [(a + b) % P for a, b in zip(acc, t)]
+        q = [(a + z * b) % P for a, b in zip(q, acc)]
+    return q
+
+
+
+def check_sampled_quotient_rows(ctx, orc, log_n, log_ldt_expansion, h, synthetic, n_random=24):
+    """Sampled-row parity of all_quotients_combined against the oracle's DAG walk (rows i and i + |Q|/N revealed from
+    the extended tables); quotient domain 8N, LDT domain N << log_ldt_expansion."""
+    from triton_vm_amd import stark
+
+    n = 1 << log_n
+    g = field.generator()
+    trace_dom = ArithmeticDomain.of_length(n)
+    quot = ArithmeticDomain.of_length(8 * n).with_offset(g)
+    ldt = ArithmeticDomain.of_length(n << log_ldt_expansion).with_offset(g)
+    tables = []
+    for fk, n_cols in ((1, 379), (3, 91)):
+        mt = MasterTable.__new__(MasterTable)
+        mt.ctx, mt.fk, mt.n_cols, mt.n_rows, mt.num_trace_randomizers = ctx, fk, n_cols, n, h
+        mt.trace_domain, mt.quotient_domain, mt.ldt_domain, mt._table = trace_dom, quot, ldt, None
+        shape = lambda k: (n_cols, k) + ((3,) if fk == 3 else ())
+        if synthetic:        # filled on the device (full-size tables)
+            mt.d_trace = ctx.synthetic(n_cols * n * fk, seed=21 + fk)
+            mt.d_randomizers = ctx.synthetic(n_cols * h * fk, seed=23 + fk)
+        else:
+            r = np.random.default_rng(fk)
+            mt.d_trace = ctx.to_device(orc.random_elements(r, shape(n)))
+            mt.d_randomizers = ctx.to_device(orc.random_elements(r, shape(h)))
+        mt.maybe_low_degree_extend_all_columns()
+        tables.append(mt)
+    main, aux = tables
+    rng = np.random.default_rng(77)
+    challenges = orc.random_elements(rng, (63, 3))
+    weights = orc.random_elements(rng, (604, 3))
+    d_q = stark.all_quotients_combined(ctx, main, aux, trace_dom, quot, challenges, weights)
+
+    Q, unit = len(quot), len(quot) // n
+    stride = len(main.evaluation_domain()) // Q          # quotient-domain row i is evaluation-domain row i * stride
+    sample = np.unique(np.concatenate([
+        np.array([0, 1, 255, 256, 257, Q // 2 - 1, Q // 2, Q - 257, Q - 256]) % Q, np.arange(max(Q - unit - 2, 0), Q),
+        rng.integers(0, Q, n_random), rng.integers(3 * Q // 4, Q, n_random)])).astype(np.uint64)
+    nxt = (sample + np.uint64(unit)) % np.uint64(Q)
+    got = np.empty((sample.size, 3), np.uint64)
+    ctx._check(ctx.lib.tvm_gather_elements(ctx.handle, d_q.ptr, 3, sample.ctypes.data, sample.size, got.ctypes.data), "gather")
+    rows_m = main.reveal_rows(np.concatenate([sample, nxt]) * np.uint64(stride))
+    rows_a = aux.reveal_rows(np.concatenate([sample, nxt]) * np.uint64(stride))
+    k = sample.size
+    P = orc.P
+    gen, off = orc.value(quot.generator), orc.value(quot.offset)
+    omega_inv = pow(orc.value(trace_dom.generator), -1, P)
+    for j, i in enumerate(sample):
+        x = off * pow(gen, int(i), P) % P
+        want = _python_quotient(orc, rows_m[j], rows_m[k + j], rows_a[j], rows_a[k + j], challenges, weights, x, n, omega_inv)
+        assert [int(v) for v in orc.from_mont(got[j])] == want, f"quotient row {i}"
+    main.clear_cache()
+    aux.clear_cache()
+
+
+@pytest.mark.parametrize("log_n,log_ldt_expansion", [(3, 3), (2, 5)])
+def test_sampled_quotient_rows_small(ctx, orc, log_n, log_ldt_expansion):
+    """The sampled-row checker of tests/test_gpu_fullsize.py (python-integer zerofiers and weighted sums over the
+    oracle's constraint values) at a size where every row is sampled, incl. the stride-4 view."""
+    check_sampled_quotient_rows(ctx, orc, log_n, log_ldt_expansion, 3, synthetic=False, n_random=64)

@@ -70,3 +70,25 @@ def test_merkle_tree_sizes_and_codeword_tree(ctx, orc, log_n):
     d_cw = ctx.to_device(cw)
     ctx._check(ctx.lib.tvm_codeword_merkle_tree(ctx.handle, d_cw.ptr, n, d_nodes.ptr), "cw tree")
     assert (d_nodes.download((2 * n, 5)) == orc.merkle_tree(orc.xfe_to_digest(cw))).all()
+
+
+def test_row_hashing_reproduces_the_reference_program_digest(ctx, orc):
+    """The device's row-hashing kernel against a REFERENCE-held value: a table whose 295 columns are constant (the words of
+    `program_executing_every_instruction`, zero randomizers) extends to rows that all equal the program's `to_bwords()`, so
+    every row digest must be `program.hash()` as snapshotted at /root/reference/triton-vm/src/stark.rs:4828-4838
+    (30 absorb blocks in overwrite mode; see tests/test_oracle_pins.py for the oracle-side pin)."""
+    import os
+
+    from oracle.vm import isa
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "program_every_instruction.tasm")) as f:
+        words = orc.to_mont(isa.parse(f.read()).to_bwords())
+    n, expansion = 4, 4
+    trace = np.repeat(words[:, None], n, axis=1)
+    trace_dom = ArithmeticDomain.of_length(n)
+    ev = ArithmeticDomain.of_length(n * expansion).with_offset(field.generator())
+    mt = MasterTable(ctx, trace, np.zeros((len(words), 2), np.uint64), trace_dom, ev, ev, 1)
+    mt.maybe_low_degree_extend_all_columns()
+    digests = orc.from_mont(mt.hash_all_ldt_domain_rows())
+    want = [16104359835754349618, 14381287807966156775, 14760563195542097310, 2080121037799184588, 13105746022149139394]
+    assert all([int(v) for v in row] == want for row in digests)

@@ -280,3 +280,30 @@ def test_deep_and_ood_consistency(orc):
     deep = orc.deep_codeword(cw, d, pt, want)
     co = orc.coset_interpolate(deep, d, fk=3).reshape(64, 3)
     assert (co[n + h - 1:] == 0).all() and co[n + h - 2].any()
+
+
+# ---- multi-block overwrite-mode hash_varlen, pinned by the reference's program digests ------------------------
+def _program_digest(orc, source):
+    from oracle.vm import isa
+
+    words = isa.parse(source).to_bwords()
+    return [int(v) for v in orc.from_mont(orc.hash_varlen(orc.to_mont(words)))], len(words)
+
+
+def test_hash_simple_program(orc):
+    """`triton_program!(halt).hash()` (/root/reference/triton-isa/src/program.rs:496-510)."""
+    digest, _ = _program_digest(orc, "halt")
+    assert digest == [0x4338de79520b3949, 0xe6a2129b28850dc9, 0xfd3cd0986a860450, 0x69fdba910ceba7bc, 0x7e5b118c9594c062]
+
+
+def test_program_hash_is_unchanged(orc):
+    """`program_executing_every_instruction().program.hash()` (/root/reference/triton-vm/src/stark.rs:4828-4838; program
+    at :4639-4768): Program::hash = Tip5::hash_varlen(to_bwords()) (triton-isa/src/program.rs:399-402) over 295 words =
+    30 absorb blocks.  The only reference-held pin of multi-block, overwrite-mode hash_varlen and of its padding."""
+    import os
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "program_every_instruction.tasm")) as f:
+        digest, n_words = _program_digest(orc, f.read())
+    assert n_words > 10 * 20
+    assert digest == [16104359835754349618, 14381287807966156775, 14760563195542097310, 2080121037799184588,
+                      13105746022149139394]

@@ -522,6 +522,7 @@ int32_t tvm_fill_derived_aux_columns(tvm_ctx* c, const uint64_t* d_main_trace, u
     u64* staged = (u64*)scratch(c, 20, (size_t)3 * TVM_NUM_CHALLENGES * sizeof(u64));
     if (!staged) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "challenge staging");
     TVM_HIP_CHECK(c, hipMemcpyAsync(staged, h_challenges, 3 * TVM_NUM_CHALLENGES * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));  // h_challenges may be a caller temporary
     return fill_degree_lowering(c, 1, const_cast<u64*>(d_main_trace), d_aux_trace, staged, n_rows);
 }
 

@@ -506,11 +506,20 @@ __global__ void __launch_bounds__(1024) k_lde_pass3_v2(LdePass3Args a) {
 
 // ------------------------------------------------------------------------------------------------
 // host side
+// hipMalloc allocates on the calling thread's CURRENT device, which another context (or the application) may have
+// changed since tvm_ctx_create: every allocating path re-selects the context's device first.
+static bool bind_device(tvm_ctx* c) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == c->device) return true;
+    return hipSetDevice(c->device) == hipSuccess;
+}
+
 const u64* pow_table(tvm_ctx* c, u64 base, u64 count, u64 scale) {
     auto key = std::make_tuple(base, count, scale);
     auto it = c->tables.find(key);
     if (it != c->tables.end()) return it->second;
     u64* d = nullptr;
+    if (!bind_device(c)) return nullptr;
     if (hipMalloc((void**)&d, (count ? count : 1) * sizeof(u64)) != hipSuccess) return nullptr;
     const int bs = 256;
     TVM_LAUNCH(k_pow_table, dim3((unsigned)((count + bs - 1) / bs)), dim3(bs), 0, c->stream, base, count, scale, d);
@@ -531,7 +540,7 @@ void* scratch(tvm_ctx* c, int slot, size_t bytes) {
             c->scratch_bytes[slot] = 0;
         }
         void* p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        if (!bind_device(c) || hipMalloc(&p, bytes) != hipSuccess) return nullptr;
         c->scratch[slot] = p;
         c->scratch_bytes[slot] = bytes;
     }
@@ -552,6 +561,7 @@ void* pool_alloc(tvm_ctx* c, size_t bytes) {
         return p;
     }
     void* p = nullptr;
+    if (!bind_device(c)) return nullptr;
     if (c->pool_limit && c->pool_bytes + want > c->pool_limit) {
         pool_trim(c);  // cached blocks count against the limit: give them back first
         if (c->pool_bytes + want > c->pool_limit) return nullptr;

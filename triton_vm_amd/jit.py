@@ -101,10 +101,12 @@ def prove(ctx, params, main_trace=None, aux_trace=None, seed=1, capture=None):
         except TritonHipError as e:
             if e.status != ERR_OUT_OF_MEMORY or passes >= expansion:
                 raise
-            prover.release()
-            del prover
-            gc.collect()  # buffers of the failed attempt that are still referenced from its frames
-            ctx.trim()
-            passes = max(2 * passes, 2)
-            while expansion % passes:
-                passes += 1
+        # outside the except block: the exception (and with it the traceback that references the failed attempt's
+        # frames and their multi-GiB DeviceBuffers) is gone, so the collection below really frees them
+        prover.release()
+        del prover
+        gc.collect()
+        ctx.trim()
+        passes = max(2 * passes, 2)
+        while expansion % passes:
+            passes += 1

@@ -195,6 +195,13 @@ def tip5_permutation(state):
     return s
 
 
+def tip5_trace(state):
+    """[6, 16]: the state before the permutation and after each round"""
+    s, out = _arr(state), np.zeros((6, 16), np.uint64)
+    lib().orc_tip5_trace(_p(s), _p(out))
+    return out
+
+
 def hash_varlen(words):
     w = _arr(words)
     out = np.zeros(5, np.uint64)

@@ -333,6 +333,33 @@ void orc_tip5_permutation(uint64_t st[16]) {
         for (int i = 0; i < 16; i++) st[i] = madd(nx[i], ORACLE_TIP5_ROUND_CONSTANTS[16 * r + i]);
     }
 }
+/* The permutation's trace: the input state and the state after each of the 5 rounds (twenty-first Tip5::trace, used by
+ * the VM for the Hash table: /root/reference/triton-vm/src/vm.rs:655-747, table/hash.rs:35-43).  out: [6][16]. */
+void orc_tip5_trace(const uint64_t in[16], uint64_t* out) {
+    u64 st[16];
+    memcpy(st, in, 128);
+    memcpy(out, st, 128);
+    for (int r = 0; r < 5; r++) {
+        for (int i = 0; i < 4; i++) {
+            u64 x = st[i], y = 0;
+            for (int b = 0; b < 8; b++) y |= (u64)ORACLE_TIP5_LOOKUP[(x >> (8 * b)) & 0xFF] << (8 * b);
+            st[i] = y;
+        }
+        for (int i = 4; i < 16; i++) {
+            u64 x = st[i], x2 = mmul(x, x), x4 = mmul(x2, x2);
+            st[i] = mmul(mmul(x4, x2), x);
+        }
+        u64 nx[16];
+        for (int i = 0; i < 16; i++) {
+            u64 acc = 0;
+            for (int j = 0; j < 16; j++)
+                acc = madd(acc, mmul(orc_bfe_new(ORACLE_TIP5_MDS_FIRST_COLUMN[(16 + i - j) % 16]), st[j]));
+            nx[i] = acc;
+        }
+        for (int i = 0; i < 16; i++) st[i] = madd(nx[i], ORACLE_TIP5_ROUND_CONSTANTS[16 * r + i]);
+        memcpy(out + 16 * (r + 1), st, 128);
+    }
+}
 /* tip-0005.md:82 fixed-length mode: capacity all ones */
 void orc_hash_10(const uint64_t in[10], uint64_t out[5]) {
     u64 st[16];

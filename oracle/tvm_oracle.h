@@ -74,6 +74,7 @@ void orc_lde_table(int fk, const uint64_t* trace, uint64_t n_rows, uint64_t n_co
 /* ---- Tip5 (tips/tip-0005/tip-0005.md:31-83) ---- */
 void orc_tip5_permutation(uint64_t state[16]);
 void orc_hash_varlen(const uint64_t* input, size_t len, uint64_t out[5]);
+void orc_tip5_trace(const uint64_t in[16], uint64_t* out /* [6][16] */);
 void orc_hash_pair(const uint64_t left[5], const uint64_t right[5], uint64_t out[5]); /* PARITY UNPINNED order */
 void orc_hash_10(const uint64_t input[10], uint64_t out[5]);
 void orc_hash_rows(const uint64_t* rows, uint64_t n_rows, uint64_t row_words, uint64_t* digests);

@@ -1,0 +1,76 @@
+"""Valid master tables for the AIR / extend tests, produced by the oracle-side VM (oracle/vm): the tiny program of
+`current_proof_version_is_still_current` (/root/reference/triton-vm/src/proof.rs:200-226) and
+`program_executing_every_instruction` (/root/reference/triton-vm/src/stark.rs:4639-4803)."""
+import functools
+import os
+
+import numpy as np
+
+from oracle import degree_lowering as dlo
+from oracle import oracle as orc
+from oracle.vm import isa, tables as T, vm
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TINY_PROGRAM = "pick 11 pick 12 pick 13 pick 14 pick 15 read_io 5 assert_vector halt"
+
+
+def hash_pair(left, right):
+    return [int(v) for v in orc.from_mont(orc.hash_pair(orc.to_mont(left), orc.to_mont(right)))]
+
+
+def run(which):
+    """-> (program, aet, public input, public output)"""
+    if which == "tiny":
+        program = isa.parse(TINY_PROGRAM)
+        public_input = vm.hash_varlen(program.to_bwords())
+        aet, output = vm.trace_execution(program, public_input)
+        return program, aet, public_input, output
+    with open(os.path.join(GOLDEN, "program_every_instruction.tasm")) as f:
+        program = isa.parse(f.read())
+    node_5, node_4, node_3 = [5] * 5, [4] * 5, [3] * 5                                  # stark.rs:4770-4786
+    node_2 = hash_pair(node_4, node_5)
+    node_1 = hash_pair(node_2, node_3)
+    ram = {i: 42 + i for i in range(1000)}
+    ram.update({100_000 + i: v for i, v in enumerate(node_3)})
+    aet, output = vm.trace_execution(program, node_5, list(reversed(node_1)) + [1337] * 10, [node_4], ram)
+    return program, aet, node_5, output
+
+
+@functools.lru_cache(maxsize=None)
+def valid_tables(which, seed=1):
+    """The padded, extended, degree-lowered master tables of a real execution, as the prover's hot path receives them:
+    main [379][n], aux [91][n][3] (Montgomery words, column-major), challenges [63][3]."""
+    program, aet, public_input, output = run(which)
+    mt = T.MasterMainTable(aet).pad()
+    n = mt.padded_height
+    main = np.zeros((379, n), np.uint64)
+    main[:T.NUM_MAIN] = orc.to_mont(np.array(mt.columns(), dtype=object))
+    rng = np.random.default_rng(seed)
+    sampled = [[int(v) for v in rng.integers(0, T.P, 3, dtype=np.uint64)] for _ in range(59)]
+    challenges = T.derive_challenges(sampled, vm.hash_varlen(program.to_bwords()), public_input, output)
+    aux = np.zeros((91, n, 3), np.uint64)
+    aux[:T.NUM_AUX] = orc.to_mont(np.array(T.extend(mt.tables, challenges), dtype=object))
+    aux[90] = orc.random_elements(rng, (n, 3))                                         # the batch-randomizer column
+    ch = orc.to_mont(np.array(challenges, dtype=object))
+    main, aux = dlo.fill(main, aux, ch)
+    return main, aux, ch, mt
+
+
+def constraint_violations(main, aux, challenges, rows=None):
+    """(row, section) pairs on which some constraint of the oracle's (reference-pinned) AIR does not vanish:
+    initial constraints on row 0, consistency on every row, transition on rows i, i+1, terminal on the last row
+    (master_table.rs:1302-1359 divides exactly these out)."""
+    n = main.shape[1]
+    mr, ar = np.ascontiguousarray(main.T), np.ascontiguousarray(aux.transpose(1, 0, 2))
+    bad = []
+    for i in (range(n) if rows is None else rows):
+        v = orc.air_constraint_values(mr[i], mr[(i + 1) % n], ar[i], ar[(i + 1) % n], challenges)
+        sections = [("cons", 81, 178)]
+        if i == 0:
+            sections.append(("init", 0, 81))
+        if i < n - 1:
+            sections.append(("tran", 178, 581))
+        if i == n - 1:
+            sections.append(("term", 581, 604))
+        bad += [(i, name) for name, a, b in sections if v[a:b].any()]
+    return bad

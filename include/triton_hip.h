@@ -157,6 +157,16 @@ int32_t tvm_fill_derived_main_columns(tvm_ctx* ctx, uint64_t* d_main_trace, uint
 int32_t tvm_fill_derived_aux_columns(tvm_ctx* ctx, const uint64_t* d_main_trace, uint64_t* d_aux_trace, uint64_t n_rows,
                                      const uint64_t* h_challenges);
 
+/* ---- auxiliary-table extend (first half) ----------------------------------------
+ * MasterMainTable::extend (master_table.rs:1006-1075) without its degree-lowering tail and without the batch-randomizer
+ * column: the 49 cross-table-argument columns of the nine tables (table/{program,processor,op_stack,ram,jump_stack,
+ * hash,cascade,lookup,u32}.rs `extend`: running products, running evaluations, logarithmic-derivative sums with
+ * Challenges' initial values) from the padded main table.  d_main_trace: [379][n_rows] words (columns 0..148 are
+ * read); d_aux_trace: [91][n_rows][3] words, columns 0..48 are written, the others left alone; h_challenges: the 63
+ * challenges incl. the 4 derived ones (host, XFE).  Call tvm_fill_derived_aux_columns afterwards. */
+int32_t tvm_extend_aux_table(tvm_ctx* ctx, const uint64_t* d_main_trace, uint64_t* d_aux_trace, uint64_t n_rows,
+                             const uint64_t* h_challenges);
+
 /* ---- A1-A3: all_quotients_combined (master_table.rs:1264-1363) ------------------------------
  * Evaluates the 81 + 97 + 403 + 23 = 604 AIR constraints of the (degree-lowered) Triton VM AIR on
  * every quotient-domain row of the two extended tables, including the zerofier inverses

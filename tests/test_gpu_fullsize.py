@@ -101,3 +101,36 @@ def test_full_size_air_sampled_rows(gctx, orc, log_n, log_ldt_expansion):
     from tests.test_kernels_air import check_sampled_quotient_rows
 
     check_sampled_quotient_rows(gctx, orc, log_n, log_ldt_expansion, H, synthetic=True)
+
+
+def test_full_size_extend_satisfies_the_transition_constraints(gctx, orc):
+    """tvm_extend_aux_table + the degree-lowering fill at 2^20 rows (1024 scan tiles per column).  The table is the valid
+    2048-row trace of `program_executing_every_instruction` tiled 512 times: inside a tile the main rows are a valid
+    execution, and every transition constraint on an auxiliary column has the form aux' = f(aux, row, row') -- it holds
+    for ANY incoming value, so the (reference-pinned) AIR must vanish on sampled row pairs away from the tile seams,
+    with running values that were carried across a million rows and a thousand workgroups."""
+    from tests import vm_fixture as vf
+    from triton_vm_amd import master_table as mtab
+
+    main, aux, ch, _ = vf.valid_tables("every")
+    tile = main.shape[1]
+    reps = (1 << LOG_N) // tile
+    n = tile * reps
+    big = np.ascontiguousarray(np.tile(main, (1, reps)))
+    d_main = gctx.to_device(big)
+    rng = np.random.default_rng(31)
+    start = np.zeros((91, n, 3), np.uint64)
+    start[90] = orc.random_elements(rng, (n, 3))
+    d_aux = gctx.to_device(start)
+    mtab.extend(gctx, d_main, d_aux, n, ch)
+    got = d_aux.download((91, n, 3))
+    assert (got[90] == start[90]).all()
+    # the first tile is the valid trace itself: identical to the oracle's extension
+    assert (got[:90, :tile] == aux[:90]).all()
+    rows = np.unique(np.concatenate([rng.integers(0, n - 1, 300), [tile + 5, n // 2 + 17, n - tile + 100]]))
+    rows = [int(i) for i in rows if i % tile < tile - 2]
+    for i in rows:
+        v = orc.air_constraint_values(np.ascontiguousarray(big[:, i]), np.ascontiguousarray(big[:, i + 1]),
+                                      np.ascontiguousarray(got[:, i]), np.ascontiguousarray(got[:, i + 1]), ch)
+        assert not v[81:178].any(), f"consistency constraints, row {i}"
+        assert not v[178:581].any(), f"transition constraints, rows {i}, {i + 1}"

@@ -526,6 +526,17 @@ int32_t tvm_fill_derived_aux_columns(tvm_ctx* c, const uint64_t* d_main_trace, u
     return fill_degree_lowering(c, 1, const_cast<u64*>(d_main_trace), d_aux_trace, staged, n_rows);
 }
 
+int32_t tvm_extend_aux_table(tvm_ctx* c, const uint64_t* d_main_trace, uint64_t* d_aux_trace, uint64_t n_rows,
+                             const uint64_t* h_challenges) {
+    if (!c || !d_main_trace || !d_aux_trace || !h_challenges || n_rows < 2)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_extend_aux_table arguments");
+    u64* staged = (u64*)scratch(c, 21, (size_t)3 * TVM_NUM_CHALLENGES * sizeof(u64));
+    if (!staged) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "challenge staging");
+    TVM_HIP_CHECK(c, hipMemcpyAsync(staged, h_challenges, 3 * TVM_NUM_CHALLENGES * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));  // h_challenges may be a caller temporary
+    return extend_aux_table(c, d_main_trace, d_aux_trace, staged, n_rows);
+}
+
 int32_t tvm_all_quotients_combined(tvm_ctx* c, const tvm_table* mt, const tvm_table* at, tvm_domain td,
                                               tvm_domain qd, const uint64_t* h_challenges, const uint64_t* h_weights,
                                               uint64_t* d_out) {

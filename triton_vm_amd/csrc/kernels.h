@@ -36,6 +36,8 @@ int stir_quotient(tvm_ctx* c, u64* vals, u64 n, u64 offset, u64 gen, const u64* 
                   u32 kb, const u64* h_r);
 // fill.hip
 int fill_degree_lowering(tvm_ctx* c, int table, u64* d_main, u64* d_aux, const u64* d_challenges, u64 n);
+// extend.hip
+int extend_aux_table(tvm_ctx* c, const u64* d_main, u64* d_aux, const u64* d_challenges, u64 n);
 // air.hip
 int all_quotients_combined(tvm_ctx* c, const u64* main_table, u64 main_rows, u64 wrap_rows, u64 main_w, const u64* aux_table,
                            u64 aux_w, u64 trace_len, u64 trace_gen, u64 q_offset, u64 q_gen, u64 q_len, const u64* d_challenges,

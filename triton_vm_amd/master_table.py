@@ -111,3 +111,21 @@ class MasterTable:
             self.clear_cache()
         except Exception:
             pass
+
+
+def extend(ctx, d_main_trace, d_aux_trace, n_rows, challenges):
+    """MasterMainTable::extend (/root/reference/triton-vm/src/table/master_table.rs:1006-1075) on the device: the 49
+    cross-table-argument columns of the nine tables (tvm_extend_aux_table), then the 41 degree-lowering columns
+    (tvm_fill_derived_aux_columns).  d_main_trace: DeviceBuffer [379][n_rows] (padded, derived columns filled);
+    d_aux_trace: DeviceBuffer [91][n_rows][3], column 90 (the batch randomizer, host RNG) is left untouched;
+    challenges: 63 XFE (Montgomery words)."""
+    import ctypes as C
+
+    from . import degree_lowering
+
+    ch = np.ascontiguousarray(np.asarray(challenges, dtype=np.uint64).reshape(63, 3))
+    if d_main_trace.n_words < 379 * n_rows or d_aux_trace.n_words < 91 * n_rows * 3:
+        raise ValueError("the traces need 379 main and 91 auxiliary columns")
+    ctx._check(ctx.lib.tvm_extend_aux_table(ctx.handle, d_main_trace.ptr, d_aux_trace.ptr, n_rows,
+                                            ch.ctypes.data_as(C.c_void_p)), "tvm_extend_aux_table")
+    degree_lowering.fill_derived_aux_columns(ctx, d_main_trace, d_aux_trace, n_rows, ch)

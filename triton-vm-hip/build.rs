@@ -1,0 +1,14 @@
+// Link against libtriton_hip.so.  TRITON_HIP_LIB_DIR = the directory that holds it (…/triton_vm_amd after
+// `python -m triton_vm_amd.build`, which runs hipcc --offload-arch=gfx950 over csrc/*.hip).
+use std::env;
+use std::path::PathBuf;
+
+fn main() {
+    println!("cargo:rerun-if-env-changed=TRITON_HIP_LIB_DIR");
+    let dir = env::var("TRITON_HIP_LIB_DIR").map(PathBuf::from).unwrap_or_else(|_| {
+        PathBuf::from(env::var("CARGO_MANIFEST_DIR").unwrap()).join("..").join("triton_vm_amd")
+    });
+    println!("cargo:rustc-link-search=native={}", dir.display());
+    println!("cargo:rustc-link-lib=dylib=triton_hip");
+    println!("cargo:rustc-link-arg=-Wl,-rpath,{}", dir.display());
+}

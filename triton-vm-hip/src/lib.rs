@@ -1,0 +1,308 @@
+//! Safe wrappers over `libtriton_hip.so` for the seams of `triton-vm`'s prover (feature `hip`, see
+//! `patches/triton-vm-hip.patch` and INTEGRATION.md).  SOURCE ONLY: the image this was written in has no Rust
+//! toolchain, so this crate has never been compiled; `ffi.rs` is generated from `include/triton_hip.h` and checked
+//! for completeness by `tests/test_rust_shim.py`.
+//!
+//! Everything Fiat–Shamir (`ProofStream`, `BFieldCodec`, `sample_scalars`, `sample_indices`), the prover's RNG and
+//! `MerkleTree::authentication_structure` stay in Rust/twenty-first; only plain words cross the boundary:
+//! `BFieldElement::raw_u64()` Montgomery words, `XFieldElement` = 3 words, `Digest` = 5 words.
+pub mod ffi;
+
+use std::cell::RefCell;
+use std::ffi::{c_void, CStr};
+use std::ptr;
+
+use ndarray::{Array2, ArrayView2};
+use twenty_first::prelude::*;
+
+use ffi::*;
+
+#[derive(Debug, Clone, PartialEq, Eq)]
+pub enum HipError {
+    /// `TVM_ERR_INVALID_ARGUMENT`: domain / length mismatches (ArithmeticDomainError and friends)
+    InvalidArgument(String),
+    /// `TVM_ERR_OUT_OF_MEMORY`: the reference's `try_reserve_exact` failure (master_table.rs:268-271); recoverable
+    OutOfMemory,
+    /// `TVM_ERR_DEVICE` / `TVM_ERR_UNSUPPORTED`
+    Device(String),
+}
+pub type Result<T> = std::result::Result<T, HipError>;
+
+/// One context per proving thread (`triton_vm::prove` may run on several threads, lib.rs:522-532).
+pub struct Context {
+    raw: *mut TvmCtx,
+}
+
+thread_local! {
+    static CONTEXT: RefCell<Option<Context>> = const { RefCell::new(None) };
+}
+
+/// Run `f` with this thread's context (created on first use on device `TRITON_HIP_DEVICE`, default 0).
+pub fn with_context<T>(f: impl FnOnce(&Context) -> Result<T>) -> Result<T> {
+    CONTEXT.with(|slot| {
+        let mut slot = slot.borrow_mut();
+        if slot.is_none() {
+            let device = std::env::var("TRITON_HIP_DEVICE").ok().and_then(|d| d.parse().ok()).unwrap_or(0);
+            *slot = Some(Context::new(device)?);
+        }
+        f(slot.as_ref().unwrap())
+    })
+}
+
+impl Context {
+    pub fn new(device: i32) -> Result<Self> {
+        let mut raw = ptr::null_mut();
+        let status = unsafe { tvm_ctx_create(device, ptr::null_mut(), &mut raw) };
+        if status != TVM_OK {
+            let what = unsafe { CStr::from_ptr(tvm_status_string(status)) }.to_string_lossy().into_owned();
+            return Err(HipError::Device(what));
+        }
+        Ok(Self { raw })
+    }
+
+    fn check(&self, status: i32) -> Result<()> {
+        match status {
+            TVM_OK => Ok(()),
+            TVM_ERR_OUT_OF_MEMORY => Err(HipError::OutOfMemory),
+            TVM_ERR_INVALID_ARGUMENT => Err(HipError::InvalidArgument(self.last_error())),
+            _ => Err(HipError::Device(self.last_error())),
+        }
+    }
+
+    fn last_error(&self) -> String {
+        unsafe { CStr::from_ptr(tvm_last_error(self.raw)) }.to_string_lossy().into_owned()
+    }
+
+    pub fn alloc(&self, words: usize) -> Result<DeviceBuffer<'_>> {
+        let mut p: *mut c_void = ptr::null_mut();
+        self.check(unsafe { tvm_malloc(self.raw, words.max(1) * 8, &mut p) })?;
+        Ok(DeviceBuffer { ctx: self, ptr: p.cast(), words })
+    }
+
+    pub fn upload(&self, words: &[u64]) -> Result<DeviceBuffer<'_>> {
+        let buf = self.alloc(words.len())?;
+        self.check(unsafe { tvm_memcpy_h2d(self.raw, buf.ptr.cast(), words.as_ptr().cast(), words.len() * 8) })?;
+        Ok(buf)
+    }
+}
+
+impl Drop for Context {
+    fn drop(&mut self) {
+        unsafe { tvm_ctx_destroy(self.raw) }
+    }
+}
+
+/// Device memory from the context's caching allocator.
+pub struct DeviceBuffer<'c> {
+    ctx: &'c Context,
+    ptr: *mut u64,
+    words: usize,
+}
+
+impl DeviceBuffer<'_> {
+    pub fn download(&self) -> Result<Vec<u64>> {
+        let mut out = vec![0_u64; self.words];
+        self.ctx.check(unsafe { tvm_memcpy_d2h(self.ctx.raw, out.as_mut_ptr().cast(), self.ptr.cast(), self.words * 8) })?;
+        Ok(out)
+    }
+}
+
+impl Drop for DeviceBuffer<'_> {
+    fn drop(&mut self) {
+        unsafe { tvm_free(self.ctx.raw, self.ptr.cast()) };
+    }
+}
+
+/// A low-degree-extended master table resident on the device (`tvm_table`).
+pub struct Table<'c> {
+    ctx: &'c Context,
+    raw: *mut TvmTable,
+}
+
+impl Drop for Table<'_> {
+    fn drop(&mut self) {
+        unsafe { tvm_table_free(self.ctx.raw, self.raw) }
+    }
+}
+
+// ---- words <-> field elements -------------------------------------------------------------------------------------
+pub fn domain(offset: BFieldElement, generator: BFieldElement, length: usize) -> TvmDomain {
+    TvmDomain { offset: offset.raw_u64(), generator: generator.raw_u64(), length: length as u64 }
+}
+
+pub fn bfe_words(elements: &[BFieldElement]) -> Vec<u64> {
+    elements.iter().map(|e| e.raw_u64()).collect()
+}
+
+pub fn xfe_words(elements: &[XFieldElement]) -> Vec<u64> {
+    elements.iter().flat_map(|x| x.coefficients.map(|c| c.raw_u64())).collect()
+}
+
+pub fn words_to_xfes(words: &[u64]) -> Vec<XFieldElement> {
+    words
+        .chunks_exact(3)
+        .map(|w| XFieldElement::new([0, 1, 2].map(|i| BFieldElement::from_raw_u64(w[i]))))
+        .collect()
+}
+
+pub fn words_to_digests(words: &[u64]) -> Vec<Digest> {
+    words
+        .chunks_exact(Digest::LEN)
+        .map(|w| Digest::new([0, 1, 2, 3, 4].map(|i| BFieldElement::from_raw_u64(w[i]))))
+        .collect()
+}
+
+/// Column-major words of a trace table of `field_kind`-word elements (`Array2::f()` order, master_table.rs:888,1013).
+fn column_major_words<F: Copy>(table: ArrayView2<F>, field_kind: usize, words_of: impl Fn(F, &mut Vec<u64>)) -> Vec<u64> {
+    let mut out = Vec::with_capacity(table.len() * field_kind);
+    for column in table.columns() {
+        for &cell in column {
+            words_of(cell, &mut out);
+        }
+    }
+    out
+}
+
+// ---- seams ---------------------------------------------------------------------------------------------------------
+/// `MasterTable::maybe_low_degree_extend_all_columns` (master_table.rs:258-322) for a main table.
+/// `randomizers[c]` = the coefficients of `trace_randomizer_for_column(c)` (host RNG, master_table.rs:423-434).
+pub fn lde_main_table<'c>(
+    ctx: &'c Context,
+    trace: ArrayView2<BFieldElement>,
+    randomizers: &[Vec<BFieldElement>],
+    trace_domain: TvmDomain,
+    evaluation_domain: TvmDomain,
+) -> Result<Table<'c>> {
+    let h = randomizers.first().map_or(0, Vec::len);
+    let d_trace = ctx.upload(&column_major_words(trace, 1, |c: BFieldElement, out| out.push(c.raw_u64())))?;
+    let d_rand = ctx.upload(&randomizers.iter().flat_map(|r| bfe_words(r)).collect::<Vec<_>>())?;
+    lde(ctx, 1, &d_trace, trace.nrows(), trace.ncols(), &d_rand, h, trace_domain, evaluation_domain)
+}
+
+/// The same for the auxiliary table (XFieldElement cells, 3 words each).
+pub fn lde_aux_table<'c>(
+    ctx: &'c Context,
+    trace: ArrayView2<XFieldElement>,
+    randomizers: &[Vec<XFieldElement>],
+    trace_domain: TvmDomain,
+    evaluation_domain: TvmDomain,
+) -> Result<Table<'c>> {
+    let h = randomizers.first().map_or(0, Vec::len);
+    let words = column_major_words(trace, 3, |c: XFieldElement, out| out.extend(c.coefficients.map(|b| b.raw_u64())));
+    let d_trace = ctx.upload(&words)?;
+    let d_rand = ctx.upload(&randomizers.iter().flat_map(|r| xfe_words(r)).collect::<Vec<_>>())?;
+    lde(ctx, 3, &d_trace, trace.nrows(), trace.ncols(), &d_rand, h, trace_domain, evaluation_domain)
+}
+
+#[allow(clippy::too_many_arguments)]
+fn lde<'c>(
+    ctx: &'c Context,
+    field_kind: i32,
+    d_trace: &DeviceBuffer,
+    n_rows: usize,
+    n_cols: usize,
+    d_rand: &DeviceBuffer,
+    h: usize,
+    trace_domain: TvmDomain,
+    evaluation_domain: TvmDomain,
+) -> Result<Table<'c>> {
+    let mut raw = ptr::null_mut();
+    ctx.check(unsafe {
+        tvm_lde_table(ctx.raw, field_kind, d_trace.ptr, n_rows as u64, n_cols as u64, d_rand.ptr, h as u64, trace_domain,
+                      evaluation_domain, &mut raw)
+    })?;
+    Ok(Table { ctx, raw })
+}
+
+impl Table<'_> {
+    pub fn num_rows(&self) -> usize {
+        unsafe { tvm_table_num_rows(self.raw) as usize }
+    }
+
+    /// The reference's row-major `Array2` (master_table.rs:304-305) -- the acceptance-test path that feeds the
+    /// unmodified downstream code; the production path keeps the table on the device.
+    pub fn to_host_bfe(&self) -> Result<Array2<BFieldElement>> {
+        let (rows, cols) = (self.num_rows(), unsafe { tvm_table_num_columns(self.raw) as usize });
+        let buf = self.ctx.alloc(rows * cols)?;
+        self.ctx.check(unsafe { tvm_table_export_row_major(self.ctx.raw, self.raw, buf.ptr) })?;
+        let words = buf.download()?;
+        Ok(Array2::from_shape_vec([rows, cols], words.into_iter().map(BFieldElement::from_raw_u64).collect()).unwrap())
+    }
+
+    pub fn to_host_xfe(&self) -> Result<Array2<XFieldElement>> {
+        let (rows, cols) = (self.num_rows(), unsafe { tvm_table_num_columns(self.raw) as usize });
+        let buf = self.ctx.alloc(rows * cols * 3)?;
+        self.ctx.check(unsafe { tvm_table_export_row_major(self.ctx.raw, self.raw, buf.ptr) })?;
+        Ok(Array2::from_shape_vec([rows, cols], words_to_xfes(&buf.download()?)).unwrap())
+    }
+
+    /// `MasterTable::hash_all_ldt_domain_rows` (master_table.rs:455-468)
+    pub fn hash_all_ldt_domain_rows(&self, ldt_length: usize) -> Result<Vec<Digest>> {
+        let buf = self.ctx.alloc(ldt_length * Digest::LEN)?;
+        self.ctx.check(unsafe { tvm_hash_rows(self.ctx.raw, self.raw, ldt_length as u64, buf.ptr) })?;
+        Ok(words_to_digests(&buf.download()?))
+    }
+
+    /// `MasterTable::reveal_rows` (master_table.rs:548-555, cached branch): `[indices.len()][row words]`
+    pub fn reveal_rows(&self, ldt_length: usize, indices: &[usize]) -> Result<Vec<u64>> {
+        let idx: Vec<u64> = indices.iter().map(|&i| i as u64).collect();
+        let row_words = unsafe { (tvm_table_num_columns(self.raw) as usize) * (tvm_table_field_kind(self.raw) as usize) };
+        let mut out = vec![0_u64; idx.len() * row_words];
+        self.ctx.check(unsafe {
+            tvm_table_reveal_rows(self.ctx.raw, self.raw, ldt_length as u64, idx.as_ptr(), idx.len() as u64, out.as_mut_ptr())
+        })?;
+        Ok(out)
+    }
+}
+
+/// `all_quotients_combined` (master_table.rs:1264-1363) on two device tables: 63 challenges, 604 quotient weights.
+pub fn all_quotients_combined(
+    ctx: &Context,
+    main: &Table,
+    aux: &Table,
+    trace_domain: TvmDomain,
+    quotient_domain: TvmDomain,
+    challenges: &[XFieldElement],
+    quotient_weights: &[XFieldElement],
+) -> Result<Vec<XFieldElement>> {
+    assert_eq!(TVM_NUM_CHALLENGES, challenges.len());
+    assert_eq!(TVM_NUM_QUOTIENT_WEIGHTS, quotient_weights.len());
+    let out = ctx.alloc(quotient_domain.length as usize * 3)?;
+    let (ch, w) = (xfe_words(challenges), xfe_words(quotient_weights));
+    ctx.check(unsafe {
+        tvm_all_quotients_combined(ctx.raw, main.raw, aux.raw, trace_domain, quotient_domain, ch.as_ptr(), w.as_ptr(), out.ptr)
+    })?;
+    Ok(words_to_xfes(&out.download()?))
+}
+pub const TVM_NUM_CHALLENGES: usize = 63;
+pub const TVM_NUM_QUOTIENT_WEIGHTS: usize = 604;
+
+/// `ProverRound::split_and_fold` (low_degree_test/fri.rs:349-366)
+pub fn fri_split_and_fold(ctx: &Context, codeword: &[XFieldElement], fri_domain: TvmDomain, challenge: XFieldElement) -> Result<Vec<XFieldElement>> {
+    let d_in = ctx.upload(&xfe_words(codeword))?;
+    let d_out = ctx.alloc(codeword.len() / 2 * 3)?;
+    let ch = xfe_words(&[challenge]);
+    ctx.check(unsafe { tvm_fri_split_and_fold(ctx.raw, d_in.ptr, fri_domain, ch.as_ptr(), d_out.ptr) })?;
+    Ok(words_to_xfes(&d_out.download()?))
+}
+
+/// All nodes of the Merkle tree over `Digest::from(xfe)` leaves (`merkle_tree_from_codeword`, fri.rs:343-347), heap
+/// order `[2n][5]` (node 1 = root, leaves at n..2n), for cross-checking twenty-first's `MerkleTree::par_new`.
+pub fn codeword_merkle_nodes(ctx: &Context, codeword: &[XFieldElement]) -> Result<Vec<Digest>> {
+    let d_in = ctx.upload(&xfe_words(codeword))?;
+    let d_nodes = ctx.alloc(2 * codeword.len() * Digest::LEN)?;
+    ctx.check(unsafe { tvm_codeword_merkle_tree(ctx.raw, d_in.ptr, codeword.len() as u64, d_nodes.ptr) })?;
+    Ok(words_to_digests(&d_nodes.download()?))
+}
+
+/// `MasterMainTable::extend`'s per-table loops + the degree-lowering fill (master_table.rs:1006-1075) on the device:
+/// `aux` is `[n_rows, 91]` column-major words with column 90 (batch randomizer) already drawn by the host RNG.
+pub fn extend_aux_table(ctx: &Context, main_trace_words: &[u64], aux_trace_words: &mut [u64], n_rows: usize, challenges: &[XFieldElement]) -> Result<()> {
+    let d_main = ctx.upload(main_trace_words)?;
+    let d_aux = ctx.upload(aux_trace_words)?;
+    let ch = xfe_words(challenges);
+    ctx.check(unsafe { tvm_extend_aux_table(ctx.raw, d_main.ptr, d_aux.ptr, n_rows as u64, ch.as_ptr()) })?;
+    ctx.check(unsafe { tvm_fill_derived_aux_columns(ctx.raw, d_main.ptr, d_aux.ptr, n_rows as u64, ch.as_ptr()) })?;
+    aux_trace_words.copy_from_slice(&d_aux.download()?);
+    Ok(())
+}

@@ -157,6 +157,15 @@ int32_t tvm_fill_derived_main_columns(tvm_ctx* ctx, uint64_t* d_main_trace, uint
 int32_t tvm_fill_derived_aux_columns(tvm_ctx* ctx, const uint64_t* d_main_trace, uint64_t* d_aux_trace, uint64_t n_rows,
                                      const uint64_t* h_challenges);
 
+/* ---- main-table pad (the `pad` half) ----------------------------------------------
+ * MasterMainTable::pad (master_table.rs:932-983) without its degree-lowering tail (tvm_fill_derived_main_columns): the
+ * nine table-specific padding rules (table/program.rs:77-127, processor.rs:70-96, op_stack.rs:205-219, ram.rs:86-101,
+ * jump_stack.rs:144-199, hash.rs:280-309, cascade.rs:60-67, lookup.rs:114-118, u32.rs:127-152), in place.
+ * d_main_trace: [379][n_rows] words whose columns 0..148 hold the filled tables in their first h_table_lengths[t]
+ * rows (t = Program, Processor, OpStack, Ram, JumpStack, Hash, Cascade, Lookup, U32; all_table_lengths,
+ * master_table.rs:985-1001) and zeros below; n_rows = the padded height (a power of two). */
+int32_t tvm_pad_main_table(tvm_ctx* ctx, uint64_t* d_main_trace, uint64_t n_rows, const uint64_t* h_table_lengths);
+
 /* ---- auxiliary-table extend (first half) ----------------------------------------
  * MasterMainTable::extend (master_table.rs:1006-1075) without its degree-lowering tail and without the batch-randomizer
  * column: the 49 cross-table-argument columns of the nine tables (table/{program,processor,op_stack,ram,jump_stack,

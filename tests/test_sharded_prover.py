@@ -1,11 +1,13 @@
-"""One proof split over two ranks (triton_vm_amd/sharded.py: coset sharding, gloo on CPU, the kernels on the
+"""One proof split over 2, 4 and 8 ranks (triton_vm_amd/sharded.py: coset sharding, gloo on CPU, the kernels on the
 TEST-ONLY fiber emulation) must commit to the same roots, sample the same challenges and hand FRI the same
-combination codeword as the single-process prover on the same traces."""
+combination codeword as the single-process prover on the same traces.  World size 8 is the full node: with the
+default expansion factor every rank then owns exactly one coset of the trace domain."""
 import os
 import socket
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LOG2_ROWS, H, QUERIES, SEED = 3, 3, 2, 5
@@ -49,7 +51,8 @@ def _worker(rank, world, port, out):
     ctx.close()
 
 
-def test_two_rank_proof_equals_single_process_proof():
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_proof_equals_single_process_proof(world):
     import torch.multiprocessing as mp
 
     from tests.emu_fixture import emu_context
@@ -60,7 +63,7 @@ def test_two_rank_proof_equals_single_process_proof():
         port = s.getsockname()[1]
     mpctx = mp.get_context("spawn")
     out = mpctx.Queue()
-    procs = [mpctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [mpctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
     for pr in procs:
         pr.start()
 
@@ -71,16 +74,24 @@ def test_two_rank_proof_equals_single_process_proof():
     want = _capture(single)
     ctx.close()
 
-    results = dict(out.get(timeout=600) for _ in procs)
+    results = {}
+    import queue
+    import time
+
+    deadline = time.time() + 900
+    while len(results) < world:
+        try:
+            rank, got = out.get(timeout=5)
+            results[rank] = got
+        except queue.Empty:
+            assert all(pr.exitcode in (None, 0) for pr in procs), "a rank died"
+            assert time.time() < deadline, "timed out"
     for pr in procs:
         pr.join(timeout=120)
         assert pr.exitcode == 0
-    for rank in (0, 1):
+    for rank in range(world):
         for key, value in want.items():
             assert (results[rank][key] == value).all(), (rank, key)
-
-
-import pytest  # noqa: E402
 
 
 @pytest.mark.gpu

@@ -74,6 +74,7 @@ _SIGNATURES = {
     "tvm_evaluate_at_points": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
     "tvm_fill_derived_main_columns": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "tvm_fill_derived_aux_columns": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "tvm_pad_main_table": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "tvm_extend_aux_table": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "tvm_all_quotients_combined": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, Domain, Domain, C.c_void_p,
                                                C.c_void_p, C.c_void_p]),

@@ -526,6 +526,12 @@ int32_t tvm_fill_derived_aux_columns(tvm_ctx* c, const uint64_t* d_main_trace, u
     return fill_degree_lowering(c, 1, const_cast<u64*>(d_main_trace), d_aux_trace, staged, n_rows);
 }
 
+int32_t tvm_pad_main_table(tvm_ctx* c, uint64_t* d_main_trace, uint64_t n_rows, const uint64_t* h_table_lengths) {
+    if (!c || !d_main_trace || !h_table_lengths || !is_pow2(n_rows) || n_rows < 2)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_pad_main_table arguments");
+    return pad_main_table(c, d_main_trace, n_rows, h_table_lengths);
+}
+
 int32_t tvm_extend_aux_table(tvm_ctx* c, const uint64_t* d_main_trace, uint64_t* d_aux_trace, uint64_t n_rows,
                              const uint64_t* h_challenges) {
     if (!c || !d_main_trace || !d_aux_trace || !h_challenges || n_rows < 2)

@@ -129,3 +129,20 @@ def extend(ctx, d_main_trace, d_aux_trace, n_rows, challenges):
     ctx._check(ctx.lib.tvm_extend_aux_table(ctx.handle, d_main_trace.ptr, d_aux_trace.ptr, n_rows,
                                             ch.ctypes.data_as(C.c_void_p)), "tvm_extend_aux_table")
     degree_lowering.fill_derived_aux_columns(ctx, d_main_trace, d_aux_trace, n_rows, ch)
+
+
+TABLE_ORDER = ("Program", "Processor", "OpStack", "Ram", "JumpStack", "Hash", "Cascade", "Lookup", "U32")
+
+
+def pad(ctx, d_main_trace, n_rows, table_lengths):
+    """MasterMainTable::pad (/root/reference/triton-vm/src/table/master_table.rs:932-983) on the device: the nine
+    table-specific padding rules (tvm_pad_main_table), then the degree-lowering fill of the main table
+    (tvm_fill_derived_main_columns).  d_main_trace: DeviceBuffer [379][n_rows] with the filled, unpadded tables in
+    columns 0..148; table_lengths: the nine lengths in TABLE_ORDER (all_table_lengths, master_table.rs:985-1001)."""
+    from . import degree_lowering
+
+    lengths = np.ascontiguousarray(table_lengths, dtype=np.uint64)
+    if lengths.size != 9 or d_main_trace.n_words < 379 * n_rows:
+        raise ValueError("pad needs nine table lengths and a 379-column main trace")
+    ctx._check(ctx.lib.tvm_pad_main_table(ctx.handle, d_main_trace.ptr, n_rows, lengths.ctypes.data), "tvm_pad_main_table")
+    degree_lowering.fill_derived_main_columns(ctx, d_main_trace, n_rows)

@@ -9,8 +9,8 @@ The trace (5 GiB at 2^20 rows) is replicated.  Exchanges (RCCL all-gather over x
 
     leaf digests of each master table   L x 40 B  (336 MB at 2^20), interleaved back into row order
     the quotient codeword               L x 24 B  (201 MB), likewise
-    the opened rows (173 x 652 words)   summed over ranks (each row is non-zero on its owner only)
-    the out-of-domain rows              columns split over the ranks, summed likewise (2 x 470 XFE)
+    the opened rows (173 x 652 words)   all-gather of each owner's rows, put back into query order
+    the out-of-domain rows              columns split over the ranks, all-gather of the shares (2 x 470 XFE)
 
 Everything after the quotient codeword (segments, out-of-domain rows, combination, DEEP, FRI: ~55 ms of a
 411 ms proof at 2^20 rows) is computed redundantly on every rank from identical inputs, so every rank derives
@@ -103,26 +103,42 @@ class ShardedProver(Prover):
                                                       local.data_ptr()), "all_quotients_combined")
         return _TensorBuffer(self._all_gather_rows(local, 3))
 
+    def _all_gather_host(self, mine, cap):
+        """all-gather of one equally sized (zero-padded to `cap` leading entries) block per rank: numpy [k, ...] ->
+        numpy [world, cap, ...].  The payloads (out-of-domain rows, opened rows) are produced on the host by the C ABI
+        and are a few hundred KB; the collective itself runs on device tensors (RCCL) / CPU tensors (gloo)."""
+        block = np.zeros((cap,) + mine.shape[1:], np.uint64)
+        block[:mine.shape[0]] = mine
+        t = self.torch.from_numpy(block.view(np.int64).reshape(-1)).to(self.device)
+        gathered = self._empty(t.numel() * self.world)
+        self.dist.all_gather_into_tensor(gathered, t)
+        return gathered.cpu().numpy().view(np.uint64).reshape((self.world,) + block.shape)
+
     def _out_of_domain_rows(self, mt, points):
-        """columns split evenly over the ranks (the trace is replicated); the rows are tiny, so the exchange is an
-        all-reduce(sum) of a zero-padded array in which every column is non-zero on its owner only"""
+        """columns split evenly over the ranks (the trace is replicated): rank r evaluates columns [r * per, (r+1) * per)
+        at both points, the shares are all-gathered"""
         per = -(-mt.n_cols // self.world)
         c0 = min(self.rank * per, mt.n_cols)
         c1 = min(c0 + per, mt.n_cols)
-        rows = np.zeros((len(points), mt.n_cols, 3), np.uint64)
-        rows[:, c0:c1] = mt.out_of_domain_rows(points, c0, c1 - c0)
-        t = self.torch.from_numpy(rows.view(np.int64)).to(self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return t.cpu().numpy().view(np.uint64)
+        mine = mt.out_of_domain_rows(points, c0, c1 - c0)                      # [n_points, c1 - c0, 3]
+        gathered = self._all_gather_host(np.ascontiguousarray(mine.transpose(1, 0, 2)), per)   # [world, per, n_points, 3]
+        cols = gathered.reshape(self.world * per, len(points), 3)[:mt.n_cols]
+        return np.ascontiguousarray(cols.transpose(1, 0, 2))
 
     def _reveal_master_rows(self, mt, row_indices):
+        """row i of the extended table lives on rank i mod world (as its local row i // world); every rank opens the
+        rows it owns, the shares are all-gathered and put back into query order"""
         idx = np.asarray(row_indices, dtype=np.uint64)
-        mine = np.nonzero(idx % np.uint64(self.world) == np.uint64(self.rank))[0]
+        owner = (idx % np.uint64(self.world)).astype(np.int64)
         width = mt.n_cols * mt.fk
-        rows = np.zeros((idx.size, width), np.uint64)
+        mine = np.nonzero(owner == self.rank)[0]
+        rows = np.zeros((0, width), np.uint64)
         if mine.size:
-            rows[mine] = mt.reveal_rows(idx[mine] // np.uint64(self.world)).reshape(mine.size, width)
-        t = self.torch.from_numpy(rows.view(np.int64)).to(self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)  # every row is non-zero on its owner only
-        out = t.cpu().numpy().view(np.uint64)
+            rows = mt.reveal_rows(idx[mine] // np.uint64(self.world)).reshape(mine.size, width)
+        cap = max(int(np.bincount(owner, minlength=self.world).max()), 1)
+        gathered = self._all_gather_host(rows, cap)                            # [world, cap, width]
+        out = np.empty((idx.size, width), np.uint64)
+        for r in range(self.world):
+            pos = np.nonzero(owner == r)[0]
+            out[pos] = gathered[r, :pos.size]
         return out.reshape((idx.size, mt.n_cols) + ((3,) if mt.fk == 3 else ()))

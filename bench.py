@@ -27,8 +27,6 @@ sys.path.insert(0, ROOT)
 
 MASTER_WORDS = 652
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
-VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4   # wave64 VALU instructions per ns: 256 CUs x 4 SIMDs, one instruction per 4 cycles
-#                                        per SIMD at 2.4 GHz (profiles/r01_valu_rates_microbench.txt: 64 lane-ops/clk/CU) = 614.4 G/s
 LDE_ALGORITHMIC_BYTES_PER_CELL = 72   # read 8 B, write 8 * (L/N = 8) B per base-field trace cell (default expansion)
 
 
@@ -58,21 +56,30 @@ def cpu_baseline(log2_rows):
 
 
 def valu_roofline(launch_ms, rows, n_words):
-    """VALU-issue roofline of the row-hashing kernel: wave64 VALU instructions per launch (dynamic count,
-    SQ_INSTS_VALU of the committed PMC run, profiles/valu_counts.json: per extended row and permutation) over the
-    live launch time, against 256 CUs x 4 SIMDs x one instruction per 4 cycles."""
+    """VALU-issue roofline of the row-hashing kernel (k_hash_rows_mfma), the kernel furthest from the HBM roofline by
+    time.  profiles/valu_counts.json (tools/valu_static_count.py) holds the kernel's static wave-level VALU instruction
+    count per row and permutation and the issue cycles those instructions cost on a SIMD according to the measured
+    per-class issue rates (profiles/r02_valu_rates_microbench.txt; nominal: plain 32-bit VOP1/VOP2 ops 2, carry-out /
+    VOP3 ops 4, v_mad_u64_u32 5.2 cycles per wave64 instruction).  peak = the SIMD cycles the chip has in the launch time
+    (256 CUs x 4 SIMDs x 2.4 GHz); achieved = the modelled issue cycles of the kernel's VALU work: frac is the share of
+    all SIMD cycles spent issuing this kernel's VALU instructions."""
     perms = n_words // 10 + 1            # absorb blocks of 10 words incl. the padding block (master_table.rs:667-716)
     try:
         with open(os.path.join(ROOT, "profiles", "valu_counts.json")) as f:
-            per_row_perm = json.load(f)["k_hash_rows_mfma"]["wave_valu_instructions_per_row_permutation"]
+            k = json.load(f)["k_hash_rows_mfma"]
     except (OSError, KeyError, ValueError):
         return None
-    instr = per_row_perm * rows * perms
-    achieved = instr / (launch_ms * 1e-3) / 1e9
+    instr = k["wave_valu_instructions_per_row_permutation"] * rows * perms
+    cycles = k["modelled_valu_issue_cycles_per_row_permutation"] * rows * perms
+    peak = 256 * 4 * 2.4                  # G SIMD-cycles per second
+    achieved = cycles / (launch_ms * 1e-3) / 1e9
     return {"bound": "valu", "kernel": "k_hash_rows_mfma (main-table row hashing)", "achieved": round(achieved, 1),
-            "peak": round(VALU_PEAK_GINSTR, 1), "unit": "G wave-instr/s", "frac": round(achieved / VALU_PEAK_GINSTR, 4),
+            "peak": round(peak, 1), "unit": "G SIMD issue cycles/s", "frac": round(achieved / peak, 4),
             "launch_ms": round(launch_ms, 3), "permutations_per_row": perms,
+            "wave_valu_instructions_per_row": round(k["wave_valu_instructions_per_row_permutation"] * perms, 1),
             "wave_valu_instructions_per_launch": int(instr),
+            "wave_valu_instructions_per_s_G": round(instr / (launch_ms * 1e-3) / 1e9, 1),
+            "lane_ops_per_clk_per_cu": round(instr * 64 / (launch_ms * 1e-3) / (256 * 2.4e9), 1),
             "hbm_frac": round(rows * n_words * 8 / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
 
 

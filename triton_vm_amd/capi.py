@@ -109,6 +109,21 @@ def load_library(path=None):
             f"{path} not found: build it with `python -m triton_vm_amd.build` (needs hipcc, gfx950); "
             "triton_vm_amd has no CPU fallback")
     lib = C.CDLL(path)
+    missing = [name for name in _SIGNATURES if not hasattr(lib, name)]
+    if missing and path == DEFAULT_LIB:
+        # a library from before the header grew: rebuild the PRODUCT library with hipcc (still no fallback: without
+        # the toolchain this raises) and load the fresh file under a new handle
+        from .build import build
+
+        rebuilt = build(force=True)
+        fresh = rebuilt + f".{os.getpid()}.so"
+        import shutil
+
+        shutil.copyfile(rebuilt, fresh)  # dlopen caches by path: the stale image is still mapped under the old name
+        try:
+            lib = C.CDLL(fresh)
+        finally:
+            os.unlink(fresh)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
         fn.restype = res

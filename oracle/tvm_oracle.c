@@ -368,7 +368,9 @@ void orc_hash_10(const uint64_t in[10], uint64_t out[5]) {
     orc_tip5_permutation(st);
     memcpy(out, st, 40);
 }
-/* [twenty-first Tip5::hash_pair, PARITY UNPINNED]: hash_10(left || right) */
+/* [twenty-first Tip5::hash_pair]: hash_10(left || right).  The fixed-length domain (capacity of ones) and the
+ * left/right order are what the pinned AIR's Hash-table and merkle_step constraints enforce on the valid traces of
+ * tests/test_vm_tables.py; the function itself has no in-tree vector. */
 void orc_hash_pair(const uint64_t l[5], const uint64_t r[5], uint64_t out[5]) {
     u64 in[10];
     memcpy(in, l, 40);

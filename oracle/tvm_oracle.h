@@ -9,9 +9,13 @@
  * The arithmetic itself lives in the third-party crate `twenty-first = "2.0.0"`
  * (/root/reference/Cargo.toml:104), which is NOT in the reference tree.  Its published algorithms
  * are restated here from the in-tree specification (specification/src/isa.md:5-8,
- * tips/tip-0005/tip-0005.md) and pinned by the known-answer vectors listed in
- * tests/test_oracle_pins.py.  Items that the tree does not pin (root-of-unity table, hash_pair
- * domain separation, Digest::from(XFE)) are marked PARITY UNPINNED where they are used.
+ * tips/tip-0005/tip-0005.md) and pinned by reference-held values: the TIP-0005 vectors and the Montgomery KAT
+ * (tests/test_oracle_pins.py), the program digests of stark.rs:4828-4838 and program.rs:496-510 (multi-block
+ * overwrite-mode hash_varlen), the AIR fingerprint of master_table.rs:2328-2414 (tests/test_air_fingerprint.py) and
+ * the vanishing of the AIR on valid traces (tests/test_vm_tables.py; this also pins the fixed-length hashing domain
+ * and merkle_step's sibling order through the Hash table's constraints).  Items that the tree does not pin
+ * (root-of-unity table, generator, Merkle node layout, Digest::from(XFE)) are marked PARITY UNPINNED where they
+ * are used.
  *
  * Data representation: a BFieldElement is one uint64_t holding the Montgomery
  * word a*2^64 mod p (triton-constraint-builder/src/codegen.rs:926-944: 42 <-> 180388626390);

@@ -261,6 +261,23 @@ void tvm_host_xfe_mul(const uint64_t a[3], const uint64_t b[3], uint64_t out[3])
 void tvm_host_xfe_inv(const uint64_t a[3], uint64_t out[3]);
 void tvm_host_xfe_powers(const uint64_t x[3], uint64_t first_exponent, uint64_t n, uint64_t* out /* n XFE */);
 
+/* ---- verifier batch work --------------------------------------------------------
+ * Verifier::verify's work over the num_first_round_queries revealed rows (stark.rs:1388-1763), all host data in / out:
+ * the leaf digests of revealed rows (Tip5::hash_varlen of each row, stark.rs:1598-1601, 1620-1660) ... */
+int32_t tvm_verifier_row_digests(tvm_ctx* ctx, const uint64_t* h_rows, uint64_t n_rows, uint64_t row_words,
+                                 uint64_t* h_digests);
+/* ... and, per revealed row, linearly_sum_main_and_aux_row (stark.rs:1765-1787), the quotient-segment sums, the four
+ * Stark::deep_update values (stark.rs:2096-2103) and their weighted sum (stark.rs:1678-1755), which must equal the
+ * value the low-degree test revealed at that index (the comparison stays with the caller).  h_main_rows [n][379],
+ * h_aux_rows [n][91][3], h_quot_rows [n][5][3], h_row_indices [n] (indices into ldt_domain), h_weights_main_aux
+ * [470][3], h_weights_quot [5][3], h_weights_deep [4][3]; h_ood_points / h_ood_values [4][3] in the order current row,
+ * next row, alpha^4, (zeta*alpha)^4 (stark.rs:1722-1745).  h_out: [n][3]. */
+int32_t tvm_verifier_deep_values(tvm_ctx* ctx, const uint64_t* h_main_rows, const uint64_t* h_aux_rows,
+                                 const uint64_t* h_quot_rows, const uint64_t* h_row_indices, uint64_t n_rows,
+                                 tvm_domain ldt_domain, const uint64_t* h_weights_main_aux,
+                                 const uint64_t* h_weights_quot, const uint64_t* h_weights_deep,
+                                 const uint64_t* h_ood_points, const uint64_t* h_ood_values, uint64_t* h_out);
+
 #ifdef __cplusplus
 }
 #endif

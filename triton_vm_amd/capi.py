@@ -91,6 +91,9 @@ _SIGNATURES = {
     "tvm_host_xfe_interpolate": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "tvm_scatter_strided": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
     "tvm_gather_elements": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "tvm_verifier_row_digests": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "tvm_verifier_deep_values": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, Domain,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tvm_host_tip5_permutation": (None, [C.c_void_p]),
     "tvm_host_sponge_pad_and_absorb": (None, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "tvm_host_xfe_mul": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),

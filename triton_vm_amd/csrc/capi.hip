@@ -1,6 +1,8 @@
 // capi.hip -- the extern "C" boundary of libtriton_hip.so (declared in include/triton_hip.h).
 // Argument validation and error mapping live here; kernels live in ntt.hip / hash.hip / poly.hip.
+#include <cstring>
 #include <new>
+#include <vector>
 
 #include "kernels.h"
 
@@ -732,5 +734,65 @@ void tvm_host_xfe_powers(const uint64_t x[3], uint64_t first, uint64_t n, uint64
         out[3 * i] = p.c0; out[3 * i + 1] = p.c1; out[3 * i + 2] = p.c2;
         p = xfe_mul(p, b);
     }
+}
+}  // extern "C"
+
+extern "C" {  // ---------------------------------------------------------------------------------- verifier batch work
+int32_t tvm_verifier_row_digests(tvm_ctx* c, const uint64_t* h_rows, uint64_t n_rows, uint64_t row_words, uint64_t* h_digests) {
+    if (!c || !h_rows || !h_digests || !n_rows || !row_words || row_words > (1u << 20))
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_verifier_row_digests arguments");
+    u64* d_rows = (u64*)pool_alloc(c, (size_t)n_rows * row_words * sizeof(u64));
+    u64* d_digests = (u64*)pool_alloc(c, (size_t)n_rows * 5 * sizeof(u64));
+    int rc = TVM_OK;
+    if (!d_rows || !d_digests) rc = set_error(c, TVM_ERR_OUT_OF_MEMORY, "row digests scratch");
+    if (rc == TVM_OK && hipMemcpyAsync(d_rows, h_rows, (size_t)n_rows * row_words * sizeof(u64), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        rc = set_error(c, TVM_ERR_DEVICE, "row upload");
+    if (rc == TVM_OK) rc = hash_varlen_rows(c, d_rows, n_rows, (int)row_words, d_digests);
+    if (rc == TVM_OK && (hipMemcpyAsync(h_digests, d_digests, (size_t)n_rows * 5 * sizeof(u64), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                         hipStreamSynchronize(c->stream) != hipSuccess))
+        rc = set_error(c, TVM_ERR_DEVICE, "digest download");
+    (void)hipStreamSynchronize(c->stream);  // h_rows may be a caller temporary
+    pool_release(c, d_rows);
+    pool_release(c, d_digests);
+    return rc;
+}
+
+int32_t tvm_verifier_deep_values(tvm_ctx* c, const uint64_t* h_main_rows, const uint64_t* h_aux_rows, const uint64_t* h_quot_rows,
+                                 const uint64_t* h_row_indices, uint64_t n_rows, tvm_domain ldt_domain,
+                                 const uint64_t* h_weights_main_aux, const uint64_t* h_weights_quot, const uint64_t* h_weights_deep,
+                                 const uint64_t* h_ood_points, const uint64_t* h_ood_values, uint64_t* h_out) {
+    if (!c || !h_main_rows || !h_aux_rows || !h_quot_rows || !h_row_indices || !n_rows || !valid_domain(ldt_domain) ||
+        !h_weights_main_aux || !h_weights_quot || !h_weights_deep || !h_ood_points || !h_ood_values || !h_out)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_verifier_deep_values arguments");
+    for (u64 j = 0; j < n_rows; j++)
+        if (h_row_indices[j] >= ldt_domain.length) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "verifier: row index out of range");
+    const size_t wm = (size_t)n_rows * TVM_NUM_MAIN_COLUMNS, wa = (size_t)n_rows * TVM_NUM_AUX_COLUMNS * 3, wq = (size_t)n_rows * 15;
+    const size_t ww = (size_t)3 * (TVM_NUM_MAIN_COLUMNS + TVM_NUM_AUX_COLUMNS), total = wm + wa + wq + n_rows + ww + 51;
+    std::vector<u64> host(total);
+    u64* p = host.data();
+    memcpy(p, h_main_rows, wm * 8); p += wm;
+    memcpy(p, h_aux_rows, wa * 8); p += wa;
+    memcpy(p, h_quot_rows, wq * 8); p += wq;
+    memcpy(p, h_row_indices, n_rows * 8); p += n_rows;
+    memcpy(p, h_weights_main_aux, ww * 8); p += ww;
+    memcpy(p, h_weights_quot, 15 * 8); p += 15;
+    memcpy(p, h_weights_deep, 12 * 8); p += 12;
+    memcpy(p, h_ood_points, 12 * 8); p += 12;
+    memcpy(p, h_ood_values, 12 * 8);
+    u64* d = (u64*)pool_alloc(c, (total + 3 * n_rows) * sizeof(u64));
+    if (!d) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "verifier scratch");
+    int rc = TVM_OK;
+    if (hipMemcpyAsync(d, host.data(), total * sizeof(u64), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess)
+        rc = set_error(c, TVM_ERR_DEVICE, "verifier upload");
+    u64* d_out = d + total;
+    if (rc == TVM_OK)
+        rc = verifier_deep_values(c, d, TVM_NUM_MAIN_COLUMNS, d + wm, TVM_NUM_AUX_COLUMNS, d + wm + wa, d + wm + wa + wq, n_rows,
+                                  ldt_domain.offset, ldt_domain.generator, d + wm + wa + wq + n_rows, d + wm + wa + wq + n_rows + ww, d_out);
+    if (rc == TVM_OK && (hipMemcpyAsync(h_out, d_out, 3 * n_rows * sizeof(u64), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                         hipStreamSynchronize(c->stream) != hipSuccess))
+        rc = set_error(c, TVM_ERR_DEVICE, "verifier download");
+    pool_release(c, d);
+    return rc;
 }
 }  // extern "C"

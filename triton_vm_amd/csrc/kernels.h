@@ -40,6 +40,10 @@ int fill_degree_lowering(tvm_ctx* c, int table, u64* d_main, u64* d_aux, const u
 int pad_main_table(tvm_ctx* c, u64* d_main, u64 n, const u64* lengths);
 // extend.hip
 int extend_aux_table(tvm_ctx* c, const u64* d_main, u64* d_aux, const u64* d_challenges, u64 n);
+// verify.hip
+int hash_varlen_rows(tvm_ctx* c, const u64* d_rows, u64 n, int W, u64* d_digests);
+int verifier_deep_values(tvm_ctx* c, const u64* d_main_rows, int n_main, const u64* d_aux_rows, int n_aux, const u64* d_quot_rows,
+                         const u64* d_row_idx, u64 q, u64 offset, u64 gen, const u64* d_w_ma, const u64* d_small, u64* d_out);
 // air.hip
 int all_quotients_combined(tvm_ctx* c, const u64* main_table, u64 main_rows, u64 wrap_rows, u64 main_w, const u64* aux_table,
                            u64 aux_w, u64 trace_len, u64 trace_gen, u64 q_offset, u64 q_gen, u64 q_len, const u64* d_challenges,

@@ -343,6 +343,7 @@ class Prover:
             qrows = np.empty((ix.size, 15), np.uint64)
             ctx._check(lib.tvm_table_reveal_rows(ctx.handle, qs.table, L, ix.ctypes.data, ix.size, qrows.ctypes.data), "q rows")
             ps.enqueue("quot rows", qrows, fiat_shamir=False)
+            self.opened_at, self.opened_quotient_rows = list(a_indices), qrows
             ps.enqueue("quot auth", self._auth_nodes(quot_nodes, L, a_indices), fiat_shamir=False)
         self.main.clear_cache()
         self.aux.clear_cache()

@@ -157,6 +157,44 @@ int32_t tvm_fill_derived_main_columns(tvm_ctx* ctx, uint64_t* d_main_trace, uint
 int32_t tvm_fill_derived_aux_columns(tvm_ctx* ctx, const uint64_t* d_main_trace, uint64_t* d_aux_trace, uint64_t n_rows,
                                      const uint64_t* h_challenges);
 
+/* ---- main-table fill from the AET (the `fill` half) ----------------------------------
+ * MasterMainTable::new's table fills (master_table.rs:881-931; table/{op_stack,ram,jump_stack,processor,program,hash,
+ * cascade,lookup,u32}.rs `fill`).  The AET is handed over as AlgebraicExecutionTrace holds it (aet.rs:41-96), all HOST
+ * pointers: trace arrays row-major in Montgomery words, multiplicities as plain integers. */
+typedef struct {
+    const uint64_t* program_words;              /* Program::to_bwords(), program_len words */
+    const uint32_t* instruction_multiplicities; /* [program_len] */
+    uint64_t program_len;
+    const uint64_t* processor_trace;            /* [processor_len][39] */
+    uint64_t processor_len;
+    const uint64_t* op_stack_trace;             /* op_stack_underflow_trace [op_stack_len][4] */
+    uint64_t op_stack_len;
+    const uint64_t* ram_trace;                  /* [ram_len][7] (RamTableCall::to_table_row: the last 3 columns are 0) */
+    uint64_t ram_len;
+    /* bezout_coefficient_polynomials_coefficients(unique RAM pointers in ascending order) (ram.rs:152-207): computed on
+     * the host (twenty-first polynomial arithmetic), num_ram_pointers words each */
+    const uint64_t* bezout_coefficients_0;
+    const uint64_t* bezout_coefficients_1;
+    uint64_t num_ram_pointers;
+    const uint64_t* program_hash_trace;         /* [program_hash_len][67] */
+    uint64_t program_hash_len;
+    const uint64_t* sponge_trace;               /* [sponge_len][67] */
+    uint64_t sponge_len;
+    const uint64_t* hash_trace;                 /* [hash_len][67] */
+    uint64_t hash_len;
+    const uint64_t* u32_entries;                /* u32_entries in IndexMap order: [u32_len][4] = opcode (plain integer),
+                                                   left operand, right operand (Montgomery words), multiplicity (plain) */
+    uint64_t u32_len;
+    const uint64_t* cascade_entries;            /* cascade_table_lookup_multiplicities in IndexMap order: [cascade_len][2] =
+                                                   16-bit limb, multiplicity (plain integers) */
+    uint64_t cascade_len;
+    const uint64_t* lookup_multiplicities;      /* [256] plain integers */
+} tvm_aet;
+/* d_main_trace: [379][n_rows] words; columns 0..148 are written (zeros below each table's length), n_rows = the padded
+ * height.  h_table_lengths_out[9]: the tables' lengths in the order of tvm_pad_main_table, which is the next call. */
+int32_t tvm_fill_main_table(tvm_ctx* ctx, const tvm_aet* aet, uint64_t* d_main_trace, uint64_t n_rows,
+                            uint64_t* h_table_lengths_out);
+
 /* ---- main-table pad (the `pad` half) ----------------------------------------------
  * MasterMainTable::pad (master_table.rs:932-983) without its degree-lowering tail (tvm_fill_derived_main_columns): the
  * nine table-specific padding rules (table/program.rs:77-127, processor.rs:70-96, op_stack.rs:205-219, ram.rs:86-101,

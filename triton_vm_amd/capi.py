@@ -26,6 +26,21 @@ class Domain(C.Structure):
         return f"Domain(offset={self.offset}, generator={self.generator}, length={self.length})"
 
 
+class Aet(C.Structure):
+    """tvm_aet (include/triton_hip.h): the algebraic execution trace as plain host arrays"""
+    _fields_ = [("program_words", C.c_void_p), ("instruction_multiplicities", C.c_void_p), ("program_len", C.c_uint64),
+                ("processor_trace", C.c_void_p), ("processor_len", C.c_uint64),
+                ("op_stack_trace", C.c_void_p), ("op_stack_len", C.c_uint64),
+                ("ram_trace", C.c_void_p), ("ram_len", C.c_uint64),
+                ("bezout_coefficients_0", C.c_void_p), ("bezout_coefficients_1", C.c_void_p), ("num_ram_pointers", C.c_uint64),
+                ("program_hash_trace", C.c_void_p), ("program_hash_len", C.c_uint64),
+                ("sponge_trace", C.c_void_p), ("sponge_len", C.c_uint64),
+                ("hash_trace", C.c_void_p), ("hash_len", C.c_uint64),
+                ("u32_entries", C.c_void_p), ("u32_len", C.c_uint64),
+                ("cascade_entries", C.c_void_p), ("cascade_len", C.c_uint64),
+                ("lookup_multiplicities", C.c_void_p)]
+
+
 class TritonHipError(RuntimeError):
     def __init__(self, status, what):
         super().__init__(f"libtriton_hip status {status}: {what}")
@@ -74,6 +89,7 @@ _SIGNATURES = {
     "tvm_evaluate_at_points": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
     "tvm_fill_derived_main_columns": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "tvm_fill_derived_aux_columns": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "tvm_fill_main_table": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "tvm_pad_main_table": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "tvm_extend_aux_table": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "tvm_all_quotients_combined": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, Domain, Domain, C.c_void_p,

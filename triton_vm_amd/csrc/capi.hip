@@ -528,6 +528,16 @@ int32_t tvm_fill_derived_aux_columns(tvm_ctx* c, const uint64_t* d_main_trace, u
     return fill_degree_lowering(c, 1, const_cast<u64*>(d_main_trace), d_aux_trace, staged, n_rows);
 }
 
+int32_t tvm_fill_main_table(tvm_ctx* c, const tvm_aet* aet, uint64_t* d_main_trace, uint64_t n_rows, uint64_t* h_table_lengths_out) {
+    if (!c || !aet || !d_main_trace || !h_table_lengths_out || !is_pow2(n_rows) || n_rows < 2 || !aet->processor_trace ||
+        !aet->lookup_multiplicities || (aet->program_len && (!aet->program_words || !aet->instruction_multiplicities)) ||
+        (aet->op_stack_len && !aet->op_stack_trace) || (aet->ram_len && (!aet->ram_trace || !aet->bezout_coefficients_0 || !aet->bezout_coefficients_1)) ||
+        (aet->program_hash_len && !aet->program_hash_trace) || (aet->sponge_len && !aet->sponge_trace) || (aet->hash_len && !aet->hash_trace) ||
+        (aet->u32_len && !aet->u32_entries) || (aet->cascade_len && !aet->cascade_entries))
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_fill_main_table arguments");
+    return fill_main_table(c, aet, d_main_trace, n_rows, h_table_lengths_out);
+}
+
 int32_t tvm_pad_main_table(tvm_ctx* c, uint64_t* d_main_trace, uint64_t n_rows, const uint64_t* h_table_lengths) {
     if (!c || !d_main_trace || !h_table_lengths || !is_pow2(n_rows) || n_rows < 2)
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_pad_main_table arguments");

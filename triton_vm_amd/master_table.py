@@ -146,3 +146,48 @@ def pad(ctx, d_main_trace, n_rows, table_lengths):
         raise ValueError("pad needs nine table lengths and a 379-column main trace")
     ctx._check(ctx.lib.tvm_pad_main_table(ctx.handle, d_main_trace.ptr, n_rows, lengths.ctypes.data), "tvm_pad_main_table")
     degree_lowering.fill_derived_main_columns(ctx, d_main_trace, n_rows)
+
+
+def fill(ctx, d_main_trace, n_rows, aet):
+    """MasterMainTable::new's table fills (/root/reference/triton-vm/src/table/master_table.rs:881-931) on the device
+    (tvm_fill_main_table).  `aet`: dict of numpy arrays shaped like AlgebraicExecutionTrace's fields (aet.rs:41-96):
+    program_words [p], instruction_multiplicities [p] (uint32), processor_trace [c][39], op_stack_trace [k][4],
+    ram_trace [k][7], bezout_coefficients_0/1 [u], program_hash_trace / sponge_trace / hash_trace [k][67],
+    u32_entries [k][4], cascade_entries [k][2], lookup_multiplicities [256].  Returns the nine table lengths
+    (TABLE_ORDER), the argument of `pad`."""
+    import ctypes as C
+
+    from .capi import Aet
+
+    keep = {}
+
+    def arr(name, dtype=np.uint64, width=None):
+        a = np.ascontiguousarray(aet.get(name, np.zeros(0, dtype)), dtype=dtype)
+        if width is not None:
+            a = a.reshape(-1, width)
+        keep[name] = a
+        return a
+
+    s = Aet()
+    words, mult = arr("program_words"), arr("instruction_multiplicities", np.uint32)
+    if words.size != mult.size:
+        raise ValueError("one multiplicity per program word")
+    s.program_words, s.instruction_multiplicities, s.program_len = words.ctypes.data, mult.ctypes.data, words.size
+    for name, field_, len_, width in (("processor_trace", "processor_trace", "processor_len", 39), ("op_stack_trace", "op_stack_trace", "op_stack_len", 4),
+                                      ("ram_trace", "ram_trace", "ram_len", 7), ("program_hash_trace", "program_hash_trace", "program_hash_len", 67),
+                                      ("sponge_trace", "sponge_trace", "sponge_len", 67), ("hash_trace", "hash_trace", "hash_len", 67),
+                                      ("u32_entries", "u32_entries", "u32_len", 4), ("cascade_entries", "cascade_entries", "cascade_len", 2)):
+        a = arr(name, width=width)
+        setattr(s, field_, a.ctypes.data)
+        setattr(s, len_, a.shape[0])
+    b0, b1 = arr("bezout_coefficients_0"), arr("bezout_coefficients_1")
+    if b0.size != b1.size:
+        raise ValueError("the two Bezout coefficient vectors have the same length")
+    s.bezout_coefficients_0, s.bezout_coefficients_1, s.num_ram_pointers = b0.ctypes.data, b1.ctypes.data, b0.size
+    lk = arr("lookup_multiplicities")
+    if lk.size != 256:
+        raise ValueError("256 lookup multiplicities")
+    s.lookup_multiplicities = lk.ctypes.data
+    lengths = np.zeros(9, np.uint64)
+    ctx._check(ctx.lib.tvm_fill_main_table(ctx.handle, C.byref(s), d_main_trace.ptr, n_rows, lengths.ctypes.data), "tvm_fill_main_table")
+    return [int(v) for v in lengths]

@@ -119,7 +119,10 @@ std::vector<u64> ProofStream::sample_indices(u64 upper_bound, u64 n) {
         u64 w[10];
         squeeze(w);
         for (int k = 0; k < 10; k++)
-            if (out.size() < n && w[k] != P - 1) out.push_back(w[k] % upper_bound);
+            if (out.size() < n) {  // the canonical value, as twenty-first's sample_indices reduces `.value()`
+                const u64 v = mont_mul(w[k], 1);
+                if (v != P - 1) out.push_back(v % upper_bound);
+            }
     }
     return out;
 }
@@ -383,6 +386,15 @@ ProofStream Prover::prove() {
 
     // 17: the low-degree test  (stark.rs:641-663)
     const std::vector<u64> a_indices = fri(combination, ps);
+
+    // 18: the out-of-domain point must not collide with a revealed in-domain point  (stark.rs:645-663)
+    if (a4.c[1] == 0 && a4.c[2] == 0) {
+        const u64 other = mont_mul(a4.c[0], mont_pow(zeta, 4));
+        for (u64 i : a_indices) {
+            const u64 x = p_.ldt.value(i);
+            if (x == a4.c[0] || x == other) throw Error(TVM_ERR_INVALID_ARGUMENT, "ZeroKnowledgeViolation (stark.rs:645-663)");
+        }
+    }
 
     // 19: open the trace leafs  (stark.rs:665-716)
     {

@@ -76,8 +76,9 @@ class ProofStream:
         out = []
         while len(out) < n:
             for w in self._squeeze():
-                if len(out) < n and int(w) != field.P - 1:
-                    out.append(int(w) % upper_bound)
+                v = field.from_mont(int(w))  # the canonical value, as twenty-first's sample_indices reduces `.value()`
+                if len(out) < n and v != field.P - 1:
+                    out.append(v % upper_bound)
         return out
 
 
@@ -96,6 +97,10 @@ def xfe_mul(lib, a, b):
 
 def xfe_add(a, b):
     return np.array([(int(x) + int(y)) % field.P for x, y in zip(a, b)], np.uint64)
+
+
+class ZeroKnowledgeViolation(RuntimeError):
+    """ProvingError::ZeroKnowledgeViolation (error.rs:150-186, stark.rs:645-663)"""
 
 
 class StarkParameters:
@@ -331,6 +336,13 @@ class Prover:
         else:
             with self._timed("FRI"):
                 a_indices = self._fri(combination, ps)
+
+        # 18: the out-of-domain point must not collide with a revealed in-domain point  (stark.rs:645-663)
+        if not a4[1] and not a4[2]:
+            zeta4 = field.mont_pow(stark.ZETA, 4)
+            revealed = {p.ldt.value(int(i)) for i in a_indices}
+            if int(a4[0]) in revealed or field.mont_mul(int(a4[0]), zeta4) in revealed:
+                raise ZeroKnowledgeViolation("the out-of-domain point conflicts with a revealed in-domain row")
 
         # 19: open the trace leafs  (stark.rs:665-716)
         with self._timed("open trace leafs"):

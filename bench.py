@@ -299,6 +299,18 @@ def main():
             "stage_wall_ms": {k: round(v, 3) for k, v in prover.wall.items()},
             "profiled_prove_wall_ms": round(t_prof, 3),
         }
+        if world == 1 and not args.jit_passes:
+            # TVM_OPTION_AIR_VALID_TRACE: what a host that feeds real (valid) execution traces would switch on.  The
+            # quotient codeword is then bit-identical to the row-by-row evaluation only on VALID traces; this bench's
+            # tables are synthetic, so `value` above is measured with the option OFF (identical to the reference on any
+            # input) and the option's timing -- the work does not depend on the table contents -- is reported beside it.
+            ctx.assume_valid_trace(True)
+            t = timed_steps(step, 3, 1, ctx.sync)
+            ctx.assume_valid_trace(False)
+            out["valid_trace_mode"] = {"option": "TVM_OPTION_AIR_VALID_TRACE", "ms_per_step": round(1e3 * t / 3, 3),
+                                       "value": round(cells_per_step * 3 / t, 1), "unit": "trace-cells/s",
+                                       "note": "consistency/transition constraints on half of the quotient domain + interpolation; "
+                                               "exact on valid traces only, hence not the headline"}
         if world == 1 and args.ldt == "fri" and not args.jit_passes and not args.no_default_ldt and args.log2_rows >= 16:
             # Stark::default() selects STIR from 2^16 padded rows on (stark.rs:1944-1951); BASELINE.json's configs name
             # FRI, which is what `value` is quoted on.  The reference-default variant is measured beside it.

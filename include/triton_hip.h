@@ -61,6 +61,13 @@ int32_t tvm_sync(tvm_ctx* ctx);
 int32_t tvm_malloc(tvm_ctx* ctx, size_t bytes, void** d_ptr);
 int32_t tvm_free(tvm_ctx* ctx, void* d_ptr);
 int32_t tvm_ctx_trim(tvm_ctx* ctx);
+/* Options.  TVM_OPTION_AIR_VALID_TRACE (default 0): the caller guarantees that the master tables come from a valid
+ * execution trace -- what Prover::prove is for.  tvm_all_quotients_combined may then use that the constraint quotients
+ * are polynomials of known degree: the consistency / transition constraints are evaluated on half of the quotient
+ * domain and the codeword completed by interpolation; bit-identical to the row-by-row evaluation on a valid trace,
+ * different on an invalid one (where both yield a proof the verifier rejects). */
+#define TVM_OPTION_AIR_VALID_TRACE 1
+int32_t tvm_ctx_set_option(tvm_ctx* ctx, int32_t option, uint64_t value);
 /* Cap on the bytes this context may hold through tvm_malloc / table handles (0 = no cap).  Requests beyond it fail
  * with TVM_ERR_OUT_OF_MEMORY exactly like a full device: the knob a host uses to share a GPU, and what the tests use to
  * walk the reference's out-of-memory fallback (master_table.rs:268-271 -> the coset-wise path). */

@@ -126,3 +126,53 @@ def test_sampled_quotient_rows_small(ctx, orc, log_n, log_ldt_expansion):
     """The sampled-row checker of tests/test_gpu_fullsize.py (python-integer zerofiers and weighted sums over the
     oracle's constraint values) at a size where every row is sampled, incl. the stride-4 view."""
     check_sampled_quotient_rows(ctx, orc, log_n, log_ldt_expansion, 3, synthetic=False, n_random=64)
+
+
+def _quotient(ctx, orc, main_trace, aux_trace, h, seed, ch=None, valid_mode=False):
+    rng = np.random.default_rng(seed)
+    n = main_trace.shape[1]
+    g = field.generator()
+    trace_dom = ArithmeticDomain.of_length(n)
+    quot = ArithmeticDomain.of_length(8 * n).with_offset(g)
+    main = MasterTable(ctx, main_trace, orc.random_elements(rng, (379, h)), trace_dom, quot, quot, 1)
+    aux = MasterTable(ctx, aux_trace, orc.random_elements(rng, (91, h, 3)), trace_dom, quot, quot, 3)
+    main.maybe_low_degree_extend_all_columns()
+    aux.maybe_low_degree_extend_all_columns()
+    challenges = orc.random_elements(rng, (63, 3)) if ch is None else ch
+    weights = orc.random_elements(rng, (604, 3))
+    ctx.assume_valid_trace(valid_mode)
+    try:
+        got = stark.all_quotients_combined(ctx, main, aux, trace_dom, quot, challenges, weights).download((len(quot), 3))
+    finally:
+        ctx.assume_valid_trace(False)
+    want = orc.quotients_combined(main.low_degree_extended_table(), aux.low_degree_extended_table(), odom(orc, trace_dom),
+                                  odom(orc, quot), challenges, weights)
+    return got, want, quot
+
+
+def test_valid_trace_mode_is_exact_on_a_valid_trace(ctx, orc):
+    """TVM_OPTION_AIR_VALID_TRACE: consistency / transition constraints on half of the quotient domain + interpolation.
+    On the valid 256-row trace of a real execution (tests/vm_fixture.py) the quotient codeword equals the oracle's
+    row-by-row evaluation bit for bit -- and it is a polynomial of degree < 4 (N + h)."""
+    from tests import vm_fixture as vf
+
+    main_trace, aux_trace, ch, _ = vf.valid_tables("tiny")
+    h = 5
+    got, want, quot = _quotient(ctx, orc, main_trace, aux_trace, h, 3, ch=ch, valid_mode=True)
+    assert (got == want).all()
+    coeffs = quot.interpolate(ctx, ctx.to_device(got), 3).download((len(quot), 3))
+    assert not coeffs[4 * (256 + h):].any() and coeffs[:4 * 256].any()
+
+
+def test_valid_trace_mode_changes_only_interpolated_rows_of_an_invalid_trace(ctx, orc):
+    """On random tables the constraint quotients are rational functions: the default (row-by-row) mode reproduces the
+    reference's values, the valid-trace mode agrees with it exactly on the rows it evaluates (the even ones) and
+    nowhere else -- which is why it is an opt-in whose precondition is a valid trace."""
+    rng = np.random.default_rng(9)
+    n, h = 16, 3
+    main_trace, aux_trace = orc.random_elements(rng, (379, n)), orc.random_elements(rng, (91, n, 3))
+    exact, want, _ = _quotient(ctx, orc, main_trace, aux_trace, h, 4)
+    assert (exact == want).all()
+    fast, _, _ = _quotient(ctx, orc, main_trace, aux_trace, h, 4, valid_mode=True)
+    assert (fast[0::2] == want[0::2]).all()
+    assert (fast[1::2] != want[1::2]).any(axis=1).all()

@@ -57,6 +57,7 @@ _SIGNATURES = {
     "tvm_malloc": (C.c_int32, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "tvm_free": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "tvm_ctx_trim": (C.c_int32, [C.c_void_p]),
+    "tvm_ctx_set_option": (C.c_int32, [C.c_void_p, C.c_int32, C.c_uint64]),
     "tvm_ctx_set_memory_limit": (C.c_int32, [C.c_void_p, C.c_size_t]),
     "tvm_ctx_memory_held": (C.c_int32, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "tvm_memcpy_h2d": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -216,6 +217,11 @@ class Context:
         n = C.c_size_t()
         self._check(self.lib.tvm_ctx_memory_held(self.handle, C.byref(n)), "tvm_ctx_memory_held")
         return n.value
+
+    def assume_valid_trace(self, on=True):
+        """TVM_OPTION_AIR_VALID_TRACE: the tables come from a valid execution -- the quotient evaluation may use the
+        degree bounds of the constraint quotients (half the rows + interpolation; identical on valid traces)"""
+        self._check(self.lib.tvm_ctx_set_option(self.handle, 1, 1 if on else 0), "tvm_ctx_set_option")
 
     def trim(self):
         """give the cached device blocks back to the driver"""

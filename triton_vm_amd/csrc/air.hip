@@ -74,7 +74,9 @@ __global__ void __launch_bounds__(256) k_zerofier_inverses(ZerofierArgs a) {
 
 int all_quotients_combined(tvm_ctx* c, const u64* main_table, u64 main_rows, u64 wrap_rows, u64 main_w, const u64* aux_table,
                            u64 aux_w, u64 trace_len, u64 trace_gen, u64 q_offset, u64 q_gen, u64 q_len,
-                           const u64* d_challenges, const u64* d_weights, u64* d_out) {
+                           const u64* d_challenges, const u64* d_weights, u64* d_out, int part_select, int accumulate) {
+    // part_select: 0 = every part, 1 = the parts with consistency / transition constraints only ("low degree"),
+    // 2 = the others (initial / terminal constraints); accumulate: the first launched part adds to d_out as well
     if (!is_pow2(q_len) || !is_pow2(trace_len) || q_len < trace_len || main_rows % q_len)
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "quotients: domain lengths");
     // the next row of quotient-domain row i is table row (i + q_len/trace_len) * (main_rows/q_len): the tables must
@@ -109,7 +111,13 @@ int all_quotients_combined(tvm_ctx* c, const u64* main_table, u64 main_rows, u64
     a.zinv = zinv;
     a.out = d_out;
     const dim3 grid((unsigned)((q_len + AIR_BLOCK - 1) / AIR_BLOCK));
-    for (int p = 0; p < TVM_AIR_NUM_PARTS; p++) TVM_LAUNCH(TVM_AIR_PARTS[p], grid, dim3(AIR_BLOCK), 0, c->stream, a);
+    a.accumulate = accumulate;
+    for (int p = 0; p < TVM_AIR_NUM_PARTS; p++) {
+        if (part_select == 1 && !TVM_AIR_PART_LOW_DEGREE[p]) continue;
+        if (part_select == 2 && TVM_AIR_PART_LOW_DEGREE[p]) continue;
+        TVM_LAUNCH(TVM_AIR_PARTS[p], grid, dim3(AIR_BLOCK), 0, c->stream, a);
+        a.accumulate = 1;
+    }
     TVM_HIP_CHECK(c, hipGetLastError());
     return TVM_OK;
 }

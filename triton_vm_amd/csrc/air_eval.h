@@ -43,6 +43,7 @@ struct AirArgs {
     const u64* weights;      // 604 XFE
     const u64* zinv;         // [4][q_len] zerofier inverses (k_zerofier_inverses)
     u64* out;                // q_len XFE
+    int accumulate;          // 0: this part stores its share of the quotient, 1: it adds to what is there
 };
 
 // The accumulator of  sum_k w_k * c_k  for one group of constraints.

@@ -92,6 +92,14 @@ int32_t tvm_ctx_memory_held(const tvm_ctx* c, size_t* bytes) {
     *bytes = c->pool_bytes;
     return TVM_OK;
 }
+int32_t tvm_ctx_set_option(tvm_ctx* c, int32_t option, uint64_t value) {
+    if (!c) return TVM_ERR_INVALID_ARGUMENT;
+    if (option == TVM_OPTION_AIR_VALID_TRACE) {
+        c->air_valid_trace = value != 0;
+        return TVM_OK;
+    }
+    return set_error(c, TVM_ERR_INVALID_ARGUMENT, "unknown option");
+}
 int32_t tvm_ctx_trim(tvm_ctx* c) {
     if (!c) return TVM_ERR_INVALID_ARGUMENT;
     pool_trim(c);
@@ -273,6 +281,7 @@ int32_t tvm_lde_table(tvm_ctx* c, int32_t fk, const uint64_t* d_trace, uint64_t 
     t->n_cols = n_cols;
     t->fk = fk;
     t->W = (int)(n_cols * fk);
+    t->interpolant_len = n_rows + h;  // randomized_column_interpolant: degree < n_rows + h (master_table.rs:392-403)
     t->data = (u64*)pool_alloc(c, t->bytes());
     if (!t->data) {
         delete t;
@@ -569,8 +578,38 @@ int32_t tvm_all_quotients_combined(tvm_ctx* c, const tvm_table* mt, const tvm_ta
     TVM_HIP_CHECK(c, hipMemcpyAsync(staged + 3 * TVM_NUM_CHALLENGES, h_weights, 3 * TVM_NUM_QUOTIENT_WEIGHTS * sizeof(u64),
                                     hipMemcpyHostToDevice, c->stream));
     TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    return all_quotients_combined(c, mt->data, mt->rows, mt->wrap_rows, (u64)mt->W, at->data, (u64)at->W, td.length, td.generator,
-                                  qd.offset, qd.generator, qd.length, staged, staged + 3 * TVM_NUM_CHALLENGES, d_out);
+    const u64* d_ch = staged;
+    const u64* d_w = staged + 3 * TVM_NUM_CHALLENGES;
+    // Valid-trace mode (tvm_ctx_set_option TVM_OPTION_AIR_VALID_TRACE; off by default).  Every column is a polynomial with at most m = interpolant_len coefficients, every constraint has degree
+    // <= 4 in the columns (the AIR is degree-lowered to 4), so a constraint polynomial has degree <= 4(m - 1).  The
+    // consistency and transition quotients divide by X^N - 1 (the transition one times X - w^-1): fewer than
+    // 4(m - 1) + 2 - N coefficients -- about 3N + 4h, when the quotient domain has 8N points.  If that fits HALF the
+    // quotient domain, those constraints (87 % of the work) are evaluated on its even points only, interpolated there and
+    // evaluated on all points.  On a VALID trace -- the constraints vanish on the trace domain, so the quotients ARE
+    // polynomials -- these are exactly the field elements the row-by-row evaluation yields, at half the cost; on an
+    // invalid trace the row-by-row values are those of a rational function and differ (either way the unmodified
+    // verifier rejects: it recomputes the quotient at the out-of-domain point).  The initial / terminal quotients
+    // (zerofier of degree 1, up to 4(m - 1) coefficients) are evaluated on every point.
+    const u64 m = mt->interpolant_len > at->interpolant_len ? mt->interpolant_len : at->interpolant_len;
+    const u64 half = qd.length / 2;
+    const bool split = c->air_valid_trace && mt->interpolant_len && at->interpolant_len && half >= 2 * td.length && half % td.length == 0 &&
+                       4 * (m - 1) + 2 <= half + td.length && mt->rows % half == 0;
+    if (!split)
+        return all_quotients_combined(c, mt->data, mt->rows, mt->wrap_rows, (u64)mt->W, at->data, (u64)at->W, td.length, td.generator,
+                                      qd.offset, qd.generator, qd.length, d_ch, d_w, d_out);
+    u64* low = (u64*)pool_alloc(c, (size_t)2 * 3 * half * sizeof(u64));
+    if (!low) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "quotient scratch");
+    u64* coeffs = low + 3 * half;
+    const tvm_domain half_dom = {qd.offset, bfe_mul(qd.generator, qd.generator), half};
+    int rc = all_quotients_combined(c, mt->data, mt->rows, mt->wrap_rows, (u64)mt->W, at->data, (u64)at->W, td.length, td.generator,
+                                    half_dom.offset, half_dom.generator, half, d_ch, d_w, low, 1, 0);
+    if (rc == TVM_OK) rc = tvm_interpolate(c, 3, low, half_dom, coeffs);
+    if (rc == TVM_OK) rc = tvm_evaluate(c, 3, coeffs, half, qd, d_out);
+    if (rc == TVM_OK)
+        rc = all_quotients_combined(c, mt->data, mt->rows, mt->wrap_rows, (u64)mt->W, at->data, (u64)at->W, td.length, td.generator,
+                                    qd.offset, qd.generator, qd.length, d_ch, d_w, d_out, 2, 1);
+    pool_release(c, low);
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------- STIR

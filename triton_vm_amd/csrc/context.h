@@ -38,6 +38,7 @@ struct tvm_ctx {
     std::map<void*, size_t> pool_live;                  // block -> capacity
     size_t pool_bytes = 0;                              // bytes held from the driver (live + cached)
     size_t pool_limit = 0;                              // tvm_ctx_set_memory_limit: 0 = whatever the device has
+    bool air_valid_trace = false;                       // TVM_OPTION_AIR_VALID_TRACE (capi.hip: tvm_all_quotients_combined)
     std::string last_error;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };

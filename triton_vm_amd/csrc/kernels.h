@@ -49,7 +49,7 @@ int verifier_deep_values(tvm_ctx* c, const u64* d_main_rows, int n_main, const u
 // air.hip
 int all_quotients_combined(tvm_ctx* c, const u64* main_table, u64 main_rows, u64 wrap_rows, u64 main_w, const u64* aux_table,
                            u64 aux_w, u64 trace_len, u64 trace_gen, u64 q_offset, u64 q_gen, u64 q_len, const u64* d_challenges,
-                           const u64* d_weights, u64* d_out);
+                           const u64* d_weights, u64* d_out, int part_select = 0, int accumulate = 0);
 }  // namespace tvm
 
 struct tvm_table {
@@ -60,5 +60,7 @@ struct tvm_table {
     u64 n_cols = 0;       // in elements of the table's field
     int fk = 1;
     int W = 0;            // base-field words per row = n_cols * fk
+    u64 interpolant_len = 0;  // tables made by tvm_lde_table: every column is a polynomial with at most this many
+                              // coefficients (trace length + trace randomizers); 0 = unknown
     size_t bytes() const { return (size_t)tvm_tab_words(rows + wrap_rows, (u64)W) * sizeof(u64); }
 };

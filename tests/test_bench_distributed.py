@@ -84,3 +84,22 @@ def test_bench_script_runs_under_torchrun_with_two_ranks(mode):
     assert rec["n_gpus"] == 2 and rec["steps"] == 1 and rec["value"] > 0
     assert rec["scaling"] == ("strong" if mode == "sharded" else "weak")
     assert {"roofline", "stage_ms", "config"} <= set(rec)
+
+
+def test_bench_script_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher (the driver's N > 1 form may be either): the script starts the two
+    ranks itself through torch.distributed.run and rank 0 prints the one JSON line."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, TVM_BENCH_TEST_EMU="1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--log2-rows", "3",
+           "--trace-randomizers", "3", "--queries", "2", "--no-cpu-baseline", "--replicas"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak"

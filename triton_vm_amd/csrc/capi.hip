@@ -784,6 +784,56 @@ void tvm_host_xfe_powers(const uint64_t x[3], uint64_t first, uint64_t n, uint64
         p = xfe_mul(p, b);
     }
 }
+
+/* StdRng of rand [not vendored in the reference tree; restated, pinned by the proof-digest snapshots through
+ * tests/test_proof_snapshot.py]: ChaCha with 12 rounds, 64-bit block counter, the blocks' 16 words as a u32 stream, next_u64 =
+ * two consecutive words (low first); `rng.random::<BFieldElement>()` = random_range(0..=MAX): widening multiply by p, one more
+ * draw when the low half leaves room for a carry (UniformInt::sample_single_inclusive). */
+namespace {
+struct StdRng {
+    uint32_t key[8];
+    uint64_t counter = 0;
+    uint32_t buf[16];
+    int idx = 16;
+    static uint32_t rotl(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+    void refill() {
+        uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+        for (int i = 0; i < 8; i++) s[4 + i] = key[i];
+        s[12] = (uint32_t)counter; s[13] = (uint32_t)(counter >> 32); s[14] = 0; s[15] = 0;
+        uint32_t x[16];
+        for (int i = 0; i < 16; i++) x[i] = s[i];
+#define TVM_QR(a, b, c, d) \
+    x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16); x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12); \
+    x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8);  x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7);
+        for (int r = 0; r < 6; r++) {
+            TVM_QR(0, 4, 8, 12) TVM_QR(1, 5, 9, 13) TVM_QR(2, 6, 10, 14) TVM_QR(3, 7, 11, 15)
+            TVM_QR(0, 5, 10, 15) TVM_QR(1, 6, 11, 12) TVM_QR(2, 7, 8, 13) TVM_QR(3, 4, 9, 14)
+        }
+#undef TVM_QR
+        for (int i = 0; i < 16; i++) buf[i] = x[i] + s[i];
+        counter++;
+        idx = 0;
+    }
+    uint32_t next_u32() { if (idx >= 16) refill(); return buf[idx++]; }
+    uint64_t next_u64() { const uint64_t lo = next_u32(); return lo | ((uint64_t)next_u32() << 32); }
+    uint64_t random_bfe() {
+        unsigned __int128 prod = (unsigned __int128)next_u64() * TVM_P;
+        uint64_t result = (uint64_t)(prod >> 64);
+        const uint64_t lo = (uint64_t)prod;
+        if (lo > (uint64_t)(0 - TVM_P)) {
+            const uint64_t new_hi = (uint64_t)(((unsigned __int128)next_u64() * TVM_P) >> 64);
+            if (lo + new_hi < lo) result++;
+        }
+        return result;
+    }
+};
+}  // namespace
+void tvm_host_stdrng_elements(const uint8_t seed[32], uint64_t n, uint64_t* out) {
+    StdRng rng;
+    for (int i = 0; i < 8; i++)
+        rng.key[i] = (uint32_t)seed[4 * i] | ((uint32_t)seed[4 * i + 1] << 8) | ((uint32_t)seed[4 * i + 2] << 16) | ((uint32_t)seed[4 * i + 3] << 24);
+    for (uint64_t i = 0; i < n; i++) out[i] = bfe_from_u64(rng.random_bfe());
+}
 }  // extern "C"
 
 extern "C" {  // ---------------------------------------------------------------------------------- verifier batch work

@@ -24,6 +24,16 @@ class MasterTable:
         self.d_randomizers = ctx.to_device(randomizers)
         self._table = None
 
+    @classmethod
+    def from_device(cls, ctx, d_trace, d_randomizers, n_cols, n_rows, num_trace_randomizers, trace_domain, quotient_domain,
+                    ldt_domain, field_kind=1, into=None):
+        """a table whose trace [n_cols][n_rows](, [3]) and randomizers [n_cols][h](, [3]) are already in HBM"""
+        mt = into if into is not None else cls.__new__(cls)
+        mt.ctx, mt.fk, mt.n_cols, mt.n_rows, mt.num_trace_randomizers = ctx, field_kind, n_cols, n_rows, num_trace_randomizers
+        mt.trace_domain, mt.quotient_domain, mt.ldt_domain, mt._table = trace_domain, quotient_domain, ldt_domain, None
+        mt.d_trace, mt.d_randomizers = d_trace, d_randomizers
+        return mt
+
     # master_table.rs:215-222
     def evaluation_domain(self):
         return self.quotient_domain if self.quotient_domain.length > self.ldt_domain.length else self.ldt_domain

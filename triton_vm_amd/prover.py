@@ -2,84 +2,44 @@
 step for step, over the C ABI.  Everything bulky stays in HBM; the host only sees Merkle roots,
 out-of-domain rows, the last FRI codeword and the opened rows.
 
-The Fiat-Shamir transcript here (``ProofStream``) is a *stand-in*: the real one (BFieldCodec encoding,
-sample_scalars / sample_indices of twenty-first) stays in the Rust host and is not re-implemented.  It
-has the same data dependencies (every challenge depends on every earlier commitment), which is what
-the pipeline's timing needs; it does not produce reference-compatible proofs.
+The Fiat-Shamir transcript is the reference's (triton_vm_amd/proof_stream.py: ProofItem encoding, Claim, sampling), the
+prover's randomness is the reference's when a 32-byte seed is given (triton_vm_amd/randomness.py): `Prover.from_execution`
+on the reference's own snapshot program yields the reference's proof, word for word (tests/test_proof_snapshot.py).
 """
 import ctypes as C
 import time
 
 import numpy as np
 
-from . import field, stark
+from . import field, master_table, randomness, stark
 from .arithmetic_domain import ArithmeticDomain
 from .master_table import MasterTable
+from .proof_stream import Claim, ProofStream  # noqa: F401  (re-exported: the tests and the other provers import it from here)
 
 NUM_MAIN, NUM_AUX = 379, 91
-NUM_CHALLENGES, NUM_CONSTRAINTS = 63, 604
+NUM_CHALLENGES, NUM_SAMPLED_CHALLENGES, NUM_CONSTRAINTS = 63, 59, 604
 NUM_DEEP = 4
+# challenges.rs:31-83: the indeterminates the four derived challenges are evaluated at
+CH_COMPRESS_PROGRAM_DIGEST, CH_STANDARD_INPUT, CH_STANDARD_OUTPUT, CH_LOOKUP_TABLE_PUBLIC = 0, 1, 2, 54
+TIP5_LOOKUP_TABLE = [(pow(x + 1, 3, 257) - 1) % 257 for x in range(256)]   # [Tip5: L(x) = (x + 1)^3 - 1 mod 257]
 
 
-class ProofStream:
-    """Tip5 sponge in overwrite mode (stand-in transcript, see module docstring)."""
+def derive_challenges(lib, sampled, claim):
+    """Challenges::new (challenges.rs:85-121): the 59 sampled challenges, then the terminals of the public input, the
+    public output, the lookup table and the program digest -- EvalArg::compute_terminal(symbols, 1, indeterminate)."""
+    sampled = np.ascontiguousarray(sampled, dtype=np.uint64).reshape(NUM_SAMPLED_CHALLENGES, 3)
 
-    def __init__(self, lib):
-        self.lib = lib
-        self.state = np.zeros(16, np.uint64)
-        self.items = []
-        self.log = []      # (name, payload, fiat_shamir) in order: what a verifier dequeues
+    def terminal(symbols, x):
+        acc = np.array([field.ONE, 0, 0], np.uint64)
+        for s in symbols:
+            acc = xfe_mul(lib, acc, x)
+            acc[0] = (int(acc[0]) + int(s)) % field.P
+        return acc
 
-    def _permute(self):
-        self.lib.tvm_host_tip5_permutation(self.state.ctypes.data)
-
-    def enqueue(self, name, words, fiat_shamir=True):
-        """ProofStream::enqueue (proof_stream.rs:36-43): the item always goes into the proof; it alters the
-        sponge only if ProofItem::include_in_fiat_shamir_heuristic says so (proof_item.rs:96-134: roots,
-        out-of-domain rows, polynomials do; authentication structures, opened rows, FRI codeword and
-        responses do not -- the prover is already committed to them through a Merkle root)."""
-        w = np.ascontiguousarray(words, dtype=np.uint64).reshape(-1)
-        self.items.append((name, w.size))
-        self.log.append((name, np.array(words, dtype=np.uint64), fiat_shamir))
-        if fiat_shamir:
-            self.lib.tvm_host_sponge_pad_and_absorb(self.state.ctypes.data, w.ctypes.data, w.size)
-
-    def verifier_view(self):
-        """a fresh transcript over the same items, for a verifier: dequeue() hands out the next item and absorbs it
-        when the prover did (ProofStream::dequeue, proof_stream.rs:56-70)"""
-        v = ProofStream(self.lib)
-        pending = list(self.log)
-
-        def dequeue(expected_prefix=None):
-            name, payload, fiat_shamir = pending.pop(0)
-            if expected_prefix is not None and not name.startswith(expected_prefix):
-                raise ValueError(f"unexpected proof item {name!r}, wanted {expected_prefix!r}")
-            if fiat_shamir:
-                w = np.ascontiguousarray(payload, dtype=np.uint64).reshape(-1)
-                v.lib.tvm_host_sponge_pad_and_absorb(v.state.ctypes.data, w.ctypes.data, w.size)
-            return payload
-
-        v.dequeue = dequeue
-        v.pending = pending
-        return v
-
-    def _squeeze(self):
-        out = self.state[:10].copy()
-        self._permute()
-        return out
-
-    def sample_scalars(self, n):
-        words = np.concatenate([self._squeeze() for _ in range((3 * n + 9) // 10)])
-        return words[:3 * n].reshape(n, 3) % np.uint64(field.P)
-
-    def sample_indices(self, upper_bound, n):
-        out = []
-        while len(out) < n:
-            for w in self._squeeze():
-                v = field.from_mont(int(w))  # the canonical value, as twenty-first's sample_indices reduces `.value()`
-                if len(out) < n and v != field.P - 1:
-                    out.append(v % upper_bound)
-        return out
+    lut = [field.to_mont(v) for v in TIP5_LOOKUP_TABLE]
+    derived = [terminal(claim.input, sampled[CH_STANDARD_INPUT]), terminal(claim.output, sampled[CH_STANDARD_OUTPUT]),
+               terminal(lut, sampled[CH_LOOKUP_TABLE_PUBLIC]), terminal(claim.program_digest, sampled[CH_COMPRESS_PROGRAM_DIGEST])]
+    return np.concatenate([sampled, np.array(derived, np.uint64)])
 
 
 def xfe_powers(lib, x, first, n):
@@ -143,9 +103,10 @@ class StarkParameters:
 
 
 class Prover:
-    """Runs the prover's hot path on synthetic (or caller-provided) padded trace tables."""
+    """Runs the prover's hot path on synthetic or caller-provided padded trace tables, or -- `from_execution` -- the
+    whole of Prover::prove from an algebraic execution trace."""
 
-    def __init__(self, ctx, params, main_trace=None, aux_trace=None, seed=1):
+    def __init__(self, ctx, params, main_trace=None, aux_trace=None, seed=1, claim=None):
         self.ctx, self.p = ctx, params
         n, h = params.trace.length, params.h
         rng = np.random.default_rng(seed)
@@ -160,14 +121,52 @@ class Prover:
             self.main = MasterTable(ctx, main_trace, rnd(NUM_MAIN, h), *dom, 1)
             self.aux = MasterTable(ctx, aux_trace, rnd(NUM_AUX, h, 3), *dom, 3)
         self.quotient_randomizer = rng.integers(0, field.P, size=(params.num_quotient_randomizers, 3), dtype=np.uint64)
+        self.claim = claim or Claim()
+        self.randomness_seed = None
         self.timings, self.wall, self.opened = {}, {}, {}
         self.capture = None
 
+    @classmethod
+    def from_execution(cls, ctx, aet, padded_height, claim, randomness_seed, log2_expansion=2, ldt="fri"):
+        """Prover::prove from the start (stark.rs:331-400): the master main table is filled from the algebraic
+        execution trace and padded on the device (MasterMainTable::new + pad, master_table.rs:881-983), all randomness
+        comes from `randomness_seed` (32 bytes) the way the reference draws it, and the auxiliary table is extended on
+        the device once the challenges are sampled (MasterMainTable::extend, master_table.rs:1006-1075).
+        aet: the arrays master_table.fill takes; padded_height: AlgebraicExecutionTrace::padded_height (aet.rs:141-146)."""
+        self = cls.__new__(cls)
+        log2 = padded_height.bit_length() - 1
+        if padded_height != 1 << log2:
+            raise ValueError("the padded height is a power of two")
+        p = StarkParameters(log2, log2_expansion=log2_expansion, ldt=ldt)
+        self.ctx, self.p, self.claim, self.randomness_seed = ctx, p, claim, bytes(randomness_seed)
+        n, h, lib = p.trace.length, p.h, ctx.lib
+        d_main = ctx.alloc(NUM_MAIN * n)
+        lengths = master_table.fill(ctx, d_main, n, aet)
+        if max(lengths) > padded_height:
+            raise ValueError("a table is longer than the padded height")
+        master_table.pad(ctx, d_main, n, lengths)
+        rnd = randomness.trace_randomizers(lib, self.randomness_seed, NUM_MAIN, h, 1)
+        self.main = MasterTable.from_device(ctx, d_main, ctx.to_device(rnd), NUM_MAIN, n, h, p.trace, p.quotient, p.ldt, 1)
+        self.aux = None     # `extend` needs the challenges
+        self.quotient_randomizer = randomness.quotient_randomizer(lib, self.randomness_seed, p.num_quotient_randomizers)
+        self.timings, self.wall, self.opened = {}, {}, {}
+        self.capture = None
+        return self
+
+    def _extend(self, challenges):
+        """MasterMainTable::extend (master_table.rs:1006-1075) -> the auxiliary MasterTable"""
+        ctx, p, lib = self.ctx, self.p, self.ctx.lib
+        n, h = p.trace.length, p.h
+        d_aux = ctx.alloc(NUM_AUX * n * 3)
+        column = randomness.batch_randomizer_column(lib, self.randomness_seed, n)
+        ctx._check(lib.tvm_memcpy_h2d(ctx.handle, d_aux.ptr + 8 * (NUM_AUX - 1) * n * 3, column.ctypes.data, column.size * 8), "h2d")
+        master_table.extend(ctx, self.main.d_trace, d_aux, n, challenges)
+        rnd = randomness.trace_randomizers(lib, randomness.aux_seed(self.randomness_seed), NUM_AUX, h, 3)
+        return MasterTable.from_device(ctx, d_aux, ctx.to_device(rnd), NUM_AUX, n, h, p.trace, p.quotient, p.ldt, 3)
+
     def _init_synthetic(self, mt, fk, n_cols, n, h, dom, seed):
-        mt.ctx, mt.fk, mt.n_cols, mt.n_rows, mt.num_trace_randomizers = self.ctx, fk, n_cols, n, h
-        mt.trace_domain, mt.quotient_domain, mt.ldt_domain, mt._table = dom[0], dom[1], dom[2], None
-        mt.d_trace = self.ctx.synthetic(n_cols * n * fk, seed)
-        mt.d_randomizers = self.ctx.synthetic(n_cols * h * fk, seed + 1)
+        MasterTable.from_device(self.ctx, self.ctx.synthetic(n_cols * n * fk, seed), self.ctx.synthetic(n_cols * h * fk, seed + 1),
+                                n_cols, n, h, *dom, fk, into=mt)
 
     def _timed(self, name):
         prover = self
@@ -237,10 +236,12 @@ class Prover:
         return a_indices
 
     def prove(self, profile=False):
-        """One pass of the hot path.  Returns the (stand-in) proof stream."""
+        """One pass of the hot path.  Returns the proof stream (`.proof()` is the reference's Proof)."""
         self.profile = profile
         ctx, lib, p = self.ctx, self.ctx.lib, self.p
         ps = self.transcript = ProofStream(lib)
+        ps.alter_fiat_shamir_state_with(self.claim.encode())                                       # stark.rs:336-339
+        ps.enqueue("log2 padded height", [field.to_mont(p.padded_height.bit_length() - 1)])        # stark.rs:354
         L = p.ldt.length
         short = p.ldt if p.ldt.length <= p.quotient.length else p.quotient
 
@@ -250,9 +251,13 @@ class Prover:
         with self._timed("main Merkle"):
             main_nodes = self._commit_master_table(self.main)
         ps.enqueue("main root", self._root(main_nodes))
-        challenges = ps.sample_scalars(NUM_CHALLENGES)
+        challenges = derive_challenges(lib, ps.sample_scalars(NUM_SAMPLED_CHALLENGES), self.claim)
 
-        # 8-9: aux table (its `extend` is host work in the reference; the trace is already resident)
+        # 8-9: aux table (`extend` runs on the device when the prover started from an execution trace; otherwise the
+        # caller's auxiliary trace is already resident)
+        if self.aux is None:
+            with self._timed("extend"):
+                self.aux = self._extend(challenges)
         with self._timed("aux LDE"):
             self._extend_master_table(self.aux)
         with self._timed("aux Merkle"):

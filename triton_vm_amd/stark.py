@@ -112,15 +112,24 @@ def merkle_tree_from_codeword(ctx, d_codeword, length):
     return nodes
 
 
-def auth_nodes(ctx, d_nodes, n_leaves, indices):
-    """the sibling nodes on the paths of the opened leaves of a device node array (what twenty-first's
-    authentication_structure needs from the tree), gathered to the host"""
+def auth_node_indices(n_leaves, indices):
+    """[twenty-first MerkleTree::authentication_structure, restated] the nodes a verifier cannot compute from the
+    revealed leaves -- the siblings along the paths that are not themselves on a path -- in descending heap order"""
     k = np.unique(np.asarray(indices, dtype=np.uint64) + np.uint64(n_leaves))
-    need = []
+    needed, computable = [], []
     while k.size and k[0] > 1:
-        need.append(k ^ np.uint64(1))
+        computable.append(k)
+        needed.append(k ^ np.uint64(1))
         k = np.unique(k >> np.uint64(1))
-    idx = np.unique(np.concatenate(need)) if need else np.zeros(0, np.uint64)
+    if not needed:
+        return np.zeros(0, np.uint64)
+    idx = np.setdiff1d(np.concatenate(needed), np.concatenate(computable))
+    return np.ascontiguousarray(idx[::-1])
+
+
+def auth_nodes(ctx, d_nodes, n_leaves, indices):
+    """MerkleTree::authentication_structure for the opened leaves of a device node array, gathered to the host"""
+    idx = auth_node_indices(n_leaves, indices)
     out = np.empty((idx.size, 5), np.uint64)
     if idx.size:
         ctx._check(ctx.lib.tvm_gather_elements(ctx.handle, d_nodes.ptr, 5, idx.ctypes.data, idx.size, out.ctypes.data),
@@ -154,6 +163,7 @@ def fri_prove(ctx, ldt_domain, num_rounds, num_collinearity_checks, d_codeword, 
         dom = dom.pow(2)
     last = cw.download((dom.length, 3))
     ps.enqueue("fri last codeword", last, fiat_shamir=False)
+    # the interpolant over the last domain with its offset set to one (fri.rs:292-300)
     last_poly = ArithmeticDomain.of_length(dom.length).interpolate(ctx, cw, 3).download((dom.length, 3))
     ps.enqueue("fri last polynomial", last_poly)
     a_indices = ps.sample_indices(ldt_domain.length, num_collinearity_checks)

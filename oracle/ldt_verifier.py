@@ -1,8 +1,8 @@
 """TEST INFRASTRUCTURE ONLY -- CPU restatements of the verifier halves of the two low-degree tests
 (/root/reference/triton-vm/src/low_degree_test/fri.rs:368-700 and stir.rs:995-1340), so that the device provers can be
 tested the way the reference tests its own: prove, then verify; honest codewords are accepted, high-degree ones and
-corrupted transcripts are rejected.  They read the stand-in transcript of triton_vm_amd/prover.py (ProofStream
-.verifier_view()); authentication structures are the sibling-node sets of triton_vm_amd/stark.py::auth_nodes.
+corrupted transcripts are rejected.  They read the proof stream of triton_vm_amd/proof_stream.py (ProofStream
+.verifier_view()); authentication structures are twenty-first's (MerkleTree::authentication_structure).
 Pure Python over the C oracle's arithmetic: small cases only.  The product never imports this file.
 """
 import numpy as np
@@ -16,13 +16,17 @@ class VerificationError(Exception):
 
 
 def _sibling_index_rule(n_leaves, leaf_indices):
-    """the node indices triton_vm_amd.stark.auth_nodes sends, in its order"""
+    """[twenty-first MerkleTree::authentication_structure] the node indices of an authentication structure, in its
+    order: the siblings along the paths that are not themselves on a path, descending"""
     k = np.unique(np.asarray(leaf_indices, dtype=np.uint64) + np.uint64(n_leaves))
-    need = []
+    needed, computable = [], []
     while k.size and k[0] > 1:
-        need.append(k ^ np.uint64(1))
+        computable.append(k)
+        needed.append(k ^ np.uint64(1))
         k = np.unique(k >> np.uint64(1))
-    return np.unique(np.concatenate(need)) if need else np.zeros(0, np.uint64)
+    if not needed:
+        return np.zeros(0, np.uint64)
+    return np.setdiff1d(np.concatenate(needed), np.concatenate(computable))[::-1]
 
 
 def verify_inclusion(root, n_leaves, leaf_indices, leaf_digests, auth_nodes):
@@ -52,11 +56,6 @@ def verify_inclusion(root, n_leaves, leaf_indices, leaf_digests, auth_nodes):
         level = sorted(parents)
     if not (known.get(1) == np.asarray(root, np.uint64)).all():
         raise VerificationError("BadMerkleAuthenticationPath")
-    # the stand-in structure also carries siblings that are computable from other opened leaves (twenty-first's
-    # authentication_structure omits them); they must agree with what was computed
-    for j, d in provided.items():
-        if j in known and not (known[j] == d).all():
-            raise VerificationError("BadMerkleAuthenticationPath: redundant node disagrees")
 
 
 def colinear_y(p0, p1, x):

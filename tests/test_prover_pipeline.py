@@ -5,7 +5,15 @@ import numpy as np
 import pytest
 
 from triton_vm_amd import field
-from triton_vm_amd.prover import Prover, StarkParameters
+from triton_vm_amd.prover import Prover, StarkParameters, derive_challenges
+
+
+def start_of_verification(prover):
+    """Verifier::verify's first steps (stark.rs:1388-1420): the claim goes into the sponge, the padded height is read"""
+    view = prover.transcript.verifier_view()
+    view.alter_fiat_shamir_state_with(prover.claim.encode())
+    assert field.from_mont(int(view.dequeue("log2 padded height")[0])) == prover.p.padded_height.bit_length() - 1
+    return view
 
 
 def odom(orc, d):
@@ -73,9 +81,9 @@ def test_hot_path_matches_oracle_recomputation(ctx, orc):
     # opened rows against the three table roots
     from oracle import ldt_verifier as lv
 
-    view = prover.transcript.verifier_view()
+    view = start_of_verification(prover)
     assert (view.dequeue("main root") == c["main_root"]).all()
-    assert (view.sample_scalars(63) == c["challenges"]).all()
+    assert (derive_challenges(prover.ctx.lib, view.sample_scalars(59), prover.claim) == c["challenges"]).all()
     view.dequeue("aux root")
     view.sample_scalars(1)
     view.dequeue("quot root")
@@ -127,9 +135,9 @@ def test_log_blowup_4_quotient_domain_is_the_short_domain(ctx, orc):
     # low degree after folding, verifier replay
     bound = p.randomized_trace_len >> p.fri_rounds
     assert (prover.last_polynomial[bound:] == 0).all() and prover.last_polynomial[:bound].any()
-    view = prover.transcript.verifier_view()
+    view = start_of_verification(prover)
     roots = {"main": view.dequeue("main root")}
-    view.sample_scalars(63)
+    view.sample_scalars(59)
     roots["aux"] = view.dequeue("aux root")
     view.sample_scalars(1)
     roots["quot"] = view.dequeue("quot root")
@@ -163,9 +171,9 @@ def test_full_size_pipeline_low_degree_invariant(orc):
     assert prover.last_codeword.shape[0] == p.ldt.length >> p.fri_rounds
     assert (prover.last_polynomial[bound:] == 0).all() and prover.last_polynomial[:bound].any()
 
-    view = prover.transcript.verifier_view()
+    view = start_of_verification(prover)
     roots = {"main": view.dequeue("main root")}
-    view.sample_scalars(63)
+    view.sample_scalars(59)
     roots["aux"] = view.dequeue("aux root")
     view.sample_scalars(1)
     roots["quot"] = view.dequeue("quot root")

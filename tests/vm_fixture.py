@@ -18,6 +18,18 @@ def hash_pair(left, right):
     return [int(v) for v in orc.from_mont(orc.hash_pair(orc.to_mont(left), orc.to_mont(right)))]
 
 
+def non_determinism(which):
+    """-> (secret input, secret digests, initial RAM) of the program's NonDeterminism"""
+    if which == "tiny":
+        return [], [], None
+    node_5, node_4, node_3 = [5] * 5, [4] * 5, [3] * 5                                  # stark.rs:4770-4786
+    node_2 = hash_pair(node_4, node_5)
+    node_1 = hash_pair(node_2, node_3)
+    ram = {i: 42 + i for i in range(1000)}
+    ram.update({100_000 + i: v for i, v in enumerate(node_3)})
+    return list(reversed(node_1)) + [1337] * 10, [node_4], ram
+
+
 def run(which):
     """-> (program, aet, public input, public output)"""
     if which == "tiny":
@@ -27,13 +39,9 @@ def run(which):
         return program, aet, public_input, output
     with open(os.path.join(GOLDEN, "program_every_instruction.tasm")) as f:
         program = isa.parse(f.read())
-    node_5, node_4, node_3 = [5] * 5, [4] * 5, [3] * 5                                  # stark.rs:4770-4786
-    node_2 = hash_pair(node_4, node_5)
-    node_1 = hash_pair(node_2, node_3)
-    ram = {i: 42 + i for i in range(1000)}
-    ram.update({100_000 + i: v for i, v in enumerate(node_3)})
-    aet, output = vm.trace_execution(program, node_5, list(reversed(node_1)) + [1337] * 10, [node_4], ram)
-    return program, aet, node_5, output
+    public_input = [5] * 5                                                              # node_5, stark.rs:4770
+    aet, output = vm.trace_execution(program, public_input, *non_determinism(which))
+    return program, aet, public_input, output
 
 
 @functools.lru_cache(maxsize=None)

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <iterator>
 
 namespace triton_vm {
 
@@ -90,12 +91,109 @@ DeviceBuffer ArithmeticDomain::interpolate(const Context& c, const u64* d_values
 }
 
 // ------------------------------------------------------------------------------------------------ ProofStream
-void ProofStream::enqueue(const std::string& name, const u64* words, u64 n, bool fiat_shamir) {
-    // the item always goes into the proof; it alters the sponge only if include_in_fiat_shamir_heuristic says so
-    // (proof_item.rs:96-134: roots, out-of-domain rows, polynomials do; authentication structures, opened rows, the FRI
-    // codeword and responses do not -- the prover is already committed to them through a Merkle root)
-    items_.push_back(Item{name, std::vector<u64>(words, words + n), fiat_shamir});
-    if (fiat_shamir) tvm_host_sponge_pad_and_absorb(state_, words, n);
+// BFieldCodec of twenty-first 2.0.0 [not in the reference tree; restated, pinned by the reference's proof-digest snapshot
+// through tests/test_proof_snapshot.py]: statically-sized types are their elements in order; Vec<T> of a statically-sized T
+// is [number of elements, elements...], of a dynamically-sized T [number of elements, (length_i, element_i)...]; a derived
+// struct is its fields LAST FIELD FIRST, each dynamically-sized one prefixed with its length; a derived enum is
+// [discriminant, fields as for a struct]; a Polynomial drops its trailing zero coefficients.
+namespace {
+enum Kind { STATIC = 0, POLYNOMIAL = -1, RESPONSE = -2 };  // > 0: Vec of that many words per element
+struct Variant {
+    const char* name;
+    int kind;
+    bool fiat_shamir;
+};
+// proof_item.rs:96-150 in declaration order (= discriminant)
+const Variant VARIANTS[] = {
+    {"MerkleRoot", STATIC, true}, {"Log2PaddedHeight", STATIC, true}, {"OutOfDomainMainRow", STATIC, true},
+    {"OutOfDomainAuxRow", STATIC, true}, {"OutOfDomainQuotientSegments", STATIC, true}, {"Polynomial", POLYNOMIAL, true},
+    {"StirOutOfDomainValues", 3, true}, {"AuthenticationStructure", 5, false}, {"MasterMainTableRows", 379, false},
+    {"MasterAuxTableRows", 273, false}, {"QuotientSegmentsElements", 15, false}, {"FriCodeword", 3, false},
+    {"FriResponse", RESPONSE, false}, {"StirResponse", RESPONSE, false}};
+// the labels this prover enqueues under -> proof item
+const struct { const char* prefix; int variant; } LABELS[] = {
+    {"log2 padded height", 1}, {"ood main", 2}, {"ood aux", 3}, {"ood quot", 4}, {"fri last codeword", 11},
+    {"fri last polynomial", 5}, {"fri response", 12}, {"fri auth", 12}, {"main rows", 8}, {"aux rows", 9}, {"quot rows", 10},
+    {"main auth", 7}, {"aux auth", 7}, {"quot auth", 7}, {"main root", 0}, {"aux root", 0}, {"quot root", 0}, {"fri root", 0}};
+int variant_of(const std::string& label) {
+    for (const auto& l : LABELS)
+        if (label.compare(0, std::strlen(l.prefix), l.prefix) == 0) return l.variant;
+    throw Error(TVM_ERR_INVALID_ARGUMENT, "no proof item for the label " + label);
+}
+typedef std::vector<u64> Words;
+void push_len(Words& v, u64 n) { v.push_back(to_mont(n)); }
+void append(Words& v, const Words& w) { v.insert(v.end(), w.begin(), w.end()); }
+void append_dynamic(Words& v, const Words& w) { push_len(v, w.size()); append(v, w); }
+Words encode_vec(const u64* w, u64 n_words, u64 elem_words) {
+    Words out;
+    push_len(out, n_words / elem_words);
+    out.insert(out.end(), w, w + n_words);
+    return out;
+}
+Words encode_polynomial(const u64* w, u64 n_words) {
+    u64 n = n_words / 3;
+    while (n && !(w[3 * n - 3] | w[3 * n - 2] | w[3 * n - 1])) n--;
+    Words out;
+    append_dynamic(out, encode_vec(w, 3 * n, 3));  // struct { coefficients: Vec<XFieldElement> }
+    return out;
+}
+Words encode_item(int variant, const Words& payload, const Words* auth_structure) {
+    const Variant& v = VARIANTS[variant];
+    Words out;
+    push_len(out, (u64)variant);
+    if (v.kind == STATIC) {
+        append(out, payload);
+    } else if (v.kind > 0) {
+        append_dynamic(out, encode_vec(payload.data(), payload.size(), (u64)v.kind));
+    } else if (v.kind == POLYNOMIAL) {
+        append_dynamic(out, encode_polynomial(payload.data(), payload.size()));
+    } else {  // FriResponse { queried_leaves: Vec<XFieldElement>, auth_structure: Vec<Digest> } (fri.rs:101-108)
+        Words response;
+        append_dynamic(response, encode_vec(auth_structure->data(), auth_structure->size(), 5));
+        append_dynamic(response, encode_vec(payload.data(), payload.size(), 3));
+        append_dynamic(out, response);
+    }
+    return out;
+}
+}  // namespace
+
+Words Claim::encode() const {  // proof.rs:62-84: program_digest, version, input, output
+    Words out;
+    append_dynamic(out, encode_vec(output.data(), output.size(), 1));
+    append_dynamic(out, encode_vec(input.data(), input.size(), 1));
+    push_len(out, version);
+    out.insert(out.end(), program_digest, program_digest + 5);
+    return out;
+}
+
+void ProofStream::alter_fiat_shamir_state_with(const Words& encoding) {  // proof_stream.rs:40-42
+    tvm_host_sponge_pad_and_absorb(state_, encoding.data(), encoding.size());
+}
+void ProofStream::enqueue(const std::string& name, const u64* words, u64 n) {
+    // proof_stream.rs:54-59: the item always goes into the proof; it alters the sponge only if
+    // ProofItem::include_in_fiat_shamir_heuristic says so (proof_item.rs:96-150: roots, out-of-domain rows, polynomials do;
+    // authentication structures, opened rows, the FRI codeword and responses do not -- the prover is already committed to
+    // them through a Merkle root)
+    const int variant = variant_of(name);
+    const bool fiat_shamir = VARIANTS[variant].fiat_shamir;
+    items_.push_back(Item{name, Words(words, words + n), fiat_shamir});
+    if (fiat_shamir) alter_fiat_shamir_state_with(encode_item(variant, items_.back().words, nullptr));
+}
+Words ProofStream::proof() const {  // impl From<&ProofStream> for Proof, proof_stream.rs:115-119
+    Words items;
+    u64 count = 0;
+    for (size_t k = 0; k < items_.size(); k++, count++) {
+        const int variant = variant_of(items_[k].name);
+        const bool response = VARIANTS[variant].kind == RESPONSE;  // its leaves and its authentication structure: one item
+        append_dynamic(items, encode_item(variant, items_[k].words, response ? &items_[k + 1].words : nullptr));
+        if (response) k++;
+    }
+    Words vec;
+    push_len(vec, count);
+    append(vec, items);
+    Words out;
+    append_dynamic(out, vec);  // struct ProofStream { items: Vec<ProofItem>, .. }
+    return out;
 }
 void ProofStream::squeeze(u64 out[10]) {
     std::memcpy(out, state_, 10 * sizeof(u64));
@@ -110,19 +208,18 @@ std::vector<Xfe> ProofStream::sample_scalars(u64 n) {
     }
     std::vector<Xfe> out(n);
     for (u64 i = 0; i < n; i++)
-        for (int k = 0; k < 3; k++) out[i].c[k] = words[3 * i + k] % P;
+        for (int k = 0; k < 3; k++) out[i].c[k] = words[3 * i + k];
     return out;
 }
 std::vector<u64> ProofStream::sample_indices(u64 upper_bound, u64 n) {
-    std::vector<u64> out;
+    std::vector<u64> out;  // [twenty-first Tip5::sample_indices] squeezed elements in order, P - 1 skipped
     while (out.size() < n) {
         u64 w[10];
         squeeze(w);
-        for (int k = 0; k < 10; k++)
-            if (out.size() < n) {  // the canonical value, as twenty-first's sample_indices reduces `.value()`
-                const u64 v = mont_mul(w[k], 1);
-                if (v != P - 1) out.push_back(v % upper_bound);
-            }
+        for (int k = 0; k < 10 && out.size() < n; k++) {
+            const u64 v = mont_mul(w[k], 1);  // the canonical value
+            if (v != P - 1) out.push_back(v % upper_bound);
+        }
     }
     return out;
 }
@@ -192,12 +289,12 @@ StarkParameters::StarkParameters(unsigned log2_padded_height, u64 num_trace_rand
 }
 
 // ------------------------------------------------------------------------------------------------ helpers of prove
-static const u64 NUM_MAIN = TVM_NUM_MAIN_COLUMNS, NUM_AUX = TVM_NUM_AUX_COLUMNS;
+static const u64 NUM_MAIN = TVM_NUM_MAIN_COLUMNS, NUM_AUX = TVM_NUM_AUX_COLUMNS, NUM_SAMPLED_CHALLENGES = TVM_NUM_CHALLENGES - 4;
 
 static std::vector<u64> merkle_root(const Context& c, const DeviceBuffer& nodes) { return nodes.download(5, 5); }  // node 1; drains the stream
 
-// the sibling nodes on the paths of the opened leaves of a device node array (what twenty-first's
-// authentication_structure needs from the tree), gathered to the host
+// [twenty-first MerkleTree::authentication_structure, restated] the nodes a verifier cannot compute from the revealed
+// leaves -- the siblings along the paths that are not themselves on a path -- in descending heap order, gathered to the host
 static std::vector<u64> auth_nodes(const Context& c, const DeviceBuffer& nodes, u64 n_leaves, const std::vector<u64>& indices) {
     auto uniq = [](std::vector<u64> v) {
         std::sort(v.begin(), v.end());
@@ -207,21 +304,46 @@ static std::vector<u64> auth_nodes(const Context& c, const DeviceBuffer& nodes, 
     std::vector<u64> k;
     for (u64 i : indices) k.push_back(i + n_leaves);
     k = uniq(k);
-    std::vector<u64> need;
+    std::vector<u64> needed, computable;
     while (!k.empty() && k[0] > 1) {
-        for (u64 x : k) need.push_back(x ^ 1);
+        for (u64 x : k) computable.push_back(x), needed.push_back(x ^ 1);
         for (u64& x : k) x >>= 1;
         k = uniq(k);
     }
-    need = uniq(need);
+    needed = uniq(needed);
+    computable = uniq(computable);
+    std::vector<u64> need;
+    std::set_difference(needed.begin(), needed.end(), computable.begin(), computable.end(), std::back_inserter(need));
+    std::reverse(need.begin(), need.end());
     std::vector<u64> out(need.size() * 5);
     if (!need.empty()) c.check(tvm_gather_elements(c.raw(), nodes.ptr(), 5, need.data(), need.size(), out.data()), "tvm_gather_elements");
     return out;
 }
 
+// Challenges::new (challenges.rs:85-121): the 59 sampled challenges, then the terminals of the public input, the public
+// output, the lookup table and the program digest -- EvalArg::compute_terminal(symbols, 1, indeterminate)
+static std::vector<Xfe> derive_challenges(std::vector<Xfe> ch, const Claim& claim) {
+    auto terminal = [](const u64* symbols, u64 n, const Xfe& x) {
+        Xfe acc{{to_mont(1), 0, 0}};
+        for (u64 i = 0; i < n; i++) {
+            acc = xfe_mul(acc, x);
+            acc.c[0] = bfe_add(acc.c[0], symbols[i]);
+        }
+        return acc;
+    };
+    u64 lut[256];  // [Tip5] L(x) = (x + 1)^3 - 1 mod 257
+    for (u64 x = 0; x < 256; x++) lut[x] = to_mont(((x + 1) * (x + 1) % 257 * (x + 1) % 257 + 256) % 257);
+    const Xfe input = terminal(claim.input.data(), claim.input.size(), ch[1]);      // StandardInputIndeterminate
+    const Xfe output = terminal(claim.output.data(), claim.output.size(), ch[2]);   // StandardOutputIndeterminate
+    const Xfe lookup = terminal(lut, 256, ch[54]);                                  // LookupTablePublicIndeterminate
+    const Xfe digest = terminal(claim.program_digest, 5, ch[0]);                    // CompressProgramDigestIndeterminate
+    ch.insert(ch.end(), {input, output, lookup, digest});
+    return ch;
+}
+
 Prover::Prover(const Context& c, const StarkParameters& p, const u64* d_main_trace, const u64* d_main_randomizers,
-               const u64* d_aux_trace, const u64* d_aux_randomizers, const std::vector<Xfe>& quotient_randomizer)
-    : c_(c), p_(p), main_(c, 1, d_main_trace, p.trace.length, NUM_MAIN, d_main_randomizers, p.h, p.trace, p.quotient, p.ldt),
+               const u64* d_aux_trace, const u64* d_aux_randomizers, const std::vector<Xfe>& quotient_randomizer, const Claim& claim)
+    : c_(c), p_(p), claim_(claim), main_(c, 1, d_main_trace, p.trace.length, NUM_MAIN, d_main_randomizers, p.h, p.trace, p.quotient, p.ldt),
       aux_(c, 3, d_aux_trace, p.trace.length, NUM_AUX, d_aux_randomizers, p.h, p.trace, p.quotient, p.ldt),
       quotient_randomizer_(quotient_randomizer) {
     if (quotient_randomizer.size() != p.num_quotient_randomizers) throw Error(TVM_ERR_INVALID_ARGUMENT, "quotient randomizer length");
@@ -255,7 +377,7 @@ std::vector<u64> Prover::fri(const DeviceBuffer& combination, ProofStream& ps) {
     }
     std::vector<u64> last(dom.length * 3);
     c_.check(tvm_memcpy_d2h(c_.raw(), last.data(), cw, last.size() * sizeof(u64)), "last codeword");
-    ps.enqueue("fri last codeword", last.data(), last.size(), false);
+    ps.enqueue("fri last codeword", last.data(), last.size());
     const DeviceBuffer last_poly_d = ArithmeticDomain::of_length(dom.length).interpolate(c_, cw, 3);
     const std::vector<u64> last_poly = last_poly_d.download(0, dom.length * 3);
     ps.enqueue("fri last polynomial", last_poly.data(), last_poly.size());
@@ -271,9 +393,9 @@ std::vector<u64> Prover::fri(const DeviceBuffer& combination, ProofStream& ps) {
             const std::vector<u64>& ix = which == 0 ? a_indices : b_idx;
             std::vector<u64> leaves(ix.size() * 3);
             c_.check(tvm_gather_elements(c_.raw(), round.cw, 3, ix.data(), ix.size(), leaves.data()), "fri leaves");
-            ps.enqueue("fri response " + std::to_string(r), leaves.data(), leaves.size(), false);
+            ps.enqueue("fri response " + std::to_string(r), leaves.data(), leaves.size());
             const std::vector<u64> auth = auth_nodes(c_, round.nodes, round.dom.length, ix);
-            ps.enqueue("fri auth " + std::to_string(r), auth.data(), auth.size(), false);
+            ps.enqueue("fri auth " + std::to_string(r), auth.data(), auth.size());
         }
     }
     (void)ps.sample_scalars(1);
@@ -282,6 +404,11 @@ std::vector<u64> Prover::fri(const DeviceBuffer& combination, ProofStream& ps) {
 
 ProofStream Prover::prove() {
     ProofStream ps;
+    ps.alter_fiat_shamir_state_with(claim_.encode());  // stark.rs:336-339
+    {
+        const u64 log2_padded_height = to_mont(bit_length(p_.padded_height) - 1);  // stark.rs:354
+        ps.enqueue("log2 padded height", &log2_padded_height, 1);
+    }
     const u64 L = p_.ldt.length;
     const ArithmeticDomain short_dom = p_.ldt.length <= p_.quotient.length ? p_.ldt : p_.quotient;
     const u64 zeta = to_mont(3);  // Stark::ZETA, stark.rs:1801
@@ -291,7 +418,7 @@ ProofStream Prover::prove() {
     main_.maybe_low_degree_extend_all_columns();
     const DeviceBuffer main_nodes = main_.merkle_tree();
     ps.enqueue("main root", merkle_root(c_, main_nodes).data(), 5);
-    const std::vector<Xfe> challenges = ps.sample_scalars(TVM_NUM_CHALLENGES);
+    const std::vector<Xfe> challenges = derive_challenges(ps.sample_scalars(NUM_SAMPLED_CHALLENGES), claim_);
 
     // 8-9: aux table (its `extend` is host work in the reference; the trace is already resident)
     aux_.maybe_low_degree_extend_all_columns();
@@ -399,20 +526,20 @@ ProofStream Prover::prove() {
     // 19: open the trace leafs  (stark.rs:665-716)
     {
         const std::vector<u64> rows = main_.reveal_rows(a_indices), auth = auth_nodes(c_, main_nodes, L, a_indices);
-        ps.enqueue("main rows", rows.data(), rows.size(), false);
-        ps.enqueue("main auth", auth.data(), auth.size(), false);
+        ps.enqueue("main rows", rows.data(), rows.size());
+        ps.enqueue("main auth", auth.data(), auth.size());
     }
     {
         const std::vector<u64> rows = aux_.reveal_rows(a_indices), auth = auth_nodes(c_, aux_nodes, L, a_indices);
-        ps.enqueue("aux rows", rows.data(), rows.size(), false);
-        ps.enqueue("aux auth", auth.data(), auth.size(), false);
+        ps.enqueue("aux rows", rows.data(), rows.size());
+        ps.enqueue("aux auth", auth.data(), auth.size());
     }
     {
         std::vector<u64> qrows(a_indices.size() * 15);
         c_.check(tvm_table_reveal_rows(c_.raw(), seg_table, L, a_indices.data(), a_indices.size(), qrows.data()), "quotient rows");
         const std::vector<u64> auth = auth_nodes(c_, quot_nodes, L, a_indices);
-        ps.enqueue("quot rows", qrows.data(), qrows.size(), false);
-        ps.enqueue("quot auth", auth.data(), auth.size(), false);
+        ps.enqueue("quot rows", qrows.data(), qrows.size());
+        ps.enqueue("quot auth", auth.data(), auth.size());
     }
     main_.clear_cache();
     aux_.clear_cache();
@@ -426,29 +553,23 @@ extern "C" int32_t tvmh_prove(tvm_ctx* ctx, uint32_t log2_padded_height, uint64_
                               uint64_t num_collinearity_checks, uint32_t log2_expansion, const uint64_t* d_main_trace,
                               const uint64_t* d_main_randomizers, const uint64_t* d_aux_trace,
                               const uint64_t* d_aux_randomizers, const uint64_t* h_quotient_randomizer,
-                              uint64_t* h_transcript, uint64_t capacity, uint64_t* transcript_words, char* error,
-                              uint64_t error_capacity) {
+                              const uint64_t* h_program_digest, const uint64_t* h_public_input, uint64_t n_public_input,
+                              const uint64_t* h_public_output, uint64_t n_public_output, uint64_t* h_proof, uint64_t capacity,
+                              uint64_t* proof_words, char* error, uint64_t error_capacity) {
     using namespace triton_vm;
     try {
         const Context c(ctx);
         const StarkParameters p(log2_padded_height, num_trace_randomizers, num_collinearity_checks, log2_expansion);
         std::vector<Xfe> qr(p.num_quotient_randomizers);
         std::memcpy(qr.data(), h_quotient_randomizer, qr.size() * sizeof(Xfe));
-        Prover prover(c, p, d_main_trace, d_main_randomizers, d_aux_trace, d_aux_randomizers, qr);
-        const ProofStream ps = prover.prove();
-        u64 need = 1;
-        for (const auto& it : ps.items()) need += 2 + it.words.size();
-        if (transcript_words) *transcript_words = need;
-        if (h_transcript && capacity >= need) {
-            u64* o = h_transcript;
-            *o++ = ps.items().size();
-            for (const auto& it : ps.items()) {
-                *o++ = it.words.size();
-                *o++ = it.fiat_shamir ? 1 : 0;
-                std::memcpy(o, it.words.data(), it.words.size() * sizeof(u64));
-                o += it.words.size();
-            }
-        }
+        Claim claim;
+        if (h_program_digest) std::memcpy(claim.program_digest, h_program_digest, sizeof(claim.program_digest));
+        if (n_public_input) claim.input.assign(h_public_input, h_public_input + n_public_input);
+        if (n_public_output) claim.output.assign(h_public_output, h_public_output + n_public_output);
+        Prover prover(c, p, d_main_trace, d_main_randomizers, d_aux_trace, d_aux_randomizers, qr, claim);
+        const std::vector<u64> proof = prover.prove().proof();
+        if (proof_words) *proof_words = proof.size();
+        if (h_proof && capacity >= proof.size()) std::memcpy(h_proof, proof.data(), proof.size() * sizeof(u64));
         return TVM_OK;
     } catch (const Error& e) {
         if (error && error_capacity) std::snprintf(error, error_capacity, "%s", e.what());

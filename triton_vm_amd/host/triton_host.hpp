@@ -4,8 +4,9 @@
 //
 //   ArithmeticDomain   /root/reference/triton-vm/src/arithmetic_domain.rs:34-92, 227-229, 280-296
 //   MasterTable        /root/reference/triton-vm/src/table/master_table.rs:190-610 (the methods on the hot path)
-//   ProofStream        /root/reference/triton-vm/src/proof_stream.rs:36-70 (a STAND-IN transcript: same data
-//                      dependencies and Fiat-Shamir inclusion rules, proof_item.rs:96-134; not the reference's encoding)
+//   ProofStream, Claim /root/reference/triton-vm/src/proof_stream.rs:8-119, proof_item.rs:96-150, proof.rs:62-84: the
+//                      reference's transcript -- BFieldCodec encoding of the items, Fiat-Shamir sampling -- so that
+//                      `ProofStream::proof()` is the reference's Proof for the same tables, randomizers and claim
 //   Stark / Prover     /root/reference/triton-vm/src/stark.rs:263-286 (domains), 331-719 (prove), fri.rs:212-366
 //
 // Everything bulky stays in HBM behind the C ABI; this file only sequences calls and keeps the transcript.
@@ -80,7 +81,16 @@ struct ArithmeticDomain {
     DeviceBuffer interpolate(const Context& c, const u64* d_values, int field_kind) const;             // :182-189
 };
 
-// Stand-in Fiat-Shamir transcript: a Tip5 sponge in overwrite mode over the items the prover sends.
+// proof.rs:62-84 (Montgomery words)
+struct Claim {
+    u64 program_digest[5] = {0, 0, 0, 0, 0};
+    uint32_t version = 6;  // proof.rs:33 CURRENT_VERSION
+    std::vector<u64> input, output;
+    std::vector<u64> encode() const;
+};
+
+// proof_stream.rs:8-104.  Items are enqueued under a label that names the ProofItem variant (see LABELS in the .cpp);
+// a FRI response is enqueued as its two parts, leaves then authentication structure.
 class ProofStream {
 public:
     struct Item {
@@ -88,14 +98,16 @@ public:
         std::vector<u64> words;
         bool fiat_shamir;
     };
-    void enqueue(const std::string& name, const u64* words, u64 n, bool fiat_shamir = true);  // proof_stream.rs:36-43
+    void alter_fiat_shamir_state_with(const std::vector<u64>& encoding);   // proof_stream.rs:40-42
+    void enqueue(const std::string& name, const u64* words, u64 n);         // proof_stream.rs:54-59
     std::vector<Xfe> sample_scalars(u64 n);
     std::vector<u64> sample_indices(u64 upper_bound, u64 n);
     const std::vector<Item>& items() const { return items_; }
+    std::vector<u64> proof() const;                                         // proof_stream.rs:115-119: Proof(encode())
 
 private:
     void squeeze(u64 out[10]);
-    u64 state_[16] = {0};
+    u64 state_[16] = {0};  // Tip5::init(): the variable-length domain
     std::vector<Item> items_;
 };
 
@@ -139,7 +151,8 @@ struct StarkParameters {
 class Prover {
 public:
     Prover(const Context& c, const StarkParameters& p, const u64* d_main_trace, const u64* d_main_randomizers,
-           const u64* d_aux_trace, const u64* d_aux_randomizers, const std::vector<Xfe>& quotient_randomizer);
+           const u64* d_aux_trace, const u64* d_aux_randomizers, const std::vector<Xfe>& quotient_randomizer,
+           const Claim& claim = Claim());
     ProofStream prove();  // the hot path of Prover::prove, stark.rs:331-719
     std::vector<Xfe> last_polynomial;
 
@@ -147,6 +160,7 @@ private:
     std::vector<u64> fri(const DeviceBuffer& combination, ProofStream& ps);  // Fri::prove, fri.rs:212-319
     const Context& c_;
     StarkParameters p_;
+    Claim claim_;
     MasterTable main_, aux_;
     std::vector<Xfe> quotient_randomizer_;
 };
@@ -154,10 +168,12 @@ private:
 }  // namespace triton_vm
 
 // C entry for hosts without a C++ ABI (the Python tests and bench.py): runs Prover::prove on device-resident traces
-// and returns the transcript, flattened as  n_items, then per item: n_words, fiat_shamir flag, the words.
+// and returns the proof (the words of the reference's `Proof`).  h_program_digest (5 words) may be null (all zero), the
+// public input / output may be empty.  *proof_words is the length of the proof; it is copied when capacity suffices.
 extern "C" int32_t tvmh_prove(tvm_ctx* ctx, uint32_t log2_padded_height, uint64_t num_trace_randomizers,
                               uint64_t num_collinearity_checks, uint32_t log2_expansion, const uint64_t* d_main_trace,
                               const uint64_t* d_main_randomizers, const uint64_t* d_aux_trace,
                               const uint64_t* d_aux_randomizers, const uint64_t* h_quotient_randomizer,
-                              uint64_t* h_transcript, uint64_t transcript_capacity_words, uint64_t* transcript_words,
-                              char* error, uint64_t error_capacity);
+                              const uint64_t* h_program_digest, const uint64_t* h_public_input, uint64_t n_public_input,
+                              const uint64_t* h_public_output, uint64_t n_public_output, uint64_t* h_proof,
+                              uint64_t proof_capacity_words, uint64_t* proof_words, char* error, uint64_t error_capacity);

@@ -12,43 +12,41 @@ def load_host_library(backend_path=None, out=None):
     lib = C.CDLL(build_host(backend_path, out))
     lib.tvmh_prove.restype = C.c_int32
     lib.tvmh_prove.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                               C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64]
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                               C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64]
     return lib
 
 
 class NativeProver:
-    """Same constructor data as triton_vm_amd.prover.Prover (device traces, device randomizers, the quotient randomizer);
-    `prove()` returns the transcript as a list of (n_words, fiat_shamir, words)."""
+    """Same constructor data as triton_vm_amd.prover.Prover (device traces, device randomizers, the quotient randomizer,
+    the claim); `prove()` returns the proof: the words of the reference's `Proof`."""
 
     def __init__(self, ctx, host_lib, params, d_main_trace, d_main_randomizers, d_aux_trace, d_aux_randomizers,
-                 quotient_randomizer):
+                 quotient_randomizer, claim=None):
+        from .proof_stream import Claim
+
         self.ctx, self.lib, self.p = ctx, host_lib, params
         self.bufs = (d_main_trace, d_main_randomizers, d_aux_trace, d_aux_randomizers)  # keep them alive
         self.qr = np.ascontiguousarray(quotient_randomizer, dtype=np.uint64).reshape(-1, 3)
         assert self.qr.shape[0] == params.num_quotient_randomizers
-        self.capacity = 1 << 21   # words; a 2^20-row transcript (173 opened rows of 3 tables + authentication nodes) is ~0.4 M words
+        self.claim = claim or Claim()
+        self.capacity = 1 << 21   # words; a 2^20-row proof (173 opened rows of 3 tables + authentication nodes) is ~0.4 M words
         self.out = np.empty(self.capacity, np.uint64)
 
     def prove(self, parse=True):
-        p = self.p
+        p, claim = self.p, self.claim
         log2 = p.padded_height.bit_length() - 1
         err = C.create_string_buffer(512)
         n = C.c_uint64(0)
         while True:
             rc = self.lib.tvmh_prove(self.ctx.handle, log2, p.h, p.num_collinearity_checks, p.log2_expansion, self.bufs[0].ptr, self.bufs[1].ptr,
-                                     self.bufs[2].ptr, self.bufs[3].ptr, self.qr.ctypes.data, self.out.ctypes.data, self.capacity,
-                                     C.byref(n), err, len(err))
+                                     self.bufs[2].ptr, self.bufs[3].ptr, self.qr.ctypes.data, claim.program_digest.ctypes.data,
+                                     claim.input.ctypes.data, claim.input.size, claim.output.ctypes.data, claim.output.size,
+                                     self.out.ctypes.data, self.capacity, C.byref(n), err, len(err))
             if rc != 0:
                 raise RuntimeError(f"tvmh_prove failed ({rc}): {err.value.decode()}")
             if n.value <= self.capacity:
                 break
-            self.capacity = int(n.value)      # the transcript did not fit: grow and run again
+            self.capacity = int(n.value)      # the proof did not fit: grow and run again
             self.out = np.empty(self.capacity, np.uint64)
-        if not parse:
-            return None
-        items, o = [], 1
-        for _ in range(int(self.out[0])):
-            k, fs = int(self.out[o]), bool(self.out[o + 1])
-            items.append((k, fs, self.out[o + 2:o + 2 + k].copy()))
-            o += 2 + k
-        return items
+        return self.out[:n.value].copy() if parse else None

@@ -127,17 +127,25 @@ class Prover:
         self.capture = None
 
     @classmethod
-    def from_execution(cls, ctx, aet, padded_height, claim, randomness_seed, log2_expansion=2, ldt="fri"):
+    def from_execution(cls, ctx, aet, padded_height, claim, randomness_seed, log2_expansion=2, ldt="fri", security_level=160):
         """Prover::prove from the start (stark.rs:331-400): the master main table is filled from the algebraic
         execution trace and padded on the device (MasterMainTable::new + pad, master_table.rs:881-983), all randomness
         comes from `randomness_seed` (32 bytes) the way the reference draws it, and the auxiliary table is extended on
         the device once the challenges are sampled (MasterMainTable::extend, master_table.rs:1006-1075).
-        aet: the arrays master_table.fill takes; padded_height: AlgebraicExecutionTrace::padded_height (aet.rs:141-146)."""
+        aet: the arrays master_table.fill takes; padded_height: AlgebraicExecutionTrace::padded_height (aet.rs:141-146);
+        security_level, log2_expansion: Stark::new's (stark.rs:1815-1830; Stark::default() is 160, 2)."""
+        import math
+
+        from .low_degree_test import ReedSolomonCode
+
         self = cls.__new__(cls)
         log2 = padded_height.bit_length() - 1
         if padded_height != 1 << log2:
             raise ValueError("the padded height is a power of two")
-        p = StarkParameters(log2, log2_expansion=log2_expansion, ldt=ldt)
+        # fri.rs:832-836: the number of collinearity checks; stark.rs:2083-2089: the number of trace randomizers
+        checks = math.ceil(-security_level / math.log2(1.0 - ReedSolomonCode(log2_expansion).proximity_parameter()))
+        p = StarkParameters(log2, num_trace_randomizers=checks + 4 * 3 * 2 + 1, num_collinearity_checks=checks,
+                            log2_expansion=log2_expansion, ldt=ldt)
         self.ctx, self.p, self.claim, self.randomness_seed = ctx, p, claim, bytes(randomness_seed)
         n, h, lib = p.trace.length, p.h, ctx.lib
         d_main = ctx.alloc(NUM_MAIN * n)

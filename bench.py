@@ -280,8 +280,8 @@ def main():
                                    "91 aux columns (652 words/row), Stark::default() with "
                                    + (f"FRI (expansion {1 << args.log2_expansion}, {params.h} trace randomizers, {args.queries} queries)" if args.ldt == "fri"
                                       else f"STIR (expansion {1 << args.log2_expansion}, {params.h} trace randomizers, {len(params.stir.round_queries)} full rounds)")
-                                   + ", traces resident in HBM; host `gen` steps (VM, pad, extend) "
-                                   "and the Rust-side transcript are not part of the path",
+                                   + ", traces resident in HBM; the reference's transcript (ProofItem encoding, Fiat-Shamir) on the host; "
+                                   "the host `gen` steps (VM, fill, pad, extend) are not part of the path",
                        "host": ("C++ mirror of Prover::prove over the C ABI (triton_vm_amd/host/triton_host.cpp)" if host == "cpp"
                                 else "Python mirror of Prover::prove over the C ABI (triton_vm_amd/prover.py)"),
                        "padded_rows": params.padded_height, "master_words": MASTER_WORDS,

@@ -1,13 +1,16 @@
 """TEST INFRASTRUCTURE (oracle): `Prover::prove` with the reference's REAL transcript -- `Claim`, `ProofStream`,
-`BFieldCodec`, Fiat-Shamir sampling, the prover's seeded randomness -- restated end to end, so that the reference's
-proof-digest snapshots can be attempted:
+`BFieldCodec`, Fiat-Shamir sampling, the prover's seeded randomness -- restated end to end.  It reproduces BOTH
+proof-digest snapshots the reference holds (tests/test_proof_snapshot.py):
     current_proof_version_is_still_current   /root/reference/triton-vm/src/proof.rs:200-226
     supplying_prover_randomness_seed_fully_derandomizes_produced_proof   /root/reference/triton-vm/src/stark.rs:2434-2460
-Everything in-tree is followed line by line (stark.rs:331-719 prove, fri.rs:130-345 + 757-775 FRI prover, proof_item.rs,
-proof_stream.rs, master_table.rs:392-434 + 612-662 + 1006-1030 randomness).  What lives only in `twenty-first = "2.0.0"`
-(not vendored) is restated from its published behaviour and exposed as VARIANT KNOBS where the behaviour is not certain:
-the struct / enum framing of the `BFieldCodec` derive, the order of `MerkleTree::authentication_structure`, how the 32
-seed bytes are drawn, how `Tip5::hash(&proof)` frames the proof.  Plain python + the C oracle; small traces only."""
+Everything in-tree is followed line by line (stark.rs:331-719 prove, low_degree_test/fri.rs:212-345 + 754-920 the FRI
+prover and its parameters, proof_item.rs, proof_stream.rs, master_table.rs:392-434 + 612-662 + 1006-1030 randomness).
+What lives only in `twenty-first = "2.0.0"` / `rand` (not vendored) is restated from its published behaviour; the
+`Variant` knobs name those behaviours, and their defaults are the ones the snapshots confirm: derive(BFieldCodec)
+encodes a struct's fields last-field-first with length prefixes on dynamically-sized fields, an enum as discriminant +
+fields, Polynomials without trailing zeros; MerkleTree::authentication_structure is in descending node order;
+`rng.random::<[u8; 32]>()` draws one u32 per byte; `Tip5::hash(&proof)` hashes the struct encoding of `Proof`.
+Plain python + the C oracle; small traces only.  The product never imports this file."""
 import itertools
 
 import numpy as np

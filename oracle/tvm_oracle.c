@@ -55,9 +55,9 @@ uint64_t orc_bfe_pow(uint64_t a, uint64_t e) {
     return r;
 }
 uint64_t orc_bfe_inv(uint64_t a) { return orc_bfe_pow(a, P - 2); }
-/* [twenty-first, not in tree; PARITY UNPINNED] BFieldElement::generator() = 7 */
+/* [twenty-first, not in tree; pinned by the proof snapshots, tests/test_proof_snapshot.py] BFieldElement::generator() = 7 */
 uint64_t orc_bfe_generator(void) { return orc_bfe_new(7); }
-/* [twenty-first, not in tree; PARITY UNPINNED] primitive_root_of_unity(2^k): the 2^32-th root is
+/* [twenty-first, not in tree; pinned by the proof snapshots, tests/test_proof_snapshot.py] primitive_root_of_unity(2^k): the 2^32-th root is
  * 7^((p-1)/2^32) = 1753635133440165772, smaller orders by repeated squaring.  Callers of the
  * product library always pass domain generators explicitly, so this only feeds tests. */
 uint64_t orc_bfe_primitive_root(uint64_t order) {
@@ -403,7 +403,7 @@ void orc_hash_rows(const uint64_t* rows, uint64_t n_rows, uint64_t w, uint64_t* 
 #pragma omp parallel for
     for (u64 i = 0; i < n_rows; i++) orc_hash_varlen(rows + i * w, w, digests + 5 * i);
 }
-/* [twenty-first MerkleTree, PARITY UNPINNED layout]: heap order, nodes[1] root, children 2i, 2i+1 */
+/* [twenty-first MerkleTree; layout pinned by the proof snapshots]: heap order, nodes[1] root, children 2i, 2i+1 */
 void orc_merkle_tree(const uint64_t* leaves, uint64_t n, uint64_t* nodes) {
     memset(nodes, 0, 40);
     memcpy(nodes + 5 * n, leaves, n * 40);
@@ -412,7 +412,7 @@ void orc_merkle_tree(const uint64_t* leaves, uint64_t n, uint64_t* nodes) {
         for (u64 i = lvl; i < 2 * lvl; i++) orc_hash_pair(nodes + 10 * i, nodes + 10 * i + 5, nodes + 5 * i);
     }
 }
-/* fri.rs:343-347 + [twenty-first Digest::from(XFE), PARITY UNPINNED]: [c0,c1,c2,0,0] */
+/* fri.rs:343-347 + [twenty-first Digest::from(XFE); pinned by the proof snapshots]: [c0,c1,c2,0,0] */
 void orc_xfe_to_digest(const uint64_t* x, uint64_t n, uint64_t* d) {
     for (u64 i = 0; i < n; i++) {
         d[5 * i] = x[3 * i]; d[5 * i + 1] = x[3 * i + 1]; d[5 * i + 2] = x[3 * i + 2];

@@ -13,9 +13,11 @@
  * (tests/test_oracle_pins.py), the program digests of stark.rs:4828-4838 and program.rs:496-510 (multi-block
  * overwrite-mode hash_varlen), the AIR fingerprint of master_table.rs:2328-2414 (tests/test_air_fingerprint.py) and
  * the vanishing of the AIR on valid traces (tests/test_vm_tables.py; this also pins the fixed-length hashing domain
- * and merkle_step's sibling order through the Hash table's constraints).  Items that the tree does not pin
- * (root-of-unity table, generator, Merkle node layout, Digest::from(XFE)) are marked PARITY UNPINNED where they
- * are used.
+ * and merkle_step's sibling order through the Hash table's constraints), and -- end to end -- the reference's two
+ * proof-digest snapshots (proof.rs:200-226, stark.rs:2434-2460): oracle/real_prover.py, which sequences these functions
+ * with the oracle-side VM and the restated transcript, reproduces Tip5::hash(proof) for both (tests/test_proof_snapshot.py).
+ * That pins every function below that prove() uses, including the items the tree has no separate vector for
+ * (root-of-unity table, generator, Merkle node layout, Digest::from(XFE)): marked "pinned by the proof snapshots".
  *
  * Data representation: a BFieldElement is one uint64_t holding the Montgomery
  * word a*2^64 mod p (triton-constraint-builder/src/codegen.rs:926-944: 42 <-> 180388626390);
@@ -44,8 +46,8 @@ uint64_t orc_bfe_sub(uint64_t a, uint64_t b);
 uint64_t orc_bfe_mul(uint64_t a, uint64_t b);
 uint64_t orc_bfe_inv(uint64_t a);
 uint64_t orc_bfe_pow(uint64_t a, uint64_t e);
-uint64_t orc_bfe_generator(void);                       /* PARITY UNPINNED: 7 */
-uint64_t orc_bfe_primitive_root(uint64_t order);        /* PARITY UNPINNED: 7^((p-1)/2^32) squared down */
+uint64_t orc_bfe_generator(void);                       /* 7; pinned by the proof snapshots */
+uint64_t orc_bfe_primitive_root(uint64_t order);        /* 7^((p-1)/2^32) squared down; pinned by the proof snapshots */
 void orc_bfe_batch_inv(uint64_t* a, size_t n);
 
 /* ---- extension field ---- */
@@ -79,7 +81,7 @@ void orc_lde_table(int fk, const uint64_t* trace, uint64_t n_rows, uint64_t n_co
 void orc_tip5_permutation(uint64_t state[16]);
 void orc_hash_varlen(const uint64_t* input, size_t len, uint64_t out[5]);
 void orc_tip5_trace(const uint64_t in[16], uint64_t* out /* [6][16] */);
-void orc_hash_pair(const uint64_t left[5], const uint64_t right[5], uint64_t out[5]); /* PARITY UNPINNED order */
+void orc_hash_pair(const uint64_t left[5], const uint64_t right[5], uint64_t out[5]); /* order pinned by the proof snapshots */
 void orc_hash_10(const uint64_t input[10], uint64_t out[5]);
 void orc_hash_rows(const uint64_t* rows, uint64_t n_rows, uint64_t row_words, uint64_t* digests);
 /* nodes: [2*n_leaves][5]; nodes[1] = root, nodes[n_leaves + i] = leaf i, nodes[0] = 0 */

@@ -69,8 +69,9 @@ def domain_value(d, i):
     return orc.lib().orc_bfe_mul(d.offset, orc.lib().orc_bfe_pow(d.generator, int(i)))
 
 
-def fri_verify(view, first_domain, num_rounds, num_collinearity_checks, last_round_max_degree):
-    """Fri::verify (fri.rs:368-700) over a verifier view of the transcript -> first-round indices"""
+def fri_verify(view, first_domain, num_rounds, num_collinearity_checks, last_round_max_degree, postscript=None):
+    """Fri::verify (fri.rs:368-700) over a verifier view of the transcript -> first-round indices; `postscript` (a dict)
+    receives the partially revealed first codeword (InitialRoundPostscript::partial_codeword)"""
     rounds = []
     dom = first_domain
     for r in range(num_rounds + 1):
@@ -101,6 +102,8 @@ def fri_verify(view, first_domain, num_rounds, num_collinearity_checks, last_rou
         return leaves
 
     partial_a = receive(0, a_indices(0))
+    if postscript is not None:
+        postscript["partial_first_codeword"] = partial_a
     for r in range(num_rounds):
         partial_b = receive(r, b_indices(r))
         d = rounds[r]["domain"]
@@ -157,8 +160,13 @@ def _coset_interpolate_and_evaluate(root, kth_root, values, at):
     return orc.poly_eval_xfe(np.array(coeffs + [so.ZERO] * (len(values) - len(coeffs))), at)
 
 
-def stir_verify(view, stir):
-    """Stir::verify (stir.rs:995-1120) -> first-round indices"""
+def stir_verify(view, stir, postscript=None):
+    """Stir::verify (stir.rs:995-1120) -> first-round indices; `postscript` (a dict) receives the partially revealed
+    first codeword (Stir::partial_codeword, stir.rs:1245-1256: of a queried stack, the value at the queried index)"""
+    def partial_codeword(round_domain, queries):
+        folded_len = round_domain.length // stir.folding_factor
+        return np.array([q["values"][q["index"] // folded_len] for q in queries], np.uint64)
+
     domain = orc.Domain(stir.initial_domain.offset, stir.initial_domain.generator, stir.initial_domain.length)
     previous_root = view.dequeue("stir root")
     previous = None  # (quotient_set, quotient_answers, degree_correction_randomness)
@@ -194,6 +202,8 @@ def stir_verify(view, stir):
         ood_queries = view.sample_scalars(out_of_domain)
         ood_answers = np.asarray(view.dequeue("stir ood values"), np.uint64).reshape(-1, 3)
         indices, queries = _stir_queries(view, stir, domain, in_domain, previous_root)
+        if postscript is not None and "partial_first_codeword" not in postscript:
+            postscript["partial_first_codeword"] = partial_codeword(domain, queries)
         answers = in_domain_answers(queries, folding_randomness)
         qset, qans, seen = [], [], set()
         for point, answer in list(zip([so.lift(q["point"]) for q in queries], answers)) + list(zip(ood_queries, ood_answers)):
@@ -214,6 +224,8 @@ def stir_verify(view, stir):
     if max(len(so.poly_trim(list(poly))) - 1, 0) > stir.final_degree:
         raise VerificationError("LastRoundPolynomialHasTooHighDegree")
     indices, queries = _stir_queries(view, stir, domain, stir.final_num_in_domain_queries, previous_root)
+    if postscript is not None and "partial_first_codeword" not in postscript:
+        postscript["partial_first_codeword"] = partial_codeword(domain, queries)
     for q, answer in zip(queries, in_domain_answers(queries, folding_randomness)):
         if not (orc.poly_eval_xfe(poly, so.lift(q["point"])) == answer).all():
             raise VerificationError("LastRoundPolynomialEvaluationMismatch")

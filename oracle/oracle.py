@@ -74,16 +74,19 @@ def value(raw):
 
 
 def to_mont(a):
-    """canonical values -> Montgomery words (vectorised through python ints; test sizes only)."""
-    a = np.asarray(a, dtype=object)
-    r = (a * (2**64)) % P
-    return np.array(r, dtype=np.uint64).reshape(a.shape)
+    """canonical values (any integers; reduced mod p) -> Montgomery words"""
+    if not (isinstance(a, np.ndarray) and a.dtype == np.uint64):   # python ints: never let numpy guess a float dtype
+        a = np.asarray(a, dtype=object)
+        a = np.array(a % P, dtype=np.uint64).reshape(a.shape)
+    out = np.ascontiguousarray(a, dtype=np.uint64).copy()
+    lib().orc_bfe_new_array(_p(out.reshape(-1)), C.c_uint64(out.size))
+    return out
 
 
 def from_mont(a):
-    rinv = pow(2**64, -1, P)
-    a = np.asarray(a, dtype=np.uint64).astype(object)
-    return np.array((a * rinv) % P, dtype=np.uint64).reshape(a.shape)
+    out = np.ascontiguousarray(np.asarray(a, dtype=np.uint64)).copy()
+    lib().orc_bfe_value_array(_p(out.reshape(-1)), C.c_uint64(out.size))
+    return out
 
 
 def random_elements(rng, shape):

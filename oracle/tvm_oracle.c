@@ -41,6 +41,8 @@ static inline u64 msub(u64 a, u64 b) { return a >= b ? a - b : (u64)((u128)a + P
 static inline u64 mneg(u64 a) { return a ? P - a : 0; }
 
 uint64_t orc_bfe_new(uint64_t v) { return mmul(v % P, R2); }
+void orc_bfe_new_array(uint64_t* a, uint64_t n) { for (uint64_t i = 0; i < n; i++) a[i] = orc_bfe_new(a[i]); }
+void orc_bfe_value_array(uint64_t* a, uint64_t n) { for (uint64_t i = 0; i < n; i++) a[i] = mmul(a[i], 1); }
 uint64_t orc_bfe_value(uint64_t raw) { return mmul(raw, 1); }
 uint64_t orc_bfe_add(uint64_t a, uint64_t b) { return madd(a, b); }
 uint64_t orc_bfe_sub(uint64_t a, uint64_t b) { return msub(a, b); }

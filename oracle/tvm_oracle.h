@@ -40,6 +40,8 @@ typedef struct {
 
 /* ---- base field ---- */
 uint64_t orc_bfe_new(uint64_t value);        /* canonical value -> Montgomery word */
+void orc_bfe_new_array(uint64_t* a, uint64_t n);            /* in place: canonical values -> Montgomery words */
+void orc_bfe_value_array(uint64_t* a, uint64_t n);          /* in place: Montgomery words -> canonical values */
 uint64_t orc_bfe_value(uint64_t raw);        /* Montgomery word -> canonical value */
 uint64_t orc_bfe_add(uint64_t a, uint64_t b);
 uint64_t orc_bfe_sub(uint64_t a, uint64_t b);

@@ -14,8 +14,15 @@ def aet_arrays(orc, aet):
     """the oracle VM's AET in the layout of AlgebraicExecutionTrace (aet.rs:41-96): Montgomery words, row-major"""
     from oracle.vm import tables as T
 
-    M = lambda rows, width: orc.to_mont(np.array([[v % T.P for v in r] for r in rows], dtype=object).reshape(-1, width)) \
-        if rows else np.zeros((0, width), np.uint64)
+    def M(rows, width):
+        if not rows:
+            return np.zeros((0, width), np.uint64)
+        try:
+            canonical = np.array(rows, dtype=np.uint64)       # the VM keeps canonical values: one pass, also at 2^20 rows
+        except OverflowError:
+            canonical = np.array([[v % T.P for v in r] for r in rows], dtype=object)
+        return orc.to_mont(canonical.reshape(-1, width))
+
     hash_rows = lambda trace: [T.hash_table_row(0, ci, rnd, state) for ci, rnd, state in trace]   # Mode is set by fill
     ram_rows, _ = (T.fill_ram(aet) if aet.ram_trace else ([], []))
     unique = list(dict.fromkeys(r[T.M["Ram"]["RamPointer"]] for r in ram_rows))

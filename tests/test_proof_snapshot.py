@@ -50,14 +50,19 @@ def test_oracle_prover_reproduces_the_second_reference_proof_digest():
     assert proof["digest"] == SNAPSHOT_EVERY
 
 
-def device_proof(ctx, orc, which, seed_u64, security_level):
-    from triton_vm_amd.prover import Claim, Prover
+def claim_of(orc, program, public_input, output):
+    from triton_vm_amd.prover import Claim
+
+    mont = lambda values: orc.to_mont(np.array(values, dtype=object)) if len(values) else ()
+    return Claim(orc.hash_varlen(mont(program.to_bwords())), mont(public_input), mont(output))
+
+
+def device_proof(ctx, orc, which, seed_u64, security_level, ldt="fri"):
+    from triton_vm_amd.prover import Prover
 
     program, aet, public_input, output = vf.run(which)
-    mont = lambda values: orc.to_mont(np.array(values, dtype=object)) if len(values) else ()
-    claim = Claim(orc.hash_varlen(mont(program.to_bwords())), mont(public_input), mont(output))
-    prover = Prover.from_execution(ctx, aet_arrays(orc, aet), aet.padded_height(), claim, prover_seed(seed_u64),
-                                   security_level=security_level)
+    prover = Prover.from_execution(ctx, aet_arrays(orc, aet), aet.padded_height(), claim_of(orc, program, public_input, output),
+                                   prover_seed(seed_u64), security_level=security_level, ldt=ldt)
     return prover.prove().proof()
 
 

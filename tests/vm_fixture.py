@@ -12,6 +12,15 @@ from oracle.vm import isa, tables as T, vm
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TINY_PROGRAM = "pick 11 pick 12 pick 13 pick 14 pick 15 read_io 5 assert_vector halt"
+# the program of the reference's headline benchmark, prove_fib (benches/prove_fib.rs:8-24 runs it with index 100;
+# triton-dev-util/src/example_programs.rs:6-38): ten instructions per iteration
+FIBONACCI_PROGRAM = """
+    push 0 push 1 read_io 1
+    dup 0 skiz call fib_loop
+    pop 1 write_io 1 halt
+    fib_loop:
+        push -1 add swap 2 dup 1 add swap 1 swap 2 dup 0 skiz recurse return
+"""
 
 
 def hash_pair(left, right):
@@ -20,7 +29,7 @@ def hash_pair(left, right):
 
 def non_determinism(which):
     """-> (secret input, secret digests, initial RAM) of the program's NonDeterminism"""
-    if which == "tiny":
+    if which != "every":
         return [], [], None
     node_5, node_4, node_3 = [5] * 5, [4] * 5, [3] * 5                                  # stark.rs:4770-4786
     node_2 = hash_pair(node_4, node_5)
@@ -31,7 +40,11 @@ def non_determinism(which):
 
 
 def run(which):
-    """-> (program, aet, public input, public output)"""
+    """-> (program, aet, public input, public output); which: "tiny", "every" or ("fib", index)"""
+    if isinstance(which, tuple) and which[0] == "fib":
+        program = isa.parse(FIBONACCI_PROGRAM)
+        aet, output = vm.trace_execution(program, [which[1]])
+        return program, aet, [which[1]], output
     if which == "tiny":
         program = isa.parse(TINY_PROGRAM)
         public_input = vm.hash_varlen(program.to_bwords())

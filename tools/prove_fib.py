@@ -1,0 +1,60 @@
+"""prove_fib for real (the reference's headline benchmark, benches/prove_fib.rs): run the Fibonacci program in the
+oracle-side VM up to 2^k cycles, hand the algebraic execution trace to Prover.from_execution -- fill, pad, extend and the
+hot path on the device, the reference's transcript on the host -- and put the proof through the restated Verifier::verify.
+The VM run stands in for the reference's Rust VM (host work there too); everything after it is the product.
+usage: python tools/prove_fib.py [log2_padded_height=20] [fri|stir] [--no-verify]"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401,E402  (first: see tests/conftest.py)
+
+from oracle import oracle as orc  # noqa: E402
+from tests import test_proof_snapshot as snap, vm_fixture as vf  # noqa: E402
+from tests.test_fill import aet_arrays  # noqa: E402
+from triton_vm_amd import Context  # noqa: E402
+from triton_vm_amd.prover import Prover  # noqa: E402
+
+log2 = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 20
+ldt = "stir" if "stir" in sys.argv else "fri"
+index = ((1 << log2) - 20) // 10            # ten instructions per iteration, a dozen around the loop
+t = {}
+t0 = time.perf_counter()
+program, aet, public_input, output = vf.run(("fib", index))
+t["vm_s"] = time.perf_counter() - t0
+assert aet.padded_height() == 1 << log2, aet.padded_height()
+t0 = time.perf_counter()
+arrays = aet_arrays(orc, aet)
+t["aet_arrays_s"] = time.perf_counter() - t0
+claim = snap.claim_of(orc, program, public_input, output)
+ctx = Context(device=0)
+seed = snap.prover_seed(1)
+result = {}
+for attempt in range(2):                    # the second pass is the warm one
+    ctx.sync()
+    t0 = time.perf_counter()
+    prover = Prover.from_execution(ctx, arrays, aet.padded_height(), claim, seed, ldt=ldt)
+    ctx.sync()
+    t1 = time.perf_counter()
+    stream = prover.prove()
+    ctx.sync()
+    t2 = time.perf_counter()
+    proof = stream.proof()
+    result = {"fill_pad_randomizers_ms": 1e3 * (t1 - t0), "extend_and_hot_path_ms": 1e3 * (t2 - t1), "proof_words": int(proof.words.size)}
+    prover.release()
+    del prover
+out = {"program": f"fibonacci_sequence, index {index}", "cycles": aet.height_of_table("Processor"), "padded_height": aet.padded_height(),
+       "ldt": ldt, **{k: round(v, 2) for k, v in t.items()}, **{k: round(v, 1) if isinstance(v, float) else v for k, v in result.items()},
+       "proof_digest": proof.digest(ctx.lib)}
+if "--no-verify" not in sys.argv:
+    from oracle import real_verifier
+    from triton_vm_amd.proof_stream import ProofStream
+
+    t0 = time.perf_counter()
+    indices = real_verifier.verify(ProofStream.from_proof(ctx.lib, proof.words).verifier_view(), claim, ldt_choice=ldt)
+    out["verified"] = True
+    out["verifier_s"] = round(time.perf_counter() - t0, 1)
+    out["revealed_rows"] = len(indices)
+print(json.dumps(out))

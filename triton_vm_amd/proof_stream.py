@@ -50,6 +50,24 @@ def variant_of(label):
     raise KeyError(f"no proof item for the label {label!r}")
 
 
+# the labels a decoded item (or, for a response, its two parts) is logged under
+DECODED_LABELS = {"FriResponse": ("fri response", "fri auth"), "StirResponse": ("stir response leafs", "stir response auth")}
+
+
+def labels_match(label, expected):
+    """does a logged item answer a verifier's request for `expected` (a label prefix or a variant name)?"""
+    if label.startswith(expected):
+        return True
+    variant = variant_of(label)
+    if variant != variant_of(expected):
+        return False
+    return VARIANT[variant][1] != "response" or ("auth" in label) == ("auth" in expected)
+
+
+class ProofDecodingError(ValueError):
+    """ProofStreamError::DecodingError (error.rs)"""
+
+
 def _m(n):
     return np.uint64(field.to_mont(int(n)))
 
@@ -183,8 +201,10 @@ class ProofStream:
         pending = list(self.log)
 
         def dequeue(expected_prefix=None):
+            if not pending:
+                raise ValueError("ProofStreamError::EmptyQueue")
             label, payload, in_heuristic = pending.pop(0)
-            if expected_prefix is not None and not label.startswith(expected_prefix):
+            if expected_prefix is not None and not labels_match(label, expected_prefix):
                 raise ValueError(f"unexpected proof item {label!r}, wanted {expected_prefix!r}")
             if in_heuristic:
                 v._absorb(label, payload)
@@ -193,6 +213,76 @@ class ProofStream:
         v.dequeue = dequeue
         v.pending = pending
         return v
+
+    @classmethod
+    def from_proof(cls, lib, proof_words):
+        """impl TryFrom<&Proof> for ProofStream (proof_stream.rs:106-113): decode the items; nothing is absorbed yet
+        (use verifier_view() to read them the way a verifier does)"""
+        w = [field.from_mont(int(x)) for x in _words(proof_words)]
+        words = _words(proof_words)
+        pos = 0
+
+        def take(n=1):
+            nonlocal pos
+            if pos + n > len(w):
+                raise ProofDecodingError("the proof ends inside an item")
+            pos += n
+            return pos - n
+
+        def vec(start, length, elem_words):
+            """Vec<T> of static elements occupying exactly `length` words from `start` -> payload words"""
+            if length < 1 or w[start] * elem_words != length - 1:
+                raise ProofDecodingError("a vector's length prefix disagrees with its field length")
+            return words[start + 1:start + length]
+
+        self = cls(lib)
+        if len(w) < 2 or w[0] != len(w) - 1:
+            raise ProofDecodingError("the items field does not span the proof")
+        take(1)
+        n_items = w[take()]
+        for _ in range(n_items):
+            size = w[take()]
+            start = take(size)
+            if size < 1 or w[start] >= len(PROOF_ITEMS):
+                raise ProofDecodingError("unknown proof item")
+            name, kind, fs = PROOF_ITEMS[w[start]]
+            if kind == "static":
+                self.log.append((name, words[start + 1:start + size].copy(), fs))
+                continue
+            if size < 2 or w[start + 1] != size - 2:
+                raise ProofDecodingError(f"{name}: the payload length disagrees with the item length")
+            body, length = start + 2, size - 2
+            if kind.startswith("vec:"):
+                self.log.append((name, vec(body, length, int(kind[4:])).copy(), fs))
+            elif kind == "polynomial":
+                if length < 1 or w[body] != length - 1:
+                    raise ProofDecodingError("Polynomial: bad field length")
+                coefficients = vec(body + 1, length - 1, 3).reshape(-1, 3)
+                if len(coefficients) and not coefficients[-1].any():
+                    raise ProofDecodingError("Polynomial: trailing zeros in the encoding")
+                self.log.append((name, coefficients.copy(), fs))
+            else:   # the struct's fields, last field first: auth_structure, then the leaves
+                auth_len = w[body]
+                auth = vec(body + 1, auth_len, 5)
+                leaves_at = body + 1 + auth_len
+                leaves_len = w[leaves_at]
+                if 2 + auth_len + leaves_len != length:
+                    raise ProofDecodingError(f"{name}: field lengths disagree with the item length")
+                if name == "FriResponse":
+                    leaves = vec(leaves_at + 1, leaves_len, 3).reshape(-1, 3)
+                else:   # Vec<Vec<XFieldElement>>
+                    stacks, q = [], leaves_at + 2
+                    for _ in range(w[leaves_at + 1]):
+                        stacks.append(vec(q + 1, w[q], 3).reshape(-1, 3))
+                        q += 1 + w[q]
+                    if q != leaves_at + 1 + leaves_len:
+                        raise ProofDecodingError("StirResponse: the stacks do not span the field")
+                    leaves = np.array(stacks, np.uint64)
+                self.log.append((DECODED_LABELS[name][0], leaves.copy(), fs))
+                self.log.append((DECODED_LABELS[name][1], auth.copy(), fs))
+        if pos != len(w):
+            raise ProofDecodingError("words after the last item")
+        return self
 
     # -- Fiat-Shamir sampling [twenty-first Tip5::sample_scalars / sample_indices] -----------------------------
     def _squeeze(self):

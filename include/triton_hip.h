@@ -308,6 +308,9 @@ void tvm_host_xfe_powers(const uint64_t x[3], uint64_t first_exponent, uint64_t 
 /* n draws of `rng.random::<BFieldElement>()` from `StdRng::from_seed(seed)` (the prover's trace, batch and quotient
  * randomizers: master_table.rs:423-434, 1006-1024, stark.rs:1315-1322; a Rust host uses rand itself), Montgomery words */
 void tvm_host_stdrng_elements(const uint8_t seed[32], uint64_t n, uint64_t* out);
+/* the same n elements into device memory, generated on the device (one ChaCha block per work-item); when a draw takes the
+ * range sampler's rare short path the stream is regenerated sequentially on the host -- the result is always the host's */
+int32_t tvm_stdrng_elements(tvm_ctx* ctx, const uint8_t seed[32], uint64_t n, uint64_t* d_out);
 
 /* ---- verifier batch work --------------------------------------------------------
  * Verifier::verify's work over the num_first_round_queries revealed rows (stark.rs:1388-1763), all host data in / out:

@@ -835,6 +835,75 @@ void tvm_host_stdrng_elements(const uint8_t seed[32], uint64_t n, uint64_t* out)
     for (uint64_t i = 0; i < n; i++) out[i] = bfe_from_u64(rng.random_bfe());
 }
 }  // extern "C"
+namespace tvm {
+struct StdRngKey {
+    uint32_t w[8];
+};
+// The same stream on the device: work-item t computes ChaCha block t (16 words = 4 draws of two u64 each) and the four
+// elements 4t .. 4t+3.  That is the host stream as long as every draw takes its second u64 -- it does unless the low
+// half of x * p is below 2^32 (probability 2^-32 per element); such a draw is reported in *short_draws and the caller
+// regenerates on the host, where the stream is consumed sequentially.
+__global__ void k_stdrng_elements(StdRngKey key, u64 n, u64* __restrict__ out, unsigned* __restrict__ short_draws) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (4 * t >= n) return;
+    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+    for (int i = 0; i < 8; i++) s[4 + i] = key.w[i];
+    s[12] = (uint32_t)t; s[13] = (uint32_t)(t >> 32); s[14] = 0; s[15] = 0;
+    uint32_t x[16];
+    for (int i = 0; i < 16; i++) x[i] = s[i];
+#define TVM_ROTL(v, k) (((v) << (k)) | ((v) >> (32 - (k))))
+#define TVM_QR(a, b, c, d) \
+    x[a] += x[b]; x[d] = TVM_ROTL(x[d] ^ x[a], 16); x[c] += x[d]; x[b] = TVM_ROTL(x[b] ^ x[c], 12); \
+    x[a] += x[b]; x[d] = TVM_ROTL(x[d] ^ x[a], 8);  x[c] += x[d]; x[b] = TVM_ROTL(x[b] ^ x[c], 7);
+    for (int r = 0; r < 6; r++) {
+        TVM_QR(0, 4, 8, 12) TVM_QR(1, 5, 9, 13) TVM_QR(2, 6, 10, 14) TVM_QR(3, 7, 11, 15)
+        TVM_QR(0, 5, 10, 15) TVM_QR(1, 6, 11, 12) TVM_QR(2, 7, 8, 13) TVM_QR(3, 4, 9, 14)
+    }
+#undef TVM_QR
+#undef TVM_ROTL
+    for (int i = 0; i < 16; i++) x[i] += s[i];
+    for (int j = 0; j < 4 && 4 * t + j < n; j++) {
+        const u64 a = (u64)x[4 * j] | ((u64)x[4 * j + 1] << 32), b = (u64)x[4 * j + 2] | ((u64)x[4 * j + 3] << 32);
+        const unsigned __int128 prod = (unsigned __int128)a * TVM_P;
+        u64 result = (u64)(prod >> 64);
+        const u64 lo = (u64)prod;
+        if (lo <= (u64)(0 - TVM_P)) *short_draws = 1u;  // a flag: every writer stores the same value
+        const u64 new_hi = (u64)(((unsigned __int128)b * TVM_P) >> 64);
+        if (lo + new_hi < lo) result++;
+        out[4 * t + j] = bfe_from_u64(result);
+    }
+}
+}  // namespace tvm
+extern "C" {
+int32_t tvm_stdrng_elements(tvm_ctx* c, const uint8_t seed[32], uint64_t n, uint64_t* d_out) {
+    if (!c || !seed || (n && !d_out)) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_stdrng_elements arguments");
+    if (!n) return TVM_OK;
+    tvm::StdRngKey key;
+    for (int i = 0; i < 8; i++)
+        key.w[i] = (uint32_t)seed[4 * i] | ((uint32_t)seed[4 * i + 1] << 8) | ((uint32_t)seed[4 * i + 2] << 16) | ((uint32_t)seed[4 * i + 3] << 24);
+    unsigned* d_flag = (unsigned*)pool_alloc(c, sizeof(unsigned));
+    if (!d_flag) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "stdrng flag");
+    int rc = TVM_OK;
+    unsigned short_draws = 0;
+    if (hipMemsetAsync(d_flag, 0, sizeof(unsigned), c->stream) != hipSuccess) rc = set_error(c, TVM_ERR_DEVICE, "stdrng flag");
+    if (rc == TVM_OK) {
+        const u64 blocks = (n + 3) / 4;
+        TVM_LAUNCH(tvm::k_stdrng_elements, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, c->stream, key, n, d_out, d_flag);
+        if (hipMemcpyAsync(&short_draws, d_flag, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess)
+            rc = set_error(c, TVM_ERR_DEVICE, "stdrng elements");
+    }
+    pool_release(c, d_flag);
+    if (rc == TVM_OK && short_draws) {  // a draw that took one u64 shifts the rest of the stream: sequential on the host
+        std::vector<uint64_t> host(n);
+        tvm_host_stdrng_elements(seed, n, host.data());
+        if (hipMemcpyAsync(d_out, host.data(), n * sizeof(u64), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess)
+            rc = set_error(c, TVM_ERR_DEVICE, "stdrng elements (host path)");
+    }
+    return rc;
+}
+}  // extern "C"
 
 extern "C" {  // ---------------------------------------------------------------------------------- verifier batch work
 int32_t tvm_verifier_row_digests(tvm_ctx* c, const uint64_t* h_rows, uint64_t n_rows, uint64_t row_words, uint64_t* h_digests) {

@@ -166,8 +166,9 @@ class Prover:
         ctx, p, lib = self.ctx, self.p, self.ctx.lib
         n, h = p.trace.length, p.h
         d_aux = ctx.alloc(NUM_AUX * n * 3)
-        column = randomness.batch_randomizer_column(lib, self.randomness_seed, n)
-        ctx._check(lib.tvm_memcpy_h2d(ctx.handle, d_aux.ptr + 8 * (NUM_AUX - 1) * n * 3, column.ctypes.data, column.size * 8), "h2d")
+        # the batch-randomizer column (master_table.rs:1017-1024): n XFieldElements of the seeded stream, made on the device
+        ctx._check(lib.tvm_stdrng_elements(ctx.handle, randomness.batch_randomizer_seed(self.randomness_seed), 3 * n,
+                                           d_aux.ptr + 8 * (NUM_AUX - 1) * n * 3), "tvm_stdrng_elements")
         master_table.extend(ctx, self.main.d_trace, d_aux, n, challenges)
         rnd = randomness.trace_randomizers(lib, randomness.aux_seed(self.randomness_seed), NUM_AUX, h, 3)
         return MasterTable.from_device(ctx, d_aux, ctx.to_device(rnd), NUM_AUX, n, h, p.trace, p.quotient, p.ldt, 3)

@@ -31,8 +31,12 @@ def trace_randomizers(lib, table_seed, n_cols, h, field_kind):
     return out.reshape((n_cols, h) + ((3,) if field_kind == 3 else ()))
 
 
+def batch_randomizer_seed(seed):
+    return offset_rng_seed(aux_seed(seed), NUM_AUX)
+
+
 def batch_randomizer_column(lib, seed, n_rows):
-    return random_elements(lib, offset_rng_seed(aux_seed(seed), NUM_AUX), 3 * n_rows).reshape(n_rows, 3)
+    return random_elements(lib, batch_randomizer_seed(seed), 3 * n_rows).reshape(n_rows, 3)
 
 
 def quotient_randomizer(lib, seed, n_coefficients):

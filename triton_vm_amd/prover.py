@@ -127,13 +127,18 @@ class Prover:
         self.capture = None
 
     @classmethod
-    def from_execution(cls, ctx, aet, padded_height, claim, randomness_seed, log2_expansion=2, ldt="fri", security_level=160):
+    def from_execution(cls, ctx, aet, padded_height, claim, randomness_seed, log2_expansion=2, ldt="fri", security_level=160,
+                       assume_valid_trace=True):
         """Prover::prove from the start (stark.rs:331-400): the master main table is filled from the algebraic
         execution trace and padded on the device (MasterMainTable::new + pad, master_table.rs:881-983), all randomness
         comes from `randomness_seed` (32 bytes) the way the reference draws it, and the auxiliary table is extended on
         the device once the challenges are sampled (MasterMainTable::extend, master_table.rs:1006-1075).
         aet: the arrays master_table.fill takes; padded_height: AlgebraicExecutionTrace::padded_height (aet.rs:141-146);
-        security_level, log2_expansion: Stark::new's (stark.rs:1815-1830; Stark::default() is 160, 2)."""
+        security_level, log2_expansion: Stark::new's (stark.rs:1815-1830; Stark::default() is 160, 2);
+        assume_valid_trace: the tables come from an execution trace, so the quotient evaluation may use the degree
+        bounds of the constraint quotients (TVM_OPTION_AIR_VALID_TRACE) -- the same proof, word for word, as
+        long as the trace satisfies the AIR (both reference snapshots are reproduced this way); an invalid trace gives a
+        proof that differs from the reference's equally unverifiable one."""
         import math
 
         from .low_degree_test import ReedSolomonCode
@@ -147,6 +152,7 @@ class Prover:
         p = StarkParameters(log2, num_trace_randomizers=checks + 4 * 3 * 2 + 1, num_collinearity_checks=checks,
                             log2_expansion=log2_expansion, ldt=ldt)
         self.ctx, self.p, self.claim, self.randomness_seed = ctx, p, claim, bytes(randomness_seed)
+        self.assume_valid_trace = assume_valid_trace
         n, h, lib = p.trace.length, p.h, ctx.lib
         d_main = ctx.alloc(NUM_MAIN * n)
         lengths = master_table.fill(ctx, d_main, n, aet)
@@ -216,8 +222,15 @@ class Prover:
 
     def _quotient_codeword(self, challenges, quotient_weights):
         """all_quotients_combined over the quotient domain (master_table.rs:1264-1363) -> device XFE vector"""
-        return stark.all_quotients_combined(self.ctx, self.main, self.aux, self.p.trace, self.p.quotient, challenges,
-                                            quotient_weights)
+        valid = getattr(self, "assume_valid_trace", False)
+        if valid:
+            self.ctx.assume_valid_trace(True)
+        try:
+            return stark.all_quotients_combined(self.ctx, self.main, self.aux, self.p.trace, self.p.quotient, challenges,
+                                                quotient_weights)
+        finally:
+            if valid:
+                self.ctx.assume_valid_trace(False)
 
     def _out_of_domain_rows(self, mt, points):
         """out_of_domain_row at several indeterminates (master_table.rs:348-390) -> host [n_points][n_cols][3]"""

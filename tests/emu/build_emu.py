@@ -30,14 +30,14 @@ def _build(force):
     for s in srcs:
         obj = os.path.join(objdir, os.path.basename(s) + ".o")
         objs.append(obj)
-        cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-DTVM_EMU", "-x", "c++", "-I", HERE, "-I", CSRC, "-I",
+        cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-pthread", "-DTVM_EMU", "-x", "c++", "-I", HERE, "-I", CSRC, "-I",
                os.path.join(ROOT, "include"), "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-c", s, "-o", obj]
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for s, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"g++ failed on {s}:\n{out}")
-    subprocess.check_call(["g++", "-shared", "-fPIC", "-o", LIB + ".tmp", *objs])
+    subprocess.check_call(["g++", "-shared", "-fPIC", "-pthread", "-o", LIB + ".tmp", *objs])
     os.replace(LIB + ".tmp", LIB)  # never a half-written library under the final name
     return LIB
 

@@ -26,7 +26,7 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
-#define __shared__ static
+#define __shared__ static thread_local   /* one copy per worker thread = per workgroup in flight */
 
 struct dim3 {
     unsigned x, y, z;
@@ -42,11 +42,12 @@ struct Fiber {
     bool done = false;
 };
 struct Group { int count = 0; int gen = 0; };
-extern Fiber* cur;
-extern uint3_emu block_idx;
-extern dim3 block_dim, grid_dim;
-extern unsigned char* dyn_smem;
-extern uint64_t xchg[];  // per-work-item exchange slots for shuffles
+// workgroups run in parallel on a pool of host threads: everything a workgroup touches is per thread
+extern thread_local Fiber* cur;
+extern thread_local uint3_emu block_idx;
+extern dim3 block_dim, grid_dim;   // the same for every workgroup of a launch
+extern thread_local unsigned char* dyn_smem;
+extern thread_local uint64_t xchg[4096];  // per-work-item exchange slots for shuffles
 void yield();
 void sync_block();
 void sync_wave();
@@ -86,7 +87,7 @@ static inline uint64_t __shfl(uint64_t v, int src, int width = 64) {
     return r;
 }
 // every lane of a wave deposits `bytes` (<= 64) bytes; `all` receives the 64 deposits of the wave in lane order
-namespace emu { extern unsigned char xchg_wide[][64]; }
+namespace emu { extern thread_local unsigned char xchg_wide[4096][64]; }
 static inline void emu_wave_gather(const void* mine, size_t bytes, void* all) {
     int flat = emu::cur->tid.x + emu::block_dim.x * (emu::cur->tid.y + emu::block_dim.y * emu::cur->tid.z);
     memcpy(emu::xchg_wide[flat], mine, bytes);

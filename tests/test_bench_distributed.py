@@ -61,7 +61,7 @@ def test_single_process_needs_no_collective():
     assert len(n) == 3
 
 
-@pytest.mark.parametrize("mode", ["sharded", "replicas"])
+@pytest.mark.parametrize("mode", ["sharded"])   # "replicas" runs in test_bench_script_spawns_its_own_ranks
 def test_bench_script_runs_under_torchrun_with_two_ranks(mode):
     """bench.py itself, launched the way the driver launches it for N = 2 (torch.distributed.run, one process per
     rank), on CPU: gloo instead of RCCL and the test-only emulation of the kernels (TVM_BENCH_TEST_EMU=1).  The

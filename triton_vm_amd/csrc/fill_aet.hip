@@ -34,7 +34,7 @@ namespace tvm {
 TVM_D u64 fa_value(u64 w) { return bfe_mul(w, 1); }
 #ifdef TVM_EMU
 static const unsigned char d_fa_lut[256] = {TVM_TIP5_LUT_LIST};
-static inline void fa_atomic_inc(u64* p) { *p += 1; }
+static inline void fa_atomic_inc(u64* p) { __atomic_fetch_add(p, 1ull, __ATOMIC_RELAXED); }  // the emulation runs workgroups on several threads
 #else
 static __device__ const unsigned char d_fa_lut[256] = {TVM_TIP5_LUT_LIST};
 static __device__ __forceinline__ void fa_atomic_inc(u64* p) { atomicAdd((unsigned long long*)p, 1ull); }

@@ -35,6 +35,20 @@ def test_cpp_prover_proof_equals_python_prover_proof(ctx, orc, log2_rows, h, che
     assert (native.prove() == got).all()
 
 
+def test_cpp_host_proves_the_reference_snapshot_from_the_execution_trace(ctx, orc):
+    """triton_vm::prove_execution -- the C++ host's Prover::prove(claim, aet): fill, pad, extend, the seeded randomness, the
+    hot path and the transcript -- on the program, claim and seed of the reference's proof-digest snapshot (proof.rs:200-226)"""
+    from tests import test_proof_snapshot as snap
+    from tests import vm_fixture as vf
+    from tests.test_fill import aet_arrays
+    from triton_vm_amd.proof_stream import Proof
+
+    program, aet, public_input, output = vf.run("tiny")
+    words = native_host.prove_execution(ctx, _host_library(ctx), aet_arrays(orc, aet), aet.padded_height(),
+                                        snap.claim_of(orc, program, public_input, output), snap.prover_seed(snap.SEED_U64))
+    assert Proof(words).digest(ctx.lib) == snap.SNAPSHOT
+
+
 def test_cpp_host_reports_errors(ctx):
     p = StarkParameters(3, num_trace_randomizers=3, num_collinearity_checks=2)
     lib = _host_library(ctx)

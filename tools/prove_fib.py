@@ -48,6 +48,17 @@ for attempt in range(2):                    # the second pass is the warm one
 out = {"program": f"fibonacci_sequence, index {index}", "cycles": aet.height_of_table("Processor"), "padded_height": aet.padded_height(),
        "ldt": ldt, **{k: round(v, 2) for k, v in t.items()}, **{k: round(v, 1) if isinstance(v, float) else v for k, v in result.items()},
        "proof_digest": proof.digest(ctx.lib)}
+if ldt == "fri":   # the same through the C++ host (triton_vm::prove_execution): one call = Prover::prove(claim, aet)
+    from triton_vm_amd import native_host
+    from triton_vm_amd.proof_stream import Proof
+
+    host_lib = native_host.load_host_library()
+    for attempt in range(2):
+        ctx.sync()
+        t0 = time.perf_counter()
+        words = native_host.prove_execution(ctx, host_lib, arrays, aet.padded_height(), claim, seed)
+        out["cpp_host_whole_prove_ms"] = round(1e3 * (time.perf_counter() - t0), 1)
+    out["cpp_host_proof_equals_python_host_proof"] = bool(words.size == proof.words.size and (words == proof.words).all())
 if "--no-verify" not in sys.argv:
     from oracle import real_verifier
     from triton_vm_amd.proof_stream import ProofStream

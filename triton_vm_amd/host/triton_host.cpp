@@ -2,6 +2,7 @@
 #include "triton_host.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <iterator>
@@ -419,6 +420,7 @@ ProofStream Prover::prove() {
     const DeviceBuffer main_nodes = main_.merkle_tree();
     ps.enqueue("main root", merkle_root(c_, main_nodes).data(), 5);
     const std::vector<Xfe> challenges = derive_challenges(ps.sample_scalars(NUM_SAMPLED_CHALLENGES), claim_);
+    if (extend) extend(challenges);  // MasterMainTable::extend (stark.rs:379-381)
 
     // 8-9: aux table (its `extend` is host work in the reference; the trace is already resident)
     aux_.maybe_low_degree_extend_all_columns();
@@ -428,8 +430,11 @@ ProofStream Prover::prove() {
 
     // 10: quotient codeword, segments, randomization  (stark.rs:405-423)
     DeviceBuffer quot(c_, p_.quotient.length * 3);
-    c_.check(tvm_all_quotients_combined(c_.raw(), main_.table(), aux_.table(), p_.trace.c(), p_.quotient.c(), challenges[0].c,
-                                        quotient_weights[0].c, quot.ptr()), "tvm_all_quotients_combined");
+    if (assume_valid_trace) c_.check(tvm_ctx_set_option(c_.raw(), TVM_OPTION_AIR_VALID_TRACE, 1), "tvm_ctx_set_option");
+    const int32_t quotient_status = tvm_all_quotients_combined(c_.raw(), main_.table(), aux_.table(), p_.trace.c(), p_.quotient.c(),
+                                                               challenges[0].c, quotient_weights[0].c, quot.ptr());
+    if (assume_valid_trace) (void)tvm_ctx_set_option(c_.raw(), TVM_OPTION_AIR_VALID_TRACE, 0);
+    c_.check(quotient_status, "tvm_all_quotients_combined");
     const u64 poly_len = std::max<u64>(p_.quotient.length / 4, quotient_randomizer_.size());
     DeviceBuffer polys(c_, 5 * poly_len * 3);
     tvm_table* seg_table = nullptr;
@@ -547,6 +552,69 @@ ProofStream Prover::prove() {
     return ps;
 }
 
+// ------------------------------------------------------------------------------------------------ from an execution trace
+StarkParameters stark_parameters(unsigned log2_padded_height, unsigned security_level, unsigned log2_expansion) {
+    const double rate = 1.0 / (double)(1ull << log2_expansion);
+    const double margin = std::sqrt(rate);                          // ReedSolomonCode::proximity_margin, proven soundness
+    const double proximity = 1.0 - margin - margin / 20.0;          // ... minus the slackness factor
+    const u64 checks = (u64)std::ceil(-(double)security_level / std::log2(1.0 - proximity));
+    return StarkParameters(log2_padded_height, checks + 4 * 3 * 2 + 1, checks, log2_expansion);
+}
+
+void offset_rng_seed(const uint8_t seed[32], u64 offset, uint8_t out[32]) {
+    unsigned carry = 0;
+    for (int k = 0; k < 32; k++) {
+        const unsigned sum = (unsigned)seed[k] + (k < 8 ? (unsigned)((offset >> (8 * k)) & 0xFF) : 0u) + carry;
+        out[k] = (uint8_t)(sum & 0xFF);
+        carry = sum >> 8;
+    }
+}
+
+// trace_randomizer_for_column for every column (master_table.rs:423-434) -> device [n_cols][h](x3)
+static DeviceBuffer trace_randomizers(const Context& c, const uint8_t table_seed[32], u64 n_cols, u64 h, int fk) {
+    std::vector<u64> host(n_cols * h * fk);
+    for (u64 col = 0; col < n_cols; col++) {
+        uint8_t seed[32];
+        offset_rng_seed(table_seed, col, seed);
+        tvm_host_stdrng_elements(seed, h * fk, host.data() + col * h * fk);
+    }
+    DeviceBuffer d(c, host.size());
+    c.check(tvm_memcpy_h2d(c.raw(), d.ptr(), host.data(), host.size() * sizeof(u64)), "tvm_memcpy_h2d");
+    return d;
+}
+
+std::vector<u64> prove_execution(const Context& c, const StarkParameters& p, const tvm_aet& aet, const Claim& claim,
+                                 const uint8_t seed[32]) {
+    const u64 n = p.trace.length;
+    // MasterMainTable::new + pad (master_table.rs:881-983)
+    DeviceBuffer main_trace(c, NUM_MAIN * n);
+    u64 lengths[9];
+    c.check(tvm_fill_main_table(c.raw(), &aet, main_trace.ptr(), n, lengths), "tvm_fill_main_table");
+    for (u64 len : lengths)
+        if (len > p.padded_height) throw Error(TVM_ERR_INVALID_ARGUMENT, "a table is longer than the padded height");
+    c.check(tvm_pad_main_table(c.raw(), main_trace.ptr(), n, lengths), "tvm_pad_main_table");
+    c.check(tvm_fill_derived_main_columns(c.raw(), main_trace.ptr(), n), "tvm_fill_derived_main_columns");
+    // the seeded randomness: offsets as in the table of master_table.rs:618-628
+    uint8_t aux_seed[32], batch_seed[32], quotient_seed[32];
+    offset_rng_seed(seed, NUM_MAIN, aux_seed);
+    offset_rng_seed(aux_seed, NUM_AUX, batch_seed);
+    offset_rng_seed(seed, NUM_MAIN + NUM_AUX + 1, quotient_seed);
+    const DeviceBuffer main_rnd = trace_randomizers(c, seed, NUM_MAIN, p.h, 1);
+    const DeviceBuffer aux_rnd = trace_randomizers(c, aux_seed, NUM_AUX, p.h, 3);
+    std::vector<Xfe> quotient_randomizer(p.num_quotient_randomizers);
+    tvm_host_stdrng_elements(quotient_seed, 3 * quotient_randomizer.size(), quotient_randomizer[0].c);
+    // MasterMainTable::extend (master_table.rs:1006-1075): the batch-randomizer column now, the rest once the challenges exist
+    DeviceBuffer aux_trace(c, NUM_AUX * n * 3);
+    c.check(tvm_stdrng_elements(c.raw(), batch_seed, 3 * n, aux_trace.ptr() + (NUM_AUX - 1) * n * 3), "tvm_stdrng_elements");
+    Prover prover(c, p, main_trace.ptr(), main_rnd.ptr(), aux_trace.ptr(), aux_rnd.ptr(), quotient_randomizer, claim);
+    prover.assume_valid_trace = true;
+    prover.extend = [&](const std::vector<Xfe>& challenges) {
+        c.check(tvm_extend_aux_table(c.raw(), main_trace.ptr(), aux_trace.ptr(), n, challenges[0].c), "tvm_extend_aux_table");
+        c.check(tvm_fill_derived_aux_columns(c.raw(), main_trace.ptr(), aux_trace.ptr(), n, challenges[0].c), "tvm_fill_derived_aux_columns");
+    };
+    return prover.prove().proof();
+}
+
 }  // namespace triton_vm
 
 extern "C" int32_t tvmh_prove(tvm_ctx* ctx, uint32_t log2_padded_height, uint64_t num_trace_randomizers,
@@ -568,6 +636,34 @@ extern "C" int32_t tvmh_prove(tvm_ctx* ctx, uint32_t log2_padded_height, uint64_
         if (n_public_output) claim.output.assign(h_public_output, h_public_output + n_public_output);
         Prover prover(c, p, d_main_trace, d_main_randomizers, d_aux_trace, d_aux_randomizers, qr, claim);
         const std::vector<u64> proof = prover.prove().proof();
+        if (proof_words) *proof_words = proof.size();
+        if (h_proof && capacity >= proof.size()) std::memcpy(h_proof, proof.data(), proof.size() * sizeof(u64));
+        return TVM_OK;
+    } catch (const Error& e) {
+        if (error && error_capacity) std::snprintf(error, error_capacity, "%s", e.what());
+        return e.status ? e.status : TVM_ERR_INVALID_ARGUMENT;
+    } catch (const std::exception& e) {
+        if (error && error_capacity) std::snprintf(error, error_capacity, "%s", e.what());
+        return TVM_ERR_DEVICE;
+    }
+}
+
+extern "C" int32_t tvmh_prove_execution(tvm_ctx* ctx, const tvm_aet* aet, uint32_t log2_padded_height, uint32_t security_level,
+                                        uint32_t log2_expansion, const uint8_t randomness_seed[32],
+                                        const uint64_t* h_program_digest, const uint64_t* h_public_input,
+                                        uint64_t n_public_input, const uint64_t* h_public_output, uint64_t n_public_output,
+                                        uint64_t* h_proof, uint64_t capacity, uint64_t* proof_words, char* error,
+                                        uint64_t error_capacity) {
+    using namespace triton_vm;
+    try {
+        if (!aet || !randomness_seed) throw Error(TVM_ERR_INVALID_ARGUMENT, "tvmh_prove_execution: null execution trace or seed");
+        const Context c(ctx);
+        const StarkParameters p = stark_parameters(log2_padded_height, security_level, log2_expansion);
+        Claim claim;
+        if (h_program_digest) std::memcpy(claim.program_digest, h_program_digest, sizeof(claim.program_digest));
+        if (n_public_input) claim.input.assign(h_public_input, h_public_input + n_public_input);
+        if (n_public_output) claim.output.assign(h_public_output, h_public_output + n_public_output);
+        const std::vector<u64> proof = prove_execution(c, p, *aet, claim, randomness_seed);
         if (proof_words) *proof_words = proof.size();
         if (h_proof && capacity >= proof.size()) std::memcpy(h_proof, proof.data(), proof.size() * sizeof(u64));
         return TVM_OK;

@@ -13,6 +13,7 @@
 // No device code, no HIP headers: it compiles with g++ and binds to whichever library exports the tvm_* symbols.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -155,6 +156,10 @@ public:
            const Claim& claim = Claim());
     ProofStream prove();  // the hot path of Prover::prove, stark.rs:331-719
     std::vector<Xfe> last_polynomial;
+    // called with the 63 challenges before the auxiliary table is extended: MasterMainTable::extend for a prover that
+    // starts from an execution trace (prove_execution); the auxiliary trace buffer is filled then
+    std::function<void(const std::vector<Xfe>&)> extend;
+    bool assume_valid_trace = false;  // TVM_OPTION_AIR_VALID_TRACE around the quotient evaluation
 
 private:
     std::vector<u64> fri(const DeviceBuffer& combination, ProofStream& ps);  // Fri::prove, fri.rs:212-319
@@ -164,6 +169,20 @@ private:
     MasterTable main_, aux_;
     std::vector<Xfe> quotient_randomizer_;
 };
+
+// Stark::new(security_level, log2_expansion) with LdtChoice::Fri: the number of collinearity checks (fri.rs:832-836,
+// low_degree_test/mod.rs:93-170, proven soundness) and of trace randomizers (stark.rs:2083-2089)
+StarkParameters stark_parameters(unsigned log2_padded_height, unsigned security_level, unsigned log2_expansion);
+
+// offset_rng_seed (master_table.rs:630-662)
+void offset_rng_seed(const uint8_t seed[32], u64 offset, uint8_t out[32]);
+
+// Prover::prove(claim, aet) from its first line (stark.rs:331-719): the master main table is filled from the algebraic
+// execution trace and padded on the device, every randomizer is drawn from `seed` the way the reference draws it
+// (master_table.rs:423-434, 1006-1024, stark.rs:1315-1322), the auxiliary table is extended on the device once the
+// challenges are sampled, the AIR runs in valid-trace mode.  Returns the proof (the words of the reference's Proof).
+std::vector<u64> prove_execution(const Context& c, const StarkParameters& p, const tvm_aet& aet, const Claim& claim,
+                                 const uint8_t seed[32]);
 
 }  // namespace triton_vm
 
@@ -177,3 +196,11 @@ extern "C" int32_t tvmh_prove(tvm_ctx* ctx, uint32_t log2_padded_height, uint64_
                               const uint64_t* h_program_digest, const uint64_t* h_public_input, uint64_t n_public_input,
                               const uint64_t* h_public_output, uint64_t n_public_output, uint64_t* h_proof,
                               uint64_t proof_capacity_words, uint64_t* proof_words, char* error, uint64_t error_capacity);
+
+// Prover::prove(claim, aet) -- triton_vm::prove_execution -- for hosts without a C++ ABI.
+extern "C" int32_t tvmh_prove_execution(tvm_ctx* ctx, const tvm_aet* aet, uint32_t log2_padded_height, uint32_t security_level,
+                                        uint32_t log2_expansion, const uint8_t randomness_seed[32],
+                                        const uint64_t* h_program_digest, const uint64_t* h_public_input,
+                                        uint64_t n_public_input, const uint64_t* h_public_output, uint64_t n_public_output,
+                                        uint64_t* h_proof, uint64_t proof_capacity_words, uint64_t* proof_words, char* error,
+                                        uint64_t error_capacity);

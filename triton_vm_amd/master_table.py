@@ -158,15 +158,11 @@ def pad(ctx, d_main_trace, n_rows, table_lengths):
     degree_lowering.fill_derived_main_columns(ctx, d_main_trace, n_rows)
 
 
-def fill(ctx, d_main_trace, n_rows, aet):
-    """MasterMainTable::new's table fills (/root/reference/triton-vm/src/table/master_table.rs:881-931) on the device
-    (tvm_fill_main_table).  `aet`: dict of numpy arrays shaped like AlgebraicExecutionTrace's fields (aet.rs:41-96):
+def aet_struct(aet):
+    """the C ABI's `tvm_aet` over a dict of numpy arrays shaped like AlgebraicExecutionTrace's fields (aet.rs:41-96):
     program_words [p], instruction_multiplicities [p] (uint32), processor_trace [c][39], op_stack_trace [k][4],
     ram_trace [k][7], bezout_coefficients_0/1 [u], program_hash_trace / sponge_trace / hash_trace [k][67],
-    u32_entries [k][4], cascade_entries [k][2], lookup_multiplicities [256].  Returns the nine table lengths
-    (TABLE_ORDER), the argument of `pad`."""
-    import ctypes as C
-
+    u32_entries [k][4], cascade_entries [k][2], lookup_multiplicities [256].  -> (struct, the arrays it points into)"""
     from .capi import Aet
 
     keep = {}
@@ -183,12 +179,11 @@ def fill(ctx, d_main_trace, n_rows, aet):
     if words.size != mult.size:
         raise ValueError("one multiplicity per program word")
     s.program_words, s.instruction_multiplicities, s.program_len = words.ctypes.data, mult.ctypes.data, words.size
-    for name, field_, len_, width in (("processor_trace", "processor_trace", "processor_len", 39), ("op_stack_trace", "op_stack_trace", "op_stack_len", 4),
-                                      ("ram_trace", "ram_trace", "ram_len", 7), ("program_hash_trace", "program_hash_trace", "program_hash_len", 67),
-                                      ("sponge_trace", "sponge_trace", "sponge_len", 67), ("hash_trace", "hash_trace", "hash_len", 67),
-                                      ("u32_entries", "u32_entries", "u32_len", 4), ("cascade_entries", "cascade_entries", "cascade_len", 2)):
+    for name, len_, width in (("processor_trace", "processor_len", 39), ("op_stack_trace", "op_stack_len", 4), ("ram_trace", "ram_len", 7),
+                              ("program_hash_trace", "program_hash_len", 67), ("sponge_trace", "sponge_len", 67), ("hash_trace", "hash_len", 67),
+                              ("u32_entries", "u32_len", 4), ("cascade_entries", "cascade_len", 2)):
         a = arr(name, width=width)
-        setattr(s, field_, a.ctypes.data)
+        setattr(s, name, a.ctypes.data)
         setattr(s, len_, a.shape[0])
     b0, b1 = arr("bezout_coefficients_0"), arr("bezout_coefficients_1")
     if b0.size != b1.size:
@@ -198,6 +193,17 @@ def fill(ctx, d_main_trace, n_rows, aet):
     if lk.size != 256:
         raise ValueError("256 lookup multiplicities")
     s.lookup_multiplicities = lk.ctypes.data
+    return s, keep
+
+
+def fill(ctx, d_main_trace, n_rows, aet):
+    """MasterMainTable::new's table fills (/root/reference/triton-vm/src/table/master_table.rs:881-931) on the device
+    (tvm_fill_main_table).  `aet`: dict of numpy arrays (see aet_struct).  Returns the nine table lengths (TABLE_ORDER),
+    the argument of `pad`."""
+    import ctypes as C
+
+    s, keep = aet_struct(aet)
     lengths = np.zeros(9, np.uint64)
     ctx._check(ctx.lib.tvm_fill_main_table(ctx.handle, C.byref(s), d_main_trace.ptr, n_rows, lengths.ctypes.data), "tvm_fill_main_table")
+    del keep
     return [int(v) for v in lengths]

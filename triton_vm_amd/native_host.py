@@ -14,7 +14,31 @@ def load_host_library(backend_path=None, out=None):
     lib.tvmh_prove.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64]
+    lib.tvmh_prove_execution.restype = C.c_int32
+    lib.tvmh_prove_execution.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.c_void_p, C.c_void_p,
+                                         C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p,
+                                         C.c_uint64]
     return lib
+
+
+def prove_execution(ctx, host_lib, aet, padded_height, claim, randomness_seed, security_level=160, log2_expansion=2):
+    """The C++ host's Prover::prove(claim, aet) (triton_vm::prove_execution): fill, pad, extend and the hot path on the
+    device, the seeded randomness and the transcript in C++.  aet: the arrays master_table.fill takes.  -> the proof words"""
+    from .master_table import aet_struct
+
+    s, keep = aet_struct(aet)
+    log2 = padded_height.bit_length() - 1
+    err, n = C.create_string_buffer(512), C.c_uint64(0)
+    out = np.empty(1 << 16, np.uint64)
+    while True:
+        rc = host_lib.tvmh_prove_execution(ctx.handle, C.addressof(s), log2, security_level, log2_expansion, bytes(randomness_seed),
+                                           claim.program_digest.ctypes.data, claim.input.ctypes.data, claim.input.size,
+                                           claim.output.ctypes.data, claim.output.size, out.ctypes.data, out.size, C.byref(n), err, len(err))
+        if rc != 0:
+            raise RuntimeError(f"tvmh_prove_execution failed ({rc}): {err.value.decode()}")
+        if n.value <= out.size:
+            return out[:n.value].copy()
+        out = np.empty(int(n.value), np.uint64)   # the proof did not fit: grow and run again
 
 
 class NativeProver:

@@ -2,7 +2,9 @@
 #include "triton_host.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <iterator>
@@ -553,6 +555,21 @@ ProofStream Prover::prove() {
 }
 
 // ------------------------------------------------------------------------------------------------ from an execution trace
+namespace {
+// TVMH_TRACE=1: wall time of the steps of prove_execution on stderr (each step drains the stream first)
+struct Stopwatch {
+    const Context& c;
+    const bool on = std::getenv("TVMH_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        (void)tvm_sync(c.raw());
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[tvmh] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+}  // namespace
 StarkParameters stark_parameters(unsigned log2_padded_height, unsigned security_level, unsigned log2_expansion) {
     const double rate = 1.0 / (double)(1ull << log2_expansion);
     const double margin = std::sqrt(rate);                          // ReedSolomonCode::proximity_margin, proven soundness
@@ -586,14 +603,17 @@ static DeviceBuffer trace_randomizers(const Context& c, const uint8_t table_seed
 std::vector<u64> prove_execution(const Context& c, const StarkParameters& p, const tvm_aet& aet, const Claim& claim,
                                  const uint8_t seed[32]) {
     const u64 n = p.trace.length;
+    Stopwatch watch{c};
     // MasterMainTable::new + pad (master_table.rs:881-983)
     DeviceBuffer main_trace(c, NUM_MAIN * n);
     u64 lengths[9];
     c.check(tvm_fill_main_table(c.raw(), &aet, main_trace.ptr(), n, lengths), "tvm_fill_main_table");
     for (u64 len : lengths)
         if (len > p.padded_height) throw Error(TVM_ERR_INVALID_ARGUMENT, "a table is longer than the padded height");
+    watch.lap("fill from the AET");
     c.check(tvm_pad_main_table(c.raw(), main_trace.ptr(), n, lengths), "tvm_pad_main_table");
     c.check(tvm_fill_derived_main_columns(c.raw(), main_trace.ptr(), n), "tvm_fill_derived_main_columns");
+    watch.lap("pad + derived main columns");
     // the seeded randomness: offsets as in the table of master_table.rs:618-628
     uint8_t aux_seed[32], batch_seed[32], quotient_seed[32];
     offset_rng_seed(seed, NUM_MAIN, aux_seed);
@@ -603,16 +623,22 @@ std::vector<u64> prove_execution(const Context& c, const StarkParameters& p, con
     const DeviceBuffer aux_rnd = trace_randomizers(c, aux_seed, NUM_AUX, p.h, 3);
     std::vector<Xfe> quotient_randomizer(p.num_quotient_randomizers);
     tvm_host_stdrng_elements(quotient_seed, 3 * quotient_randomizer.size(), quotient_randomizer[0].c);
+    watch.lap("trace randomizers");
     // MasterMainTable::extend (master_table.rs:1006-1075): the batch-randomizer column now, the rest once the challenges exist
     DeviceBuffer aux_trace(c, NUM_AUX * n * 3);
     c.check(tvm_stdrng_elements(c.raw(), batch_seed, 3 * n, aux_trace.ptr() + (NUM_AUX - 1) * n * 3), "tvm_stdrng_elements");
+    watch.lap("batch randomizer column");
     Prover prover(c, p, main_trace.ptr(), main_rnd.ptr(), aux_trace.ptr(), aux_rnd.ptr(), quotient_randomizer, claim);
     prover.assume_valid_trace = true;
     prover.extend = [&](const std::vector<Xfe>& challenges) {
         c.check(tvm_extend_aux_table(c.raw(), main_trace.ptr(), aux_trace.ptr(), n, challenges[0].c), "tvm_extend_aux_table");
         c.check(tvm_fill_derived_aux_columns(c.raw(), main_trace.ptr(), aux_trace.ptr(), n, challenges[0].c), "tvm_fill_derived_aux_columns");
     };
-    return prover.prove().proof();
+    const ProofStream stream = prover.prove();
+    watch.lap("prove (extend + hot path)");
+    std::vector<u64> proof = stream.proof();
+    watch.lap("proof encoding");
+    return proof;
 }
 
 }  // namespace triton_vm

@@ -29,7 +29,7 @@ def prove_execution(ctx, host_lib, aet, padded_height, claim, randomness_seed, s
     s, keep = aet_struct(aet)
     log2 = padded_height.bit_length() - 1
     err, n = C.create_string_buffer(512), C.c_uint64(0)
-    out = np.empty(1 << 16, np.uint64)
+    out = np.empty(1 << 20, np.uint64)   # a 2^20-row proof is ~0.3 M words
     while True:
         rc = host_lib.tvmh_prove_execution(ctx.handle, C.addressof(s), log2, security_level, log2_expansion, bytes(randomness_seed),
                                            claim.program_digest.ctypes.data, claim.input.ctypes.data, claim.input.size,

@@ -1,9 +1,9 @@
 """Time tvm_extend_aux_table and the two degree-lowering fills at 2^k rows on the GPU (valid 2048-row trace tiled).
-usage: python tools/extend_probe.py [log2_rows]"""
+usage: python tests/perf/extend_probe.py [log2_rows]"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np  # noqa: E402
 
 from tests import vm_fixture as vf  # noqa: E402

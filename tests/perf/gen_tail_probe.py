@@ -1,12 +1,12 @@
 """Time the host `gen` tail on the device at BASELINE size: tvm_fill_main_table -> tvm_pad_main_table ->
 tvm_fill_derived_main_columns -> tvm_extend_aux_table -> tvm_fill_derived_aux_columns, on an AET made by repeating the
 trace arrays of `program_executing_every_instruction` until the processor table has ~2^k rows (timing only: a repeated
-trace is not a valid execution).  usage: python tools/gen_tail_probe.py [log2_rows]"""
+trace is not a valid execution).  usage: python tests/perf/gen_tail_probe.py [log2_rows]"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np  # noqa: E402
 
 from oracle import oracle as orc  # noqa: E402

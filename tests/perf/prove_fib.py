@@ -2,13 +2,13 @@
 oracle-side VM up to 2^k cycles, hand the algebraic execution trace to Prover.from_execution -- fill, pad, extend and the
 hot path on the device, the reference's transcript on the host -- and put the proof through the restated Verifier::verify.
 The VM run stands in for the reference's Rust VM (host work there too); everything after it is the product.
-usage: python tools/prove_fib.py [log2_padded_height=20] [fri|stir] [--no-verify]"""
+usage: python tests/perf/prove_fib.py [log2_padded_height=20] [fri|stir] [--no-verify]"""
 import json
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: F401,E402  (first: see tests/conftest.py)
 
 from oracle import oracle as orc  # noqa: E402

@@ -6,7 +6,7 @@ restated in oracle/real_verifier.py over the decoded proof (`ProofStream::try_fr
     claim, a truncated and an extended proof are rejected;
   * device proofs (GPU): the reference's headline program prove_fib (index 100: 2^10 padded rows) with FRI and with STIR,
     are accepted; the FRI one is also the oracle prover's proof, word for word.  (The same at 2^20 padded rows, FRI and the
-    STIR the reference picks there, stark.rs:1944-1951: tools/prove_fib.py, results under profiles/r02_l_*.)
+    STIR the reference picks there, stark.rs:1944-1951: tests/perf/prove_fib.py, results under profiles/r02_l_*.)
 """
 import functools
 
@@ -116,7 +116,7 @@ def test_prove_fib_100_on_the_device_is_the_oracle_provers_proof_and_is_accepted
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("index,log2_padded_height", [(100, 10)])   # 2^16 and 2^20 rows: tools/prove_fib.py (profiles/r02_l_*)
+@pytest.mark.parametrize("index,log2_padded_height", [(100, 10)])   # 2^16 and 2^20 rows: tests/perf/prove_fib.py (profiles/r02_l_*)
 def test_prove_fib_with_stir_on_the_device_is_accepted(gpu_ctx, orc, index, log2_padded_height):
     """STIR is what Stark::ldt picks from 2^16 padded rows on (stark.rs:1944-1951)"""
     program, aet, public_input, output = vf.run(("fib", index))

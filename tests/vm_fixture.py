@@ -23,6 +23,46 @@ FIBONACCI_PROGRAM = """
 """
 
 
+# more of the programs the reference proves and verifies (stark.rs:4257-4317, triton-dev-util/src/example_programs.rs:70-96)
+MANY_U32_PROGRAM = """
+    push 1311768464867721216 split
+    push 13387 push 78810 lt
+    push 5 push 7 pow
+    push 69584 push 6796 xor
+    push 64972 push 3915 and
+    push 98668 push 15787 div_mod
+    push 15787 push 98668 div_mod
+    push 98141 push 7397 and
+    push 67749 push 60797 lt
+    push 49528 split
+    push 53483 call lsb
+    push 79655 call is_u32
+    push 60615 log_2_floor
+    push 13 push 5 pow
+    push 86323 push 37607 xor
+    push 32374 push 20636 pow
+    push 97416 log_2_floor
+    push 14392 push 31589 div_mod
+    halt
+    lsb: push 2 swap 1 div_mod return
+    is_u32: split pop 1 push 0 eq return
+"""
+PICK_AND_PLACE_PROGRAM = """
+    read_io 5 read_io 5 read_io 4
+    pick 2 pick 9 place 13 place 13
+    pick 0 pick 7 place 13 place 13
+    pick 2 pick 8 place 13 place 13
+    pick 3 pick 4 place 13 place 13
+    pick 0 pick 3 place 13 place 13
+    pick 0 pick 3 place 13 place 13
+    pick 1 pick 1 place 13 place 13
+    write_io 5 write_io 5 write_io 4
+    halt
+"""
+PICK_AND_PLACE_INPUT = [6, 3, 7, 5, 1, 2, 4, 4, 7, 3, 6, 1, 5, 2]
+PROGRAMS = {"halt": ("halt", []), "many_u32": (MANY_U32_PROGRAM, []), "pick_and_place": (PICK_AND_PLACE_PROGRAM, PICK_AND_PLACE_INPUT)}
+
+
 def hash_pair(left, right):
     return [int(v) for v in orc.from_mont(orc.hash_pair(orc.to_mont(left), orc.to_mont(right)))]
 
@@ -40,7 +80,12 @@ def non_determinism(which):
 
 
 def run(which):
-    """-> (program, aet, public input, public output); which: "tiny", "every" or ("fib", index)"""
+    """-> (program, aet, public input, public output); which: "tiny", "every", ("fib", index) or a key of PROGRAMS"""
+    if which in PROGRAMS:
+        text, public_input = PROGRAMS[which]
+        program = isa.parse(text)
+        aet, output = vm.trace_execution(program, public_input)
+        return program, aet, list(public_input), output
     if isinstance(which, tuple) and which[0] == "fib":
         program = isa.parse(FIBONACCI_PROGRAM)
         aet, output = vm.trace_execution(program, [which[1]])

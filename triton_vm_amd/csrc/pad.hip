@@ -143,8 +143,8 @@ int pad_main_table(tvm_ctx* c, u64* d_main, u64 n, const u64* lengths) {
         a.len[t] = lengths[t];
         if (lengths[t] > n) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "pad: a table is longer than the padded height");
     }
-    if (a.len[1] < 2 || a.len[4] != a.len[1])
-        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "pad: the processor table needs two rows and the jump stack table its length");
+    if (a.len[1] < 1 || a.len[4] != a.len[1] || n < 2)  // a one-row table (`halt`): row 1 is the first padding row (processor.rs:92-94)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "pad: the processor table needs a row and the jump stack table its length");
     const int bs = 256;
     u64* d_pivot = (u64*)scratch(c, 22, sizeof(u64));
     if (!d_pivot) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "pad scratch");

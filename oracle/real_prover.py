@@ -26,6 +26,15 @@ ZETA = 3
 PROOF_VERSION = 6                      # proof.rs:33 CURRENT_VERSION
 
 
+def fri_num_collinearity_checks(security_level, log2_expansion):
+    """fri.rs:832-836 with ReedSolomonCode::proximity_parameter for proven soundness (low_degree_test/mod.rs:93-170):
+    the proximity margin is sqrt(rate), the slackness a twentieth of it"""
+    import math
+
+    margin = math.sqrt(1.0 / (1 << log2_expansion))
+    return math.ceil(-security_level / math.log2(1.0 - (1.0 - margin - margin / 20.0)))
+
+
 # ---- small field helpers on Montgomery words -------------------------------------------------------------------------------
 def M(v):
     return int(orc.bfe(v))
@@ -236,10 +245,7 @@ def prove(program, public_input, secret_input=(), secret_digests=(), ram=None, s
     # parameters: Stark::default() (stark.rs:1885-2089), FRI below 2^16 rows (fri.rs:797-920)
     import math
 
-    from triton_vm_amd.low_degree_test import ReedSolomonCode  # the f64 restatement pinned by the reference's tables
-
-    proximity = ReedSolomonCode(2).proximity_parameter()
-    num_checks = math.ceil(-security_level / math.log2(1.0 - proximity))
+    num_checks = fri_num_collinearity_checks(security_level, 2)
     h = num_checks + 4 * 3 * 2 + 1
     padded_height = aet.padded_height()
     rtl = 1 << (max(padded_height + h, 2 * h + 1, (h + 1) * 5) - 1).bit_length()

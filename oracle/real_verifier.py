@@ -37,7 +37,7 @@ def verify(view, claim, security_level=160, log2_expansion=2, ldt_choice="fri"):
     """view: ProofStream.verifier_view() of the decoded proof; claim: triton_vm_amd.proof_stream.Claim; ldt_choice: "fri" or
     "stir" (Stark::ldt picks by padded height, stark.rs:1944-1951; the caller says which the prover used).
     Raises VerificationError; returns the first-round indices on acceptance."""
-    from triton_vm_amd.low_degree_test import ReedSolomonCode, stark_stir  # f64 restatements pinned by the reference's tables
+    from .real_prover import fri_num_collinearity_checks
 
     values = lambda a: [int(v) for v in orc.from_mont(np.asarray(a, np.uint64).reshape(-1))]
     view.alter_fiat_shamir_state_with(claim.encode())
@@ -48,10 +48,14 @@ def verify(view, claim, security_level=160, log2_expansion=2, ldt_choice="fri"):
     # Stark::ldt with FRI, num_trace_randomizers, the domains (stark.rs:1885-2089, fri.rs:797-920)
     stir = None
     if ldt_choice == "stir":
+        # the STIR parameter derivation (f64 formulas pinned by the reference's own tables, tests/test_stir_parameters.py)
+        # is the one restatement the oracle shares with the product
+        from triton_vm_amd.low_degree_test import stark_stir
+
         stir = stark_stir(padded_height, security_level=security_level, log2_ldt_expansion_factor=log2_expansion)
         checks = stir.num_first_round_queries()
     else:
-        checks = math.ceil(-security_level / math.log2(1.0 - ReedSolomonCode(log2_expansion).proximity_parameter()))
+        checks = fri_num_collinearity_checks(security_level, log2_expansion)
     h = checks + 4 * 3 * 2 + 1
     rtl = 1 << (max(padded_height + h, 2 * h + 1, (h + 1) * 5) - 1).bit_length()
     trace_len = rtl // 2

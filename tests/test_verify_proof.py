@@ -128,3 +128,39 @@ def test_prove_fib_with_stir_on_the_device_is_accepted(gpu_ctx, orc, index, log2
 
     with pytest.raises(VerificationError):
         verify(gpu_ctx.lib, proof.words, snap.claim_of(orc, program, [index + 1], output), ldt_choice="stir")
+
+
+def test_arbitrary_corruptions_never_escape_as_other_errors(host_lib):
+    """`decoding_arbitrary_proof_data_does_not_panic` / `verifying_arbitrary_proof_does_not_panic` (proof.rs:191-196,
+    stark.rs:4319-4326) in spirit: random overwrites, truncations and splices of a valid proof are either rejected with a
+    decoding / verification error or (never observed) accepted -- nothing else escapes"""
+    from oracle.real_verifier import VerificationError
+
+    words, claim, _ = oracle_proof("tiny", snap.SEED_U64, 160)
+    rng = np.random.default_rng(99)
+    outcomes = {"rejected": 0, "accepted": 0}
+    for trial in range(60):
+        bad = words.copy()
+        kind = trial % 4
+        if kind == 0:      # a few random words anywhere (length prefixes included)
+            for k in rng.integers(0, bad.size, int(rng.integers(1, 4))):
+                bad[k] = np.uint64(rng.integers(0, 2**63))
+        elif kind == 1:    # truncation
+            bad = bad[:int(rng.integers(0, bad.size))]
+        elif kind == 2:    # small canonical values where length prefixes tend to live: the head of the proof
+            bad[int(rng.integers(0, 64))] = np.uint64(int(orc_mont(int(rng.integers(0, 40)))))
+        else:              # a block moved elsewhere
+            a, b = sorted(int(v) for v in rng.integers(0, bad.size, 2))
+            bad = np.concatenate([bad[:a], bad[b:], bad[a:b]])
+        try:
+            verify(host_lib, bad, claim)
+            outcomes["accepted"] += 1
+        except (VerificationError, ValueError):   # ProofDecodingError is a ValueError
+            outcomes["rejected"] += 1
+    assert outcomes == {"rejected": 60, "accepted": 0}
+
+
+def orc_mont(v):
+    from triton_vm_amd import field
+
+    return field.to_mont(v)

@@ -236,6 +236,12 @@ class ProofStream:
             return words[start + 1:start + length]
 
         self = cls(lib)
+        try:
+            return self._decode(w, words, take, vec)
+        except IndexError:
+            raise ProofDecodingError("a length prefix points outside the proof")
+
+    def _decode(self, w, words, take, vec):
         if len(w) < 2 or w[0] != len(w) - 1:
             raise ProofDecodingError("the items field does not span the proof")
         take(1)
@@ -280,7 +286,7 @@ class ProofStream:
                     leaves = np.array(stacks, np.uint64)
                 self.log.append((DECODED_LABELS[name][0], leaves.copy(), fs))
                 self.log.append((DECODED_LABELS[name][1], auth.copy(), fs))
-        if pos != len(w):
+        if take(0) != len(w):
             raise ProofDecodingError("words after the last item")
         return self
 

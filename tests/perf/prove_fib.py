@@ -2,7 +2,8 @@
 oracle-side VM up to 2^k cycles, hand the algebraic execution trace to Prover.from_execution -- fill, pad, extend and the
 hot path on the device, the reference's transcript on the host -- and put the proof through the restated Verifier::verify.
 The VM run stands in for the reference's Rust VM (host work there too); everything after it is the product.
-usage: python tests/perf/prove_fib.py [log2_padded_height=20] [fri|stir] [--no-verify]"""
+With `u32` instead: a loop of u32 operations whose U32 table fills the padded height (BASELINE.json's many-u32-ops shape).
+usage: python tests/perf/prove_fib.py [log2_padded_height=20] [fri|stir] [u32] [--no-verify]"""
 import json
 import os
 import sys
@@ -19,10 +20,12 @@ from triton_vm_amd.prover import Prover  # noqa: E402
 
 log2 = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 20
 ldt = "stir" if "stir" in sys.argv else "fri"
-index = ((1 << log2) - 20) // 10            # ten instructions per iteration, a dozen around the loop
+u32 = "u32" in sys.argv
+# fib: ten instructions per iteration, a dozen around the loop; u32: 33 rows of the U32 table per iteration
+index = (1 << log2) // 33 if u32 else ((1 << log2) - 20) // 10
 t = {}
 t0 = time.perf_counter()
-program, aet, public_input, output = vf.run(("fib", index))
+program, aet, public_input, output = vf.run(("u32" if u32 else "fib", index))
 t["vm_s"] = time.perf_counter() - t0
 assert aet.padded_height() == 1 << log2, aet.padded_height()
 t0 = time.perf_counter()
@@ -45,7 +48,9 @@ for attempt in range(2):                    # the second pass is the warm one
     result = {"fill_pad_randomizers_ms": 1e3 * (t1 - t0), "extend_and_hot_path_ms": 1e3 * (t2 - t1), "proof_words": int(proof.words.size)}
     prover.release()
     del prover
-out = {"program": f"fibonacci_sequence, index {index}", "cycles": aet.height_of_table("Processor"), "padded_height": aet.padded_height(),
+out = {"program": f"u32 loop, {index} iterations" if u32 else f"fibonacci_sequence, index {index}",
+       "table_heights": {name: aet.height_of_table(name) for name in ("Processor", "OpStack", "U32", "Hash")},
+       "cycles": aet.height_of_table("Processor"), "padded_height": aet.padded_height(),
        "ldt": ldt, **{k: round(v, 2) for k, v in t.items()}, **{k: round(v, 1) if isinstance(v, float) else v for k, v in result.items()},
        "proof_digest": proof.digest(ctx.lib)}
 if ldt == "fri":   # the same through the C++ host (triton_vm::prove_execution): one call = Prover::prove(claim, aet)

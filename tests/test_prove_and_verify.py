@@ -13,7 +13,7 @@ CASES = [
     # program, security level, log2 expansion, runs on the emulation too
     ("halt", 32, 2, True), ("halt", 64, 3, False), ("halt", 160, 2, False), ("halt", 48, 4, False),
     ("many_u32", 32, 2, False), ("pick_and_place", 32, 2, False), (("fib", 100), 32, 2, False), ("every", 32, 2, False),
-    ("every", 64, 3, False),
+    ("every", 64, 3, False), (("u32", 100), 32, 2, False),
 ]
 
 

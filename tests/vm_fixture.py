@@ -60,6 +60,17 @@ PICK_AND_PLACE_PROGRAM = """
     halt
 """
 PICK_AND_PLACE_INPUT = [6, 3, 7, 5, 1, 2, 4, 4, 7, 3, 6, 1, 5, 2]
+# a loop of u32 operations on fresh operand pairs: every iteration adds a 33-row section to the U32 table (BASELINE.json's
+# "many_u32_ops at 2^20 rows": 31775 iterations fill 1 048 575 rows)
+U32_LOOP_PROGRAM = """
+    read_io 1
+    call loop
+    pop 1 halt
+    loop:
+        dup 0 push 2147483648 add
+        dup 1 xor pop 1
+        push -1 add dup 0 skiz recurse return
+"""
 PROGRAMS = {"halt": ("halt", []), "many_u32": (MANY_U32_PROGRAM, []), "pick_and_place": (PICK_AND_PLACE_PROGRAM, PICK_AND_PLACE_INPUT)}
 
 
@@ -80,14 +91,15 @@ def non_determinism(which):
 
 
 def run(which):
-    """-> (program, aet, public input, public output); which: "tiny", "every", ("fib", index) or a key of PROGRAMS"""
+    """-> (program, aet, public input, public output); which: "tiny", "every", ("fib", index), ("u32", iterations) or a
+    key of PROGRAMS"""
     if which in PROGRAMS:
         text, public_input = PROGRAMS[which]
         program = isa.parse(text)
         aet, output = vm.trace_execution(program, public_input)
         return program, aet, list(public_input), output
-    if isinstance(which, tuple) and which[0] == "fib":
-        program = isa.parse(FIBONACCI_PROGRAM)
+    if isinstance(which, tuple) and which[0] in ("fib", "u32"):
+        program = isa.parse(FIBONACCI_PROGRAM if which[0] == "fib" else U32_LOOP_PROGRAM)
         aet, output = vm.trace_execution(program, [which[1]])
         return program, aet, [which[1]], output
     if which == "tiny":

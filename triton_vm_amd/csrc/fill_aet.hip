@@ -161,13 +161,12 @@ __global__ void k_fa_u32(const u64* __restrict__ entries, const u64* __restrict_
     const u64 lhs_word = entries[4 * e + 1];
     const bool is_pow = op == OP_POW;
     const u64 row0 = offsets[e];
-    const u64 ci = FA_MONT(op), minus33 = bfe_neg(FA_MONT(33));
+    const u64 ci = FA_MONT(op);
     u64 r = row0;
     int bits = 0;
     for (;; bits++, r++) {
         U32C(MC_U32_COPY_FLAG, r) = bits == 0 ? FA_MONT(1) : 0;
         U32C(MC_U32_BITS, r) = FA_MONT(bits);
-        U32C(MC_U32_BITS_MINUS33_INV, r) = bfe_inv(bfe_add(FA_MONT(bits), minus33));
         U32C(MC_U32_CI, r) = ci;
         U32C(MC_U32_LHS, r) = is_pow ? lhs_word : bfe_from_u64(lhs);
         U32C(MC_U32_RHS, r) = bfe_from_u64(rhs);
@@ -185,16 +184,12 @@ __global__ void k_fa_u32(const u64* __restrict__ entries, const u64* __restrict_
         default: res = 0; break;   // split, and, pop_count
     }
     U32C(MC_U32_RESULT, r) = res;
-    U32C(MC_U32_LHS_INV, r) = U32C(MC_U32_LHS, r) ? bfe_inv(U32C(MC_U32_LHS, r)) : 0;
-    U32C(MC_U32_RHS_INV, r) = 0;
-    // the rows above it, bottom-up
+    // the rows above it, bottom-up (the three inverse columns are k_fa_u32_inverses' job: one work-item per ROW)
     while (r > row0) {
         r--;
         const u64 lw = U32C(MC_U32_LHS, r), rw = U32C(MC_U32_RHS, r);
         const u64 lv = is_pow ? 0 : fa_value(lw), rv = fa_value(rw);
         const u64 lhs_lsb = lv & 1, rhs_lsb = rv & 1;
-        U32C(MC_U32_LHS_INV, r) = lw ? bfe_inv(lw) : 0;
-        U32C(MC_U32_RHS_INV, r) = rw ? bfe_inv(rw) : 0;
         const u64 next = U32C(MC_U32_RESULT, r + 1);
         u64 out;
         switch (op) {
@@ -216,6 +211,17 @@ __global__ void k_fa_u32(const u64* __restrict__ entries, const u64* __restrict_
         }
         U32C(MC_U32_RESULT, r) = out;
     }
+}
+
+// LhsInv, RhsInv and BitsMinus33Inv of every section row: the inversions (a 64-step power each) are the bulk of the
+// table's arithmetic; per row they fill the chip, per entry (31 775 sections of 33 rows at 2^20 rows) they took 35 ms
+__global__ void k_fa_u32_inverses(u64 u32_len, u64* __restrict__ main, u64 n) {
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= u32_len) return;
+    const u64 lw = U32C(MC_U32_LHS, r), rw = U32C(MC_U32_RHS, r);
+    U32C(MC_U32_LHS_INV, r) = lw ? bfe_inv(lw) : 0;
+    U32C(MC_U32_RHS_INV, r) = rw ? bfe_inv(rw) : 0;
+    U32C(MC_U32_BITS_MINUS33_INV, r) = bfe_inv(bfe_sub(U32C(MC_U32_BITS, r), FA_MONT(33)));
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -336,7 +342,10 @@ int fill_main_table(tvm_ctx* c, const tvm_aet* aet, u64* d_main, u64 n, u64* h_l
     }
     if (aet->cascade_len) TVM_LAUNCH(k_fa_cascade, fa_grid(aet->cascade_len), dim3(256), 0, c->stream, d_casc, aet->cascade_len, d_main, n);
     TVM_LAUNCH(k_fa_lookup, fa_grid(256), dim3(256), 0, c->stream, d_lkm, d_main, n);
-    if (aet->u32_len) TVM_LAUNCH(k_fa_u32, fa_grid(aet->u32_len), dim3(256), 0, c->stream, d_u32e, d_u32o, aet->u32_len, d_main, n);
+    if (aet->u32_len) {
+        TVM_LAUNCH(k_fa_u32, fa_grid(aet->u32_len), dim3(256), 0, c->stream, d_u32e, d_u32o, aet->u32_len, d_main, n);
+        TVM_LAUNCH(k_fa_u32_inverses, fa_grid(u32_len), dim3(256), 0, c->stream, u32_len, d_main, n);
+    }
 
     // OpStack: stable sort by stack pointer (column 2 of the trace rows)
     if (aet->op_stack_len) {

@@ -560,7 +560,10 @@ namespace {
 struct Stopwatch {
     const Context& c;
     const bool on = std::getenv("TVMH_TRACE") != nullptr;
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), start = t0;
+    ~Stopwatch() {
+        if (on) std::fprintf(stderr, "[tvmh] %-28s %8.2f ms\n", "total", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - start).count());
+    }
     void lap(const char* what) {
         if (!on) return;
         (void)tvm_sync(c.raw());

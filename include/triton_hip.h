@@ -329,6 +329,13 @@ int32_t tvm_verifier_deep_values(tvm_ctx* ctx, const uint64_t* h_main_rows, cons
                                  const uint64_t* h_weights_quot, const uint64_t* h_weights_deep,
                                  const uint64_t* h_ood_points, const uint64_t* h_ood_values, uint64_t* h_out);
 
+/* host: the 604 AIR constraints on ONE row pair whose main rows are XFieldElements -- what Verifier::verify evaluates on the
+ * out-of-domain rows (stark.rs:1466-1491; MasterAuxTable::evaluate_{initial,consistency,transition,terminal}_constraints in
+ * this order).  h_main_* [379][3], h_aux_* [91][3], h_challenges [63][3]; h_out [604][3]: initial (81), consistency (97),
+ * transition (403), terminal (23). */
+int32_t tvm_host_air_constraints(const uint64_t* h_main_cur, const uint64_t* h_aux_cur, const uint64_t* h_main_next,
+                                 const uint64_t* h_aux_next, const uint64_t* h_challenges, uint64_t* h_out);
+
 #ifdef __cplusplus
 }
 #endif

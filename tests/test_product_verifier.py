@@ -1,0 +1,51 @@
+"""triton_vm_amd.verifier.Verifier -- the product's Verifier::verify (/root/reference/triton-vm/src/stark.rs:1388-1763, FRI):
+row hashing and the per-row combination values on the device, the AIR at the out-of-domain rows through
+tvm_host_air_constraints, Fiat-Shamir and the decisions on the host -- against the reference-pinned proof and against the
+oracle's independent restatement of the same procedure (oracle/real_verifier.py): same verdict on every input tried."""
+import numpy as np
+import pytest
+
+from tests import test_proof_snapshot as snap
+from tests.test_verify_proof import item_offsets, oracle_proof
+
+
+def test_air_constraints_at_one_row_pair_equal_the_oracle_circuit(ctx, orc):
+    rng = np.random.default_rng(8)
+    rows = [orc.random_elements(rng, (n, 3)) for n in (379, 91, 379, 91, 63)]
+    got = np.zeros((604, 3), np.uint64)
+    ctx._check(ctx.lib.tvm_host_air_constraints(*[r.ctypes.data for r in rows], got.ctypes.data), "tvm_host_air_constraints")
+    main_cur, aux_cur, main_next, aux_next, challenges = rows
+    assert (got == orc.air_constraint_values(main_cur, main_next, aux_cur, aux_next, challenges)).all()
+
+
+def test_product_verifier_accepts_the_reference_pinned_proof_and_agrees_with_the_oracle_on_rejections(ctx):
+    from oracle import real_verifier
+    from triton_vm_amd.proof_stream import Claim, ProofDecodingError, ProofStream
+    from triton_vm_amd.verifier import VerificationError, Verifier
+
+    words, claim, indices = oracle_proof("tiny", snap.SEED_U64, 160)
+    verifier = Verifier(ctx)
+    assert verifier.verify(claim, words) == indices
+
+    def verdicts(bad_words, bad_claim, **kw):
+        out = []
+        for run in (lambda: (Verifier(ctx, **kw) if kw else verifier).verify(bad_claim, bad_words),
+                    lambda: real_verifier.verify(ProofStream.from_proof(ctx.lib, bad_words).verifier_view(), bad_claim, **kw)):
+            try:
+                run()
+                out.append("accepted")
+            except (VerificationError, real_verifier.VerificationError, ProofDecodingError, ValueError):
+                out.append("rejected")
+        return out
+
+    rng = np.random.default_rng(6)
+    for name, places in item_offsets(ctx.lib, words).items():
+        if name == "Log2PaddedHeight":
+            continue
+        start, size = places[int(rng.integers(len(places)))]
+        bad = words.copy()
+        bad[start + (size // 2 if size > 8 else size - 1)] ^= np.uint64(1)
+        assert verdicts(bad, claim) == ["rejected", "rejected"], name
+    assert verdicts(words, Claim(claim.program_digest, claim.input, claim.output, version=5)) == ["rejected", "rejected"]
+    assert verdicts(words[:-7], claim) == ["rejected", "rejected"]
+    assert verdicts(words, claim, security_level=128) == ["rejected", "rejected"]

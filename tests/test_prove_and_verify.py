@@ -1,7 +1,7 @@
 """The reference's prove-and-verify tests (`prove_and_verify_*`, /root/reference/triton-vm/src/stark.rs:4257-4317) over the
 device path: Prover.from_execution (fill, pad, extend and the hot path through the C ABI) proves, the restated
 Verifier::verify (oracle/real_verifier.py, anchored to the reference-pinned proofs in tests/test_verify_proof.py) accepts
--- and rejects the same proof under another claim.  Stark::low_security() (security level 32) like the reference's
+-- and rejects the same proof under another claim; so does the product's own verifier (triton_vm_amd/verifier.py).  Stark::low_security() (security level 32) like the reference's
 TestableProgram, plus other parameter sets for `halt`."""
 import pytest
 
@@ -33,7 +33,14 @@ def test_prove_and_verify(ctx, orc, which, security_level, log2_expansion, on_em
                                    security_level=security_level, log2_expansion=log2_expansion)
     proof = prover.prove().proof()
     kw = dict(security_level=security_level, log2_expansion=log2_expansion)
-    assert len(verify(ctx.lib, proof.words, claim, **kw)) > 0
+    accepted_at = verify(ctx.lib, proof.words, claim, **kw)
+    assert len(accepted_at) > 0
     wrong = snap.claim_of(orc, program, public_input, list(output) + [1])
     with pytest.raises(VerificationError):
         verify(ctx.lib, proof.words, wrong, **kw)
+    # ... and the product's own Verifier::verify (device batch work) gives the same verdicts
+    from triton_vm_amd import verifier as product
+
+    assert product.Verifier(ctx, **kw).verify(claim, proof.words) == accepted_at
+    with pytest.raises(product.VerificationError):
+        product.Verifier(ctx, **kw).verify(wrong, proof.words)

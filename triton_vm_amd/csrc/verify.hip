@@ -102,3 +102,60 @@ int verifier_deep_values(tvm_ctx* c, const u64* d_main_rows, int n_main, const u
 }
 
 }  // namespace tvm
+
+// ---------------------------------------------------------------------------------------------- the AIR at ONE row pair
+// Verifier::verify evaluates every constraint on the out-of-domain row pair, with XFieldElement main rows (stark.rs:1466-1523;
+// the generated evaluators are generic over the main row's field, codegen.rs:141-367).  One row pair: a walk over the lowered
+// multicircuit's DAG on the host (csrc/air_circuit_data.h, the same export as the device kernels and the oracle's header).
+#include "air_circuit_data.h"
+namespace tvm {
+static void air_dag_section(const uint32_t (*nodes)[3], uint32_t n_nodes, const uint32_t* roots, uint32_t n_roots, const u64* consts,
+                            const u64 (*xconsts)[3], const xfe* mc, const xfe* mn, const xfe* ac, const xfe* an, const xfe* ch,
+                            std::vector<xfe>& val, xfe* out) {
+    val.resize(n_nodes);
+    for (uint32_t i = 0; i < n_nodes; i++) {
+        const uint32_t kind = nodes[i][0], a = nodes[i][1], b = nodes[i][2];
+        switch (kind) {
+            case 0: val[i] = xfe_lift(consts[a]); break;
+            case 1: val[i] = xfe_make(xconsts[a][0], xconsts[a][1], xconsts[a][2]); break;
+            case 2: val[i] = mc[a]; break;
+            case 3: val[i] = mn[a]; break;
+            case 4: val[i] = ac[a]; break;
+            case 5: val[i] = an[a]; break;
+            case 6: val[i] = ch[a]; break;
+            case 7: val[i] = xfe_add(val[a], val[b]); break;
+            default: val[i] = xfe_mul(val[a], val[b]); break;
+        }
+    }
+    for (uint32_t r = 0; r < n_roots; r++) out[r] = val[roots[r]];
+}
+}  // namespace tvm
+
+extern "C" {
+int32_t tvm_host_air_constraints(const uint64_t* h_main_cur, const uint64_t* h_aux_cur, const uint64_t* h_main_next,
+                                 const uint64_t* h_aux_next, const uint64_t* h_challenges, uint64_t* h_out) {
+    using namespace tvm;
+    if (!h_main_cur || !h_aux_cur || !h_main_next || !h_aux_next || !h_challenges || !h_out) return TVM_ERR_INVALID_ARGUMENT;
+    auto rows = [](const uint64_t* w, size_t n) {
+        std::vector<xfe> v(n);
+        for (size_t i = 0; i < n; i++) v[i] = xfe_make(w[3 * i], w[3 * i + 1], w[3 * i + 2]);
+        return v;
+    };
+    const std::vector<xfe> mc = rows(h_main_cur, TVM_NUM_MAIN_COLUMNS), ac = rows(h_aux_cur, TVM_NUM_AUX_COLUMNS),
+                           mn = rows(h_main_next, TVM_NUM_MAIN_COLUMNS), an = rows(h_aux_next, TVM_NUM_AUX_COLUMNS),
+                           ch = rows(h_challenges, TVM_NUM_CHALLENGES);
+    std::vector<xfe> val, out(TVM_NUM_QUOTIENT_WEIGHTS);
+    xfe* o = out.data();
+#define TVM_AIR_DAG_SECTION(S)                                                                                              \
+    air_dag_section(TVM_AIR_DAG_##S##_NODES, TVM_AIR_DAG_##S##_NUM_NODES, TVM_AIR_DAG_##S##_ROOTS, TVM_AIR_DAG_##S##_NUM_ROOTS, \
+                    TVM_AIR_DAG_##S##_CONSTS, TVM_AIR_DAG_##S##_XCONSTS, mc.data(), mn.data(), ac.data(), an.data(), ch.data(), val, o); \
+    o += TVM_AIR_DAG_##S##_NUM_ROOTS;
+    TVM_AIR_DAG_SECTION(INIT) TVM_AIR_DAG_SECTION(CONS) TVM_AIR_DAG_SECTION(TRAN) TVM_AIR_DAG_SECTION(TERM)
+#undef TVM_AIR_DAG_SECTION
+    static_assert(TVM_AIR_DAG_INIT_NUM_ROOTS + TVM_AIR_DAG_CONS_NUM_ROOTS + TVM_AIR_DAG_TRAN_NUM_ROOTS + TVM_AIR_DAG_TERM_NUM_ROOTS ==
+                      TVM_NUM_QUOTIENT_WEIGHTS, "604 constraints");
+    for (size_t i = 0; i < out.size(); i++) h_out[3 * i] = out[i].c0, h_out[3 * i + 1] = out[i].c1, h_out[3 * i + 2] = out[i].c2;
+    return TVM_OK;
+}
+}  // extern "C"
+

@@ -133,7 +133,14 @@ def test_prove_with_stir_as_the_low_degree_test(ctx, orc):
     p2.stir = stir
     assert p2.ldt.length == stir.initial_domain.length
     prover = Prover(ctx, p2, seed=4)
-    prover.prove()
+    stream = prover.prove()
+    # the proof with its StirResponse / StirOutOfDomainValues items decodes and re-encodes to itself
+    from triton_vm_amd.proof_stream import ProofStream
+
+    words = stream.proof().words
+    decoded = ProofStream.from_proof(ctx.lib, words)
+    assert (decoded.proof().words == words).all()
+    assert [v for v, _ in decoded.items].count("stir response leafs") == len(stir.round_queries) + 1
     final = so.poly_trim(list(prover.last_polynomial))
     assert 0 < len(final) <= stir.final_degree + 1
     assert set(prover.opened) == {"main", "aux"} and prover.opened["main"].shape[0] == stir.num_first_round_queries()

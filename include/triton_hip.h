@@ -305,6 +305,9 @@ void tvm_host_sponge_pad_and_absorb(uint64_t state[16], const uint64_t* words, u
 void tvm_host_xfe_mul(const uint64_t a[3], const uint64_t b[3], uint64_t out[3]);
 void tvm_host_xfe_inv(const uint64_t a[3], uint64_t out[3]);
 void tvm_host_xfe_powers(const uint64_t x[3], uint64_t first_exponent, uint64_t n, uint64_t* out /* n XFE */);
+/* out[j] = sum_i coeffs[i] * points[j]^i, or with zerofier != 0: prod_i (points[j] - coeffs[i]); n, m XFE in, m XFE out */
+void tvm_host_xfe_poly_eval(const uint64_t* coeffs, uint64_t n, const uint64_t* points, uint64_t m, int32_t zerofier,
+                            uint64_t* out);
 /* n draws of `rng.random::<BFieldElement>()` from `StdRng::from_seed(seed)` (the prover's trace, batch and quotient
  * randomizers: master_table.rs:423-434, 1006-1024, stark.rs:1315-1322; a Rust host uses rand itself), Montgomery words */
 void tvm_host_stdrng_elements(const uint8_t seed[32], uint64_t n, uint64_t* out);

@@ -74,10 +74,10 @@ if "--no-verify" not in sys.argv:
     out["verified"] = True
     out["verifier_s"] = round(time.perf_counter() - t0, 1)
     out["revealed_rows"] = len(indices)
-    if ldt == "fri":   # the product's own Verifier::verify (device batch work)
+    if True:   # the product's own Verifier::verify (device batch work)
         from triton_vm_amd.verifier import Verifier
 
         t0 = time.perf_counter()
-        out["product_verifier_agrees"] = Verifier(ctx).verify(claim, proof.words) == indices
+        out["product_verifier_agrees"] = Verifier(ctx, ldt=ldt).verify(claim, proof.words) == indices
         out["product_verifier_s"] = round(time.perf_counter() - t0, 2)
 print(json.dumps(out))

@@ -49,3 +49,48 @@ def test_product_verifier_accepts_the_reference_pinned_proof_and_agrees_with_the
     assert verdicts(words, Claim(claim.program_digest, claim.input, claim.output, version=5)) == ["rejected", "rejected"]
     assert verdicts(words[:-7], claim) == ["rejected", "rejected"]
     assert verdicts(words, claim, security_level=128) == ["rejected", "rejected"]
+
+
+def test_product_stir_verifier_agrees_with_the_oracle_restatement(ctx, orc):
+    """Verifier._stir_verify (stir.rs:995-1340) on the transcripts of tests/test_ldt_verifiers.py: accepted with the prover's
+    first-round indices and the values of the codeword there; high degree and tampering rejected"""
+    from tests.test_ldt_verifiers import odom, small_stir
+    from triton_vm_amd.prover import ProofStream
+    from triton_vm_amd.verifier import VerificationError, Verifier, _xfe
+
+    verifier = Verifier(ctx, ldt="stir")
+    X = _xfe(ctx.lib)
+
+    def run(stream, stir):
+        view = stream.verifier_view()
+        return verifier._stir_verify(view, view.dequeue, stir, X)
+
+    for log2_bound, queries in [(6, [(3, 1), (2, 0)]), (8, [(5, 2), (3, 1), (4, 0)]), (4, [(3, 0)])]:
+        rng = np.random.default_rng(log2_bound)
+        stir = small_stir(log2_bound, queries)
+        poly = orc.random_elements(rng, (1 << log2_bound, 3))
+        codeword = orc.coset_evaluate(poly, odom(orc, stir.initial_domain), 3).reshape(-1, 3)
+        ps = ProofStream(ctx.lib)
+        first = stir.prove(ctx, ctx.to_device(codeword), ps)
+        indices, values = run(ps, stir)
+        assert indices == first and (values == codeword[first]).all()
+    # too high a degree
+    poly = orc.random_elements(rng, (stir.initial_domain.length, 3))
+    codeword = orc.coset_evaluate(poly, odom(orc, stir.initial_domain), 3).reshape(-1, 3)
+    ps = ProofStream(ctx.lib)
+    stir.prove(ctx, ctx.to_device(codeword), ps)
+    with pytest.raises(VerificationError):
+        run(ps, stir)
+    # tampering
+    stir = small_stir(6, [(3, 1), (2, 0)])
+    codeword = orc.coset_evaluate(orc.random_elements(rng, (1 << 6, 3)), odom(orc, stir.initial_domain), 3).reshape(-1, 3)
+    ps = ProofStream(ctx.lib)
+    stir.prove(ctx, ctx.to_device(codeword), ps)
+    run(ps, stir)
+    for victim in ("stir response leafs", "stir response auth", "stir ood values", "stir final polynomial", "stir root"):
+        bad = ProofStream(ctx.lib)
+        bad.log = [(n, pl.copy(), fs) for n, pl, fs in ps.log]
+        k = next(i for i, (n, pl, _) in enumerate(bad.log) if n == victim and pl.size)
+        bad.log[k][1].reshape(-1)[0] ^= np.uint64(1)
+        with pytest.raises(VerificationError):
+            run(bad, stir)

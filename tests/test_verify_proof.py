@@ -128,6 +128,12 @@ def test_prove_fib_with_stir_on_the_device_is_accepted(gpu_ctx, orc, index, log2
 
     with pytest.raises(VerificationError):
         verify(gpu_ctx.lib, proof.words, snap.claim_of(orc, program, [index + 1], output), ldt_choice="stir")
+    # the product's Verifier::verify with STIR: the same verdicts
+    from triton_vm_amd import verifier as product
+
+    assert product.Verifier(gpu_ctx, ldt="stir").verify(claim, proof.words) == verify(gpu_ctx.lib, proof.words, claim, ldt_choice="stir")
+    with pytest.raises(product.VerificationError):
+        product.Verifier(gpu_ctx, ldt="stir").verify(snap.claim_of(orc, program, [index + 1], output), proof.words)
 
 
 def test_arbitrary_corruptions_never_escape_as_other_errors(host_lib):

@@ -796,6 +796,19 @@ void tvm_host_xfe_powers(const uint64_t x[3], uint64_t first, uint64_t n, uint64
         p = xfe_mul(p, b);
     }
 }
+// out[j] = sum_i coeffs[i] * points[j]^i (Horner) -- and, with `zerofier` set, prod_i (points[j] - coeffs[i]):
+// the verifier's scalar polynomial work (STIR's answer polynomial and quotient-set zerofier at the queried points)
+void tvm_host_xfe_poly_eval(const uint64_t* coeffs, uint64_t n, const uint64_t* points, uint64_t m, int32_t zerofier, uint64_t* out) {
+    for (uint64_t j = 0; j < m; j++) {
+        const xfe x = xfe_make(points[3 * j], points[3 * j + 1], points[3 * j + 2]);
+        xfe acc = zerofier ? xfe_one() : xfe_zero();
+        if (zerofier)
+            for (uint64_t i = 0; i < n; i++) acc = xfe_mul(acc, xfe_sub(x, xfe_make(coeffs[3 * i], coeffs[3 * i + 1], coeffs[3 * i + 2])));
+        else
+            for (uint64_t i = n; i-- > 0;) acc = xfe_add(xfe_mul(acc, x), xfe_make(coeffs[3 * i], coeffs[3 * i + 1], coeffs[3 * i + 2]));
+        out[3 * j] = acc.c0; out[3 * j + 1] = acc.c1; out[3 * j + 2] = acc.c2;
+    }
+}
 
 /* StdRng of rand [not vendored in the reference tree; restated, pinned by the proof-digest snapshots through
  * tests/test_proof_snapshot.py]: ChaCha with 12 rounds, 64-bit block counter, the blocks' 16 words as a u32 stream, next_u64 =

@@ -91,6 +91,15 @@ def _xfe(lib):
     return X
 
 
+def _trimmed(polynomial):
+    """coefficients without trailing zeros (a decoded Polynomial has none; a prover's own stream may)"""
+    c = _h(polynomial).reshape(-1, 3)
+    n = len(c)
+    while n and not c[n - 1].any():
+        n -= 1
+    return c[:n]
+
+
 def hash_pair(lib, left, right):
     """Tip5::hash_pair on the host: the fixed-length domain (capacity of ones)"""
     from . import field
@@ -135,10 +144,11 @@ class Verifier:
     """Verifier::verify (/root/reference/triton-vm/src/stark.rs:1388-1763) with FRI as the low-degree test (fri.rs:368-700):
     the host sequences the Fiat-Shamir schedule and the decisions; the row hashing and the per-row combination values run
     on the device (tvm_verifier_row_digests, tvm_verifier_deep_values), the AIR at the out-of-domain rows through
-    tvm_host_air_constraints.  STIR proofs (Stark::ldt's choice from 2^16 padded rows on) are not handled here."""
+    tvm_host_air_constraints.  ldt: "fri" or "stir" (stir.rs:995-1340) -- Stark::ldt picks by padded height
+    (stark.rs:1944-1951: STIR from 2^16 on); None applies that rule."""
 
-    def __init__(self, ctx, security_level=160, log2_expansion=2):
-        self.ctx, self.security_level, self.log2_expansion = ctx, security_level, log2_expansion
+    def __init__(self, ctx, security_level=160, log2_expansion=2, ldt="fri"):
+        self.ctx, self.security_level, self.log2_expansion, self.ldt = ctx, security_level, log2_expansion, ldt
 
     def verify(self, claim, proof_words):
         """raises VerificationError / ProofDecodingError; returns the revealed row indices on acceptance"""
@@ -165,9 +175,18 @@ class Verifier:
         log2_padded_height = field.from_mont(int(dequeue("Log2PaddedHeight")[0]))
         if log2_padded_height >= 32:
             raise VerificationError("Log2PaddedHeightTooLarge")
-        checks = math.ceil(-self.security_level / math.log2(1.0 - ReedSolomonCode(self.log2_expansion).proximity_parameter()))
-        p = StarkParameters(log2_padded_height, num_trace_randomizers=checks + 4 * 3 * 2 + 1, num_collinearity_checks=checks,
-                            log2_expansion=self.log2_expansion)
+        ldt = self.ldt or ("fri" if log2_padded_height < 16 else "stir")
+        if ldt == "stir":
+            from .low_degree_test import stark_stir
+
+            stir = stark_stir(1 << log2_padded_height, security_level=self.security_level, log2_ldt_expansion_factor=self.log2_expansion)
+            checks = stir.num_first_round_queries()
+            p = StarkParameters(log2_padded_height, num_trace_randomizers=stir.num_trace_randomizers(), log2_expansion=self.log2_expansion)
+            p.ldt = stir.initial_domain
+        else:
+            checks = math.ceil(-self.security_level / math.log2(1.0 - ReedSolomonCode(self.log2_expansion).proximity_parameter()))
+            p = StarkParameters(log2_padded_height, num_trace_randomizers=checks + 4 * 3 * 2 + 1, num_collinearity_checks=checks,
+                                log2_expansion=self.log2_expansion)
         L = p.ldt.length
 
         # Fiat-Shamir 1 (stark.rs:1418-1437)
@@ -213,7 +232,9 @@ class Verifier:
                       X.sum(X.mul(seg_p[i], w_q[i]) for i in range(4)), X.sum(X.mul(seg_r[i], w_q[i + 1]) for i in range(4))]
 
         # the low-degree test (stark.rs:1577-1590)
-        indices, revealed = self._fri_verify(view, dequeue, p, X)
+        indices, revealed = self._stir_verify(view, dequeue, stir, X) if ldt == "stir" else self._fri_verify(view, dequeue, p, X)
+        if len(indices) != checks or len(revealed) != checks:
+            raise VerificationError("IncorrectNumberOfRowIndices")
 
         # the revealed rows against their roots, hashed on the device (stark.rs:1592-1672)
         def rows_of(variant, width, root, error):
@@ -250,7 +271,7 @@ class Verifier:
             dom = dom.pow(2)
         last_domain = rounds[-1][0]
         last_codeword = _h(dequeue("FriCodeword")).reshape(-1, 3)
-        last_polynomial = _h(dequeue("Polynomial")).reshape(-1, 3)
+        last_polynomial = _trimmed(dequeue("Polynomial"))
         if len(last_codeword) != last_domain.length:
             raise VerificationError("LastCodewordMismatch")
         a0 = view.sample_indices(p.ldt.length, checks)
@@ -297,3 +318,114 @@ class Verifier:
         if not (claimed == at_x).all():
             raise VerificationError("LastRoundPolynomialEvaluationMismatch")
         return a0, first
+
+    def _stir_verify(self, view, dequeue, stir, X):
+        """Stir::verify (stir.rs:995-1340) -> (first-round indices, the partially revealed first codeword)"""
+        from . import field
+        from .low_degree_test import Stir
+
+        ctx, lib, ff = self.ctx, self.ctx.lib, stir.folding_factor
+
+        def poly_eval(coefficients, points, zerofier=False):
+            c, pts = _h(coefficients).reshape(-1, 3), _h(points).reshape(-1, 3)
+            out = np.zeros((len(pts), 3), np.uint64)
+            lib.tvm_host_xfe_poly_eval(c.ctypes.data, len(c), pts.ctypes.data, len(pts), 1 if zerofier else 0, out.ctypes.data)
+            return out
+
+        def interpolate(points, values):
+            pts, vals = _h(points).reshape(-1, 3), _h(values).reshape(-1, 3)
+            out = np.zeros((len(pts), 3), np.uint64)
+            if lib.tvm_host_xfe_interpolate(pts.ctypes.data, vals.ctypes.data, len(pts), out.ctypes.data):
+                raise VerificationError("repeated point in an interpolation")
+            return out
+
+        def queries(domain, num_queries, root):
+            """extract_inclusion_proof + authenticated_queries (stir.rs:1157-1226)"""
+            indices = view.sample_indices(domain.length, num_queries)
+            leafs = _h(dequeue("stir response leafs"))
+            auth = dequeue("stir response auth")
+            folded_len = domain.length // ff
+            folded = list(dict.fromkeys(i % folded_len for i in indices))
+            if leafs.ndim != 3 or leafs.shape[1:] != (ff, 3) or len(leafs) != len(folded):
+                raise VerificationError("IncorrectNumberOfRevealedLeaves")
+            verify_inclusion(lib, root, folded_len, folded, row_digests(ctx, leafs.reshape(len(folded), ff * 3)), auth,
+                             "BadMerkleAuthenticationPath")
+            by_index = dict(zip(folded, leafs))
+            folded_domain = domain.pow(ff)
+            kth_root = field.mont_pow(domain.generator, folded_len)
+            return indices, [dict(index=i, point=folded_domain.value(i % folded_len), root=domain.value(i % folded_len), kth_root=kth_root,
+                                  values=by_index[i % folded_len]) for i in indices]
+
+        def fold_at(query, values, randomness):
+            """fast_coset_interpolate(root, values).evaluate(randomness): degree < ff through root * <kth_root>"""
+            pts, x = [], query["root"]
+            for _ in range(ff):
+                pts.append(X.lift(x))
+                x = field.mont_mul(x, query["kth_root"])
+            return poly_eval(interpolate(pts, values), [randomness])[0]
+
+        def partial_codeword(domain, qs):
+            return np.array([q["values"][q["index"] // (domain.length // ff)] for q in qs], np.uint64)
+
+        def in_domain_answers(qs, folding_randomness, previous):
+            if previous is None:        # initial_in_domain_answers (stir.rs:1259-1268)
+                return [fold_at(q, q["values"], folding_randomness) for q in qs]
+            quotient_set, quotient_answers, rc = previous   # subsequent_in_domain_answers (stir.rs:1270-1340)
+            answer_poly = interpolate(quotient_set, quotient_answers)
+            e = len(quotient_set) + 1
+            one = X.lift(field.ONE)
+            out = []
+            for q in qs:
+                xs, x = [], q["root"]
+                for _ in range(ff):
+                    xs.append(X.lift(x))
+                    x = field.mont_mul(x, q["kth_root"])
+                answers, zerofiers = poly_eval(answer_poly, xs), poly_eval(quotient_set, xs, zerofier=True)
+                evaluations = []
+                for j in range(ff):
+                    quotient = X.mul(X.sub(q["values"][j], answers[j]), X.inv(zerofiers[j]))
+                    common = X.mul(xs[j], rc)
+                    if (common == one).all():
+                        factor = X.lift(field.to_mont(e))
+                    else:
+                        factor = X.mul(X.sub(one, X.powers(common, 1, e)[0]), X.inv(X.sub(one, common)))
+                    evaluations.append(X.mul(factor, quotient))
+                out.append(fold_at(q, evaluations, folding_randomness))
+            return out
+
+        domain = stir.initial_domain
+        previous_root = dequeue("MerkleRoot")
+        previous = first_indices = first_codeword = None
+        for in_domain, out_of_domain in stir.round_queries:
+            folding_randomness = view.sample_scalars(1)[0]
+            current_root = dequeue("MerkleRoot")
+            ood_queries = view.sample_scalars(out_of_domain)
+            ood_answers = _h(dequeue("StirOutOfDomainValues")).reshape(-1, 3)
+            if len(ood_answers) != out_of_domain:
+                raise VerificationError("IncorrectNumberOfOutOfDomainValues")
+            indices, qs = queries(domain, in_domain, previous_root)
+            if first_indices is None:
+                first_indices, first_codeword = indices, partial_codeword(domain, qs)
+            answers = in_domain_answers(qs, folding_randomness, previous)
+            quotient_set, quotient_answers, seen = [], [], set()   # queried indices repeat; interpolation points must not
+            for point, answer in list(zip([X.lift(q["point"]) for q in qs], answers)) + list(zip(ood_queries, ood_answers)):
+                key = tuple(int(c) for c in point)
+                if key not in seen:
+                    seen.add(key)
+                    quotient_set.append(_h(point))
+                    quotient_answers.append(_h(answer))
+            previous = (np.array(quotient_set, np.uint64), np.array(quotient_answers, np.uint64), view.sample_scalars(1)[0])
+            domain, previous_root = Stir.next_round_domain(domain), current_root
+        folding_randomness = view.sample_scalars(1)[0]
+        final = _trimmed(dequeue("Polynomial"))
+        if max(len(final) - 1, 0) > stir.final_degree:
+            raise VerificationError("LastRoundPolynomialHasTooHighDegree")
+        indices, qs = queries(domain, stir.final_num_in_domain_queries, previous_root)
+        if first_indices is None:
+            first_indices, first_codeword = indices, partial_codeword(domain, qs)
+        want = poly_eval(final, [X.lift(q["point"]) for q in qs]) if len(final) else np.zeros((len(qs), 3), np.uint64)
+        for got, expected in zip(in_domain_answers(qs, folding_randomness, previous), want):
+            if not (got == expected).all():
+                raise VerificationError("LastRoundPolynomialEvaluationMismatch")
+        return first_indices, first_codeword
+

@@ -42,10 +42,12 @@ for attempt in range(2):                    # the second pass is the warm one
     prover = Prover.from_execution(ctx, arrays, padded_height, claim, seed, ldt=ldt)
     ctx.sync()
     t1 = time.perf_counter()
-    stream = prover.prove()
+    stream = prover.prove(profile="--profile" in sys.argv)
     ctx.sync()
     t2 = time.perf_counter()
     proof = stream.proof()
+    if "--profile" in sys.argv:
+        print({k: round(v, 1) for k, v in prover.timings.items()}, file=sys.stderr)
     result = {"fill_pad_randomizers_ms": 1e3 * (t1 - t0), "extend_and_hot_path_ms": 1e3 * (t2 - t1), "proof_words": int(proof.words.size)}
     prover.release()
     del prover

@@ -206,7 +206,7 @@ def main():
     cells_per_step = params.padded_height * MASTER_WORDS * (1 if sharded else world)
 
     step, host = prover.prove, "python"
-    if args.host == "cpp" and not sharded and not args.jit_passes and args.ldt == "fri" and not test_emu:
+    if args.host == "cpp" and not sharded and not args.jit_passes and not test_emu:
         from triton_vm_amd import native_host
 
         try:
@@ -317,10 +317,15 @@ def main():
             prover.release()
             sp = StarkParameters(args.log2_rows, ldt="stir", log2_expansion=args.log2_expansion)
             stir = Prover(ctx, sp, seed=1000)
-            t = timed_steps(stir.prove, 2, 1, ctx.sync)
+            stir_step, stir_host = stir.prove, "python"
+            if host == "cpp":
+                native_stir = native_host.NativeProver(ctx, host_lib, sp, stir.main.d_trace, stir.main.d_randomizers, stir.aux.d_trace,
+                                                       stir.aux.d_randomizers, stir.quotient_randomizer)
+                stir_step, stir_host = (lambda: native_stir.prove(parse=False)), "cpp"
+            t = timed_steps(stir_step, 2, 1, ctx.sync)
             out["reference_default_ldt"] = {"ldt": "stir", "trace_randomizers": sp.h, "ms_per_step": round(1e3 * t / 2, 3),
                                             "value": round(sp.padded_height * MASTER_WORDS * 2 / t, 1), "unit": "trace-cells/s",
-                                            "host": "python"}
+                                            "host": stir_host}
             stir.release()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.log2_rows)

@@ -49,6 +49,47 @@ def test_cpp_host_proves_the_reference_snapshot_from_the_execution_trace(ctx, or
     assert Proof(words).digest(ctx.lib) == snap.SNAPSHOT
 
 
+@pytest.mark.parametrize("log2_bound,queries", [(6, [(3, 1), (2, 0)]), (8, [(5, 2), (3, 1), (4, 0)]), (4, [(3, 0)])])
+def test_cpp_stir_prover_equals_python_stir_prover(ctx, orc, log2_bound, queries):
+    """Stir::prove of the C++ host (quotienting rounds included) against the Python host's: the same proof words"""
+    from tests.test_ldt_verifiers import odom, small_stir
+    from triton_vm_amd.prover import ProofStream
+
+    rng = np.random.default_rng(log2_bound)
+    stir = small_stir(log2_bound, queries)
+    poly = orc.random_elements(rng, (1 << log2_bound, 3))
+    d_codeword = ctx.to_device(orc.coset_evaluate(poly, odom(orc, stir.initial_domain), 3).reshape(-1, 3))
+    ps = ProofStream(ctx.lib)
+    want_first = stir.prove(ctx, d_codeword, ps)
+    first, words = native_host.stir_prove(ctx, _host_library(ctx), stir, d_codeword)
+    assert first == want_first
+    assert (words == ps.proof().words).all()
+
+
+def test_cpp_stir_parameters_and_whole_proof_equal_the_python_hosts(ctx, orc):
+    """LdtChoice::Stir through tvmh_prove: Stark::stir's instance (derived in C++) and the proof equal the Python host's.
+    On the emulation the default-security instance at this size has no quotienting round (covered above); on the GPU the
+    test runs at 2^16 padded rows, where it has four."""
+    from triton_vm_amd.low_degree_test import stark_stir
+
+    host = _host_library(ctx)
+    for log2_height, security_level, log2_expansion in ((3, 160, 2), (10, 160, 2), (16, 160, 2), (20, 160, 2), (22, 128, 3), (20, 80, 1), (24, 160, 4)):
+        want = stark_stir(1 << log2_height, security_level=security_level, log2_ldt_expansion_factor=log2_expansion)
+        got = native_host.stir_parameters(host, 1 << log2_height, security_level, log2_expansion)
+        assert got == dict(domain_length=want.initial_domain.length, folding_factor=want.folding_factor, round_queries=want.round_queries,
+                           final_num_in_domain_queries=want.final_num_in_domain_queries, final_degree=want.final_degree)
+    if ctx.kind == "emu":
+        return   # the whole proof with the derived instance: GPU (2^16 padded rows, four quotienting rounds)
+    p = StarkParameters(16, ldt="stir")
+    assert len(p.stir.round_queries) >= 3
+    py = Prover(ctx, p, seed=12)
+    want = py.prove().proof().words
+    native = native_host.NativeProver(ctx, _host_library(ctx), p, py.main.d_trace, py.main.d_randomizers, py.aux.d_trace,
+                                      py.aux.d_randomizers, py.quotient_randomizer)
+    got = native.prove()
+    assert got.size == want.size and (got == want).all()
+
+
 def test_cpp_host_reports_errors(ctx):
     p = StarkParameters(3, num_trace_randomizers=3, num_collinearity_checks=2)
     lib = _host_library(ctx)

@@ -117,7 +117,8 @@ const Variant VARIANTS[] = {
 const struct { const char* prefix; int variant; } LABELS[] = {
     {"log2 padded height", 1}, {"ood main", 2}, {"ood aux", 3}, {"ood quot", 4}, {"fri last codeword", 11},
     {"fri last polynomial", 5}, {"fri response", 12}, {"fri auth", 12}, {"main rows", 8}, {"aux rows", 9}, {"quot rows", 10},
-    {"main auth", 7}, {"aux auth", 7}, {"quot auth", 7}, {"main root", 0}, {"aux root", 0}, {"quot root", 0}, {"fri root", 0}};
+    {"main auth", 7}, {"aux auth", 7}, {"quot auth", 7}, {"main root", 0}, {"aux root", 0}, {"quot root", 0}, {"fri root", 0},
+    {"stir root", 0}, {"stir ood values", 6}, {"stir final polynomial", 5}, {"stir response leafs", 13}, {"stir response auth", 13}};
 int variant_of(const std::string& label) {
     for (const auto& l : LABELS)
         if (label.compare(0, std::strlen(l.prefix), l.prefix) == 0) return l.variant;
@@ -140,7 +141,7 @@ Words encode_polynomial(const u64* w, u64 n_words) {
     append_dynamic(out, encode_vec(w, 3 * n, 3));  // struct { coefficients: Vec<XFieldElement> }
     return out;
 }
-Words encode_item(int variant, const Words& payload, const Words* auth_structure) {
+Words encode_item(int variant, const Words& payload, const Words* auth_structure, u64 stack_words = 0) {
     const Variant& v = VARIANTS[variant];
     Words out;
     push_len(out, (u64)variant);
@@ -151,9 +152,15 @@ Words encode_item(int variant, const Words& payload, const Words* auth_structure
     } else if (v.kind == POLYNOMIAL) {
         append_dynamic(out, encode_polynomial(payload.data(), payload.size()));
     } else {  // FriResponse { queried_leaves: Vec<XFieldElement>, auth_structure: Vec<Digest> } (fri.rs:101-108)
-        Words response;
+        Words response, leaves;
         append_dynamic(response, encode_vec(auth_structure->data(), auth_structure->size(), 5));
-        append_dynamic(response, encode_vec(payload.data(), payload.size(), 3));
+        if (stack_words) {  // StirResponse { queried_leafs: Vec<Vec<XFieldElement>>, .. } (stir.rs:150-168)
+            push_len(leaves, payload.size() / stack_words);
+            for (u64 at = 0; at < payload.size(); at += stack_words) append_dynamic(leaves, encode_vec(payload.data() + at, stack_words, 3));
+        } else {
+            leaves = encode_vec(payload.data(), payload.size(), 3);
+        }
+        append_dynamic(response, leaves);
         append_dynamic(out, response);
     }
     return out;
@@ -172,14 +179,14 @@ Words Claim::encode() const {  // proof.rs:62-84: program_digest, version, input
 void ProofStream::alter_fiat_shamir_state_with(const Words& encoding) {  // proof_stream.rs:40-42
     tvm_host_sponge_pad_and_absorb(state_, encoding.data(), encoding.size());
 }
-void ProofStream::enqueue(const std::string& name, const u64* words, u64 n) {
+void ProofStream::enqueue(const std::string& name, const u64* words, u64 n, u64 stack_words) {
     // proof_stream.rs:54-59: the item always goes into the proof; it alters the sponge only if
     // ProofItem::include_in_fiat_shamir_heuristic says so (proof_item.rs:96-150: roots, out-of-domain rows, polynomials do;
     // authentication structures, opened rows, the FRI codeword and responses do not -- the prover is already committed to
     // them through a Merkle root)
     const int variant = variant_of(name);
     const bool fiat_shamir = VARIANTS[variant].fiat_shamir;
-    items_.push_back(Item{name, Words(words, words + n), fiat_shamir});
+    items_.push_back(Item{name, Words(words, words + n), fiat_shamir, stack_words});
     if (fiat_shamir) alter_fiat_shamir_state_with(encode_item(variant, items_.back().words, nullptr));
 }
 Words ProofStream::proof() const {  // impl From<&ProofStream> for Proof, proof_stream.rs:115-119
@@ -188,7 +195,7 @@ Words ProofStream::proof() const {  // impl From<&ProofStream> for Proof, proof_
     for (size_t k = 0; k < items_.size(); k++, count++) {
         const int variant = variant_of(items_[k].name);
         const bool response = VARIANTS[variant].kind == RESPONSE;  // its leaves and its authentication structure: one item
-        append_dynamic(items, encode_item(variant, items_[k].words, response ? &items_[k + 1].words : nullptr));
+        append_dynamic(items, encode_item(variant, items_[k].words, response ? &items_[k + 1].words : nullptr, items_[k].stack_words));
         if (response) k++;
     }
     Words vec;
@@ -289,6 +296,7 @@ StarkParameters::StarkParameters(unsigned log2_padded_height, u64 num_trace_rand
     const int rounds = max_rounds - ((int)bit_length(checks) - 1) - 1;
     fri_rounds = rounds > 0 ? (unsigned)rounds : 0;
     num_quotient_randomizers = (h + 1) * 5;
+    this->log2_expansion = log2_expansion;
 }
 
 // ------------------------------------------------------------------------------------------------ helpers of prove
@@ -519,7 +527,7 @@ ProofStream Prover::prove() {
     }
 
     // 17: the low-degree test  (stark.rs:641-663)
-    const std::vector<u64> a_indices = fri(combination, ps);
+    const std::vector<u64> a_indices = p_.use_stir ? p_.stir.prove(c_, combination.ptr(), ps) : fri(combination, ps);
 
     // 18: the out-of-domain point must not collide with a revealed in-domain point  (stark.rs:645-663)
     if (a4.c[1] == 0 && a4.c[2] == 0) {
@@ -554,6 +562,203 @@ ProofStream Prover::prove() {
     return ps;
 }
 
+// ------------------------------------------------------------------------------------------------ STIR
+namespace {
+const double LOG2_FIELD_SIZE_F = 191.99999999899228;  // ReedSolomonCode::LOG2_FIELD_SIZE (low_degree_test/mod.rs:226)
+const int LOG2_FIELD_SIZE = 64 * 3, LOG2_DOMAIN_SHRINKAGE = 1, LOG2_FOLDING_FACTOR = 2;  // stir.rs:404-412
+// ReedSolomonCode with proven soundness (mod.rs:93-170)
+double proximity_parameter(unsigned log2_expansion) {
+    const double margin = std::sqrt(1.0 / (double)(1ull << log2_expansion));
+    return 1.0 - margin - margin / 20.0;
+}
+double log2_list_size(unsigned log2_expansion) {
+    const double rate = 1.0 / (double)(1ull << log2_expansion);
+    return std::log2(1.0 / (2.0 * std::sqrt(rate) * (std::sqrt(rate) / 20.0)));
+}
+double log2_binomial_coefficient(u64 a, u64 b) {  // stir.rs:779-793: Kahan-compensated sum of log2 terms
+    double log2_binom = 0.0, compensation = 0.0;
+    for (u64 i = 0; i < std::min(b, a - b); i++) {
+        const double summand = std::log2((double)(a - i)) - std::log2((double)(i + 1));
+        const double corrected = summand - compensation;
+        const double next = log2_binom + corrected;
+        compensation = (next - log2_binom) - corrected;
+        log2_binom = next;
+    }
+    return log2_binom;
+}
+u64 num_in_domain_queries(unsigned security_level, unsigned log2_domain_size, unsigned log2_expansion) {  // stir.rs:597-700
+    u64 uniques = (u64)std::ceil(-(double)security_level / std::log2(1.0 - proximity_parameter(log2_expansion)));
+    uniques = std::min<u64>(uniques, 1ull << log2_domain_size);
+    const u64 k_minus_1 = uniques - 1, domain_len = 1ull << log2_domain_size;
+    const double log2_u_choose_l = log2_binomial_coefficient(domain_len, std::min(k_minus_1, domain_len / 2));
+    const double log2_k_minus_1 = k_minus_1 ? std::max(std::log2((double)k_minus_1), 0.0) : 0.0;
+    return (u64)std::ceil(((double)security_level + log2_k_minus_1 + log2_u_choose_l) / ((double)log2_domain_size - log2_k_minus_1));
+}
+u64 num_ood_queries(unsigned security_level, unsigned log2_poly_degree, unsigned log2_expansion) {  // stir.rs:702-777
+    return (u64)std::ceil(((double)security_level - 1.0 + 2.0 * log2_list_size(log2_expansion)) / (double)(LOG2_FIELD_SIZE - (int)log2_poly_degree));
+}
+// StirParameters::try_into_stir (stir.rs:420-560) with folding factor 4
+bool try_into_stir(unsigned security_level, unsigned log2_expansion, unsigned log2_high_degree_bound, Stir* out) {
+    if (log2_expansion == 0 || log2_high_degree_bound < (unsigned)LOG2_FOLDING_FACTOR) throw Error(TVM_ERR_INVALID_ARGUMENT, "LdtParameterError");
+    const unsigned log2_len = log2_high_degree_bound + log2_expansion;
+    if (log2_len > 32) throw Error(TVM_ERR_INVALID_ARGUMENT, "InitialDomainTooBig");
+    Stir stir;
+    stir.folding_factor = 1ull << LOG2_FOLDING_FACTOR;
+    stir.initial_domain = ArithmeticDomain::of_length(1ull << log2_len).with_offset(generator());
+    u64 folded_poly_degree = ((1ull << log2_high_degree_bound) - 1) / stir.folding_factor;
+    unsigned log2_exp = log2_expansion, log2_folded_domain_size = log2_len - LOG2_FOLDING_FACTOR;
+    auto ilog2 = [](u64 v) { unsigned n = 0; while (v >>= 1) n++; return n; };
+    while (folded_poly_degree > stir.folding_factor) {
+        const u64 in_domain = num_in_domain_queries(security_level, log2_folded_domain_size, log2_exp);
+        const unsigned log2_next_exp = log2_exp + LOG2_FOLDING_FACTOR - LOG2_DOMAIN_SHRINKAGE;
+        const u64 out_of_domain = num_ood_queries(security_level, ilog2(folded_poly_degree), log2_next_exp);
+        const u64 next_degree = folded_poly_degree / stir.folding_factor;
+        if (in_domain + out_of_domain > next_degree) break;
+        stir.round_queries.push_back({in_domain, out_of_domain});
+        folded_poly_degree = next_degree;
+        log2_exp = log2_next_exp;
+        log2_folded_domain_size -= LOG2_DOMAIN_SHRINKAGE;
+    }
+    stir.final_num_in_domain_queries = num_in_domain_queries(security_level, log2_folded_domain_size, log2_exp);
+    stir.final_degree = folded_poly_degree;
+    *out = stir;
+    return true;
+}
+u64 randomized_trace_len_for(u64 padded_height, u64 h) {  // stark.rs:1885-1896
+    const u64 total = std::max({padded_height + h, 2 * h + 1, (h + 1) * 5});
+    u64 len = 1;
+    while (len < total) len <<= 1;
+    return len;
+}
+}  // namespace
+
+Stir Stir::for_stark(u64 padded_height, unsigned security_level, unsigned log2_expansion) {
+    unsigned log2_bound = 0;
+    while ((1ull << log2_bound) < padded_height) log2_bound++;
+    padded_height = 1ull << log2_bound;
+    // the instance's query count fixes the number of trace randomizers, which fixes how long the domain must be: a
+    // linear search over the bound at which a degree counts as high (stark.rs:2004-2031)
+    for (int attempt = 0; attempt < 33; attempt++) {
+        log2_bound++;
+        Stir stir;
+        try_into_stir(security_level, log2_expansion, log2_bound, &stir);
+        if (stir.initial_domain.length >= randomized_trace_len_for(padded_height, stir.num_trace_randomizers()) << log2_expansion) return stir;
+    }
+    throw Error(TVM_ERR_INVALID_ARGUMENT, "no suitable STIR parameters found");
+}
+
+// Stir::prove (stir.rs:885-993).  Device work through the C ABI: stacked Merkle trees, polynomial folding, the witness
+// polynomial of the next round; host: sampling, the answer polynomial (tvm_host_xfe_interpolate), inclusion proofs.
+std::vector<u64> Stir::prove(const Context& c, const u64* d_codeword, ProofStream& ps) const {
+    const u64 ff = folding_factor;
+    struct Commitment {
+        const u64* codeword;
+        u64 length, n_leaves;
+        DeviceBuffer nodes;
+    };
+    auto commit = [&](const u64* cw, u64 length) {
+        Commitment t{cw, length, length / ff, DeviceBuffer(c, 10 * (length / ff))};
+        c.check(tvm_stir_merkle_tree(c.raw(), cw, length, (uint32_t)ff, t.nodes.ptr()), "tvm_stir_merkle_tree");
+        const std::vector<u64> root = merkle_root(c, t.nodes);
+        ps.enqueue("stir root", root.data(), 5);
+        return t;
+    };
+    auto respond = [&](const Commitment& t, const std::vector<u64>& folded_indices) {  // StirMerkleTree::inclusion_proof
+        std::vector<u64> idx;
+        for (u64 i : folded_indices)
+            for (u64 j = 0; j < ff; j++) idx.push_back(i + j * t.n_leaves);
+        std::vector<u64> leafs(idx.size() * 3);
+        if (!idx.empty()) c.check(tvm_gather_elements(c.raw(), t.codeword, 3, idx.data(), idx.size(), leafs.data()), "stir leafs");
+        ps.enqueue("stir response leafs", leafs.data(), leafs.size(), ff * 3);
+        const std::vector<u64> auth = auth_nodes(c, t.nodes, t.n_leaves, folded_indices);
+        ps.enqueue("stir response auth", auth.data(), auth.size());
+    };
+    auto unique_folded = [](const std::vector<u64>& indices, u64 folded_len) {  // .map(|i| i % len).unique()
+        std::vector<u64> out;
+        for (u64 i : indices) {
+            const u64 f = i % folded_len;
+            if (std::find(out.begin(), out.end(), f) == out.end()) out.push_back(f);
+        }
+        return out;
+    };
+    auto fold = [&](const u64* poly, u64 n_coeffs, const Xfe& randomness, u64* n_out) {
+        *n_out = (n_coeffs + ff - 1) / ff;
+        DeviceBuffer out(c, 3 * std::max<u64>(*n_out, 1));
+        c.check(tvm_fold_polynomial(c.raw(), poly, n_coeffs, (uint32_t)ff, randomness.c, out.ptr()), "tvm_fold_polynomial");
+        return out;
+    };
+
+    ArithmeticDomain domain = initial_domain;
+    std::vector<DeviceBuffer> owned;  // codewords and polynomials of the rounds
+    Commitment commitment = commit(d_codeword, domain.length);
+    owned.push_back(domain.interpolate(c, d_codeword, 3));
+    const u64* poly = owned.back().ptr();
+    u64 n_coeffs = domain.length;
+    std::vector<u64> first_round_indices;
+    bool have_first = false;
+    for (const auto& q : round_queries) {
+        const Xfe folding_randomness = ps.sample_scalars(1)[0];
+        u64 n_folded = 0;
+        DeviceBuffer folded = fold(poly, n_coeffs, folding_randomness, &n_folded);
+        ArithmeticDomain next_domain = domain.pow(1ull << LOG2_DOMAIN_SHRINKAGE);  // stir.rs:1149-1155
+        next_domain = next_domain.with_offset(mont_mul(next_domain.offset, domain.offset));
+        owned.push_back(next_domain.evaluate(c, folded.ptr(), n_folded, 3));
+        const u64* folded_evaluations = owned.back().ptr();
+        Commitment folded_commitment = commit(folded_evaluations, next_domain.length);
+
+        const std::vector<Xfe> ood_queries = ps.sample_scalars(q.second);
+        std::vector<Xfe> ood_values(q.second);
+        if (q.second) c.check(tvm_evaluate_at_points(c.raw(), folded.ptr(), n_folded, ood_queries[0].c, (uint32_t)q.second, ood_values[0].c), "stir ood");
+        ps.enqueue("stir ood values", q.second ? ood_values[0].c : nullptr, 3 * q.second);
+
+        const std::vector<u64> queried = ps.sample_indices(domain.length, q.first);
+        const ArithmeticDomain folded_domain = domain.pow(ff);
+        const std::vector<u64> folded_queried = unique_folded(queried, folded_domain.length);
+        respond(commitment, folded_queried);
+
+        // the witness polynomial of the next round (stir.rs:945-966)
+        const u64 k = folded_queried.size() + q.second;
+        std::vector<Xfe> quotient_set(k), quotient_answers(k), answer_poly(k);
+        {
+            const DeviceBuffer on_folded_domain = folded_domain.evaluate(c, folded.ptr(), n_folded, 3);
+            std::vector<u64> answers(folded_queried.size() * 3);
+            c.check(tvm_gather_elements(c.raw(), on_folded_domain.ptr(), 3, folded_queried.data(), folded_queried.size(), answers.data()), "stir answers");
+            for (size_t i = 0; i < folded_queried.size(); i++) {
+                quotient_set[i] = Xfe{{folded_domain.value(folded_queried[i]), 0, 0}};
+                std::memcpy(quotient_answers[i].c, &answers[3 * i], sizeof(Xfe));
+            }
+        }
+        for (u64 i = 0; i < q.second; i++) quotient_set[folded_queried.size() + i] = ood_queries[i], quotient_answers[folded_queried.size() + i] = ood_values[i];
+        if (tvm_host_xfe_interpolate(quotient_set[0].c, quotient_answers[0].c, (uint32_t)k, answer_poly[0].c))
+            throw Error(TVM_ERR_INVALID_ARGUMENT, "STIR quotient set has repeated points");
+        const Xfe degree_correction_randomness = ps.sample_scalars(1)[0];
+        // any coset of >= n_folded points that avoids the quotient set: 7 generates F_p^*, so 7 * offset * <w> is disjoint from
+        // offset * <w'> for every 2-power subgroup; the out-of-domain points are not in F_p
+        u64 work_len = 1;
+        while (work_len < n_folded) work_len <<= 1;
+        const ArithmeticDomain work = ArithmeticDomain::of_length(work_len).with_offset(mont_mul(folded_domain.offset, generator()));
+        DeviceBuffer next_poly(c, 3 * work_len);
+        c.check(tvm_stir_next_polynomial(c.raw(), folded.ptr(), n_folded, quotient_set[0].c, answer_poly[0].c, (uint32_t)k,
+                                         degree_correction_randomness.c, work.c(), next_poly.ptr()), "tvm_stir_next_polynomial");
+        owned.push_back(std::move(next_poly));
+        poly = owned.back().ptr();
+        n_coeffs = n_folded;
+        domain = next_domain;
+        commitment = std::move(folded_commitment);
+        if (!have_first) first_round_indices = queried, have_first = true;
+    }
+    // the final round has no quotienting (stir.rs:975-992)
+    const Xfe folding_randomness = ps.sample_scalars(1)[0];
+    u64 n_final = 0;
+    const DeviceBuffer final_poly = fold(poly, n_coeffs, folding_randomness, &n_final);
+    const std::vector<u64> final_words = final_poly.download(0, 3 * n_final);
+    ps.enqueue("stir final polynomial", final_words.data(), final_words.size());
+    const ArithmeticDomain folded_domain = domain.pow(ff);
+    const std::vector<u64> queried = ps.sample_indices(domain.length, final_num_in_domain_queries);
+    respond(commitment, unique_folded(queried, folded_domain.length));
+    return have_first ? first_round_indices : queried;
+}
+
 // ------------------------------------------------------------------------------------------------ from an execution trace
 namespace {
 // TVMH_TRACE=1: wall time of the steps of prove_execution on stderr (each step drains the stream first)
@@ -573,11 +778,16 @@ struct Stopwatch {
     }
 };
 }  // namespace
-StarkParameters stark_parameters(unsigned log2_padded_height, unsigned security_level, unsigned log2_expansion) {
-    const double rate = 1.0 / (double)(1ull << log2_expansion);
-    const double margin = std::sqrt(rate);                          // ReedSolomonCode::proximity_margin, proven soundness
-    const double proximity = 1.0 - margin - margin / 20.0;          // ... minus the slackness factor
-    const u64 checks = (u64)std::ceil(-(double)security_level / std::log2(1.0 - proximity));
+StarkParameters stark_parameters(unsigned log2_padded_height, unsigned security_level, unsigned log2_expansion, bool use_stir) {
+    if (use_stir) {  // Stark::stir (stark.rs:1972-2032): the instance fixes the trace randomizers and the LDT domain
+        const Stir stir = Stir::for_stark(1ull << log2_padded_height, security_level, log2_expansion);
+        StarkParameters p(log2_padded_height, stir.num_trace_randomizers(), stir.num_first_round_queries(), log2_expansion);
+        p.use_stir = true;
+        p.stir = stir;
+        p.ldt = stir.initial_domain;
+        return p;
+    }
+    const u64 checks = (u64)std::ceil(-(double)security_level / std::log2(1.0 - proximity_parameter(log2_expansion)));
     return StarkParameters(log2_padded_height, checks + 4 * 3 * 2 + 1, checks, log2_expansion);
 }
 
@@ -651,12 +861,13 @@ extern "C" int32_t tvmh_prove(tvm_ctx* ctx, uint32_t log2_padded_height, uint64_
                               const uint64_t* d_main_randomizers, const uint64_t* d_aux_trace,
                               const uint64_t* d_aux_randomizers, const uint64_t* h_quotient_randomizer,
                               const uint64_t* h_program_digest, const uint64_t* h_public_input, uint64_t n_public_input,
-                              const uint64_t* h_public_output, uint64_t n_public_output, uint64_t* h_proof, uint64_t capacity,
-                              uint64_t* proof_words, char* error, uint64_t error_capacity) {
+                              const uint64_t* h_public_output, uint64_t n_public_output, uint32_t use_stir, uint64_t* h_proof,
+                              uint64_t capacity, uint64_t* proof_words, char* error, uint64_t error_capacity) {
     using namespace triton_vm;
     try {
         const Context c(ctx);
-        const StarkParameters p(log2_padded_height, num_trace_randomizers, num_collinearity_checks, log2_expansion);
+        const StarkParameters p = use_stir ? stark_parameters(log2_padded_height, 160, log2_expansion, true)
+                                           : StarkParameters(log2_padded_height, num_trace_randomizers, num_collinearity_checks, log2_expansion);
         std::vector<Xfe> qr(p.num_quotient_randomizers);
         std::memcpy(qr.data(), h_quotient_randomizer, qr.size() * sizeof(Xfe));
         Claim claim;
@@ -678,7 +889,7 @@ extern "C" int32_t tvmh_prove(tvm_ctx* ctx, uint32_t log2_padded_height, uint64_
 }
 
 extern "C" int32_t tvmh_prove_execution(tvm_ctx* ctx, const tvm_aet* aet, uint32_t log2_padded_height, uint32_t security_level,
-                                        uint32_t log2_expansion, const uint8_t randomness_seed[32],
+                                        uint32_t log2_expansion, uint32_t use_stir, const uint8_t randomness_seed[32],
                                         const uint64_t* h_program_digest, const uint64_t* h_public_input,
                                         uint64_t n_public_input, const uint64_t* h_public_output, uint64_t n_public_output,
                                         uint64_t* h_proof, uint64_t capacity, uint64_t* proof_words, char* error,
@@ -687,7 +898,7 @@ extern "C" int32_t tvmh_prove_execution(tvm_ctx* ctx, const tvm_aet* aet, uint32
     try {
         if (!aet || !randomness_seed) throw Error(TVM_ERR_INVALID_ARGUMENT, "tvmh_prove_execution: null execution trace or seed");
         const Context c(ctx);
-        const StarkParameters p = stark_parameters(log2_padded_height, security_level, log2_expansion);
+        const StarkParameters p = stark_parameters(log2_padded_height, security_level, log2_expansion, use_stir != 0);
         Claim claim;
         if (h_program_digest) std::memcpy(claim.program_digest, h_program_digest, sizeof(claim.program_digest));
         if (n_public_input) claim.input.assign(h_public_input, h_public_input + n_public_input);
@@ -704,3 +915,52 @@ extern "C" int32_t tvmh_prove_execution(tvm_ctx* ctx, const tvm_aet* aet, uint32
         return TVM_ERR_DEVICE;
     }
 }
+
+// Stir::prove alone, for an explicitly given instance (the tests' small instances; Stark::stir derives them otherwise):
+// round_queries = [in-domain, out-of-domain] pairs.  Returns the proof of a stream that holds only the STIR items.
+extern "C" int32_t tvmh_stir_prove(tvm_ctx* ctx, tvm_domain initial_domain, uint32_t folding_factor, const uint64_t* round_queries,
+                                   uint32_t n_rounds, uint64_t final_num_in_domain_queries, uint64_t final_degree,
+                                   const uint64_t* d_codeword, uint64_t* h_first_round_indices, uint64_t* h_proof, uint64_t capacity,
+                                   uint64_t* proof_words, char* error, uint64_t error_capacity) {
+    using namespace triton_vm;
+    try {
+        const Context c(ctx);
+        Stir stir;
+        stir.initial_domain = ArithmeticDomain{initial_domain.offset, initial_domain.generator, initial_domain.length};
+        stir.folding_factor = folding_factor;
+        for (uint32_t r = 0; r < n_rounds; r++) stir.round_queries.push_back({round_queries[2 * r], round_queries[2 * r + 1]});
+        stir.final_num_in_domain_queries = final_num_in_domain_queries;
+        stir.final_degree = final_degree;
+        ProofStream ps;
+        const std::vector<u64> first = stir.prove(c, d_codeword, ps);
+        if (h_first_round_indices) std::memcpy(h_first_round_indices, first.data(), first.size() * sizeof(u64));
+        const std::vector<u64> proof = ps.proof();
+        if (proof_words) *proof_words = proof.size();
+        if (h_proof && capacity >= proof.size()) std::memcpy(h_proof, proof.data(), proof.size() * sizeof(u64));
+        return TVM_OK;
+    } catch (const Error& e) {
+        if (error && error_capacity) std::snprintf(error, error_capacity, "%s", e.what());
+        return e.status ? e.status : TVM_ERR_INVALID_ARGUMENT;
+    } catch (const std::exception& e) {
+        if (error && error_capacity) std::snprintf(error, error_capacity, "%s", e.what());
+        return TVM_ERR_DEVICE;
+    }
+}
+
+// Stark::stir's instance for a padded height: out = [initial domain length, folding factor, final in-domain queries, final
+// degree, number of full rounds, then (in-domain, out-of-domain) per round]; returns the number of words, 0 on error
+extern "C" uint64_t tvmh_stir_parameters(uint64_t padded_height, uint32_t security_level, uint32_t log2_expansion, uint64_t* out,
+                                         uint64_t capacity) {
+    try {
+        const triton_vm::Stir stir = triton_vm::Stir::for_stark(padded_height, security_level, log2_expansion);
+        std::vector<uint64_t> w = {stir.initial_domain.length, stir.folding_factor, stir.final_num_in_domain_queries, stir.final_degree,
+                                   stir.round_queries.size()};
+        for (const auto& q : stir.round_queries) w.push_back(q.first), w.push_back(q.second);
+        if (w.size() > capacity) return 0;
+        std::memcpy(out, w.data(), w.size() * sizeof(uint64_t));
+        return w.size();
+    } catch (...) {
+        return 0;
+    }
+}
+

@@ -98,9 +98,10 @@ public:
         std::string name;
         std::vector<u64> words;
         bool fiat_shamir;
+        u64 stack_words = 0;  // a StirResponse's leaves: words per stacked leaf (Vec<Vec<XFieldElement>>), else 0
     };
     void alter_fiat_shamir_state_with(const std::vector<u64>& encoding);   // proof_stream.rs:40-42
-    void enqueue(const std::string& name, const u64* words, u64 n);         // proof_stream.rs:54-59
+    void enqueue(const std::string& name, const u64* words, u64 n, u64 stack_words = 0);   // proof_stream.rs:54-59
     std::vector<Xfe> sample_scalars(u64 n);
     std::vector<u64> sample_indices(u64 upper_bound, u64 n);
     const std::vector<Item>& items() const { return items_; }
@@ -139,14 +140,31 @@ private:
     tvm_table* table_ = nullptr;
 };
 
+// The STIR low-degree test (low_degree_test/stir.rs): parameter derivation (stir.rs:403-560, 597-793; the f64 formulas are
+// the reference's) and the prover (stir.rs:885-993) over the C ABI.  The reference's automatic choice from 2^16 padded rows.
+struct Stir {
+    ArithmeticDomain initial_domain;
+    u64 folding_factor = 4;
+    std::vector<std::pair<u64, u64>> round_queries;  // (in-domain, out-of-domain) per full round
+    u64 final_num_in_domain_queries = 0, final_degree = 0;
+    u64 num_first_round_queries() const { return round_queries.empty() ? final_num_in_domain_queries : round_queries[0].first; }
+    u64 num_trace_randomizers() const { return num_first_round_queries() + 4 * 3 * 2 + 1; }  // stark.rs:2083-2089
+    // Stark::stir (stark.rs:1972-2032): the smallest instance whose initial domain holds the randomized trace
+    static Stir for_stark(u64 padded_height, unsigned security_level, unsigned log2_expansion);
+    // Stir::prove: enqueues roots, out-of-domain values, responses and the final polynomial; -> first-round indices
+    std::vector<u64> prove(const Context& c, const u64* d_codeword, ProofStream& ps) const;
+};
+
 // Domains for a padded height as Stark::default() with LdtChoice::Fri derives them
 // (stark.rs:263-286, 1885-1916, 2083-2089; fri.rs:832-836, 907-920).
 struct StarkParameters {
     StarkParameters(unsigned log2_padded_height, u64 num_trace_randomizers = 198, u64 num_collinearity_checks = 173,
                     unsigned log2_expansion = 2);
     u64 padded_height, h, num_collinearity_checks, randomized_trace_len, num_quotient_randomizers;
-    unsigned fri_rounds;
+    unsigned fri_rounds, log2_expansion;
     ArithmeticDomain trace, quotient, ldt;
+    bool use_stir = false;  // LdtChoice::Stir: `stir` fixes h and the LDT domain (stark_parameters)
+    Stir stir;
 };
 
 class Prover {
@@ -172,7 +190,8 @@ private:
 
 // Stark::new(security_level, log2_expansion) with LdtChoice::Fri: the number of collinearity checks (fri.rs:832-836,
 // low_degree_test/mod.rs:93-170, proven soundness) and of trace randomizers (stark.rs:2083-2089)
-StarkParameters stark_parameters(unsigned log2_padded_height, unsigned security_level, unsigned log2_expansion);
+StarkParameters stark_parameters(unsigned log2_padded_height, unsigned security_level, unsigned log2_expansion,
+                                 bool use_stir = false);
 
 // offset_rng_seed (master_table.rs:630-662)
 void offset_rng_seed(const uint8_t seed[32], u64 offset, uint8_t out[32]);
@@ -188,19 +207,33 @@ std::vector<u64> prove_execution(const Context& c, const StarkParameters& p, con
 
 // C entry for hosts without a C++ ABI (the Python tests and bench.py): runs Prover::prove on device-resident traces
 // and returns the proof (the words of the reference's `Proof`).  h_program_digest (5 words) may be null (all zero), the
-// public input / output may be empty.  *proof_words is the length of the proof; it is copied when capacity suffices.
+// public input / output may be empty.  use_stir != 0: LdtChoice::Stir at security level 160 (the two query-count arguments are
+// ignored: the STIR instance fixes them).  *proof_words is the length of the proof; it is copied when capacity suffices.
 extern "C" int32_t tvmh_prove(tvm_ctx* ctx, uint32_t log2_padded_height, uint64_t num_trace_randomizers,
                               uint64_t num_collinearity_checks, uint32_t log2_expansion, const uint64_t* d_main_trace,
                               const uint64_t* d_main_randomizers, const uint64_t* d_aux_trace,
                               const uint64_t* d_aux_randomizers, const uint64_t* h_quotient_randomizer,
                               const uint64_t* h_program_digest, const uint64_t* h_public_input, uint64_t n_public_input,
-                              const uint64_t* h_public_output, uint64_t n_public_output, uint64_t* h_proof,
+                              const uint64_t* h_public_output, uint64_t n_public_output, uint32_t use_stir, uint64_t* h_proof,
                               uint64_t proof_capacity_words, uint64_t* proof_words, char* error, uint64_t error_capacity);
 
 // Prover::prove(claim, aet) -- triton_vm::prove_execution -- for hosts without a C++ ABI.
 extern "C" int32_t tvmh_prove_execution(tvm_ctx* ctx, const tvm_aet* aet, uint32_t log2_padded_height, uint32_t security_level,
-                                        uint32_t log2_expansion, const uint8_t randomness_seed[32],
+                                        uint32_t log2_expansion, uint32_t use_stir, const uint8_t randomness_seed[32],
                                         const uint64_t* h_program_digest, const uint64_t* h_public_input,
                                         uint64_t n_public_input, const uint64_t* h_public_output, uint64_t n_public_output,
                                         uint64_t* h_proof, uint64_t proof_capacity_words, uint64_t* proof_words, char* error,
                                         uint64_t error_capacity);
+
+// Stir::prove alone for an explicitly given instance (round_queries: [in-domain, out-of-domain] pairs); the proof of a
+// stream holding only the STIR items; h_first_round_indices: room for the first round's in-domain query count.
+extern "C" int32_t tvmh_stir_prove(tvm_ctx* ctx, tvm_domain initial_domain, uint32_t folding_factor, const uint64_t* round_queries,
+                                   uint32_t n_rounds, uint64_t final_num_in_domain_queries, uint64_t final_degree,
+                                   const uint64_t* d_codeword, uint64_t* h_first_round_indices, uint64_t* h_proof,
+                                   uint64_t proof_capacity_words, uint64_t* proof_words, char* error, uint64_t error_capacity);
+
+// Stark::stir's instance for a padded height: out = [initial domain length, folding factor, final in-domain queries, final
+// degree, number of full rounds, then (in-domain, out-of-domain) per round]; returns the number of words, 0 on error.
+extern "C" uint64_t tvmh_stir_parameters(uint64_t padded_height, uint32_t security_level, uint32_t log2_expansion, uint64_t* out,
+                                         uint64_t capacity);
+

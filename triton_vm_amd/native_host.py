@@ -12,16 +12,49 @@ def load_host_library(backend_path=None, out=None):
     lib = C.CDLL(build_host(backend_path, out))
     lib.tvmh_prove.restype = C.c_int32
     lib.tvmh_prove.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64,
                                C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64]
     lib.tvmh_prove_execution.restype = C.c_int32
-    lib.tvmh_prove_execution.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.c_void_p, C.c_void_p,
+    lib.tvmh_prove_execution.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.c_void_p, C.c_void_p,
                                          C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p,
                                          C.c_uint64]
+    lib.tvmh_stir_prove.restype = C.c_int32
+    from .capi import Domain
+
+    lib.tvmh_stir_prove.argtypes = [C.c_void_p, Domain, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64]
+    lib.tvmh_stir_parameters.restype = C.c_uint64
+    lib.tvmh_stir_parameters.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64]
     return lib
 
 
-def prove_execution(ctx, host_lib, aet, padded_height, claim, randomness_seed, security_level=160, log2_expansion=2):
+def stir_parameters(host_lib, padded_height, security_level=160, log2_expansion=2):
+    """Stark::stir's instance as the C++ host derives it -> dict"""
+    out = np.zeros(128, np.uint64)
+    n = host_lib.tvmh_stir_parameters(padded_height, security_level, log2_expansion, out.ctypes.data, out.size)
+    if not n:
+        raise RuntimeError("tvmh_stir_parameters failed")
+    rounds = int(out[4])
+    return dict(domain_length=int(out[0]), folding_factor=int(out[1]), final_num_in_domain_queries=int(out[2]), final_degree=int(out[3]),
+                round_queries=[(int(out[5 + 2 * r]), int(out[6 + 2 * r])) for r in range(rounds)])
+
+
+def stir_prove(ctx, host_lib, stir, d_codeword):
+    """the C++ host's Stir::prove for the instance `stir` (low_degree_test.Stir) -> (first-round indices, proof words of a
+    stream that holds only the STIR items)"""
+    rounds = np.array(stir.round_queries, np.uint64).reshape(-1, 2)
+    n_first = stir.num_first_round_queries()
+    first, out = np.zeros(n_first, np.uint64), np.empty(1 << 20, np.uint64)
+    err, n = C.create_string_buffer(512), C.c_uint64(0)
+    rc = host_lib.tvmh_stir_prove(ctx.handle, stir.initial_domain.c(), stir.folding_factor, rounds.ctypes.data, len(rounds),
+                                  stir.final_num_in_domain_queries, stir.final_degree, d_codeword.ptr, first.ctypes.data, out.ctypes.data,
+                                  out.size, C.byref(n), err, len(err))
+    if rc != 0 or n.value > out.size:
+        raise RuntimeError(f"tvmh_stir_prove failed ({rc}): {err.value.decode()}")
+    return [int(i) for i in first], out[:n.value].copy()
+
+
+def prove_execution(ctx, host_lib, aet, padded_height, claim, randomness_seed, security_level=160, log2_expansion=2, ldt="fri"):
     """The C++ host's Prover::prove(claim, aet) (triton_vm::prove_execution): fill, pad, extend and the hot path on the
     device, the seeded randomness and the transcript in C++.  aet: the arrays master_table.fill takes.  -> the proof words"""
     from .master_table import aet_struct
@@ -31,7 +64,8 @@ def prove_execution(ctx, host_lib, aet, padded_height, claim, randomness_seed, s
     err, n = C.create_string_buffer(512), C.c_uint64(0)
     out = np.empty(1 << 20, np.uint64)   # a 2^20-row proof is ~0.3 M words
     while True:
-        rc = host_lib.tvmh_prove_execution(ctx.handle, C.addressof(s), log2, security_level, log2_expansion, bytes(randomness_seed),
+        rc = host_lib.tvmh_prove_execution(ctx.handle, C.addressof(s), log2, security_level, log2_expansion, 1 if ldt == "stir" else 0,
+                                           bytes(randomness_seed),
                                            claim.program_digest.ctypes.data, claim.input.ctypes.data, claim.input.size,
                                            claim.output.ctypes.data, claim.output.size, out.ctypes.data, out.size, C.byref(n), err, len(err))
         if rc != 0:
@@ -66,7 +100,7 @@ class NativeProver:
             rc = self.lib.tvmh_prove(self.ctx.handle, log2, p.h, p.num_collinearity_checks, p.log2_expansion, self.bufs[0].ptr, self.bufs[1].ptr,
                                      self.bufs[2].ptr, self.bufs[3].ptr, self.qr.ctypes.data, claim.program_digest.ctypes.data,
                                      claim.input.ctypes.data, claim.input.size, claim.output.ctypes.data, claim.output.size,
-                                     self.out.ctypes.data, self.capacity, C.byref(n), err, len(err))
+                                     1 if p.stir is not None else 0, self.out.ctypes.data, self.capacity, C.byref(n), err, len(err))
             if rc != 0:
                 raise RuntimeError(f"tvmh_prove failed ({rc}): {err.value.decode()}")
             if n.value <= self.capacity:

@@ -34,10 +34,12 @@ namespace tvm {
 TVM_D u64 fa_value(u64 w) { return bfe_mul(w, 1); }
 #ifdef TVM_EMU
 static const unsigned char d_fa_lut[256] = {TVM_TIP5_LUT_LIST};
-static inline void fa_atomic_inc(u64* p) { __atomic_fetch_add(p, 1ull, __ATOMIC_RELAXED); }  // the emulation runs workgroups on several threads
+static inline void fa_atomic_add(u64* p, u64 v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }  // the emulation runs workgroups on several threads
+static inline void fa_atomic_inc_local(unsigned* p) { *p += 1; }                                  // ... and a workgroup's work-items on one
 #else
 static __device__ const unsigned char d_fa_lut[256] = {TVM_TIP5_LUT_LIST};
-static __device__ __forceinline__ void fa_atomic_inc(u64* p) { atomicAdd((unsigned long long*)p, 1ull); }
+static __device__ __forceinline__ void fa_atomic_add(u64* p, u64 v) { atomicAdd((unsigned long long*)p, (unsigned long long)v); }
+static __device__ __forceinline__ void fa_atomic_inc_local(unsigned* p) { atomicAdd(p, 1u); }
 #endif
 
 // row-major [len][w] -> columns col0 .. col0+w-1 of the column-major trace, rows row0 .. row0+len-1
@@ -95,13 +97,24 @@ __global__ void k_fa_jump_stack(const u64* __restrict__ proc, const u64* __restr
 }
 // clock jump differences of a sorted memory-like table: rows r-1, r with the same pointer contribute clk_r - clk_{r-1}
 // (op_stack.rs:261-281, ram.rs:236-248, jump_stack.rs:128-141); hist[d] counts them
+// Most differences are tiny and equal (a loop body touches the same stack depth every few cycles): one global atomic per
+// row put 600 000 increments on a handful of addresses (8 ms at 2^20 rows).  Each workgroup counts the small differences in
+// LDS first and adds its non-zero bins to the global histogram once.
+#define FA_HIST_LOCAL 1024
 __global__ void k_fa_clock_jump_differences(const u64* __restrict__ main, u64 n, int clk_col, int ptr_col, u64 len, u64* __restrict__ hist,
                                             u64 hist_len) {
+    __shared__ unsigned local[FA_HIST_LOCAL];
+    for (int i = threadIdx.x; i < FA_HIST_LOCAL; i += blockDim.x) local[i] = 0;
+    __syncthreads();
     const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r == 0 || r >= len) return;
-    if (main[(u64)ptr_col * n + r] != main[(u64)ptr_col * n + r - 1]) return;
-    const u64 d = fa_value(bfe_sub(main[(u64)clk_col * n + r], main[(u64)clk_col * n + r - 1]));
-    if (d < hist_len) fa_atomic_inc(hist + d);
+    if (r != 0 && r < len && main[(u64)ptr_col * n + r] == main[(u64)ptr_col * n + r - 1]) {
+        const u64 d = fa_value(bfe_sub(main[(u64)clk_col * n + r], main[(u64)clk_col * n + r - 1]));
+        if (d < FA_HIST_LOCAL && d < hist_len) fa_atomic_inc_local(local + d);
+        else if (d < hist_len) fa_atomic_add(hist + d, 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < FA_HIST_LOCAL; i += blockDim.x)
+        if (local[i]) fa_atomic_add(hist + i, local[i]);
 }
 __global__ void k_fa_multiplicities(const u64* __restrict__ hist, u64 len, u64* __restrict__ main, u64 n) {
     const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;

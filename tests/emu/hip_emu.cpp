@@ -6,6 +6,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <pthread.h>
 #include <thread>
 
 namespace emu {
@@ -161,9 +162,16 @@ struct Pool {
         for (auto& w : workers) w.join();
     }
 };
+Pool* g_pool = nullptr;  // never destroyed: worker threads may outlive static destruction order otherwise
 Pool& pool() {
-    static Pool* p = new Pool();  // never destroyed: worker threads may outlive static destruction order otherwise
-    return *p;
+    static const bool registered = [] {
+        // a forked child has none of the parent's worker threads: it starts a pool of its own (the parent's object is leaked)
+        pthread_atfork(nullptr, nullptr, [] { g_pool = nullptr; });
+        return true;
+    }();
+    (void)registered;
+    if (!g_pool) g_pool = new Pool();
+    return *g_pool;
 }
 std::mutex launch_mutex;  // launches from different host threads (two contexts) run one after the other
 }  // namespace

@@ -49,6 +49,18 @@ def test_verifier_accepts_the_reference_pinned_proof(host_lib):
     assert verify(host_lib, words, claim) == indices
     # decoding and re-encoding is the identity (BFieldCodec round trip, proof_stream.rs decode tests)
     assert (ProofStream.from_proof(host_lib, words).proof().words == words).all()
+    # Proof::padded_height (proof.rs:45-59, tests proof.rs:172-189)
+    from triton_vm_amd.proof_stream import Proof, ProofDecodingError
+
+    assert Proof(words).padded_height(host_lib) == 256
+    stream = ProofStream.from_proof(host_lib, words)
+    stream.log = [entry for entry in stream.log if entry[0] != "Log2PaddedHeight"]
+    with pytest.raises(ProofDecodingError, match="NoLog2PaddedHeight"):
+        stream.proof().padded_height(host_lib)
+    stream = ProofStream.from_proof(host_lib, words)
+    stream.log.append(stream.log[0])
+    with pytest.raises(ProofDecodingError, match="TooManyLog2PaddedHeights"):
+        stream.proof().padded_height(host_lib)
 
 
 def item_offsets(host_lib, words):

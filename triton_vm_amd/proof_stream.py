@@ -163,6 +163,15 @@ class Proof:
         """Tip5::hash(&proof), canonical values (what the reference's snapshots print)"""
         return [field.from_mont(int(w)) for w in hash_varlen(lib, self.encode())]
 
+    def padded_height(self, lib):
+        """Proof::padded_height (proof.rs:45-59): from the one Log2PaddedHeight item"""
+        heights = [payload for label, payload, _ in ProofStream.from_proof(lib, self.words).log if variant_of(label) == "Log2PaddedHeight"]
+        if not heights:
+            raise ProofDecodingError("NoLog2PaddedHeight")
+        if len(heights) > 1:
+            raise ProofDecodingError("TooManyLog2PaddedHeights")
+        return 1 << field.from_mont(int(heights[0][0]))
+
 
 class ProofStream:
     """proof_stream.rs:8-104.  `enqueue` takes a label (see LABELS) or a ProofItem variant name and the payload words."""

@@ -10,15 +10,16 @@ from tests import vm_fixture as vf
 from tests.test_verify_proof import verify
 
 CASES = [
-    # program, security level, log2 expansion, runs on the emulation too
-    ("halt", 32, 2, True), ("halt", 64, 3, False), ("halt", 160, 2, False), ("halt", 48, 4, False),
-    ("many_u32", 32, 2, False), ("pick_and_place", 32, 2, False), (("fib", 100), 32, 2, False), ("every", 32, 2, False),
-    ("every", 64, 3, False), (("u32", 100), 32, 2, False),
+    # program, security level, log2 expansion, low-degree test, runs on the emulation too
+    ("halt", 32, 2, "fri", True), ("halt", 64, 3, "fri", False), ("halt", 160, 2, "fri", False), ("halt", 48, 4, "fri", False),
+    ("many_u32", 32, 2, "fri", False), ("pick_and_place", 32, 2, "fri", False), (("fib", 100), 32, 2, "fri", False),
+    ("every", 32, 2, "fri", False), ("every", 64, 3, "fri", False), (("u32", 100), 32, 2, "fri", False),
+    ("halt", 32, 2, "stir", False), ("every", 48, 2, "stir", False), (("fib", 100), 160, 2, "stir", False),
 ]
 
 
-@pytest.mark.parametrize("which,security_level,log2_expansion,on_emulation", CASES)
-def test_prove_and_verify(ctx, orc, which, security_level, log2_expansion, on_emulation):
+@pytest.mark.parametrize("which,security_level,log2_expansion,ldt,on_emulation", CASES)
+def test_prove_and_verify(ctx, orc, which, security_level, log2_expansion, ldt, on_emulation):
     from oracle.real_verifier import VerificationError
     from tests.test_fill import aet_arrays
     from triton_vm_amd.prover import Prover
@@ -30,9 +31,9 @@ def test_prove_and_verify(ctx, orc, which, security_level, log2_expansion, on_em
         assert output == [1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7]
     claim = snap.claim_of(orc, program, public_input, output)
     prover = Prover.from_execution(ctx, aet_arrays(orc, aet), aet.padded_height(), claim, snap.prover_seed(len(str(which))),
-                                   security_level=security_level, log2_expansion=log2_expansion)
+                                   security_level=security_level, log2_expansion=log2_expansion, ldt=ldt)
     proof = prover.prove().proof()
-    kw = dict(security_level=security_level, log2_expansion=log2_expansion)
+    kw = dict(security_level=security_level, log2_expansion=log2_expansion, ldt_choice=ldt)
     accepted_at = verify(ctx.lib, proof.words, claim, **kw)
     assert len(accepted_at) > 0
     wrong = snap.claim_of(orc, program, public_input, list(output) + [1])
@@ -41,6 +42,7 @@ def test_prove_and_verify(ctx, orc, which, security_level, log2_expansion, on_em
     # ... and the product's own Verifier::verify (device batch work) gives the same verdicts
     from triton_vm_amd import verifier as product
 
+    kw = dict(security_level=security_level, log2_expansion=log2_expansion, ldt=ldt)
     assert product.Verifier(ctx, **kw).verify(claim, proof.words) == accepted_at
     with pytest.raises(product.VerificationError):
         product.Verifier(ctx, **kw).verify(wrong, proof.words)

@@ -68,7 +68,7 @@ class StarkParameters:
     (stark.rs:263-286, 1885-1916, 2083-2089; fri.rs:832-836, 907-920).  expansion = 4."""
 
     def __init__(self, log2_padded_height, num_trace_randomizers=198, num_collinearity_checks=173, log2_expansion=2,
-                 ldt="fri"):
+                 ldt="fri", security_level=160):
         """ldt = "fri" (LdtChoice::Fri, what BASELINE.json's configs name) or "stir" (the reference's automatic choice
         from 2^16 rows on, stark.rs:1944-1951): then the STIR instance fixes the number of trace randomizers and the
         LDT domain (Stark::stir, stark.rs:1972-2032) and the two query-count arguments are ignored."""
@@ -78,7 +78,7 @@ class StarkParameters:
         if ldt == "stir":
             from .low_degree_test import stark_stir
 
-            self.stir = stark_stir(self.padded_height, log2_ldt_expansion_factor=log2_expansion)
+            self.stir = stark_stir(self.padded_height, security_level=security_level, log2_ldt_expansion_factor=log2_expansion)
             num_trace_randomizers = self.stir.num_trace_randomizers()
         elif ldt != "fri":
             raise ValueError("ldt must be 'fri' or 'stir'")
@@ -134,7 +134,8 @@ class Prover:
         comes from `randomness_seed` (32 bytes) the way the reference draws it, and the auxiliary table is extended on
         the device once the challenges are sampled (MasterMainTable::extend, master_table.rs:1006-1075).
         aet: the arrays master_table.fill takes; padded_height: AlgebraicExecutionTrace::padded_height (aet.rs:141-146);
-        security_level, log2_expansion: Stark::new's (stark.rs:1815-1830; Stark::default() is 160, 2);
+        security_level, log2_expansion: Stark::new's (stark.rs:1815-1830; Stark::default() is 160, 2); ldt: "fri", "stir" or
+        None for the reference's automatic choice (STIR from 2^16 padded rows on);
         assume_valid_trace: the tables come from an execution trace, so the quotient evaluation may use the degree
         bounds of the constraint quotients (TVM_OPTION_AIR_VALID_TRACE) -- the same proof, word for word, as
         long as the trace satisfies the AIR (both reference snapshots are reproduced this way); an invalid trace gives a
@@ -147,10 +148,12 @@ class Prover:
         log2 = padded_height.bit_length() - 1
         if padded_height != 1 << log2:
             raise ValueError("the padded height is a power of two")
+        if ldt is None:      # Stark::ldt's heuristic for proven soundness (stark.rs:1944-1951)
+            ldt = "fri" if log2 < 16 else "stir"
         # fri.rs:832-836: the number of collinearity checks; stark.rs:2083-2089: the number of trace randomizers
         checks = math.ceil(-security_level / math.log2(1.0 - ReedSolomonCode(log2_expansion).proximity_parameter()))
         p = StarkParameters(log2, num_trace_randomizers=checks + 4 * 3 * 2 + 1, num_collinearity_checks=checks,
-                            log2_expansion=log2_expansion, ldt=ldt)
+                            log2_expansion=log2_expansion, ldt=ldt, security_level=security_level)
         self.ctx, self.p, self.claim, self.randomness_seed = ctx, p, claim, bytes(randomness_seed)
         self.assume_valid_trace = assume_valid_trace
         n, h, lib = p.trace.length, p.h, ctx.lib

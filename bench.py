@@ -289,7 +289,7 @@ def main():
                                        "quotient codeword" if sharded else f"{world} independent proofs, one per GPU" if world > 1
                                        else f"single GPU, tables evaluated coset-wise in {args.jit_passes} passes (nothing cached)"
                                        if args.jit_passes else "single GPU")},
-            "roofline": {"bound": "hbm", "kernel": "main-table LDE (k_ntt2_pass1 + k_lde_pass2 + k_lde_pass3, 12 column chunks)",
+            "roofline": {"bound": "hbm", "kernel": "main-table LDE (k_ntt2_pass1 + k_lde_pass2 + k_lde_pass3, 4 column chunks of 96)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "launch_ms": round(lde_avg_ms, 3),

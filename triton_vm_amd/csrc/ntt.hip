@@ -758,7 +758,9 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     const Split sp = split_for(N);
     const u64 n1 = 1ull << sp.log_n1, n2 = 1ull << sp.log_n2;
     const int W = (int)(n_cols * fk);
-    if (chunk_cols <= 0) chunk_cols = 32;  // 64 / 128 columns per chunk measured the same (62.9 / 61.3 / 60.8 ms)
+    // columns per chunk: 96 while the chunk's intermediate (96 * L words) stays below 8 GiB, else 32.  Measured at 2^20 rows
+    // (main table, with 8 row tiles per pass-3 workgroup): 16 -> 48.0 ms, 32 -> 47.0, 96 -> 45.6, 192 -> 45.5, 379 -> 45.1
+    if (chunk_cols <= 0) chunk_cols = ((size_t)96 * X * n_rows * sizeof(u64) <= ((size_t)8 << 30)) ? 96 : 32;
 
     const u64 w = trace_gen, wi = bfe_inv(trace_gen);
     const u64 n_inv = bfe_inv(bfe_from_u64(N));
@@ -853,7 +855,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             dim3 grid((unsigned)((X * n2 + RB - 1) / RB), (unsigned)nc);
             const size_t lds = ((size_t)(n1 + TVM_ROW_PAD) << a.rows_log) * sizeof(u64);
             if (a.rows_log == 4 && n1 >= 64 && (X * n2) % 16 == 0 && X * n2 / 16 < 65536) {
-                a.tiles = grid.x % 4 == 0 ? 4 : 1;
+                a.tiles = grid.x % 8 == 0 ? 8 : grid.x % 4 == 0 ? 4 : 1;  // 1 -> 49.2 ms, 2 -> 47.5, 4 -> 47.0, 8 -> 46.3 (2^20 rows)
                 TVM_LAUNCH(k_lde_pass3_v2, dim3(grid.y, grid.x / a.tiles), dim3((unsigned)n1), lds + (n1 / 2) * sizeof(u64), c->stream, a);
             }
             else

@@ -16,7 +16,9 @@
 namespace tvm {
 
 
+#ifndef TVM_HASH_BLOCK
 #define TVM_HASH_BLOCK 256
+#endif
 
 // digests[r] = Tip5::hash_varlen(row r*stride of the table), W words per row, with the permutation's MDS layer on
 // the matrix cores (tip5_permute_mfma): four lanes per row, sixteen rows per wavefront.  Lane (n, g) absorbs the

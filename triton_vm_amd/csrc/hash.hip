@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(TVM_HASH_BLOCK) k_hash_rows_mfma(const u64* __
         for (int t = 0; t < 3; t++) {
             const int q = g + 4 * t;  // word of the state, overwritten if it is in the rate part
             const int wi = perm * TIP5_RATE + q;
-            if (q < TIP5_RATE) st[t] = wi < W ? base[(u64)wi * TVM_RB] : (wi == W ? TVM_ONE : 0);  // padding: 1 then 0s
+            if (q < TIP5_RATE) st[t] = wi < W ? TVM_LOAD_STREAM(&base[(u64)wi * TVM_RB]) : (wi == W ? TVM_ONE : 0);  // padding: 1 then 0s
         }
         tip5_permute_mfma(st, a, g, lut, ctab);
     }

@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(1024) k_ntt2_pass1(Ntt2Args a) {
         const int b = idx & (B - 1), i1 = idx >> a.batch_log;
         const u64 i2 = i2_0 + b;
         const u64 i = (u64)i1 * n2 + i2;
-        u64 x = (i2 < n2 && i < a.in_len) ? in[i * a.in_fk] : 0;
+        u64 x = (i2 < n2 && i < a.in_len) ? TVM_LOAD_STREAM(&in[i * a.in_fk]) : 0;
         if (a.pre_lo && x) x = bfe_mul(x, bfe_mul(a.pre_hi[i1], a.pre_lo[i2]));
         s[idx] = x;
     }
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(1024) k_ntt2_pass1(Ntt2Args a) {
         const u64 i2 = i2_0 + b;
         if (i2 >= n2) continue;
         const u64 k1 = brev_bits((u32)p, a.log_n1);
-        tmp[(u64)p * n2 + i2] = bfe_mul(s[idx], pow2_get(a.tw_inter, i2 * k1));
+        TVM_STORE_STREAM(&tmp[(u64)p * n2 + i2], bfe_mul(s[idx], pow2_get(a.tw_inter, i2 * k1)));
     }
 }
 
@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(1024) k_lde_pass2_v2(LdePass2Args a) {
     const u64 n = n1 << a.log_n2;
     const u64* y = a.y + (u64)vl * n + p0 * n2;
 #pragma unroll
-    for (int e = 0; e < 16; e++) s[e * RS + tid] = y[(u64)e * n2 + tid];
+    for (int e = 0; e < 16; e++) s[e * RS + tid] = TVM_LOAD_STREAM(&y[(u64)e * n2 + tid]);
     tvm_lds_barrier();
     // position q of row e: N * t[m1*n1 + m2], m1 = brev(q)
     if (a.log_n2 == 10) lds_ntt_fixed<false, 4, 10>(s, a.tw_a2, tid, nt);
@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(1024) k_lde_pass2_v2(LdePass2Args a) {
 #pragma unroll 4
         for (int i = 0; i < 16; i++) {
             const int j1 = j1_0 + i * j1_step;
-            z[(u64)j1 * n1] = bfe_mul(s[b_out * RS + j1], t);
+            TVM_STORE_STREAM(&z[(u64)j1 * n1], bfe_mul(s[b_out * RS + j1], t));
             t = bfe_mul(t, t_step);
         }
         gh = bfe_mul(gh, gh_step);
@@ -477,7 +477,7 @@ __global__ void __launch_bounds__(1024) k_lde_pass3_v2(LdePass3Args a) {
 #pragma unroll
     for (int e = 0; e < 16; e++) {
         const u64 rho = rho0 + e, j1 = rho >> log_x, k = rho & (X - 1);  // uniform; X is a power of two
-        nxt[e] = zc[(k * n2 + j1) << a.log_n1];
+        nxt[e] = TVM_LOAD_STREAM(&zc[(k * n2 + j1) << a.log_n1]);
     }
     for (int it = 0; it < a.tiles; it++, rho0 += 16) {
         if (it) tvm_lds_barrier();  // the stores of the previous tile have read s
@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(1024) k_lde_pass3_v2(LdePass3Args a) {
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const u64 rho = rho0 + 16 + e, j1 = rho >> log_x, k = rho & (X - 1);
-                nxt[e] = zc[(k * n2 + j1) << a.log_n1];
+                nxt[e] = TVM_LOAD_STREAM(&zc[(k * n2 + j1) << a.log_n1]);
             }
         }
         if (a.log_n1 == 10) lds_ntt_fixed<true, 4, 10>(s, tw_fwd, tid, nt);
@@ -499,7 +499,7 @@ __global__ void __launch_bounds__(1024) k_lde_pass3_v2(LdePass3Args a) {
 #pragma unroll 4
         for (int i = 0; i < 16; i++) {
             const int j2 = j2_0 + i * j2_step;
-            out[(u64)j2 * j2_stride] = s[b * RS + j2];
+            TVM_STORE_STREAM(&out[(u64)j2 * j2_stride], s[b * RS + j2]);
         }
     }
 }

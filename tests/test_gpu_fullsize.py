@@ -91,6 +91,27 @@ def test_large_xfe_transform_round_trip_and_point_values(gctx, log_len):
 
 
 
+@pytest.mark.parametrize("log_n,fk,n_cols,sample_cols", [(21, 1, 40, (0, 17, 39)), (22, 1, 24, (0, 23)), (22, 3, 3, (2,)), (21, 3, 7, (6,))])
+def test_lde_of_longer_traces(gctx, orc, log_n, fk, n_cols, sample_cols):
+    """2^21 and 2^22 rows (BASELINE config 3's height): 2048-point axes, the kernels with two positions per work-item and
+    8-row tiles (k_lde_pass2_v3 / k_lde_pass3_v3).  Sampled columns through the oracle at sampled rows."""
+    ctx, n = gctx, 1 << log_n
+    trace_dom = ArithmeticDomain.of_length(n)
+    ev = ArithmeticDomain.of_length(8 * n).with_offset(field.generator())
+    mt = MasterTable.from_device(ctx, ctx.synthetic(n_cols * n * fk, seed=21 + fk), ctx.synthetic(n_cols * H * fk, seed=23 + fk), n_cols, n, H,
+                                 trace_dom, ev, ev, fk)
+    mt.maybe_low_degree_extend_all_columns()
+    rng = np.random.default_rng(log_n)
+    rows = np.unique(np.concatenate([[0, 1, 7, 8, 15, 16, len(ev) - 1], rng.integers(0, len(ev), 300)])).astype(np.uint64)
+    revealed = mt.reveal_rows(rows)
+    trace_host = mt.d_trace.download().reshape((n_cols, n) + ((3,) if fk == 3 else ()))
+    rnd_host = mt.d_randomizers.download().reshape((n_cols, H) + ((3,) if fk == 3 else ()))
+    for c in sample_cols:
+        want = orc.lde_table(trace_host[c:c + 1], rnd_host[c:c + 1], odom(orc, ev), fk)
+        assert (revealed[:, c] == want[rows.astype(np.int64), 0]).all(), f"column {c}"
+    mt.clear_cache()
+
+
 @pytest.mark.parametrize("log_n,log_ldt_expansion", [(20, 3), (18, 5)])
 def test_full_size_air_sampled_rows(gctx, orc, log_n, log_ldt_expansion):
     """all_quotients_combined at BASELINE config 1's size (2^20 rows: quotient = LDT domain 2^23, tables of 23.7 +

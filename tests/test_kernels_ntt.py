@@ -39,7 +39,10 @@ def test_evaluate_interpolate_match_oracle(ctx, orc, log_len, n_coeffs, fk):
 
 @pytest.mark.parametrize("log_n,expansion,n_cols,h", [(4, 8, 3, 5), (5, 4, 18, 7), (6, 8, 33, 20), (3, 2, 1, 8), (1, 4, 2, 1),
                                                        (12, 8, 2, 70), (13, 4, 1, 9), (12, 2, 1, 4096),
-                                                       (4, 1, 3, 5), (12, 1, 2, 7)])  # expansion 1: a rank's share at 8 GPUs
+                                                       (4, 1, 3, 5), (12, 1, 2, 7),   # expansion 1: a rank's share at 8 GPUs
+                                                       # 2^13 / 2^14 / 2^15 rows: the kernels with two positions per work-item and
+                                                       # 8-row tiles (the shape of 2^21 / 2^22-row traces)
+                                                       (13, 8, 3, 198), (14, 8, 2, 198), (14, 4, 17, 5), (15, 2, 2, 9000), (14, 1, 2, 3)])
 @pytest.mark.parametrize("fk", [1, 3])
 def test_lde_table_matches_oracle(ctx, orc, log_n, expansion, n_cols, h, fk):
     rng = np.random.default_rng(log_n + 31 * n_cols + fk)

@@ -58,10 +58,10 @@ __global__ void k_pow_table(u64 base, u64 count, u64 scale, u64* out) {
 // production tile (16 transforms side by side, element (a, b) at s[a + b * (n + TVM_ROW_PAD)]): every LDS address
 // of the group is then the work-item's base plus an immediate offset, and the twiddle indices are shifts by
 // constants -- the generic form spends ~190 of its ~1050 instructions per group on that arithmetic.
-template <bool DIT, int K, bool L0, int CL = -1, int CLOGN = -1>
+template <bool DIT, int K, bool L0, int CL = -1, int CLOGN = -1, int CB = 4>
 TVM_D void lds_ntt_group(u64* s, int log_n_rt, int batch_log_rt, int SA_rt, int SB_rt, const u64* __restrict__ tw, int l_rt, int tid, int nt) {
     constexpr int R = 1 << K;
-    const int log_n = CLOGN >= 0 ? CLOGN : log_n_rt, batch_log = CLOGN >= 0 ? 4 : batch_log_rt, l = CL >= 0 ? CL : l_rt;
+    const int log_n = CLOGN >= 0 ? CLOGN : log_n_rt, batch_log = CLOGN >= 0 ? CB : batch_log_rt, l = CL >= 0 ? CL : l_rt;
     const int SA = CLOGN >= 0 ? 1 : SA_rt, SB = CLOGN >= 0 ? (1 << (CLOGN >= 0 ? CLOGN : 0)) + TVM_ROW_PAD : SB_rt;
     const int n_groups = (1 << (log_n - K)) << batch_log;
     const int bmask = (1 << batch_log) - 1, lmask = (1 << l) - 1;
@@ -130,13 +130,13 @@ TVM_D void lds_ntt(u64* s, int log_n, int batch_log, int SA, int SB, const u64* 
 }
 
 // The same sequence of groups with everything known at compile time (see lds_ntt_group).
-template <bool DIT, int MAXK, int LOGN, int DONE = 0>
+template <bool DIT, int MAXK, int LOGN, int DONE = 0, int CB = 4>
 TVM_D void lds_ntt_fixed(u64* s, const u64* __restrict__ tw, int tid, int nt) {
     if constexpr (DONE < LOGN) {
         constexpr int k = (LOGN - DONE) >= MAXK ? MAXK : (LOGN - DONE);
         constexpr int l = DIT ? DONE : (LOGN - DONE - k);
-        lds_ntt_group<DIT, k, l == 0, l, LOGN>(s, LOGN, 4, 1, (1 << LOGN) + TVM_ROW_PAD, tw, l, tid, nt);
-        lds_ntt_fixed<DIT, MAXK, LOGN, DONE + k>(s, tw, tid, nt);
+        lds_ntt_group<DIT, k, l == 0, l, LOGN, CB>(s, LOGN, CB, 1, (1 << LOGN) + TVM_ROW_PAD, tw, l, tid, nt);
+        lds_ntt_fixed<DIT, MAXK, LOGN, DONE + k, CB>(s, tw, tid, nt);
     }
 }
 
@@ -505,6 +505,129 @@ __global__ void __launch_bounds__(1024) k_lde_pass3_v2(LdePass3Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same two passes for an LDS-resident axis LONGER than a workgroup: 2^LOGN points on 2^TLOG work-items, i.e.
+// PPT = 2^(LOGN - TLOG) positions per work-item and tiles of 16 / PPT rows, so that a work-item still owns 16 elements and
+// the tile still holds 16 * 2^TLOG words (2048-point axes on 1024 work-items with 8-row tiles: traces of 2^21 and 2^22
+// rows, which the production kernels above -- one position per work-item -- cannot take; <7, 6> is the same shape at a
+// size the CPU suite can run).  Element e of a work-item: row e % ROWS, position tid + (e / ROWS) * 2^TLOG.
+template <int LOGN, int TLOG>
+__global__ void __launch_bounds__(1 << TLOG) k_lde_pass2_v3(LdePass2Args a) {
+    constexpr int NT = 1 << TLOG, RLOG = 4 - (LOGN - TLOG), ROWS = 1 << RLOG, PPT = 16 / ROWS;
+    constexpr int n2 = 1 << LOGN, RS = n2 + TVM_ROW_PAD;
+    TVM_DYN_SMEM(u64, s);
+    const int tid = threadIdx.x;
+    const u64 n1 = 1ull << a.log_n1;
+    const int vl = blockIdx.y, v = a.col0 + vl;
+    const u64 p0 = (u64)blockIdx.x * ROWS;
+    const u64 n = n1 << LOGN;
+    const u64* y = a.y + (u64)vl * n + p0 * n2;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int r = e & (ROWS - 1), q = tid + (e >> RLOG) * NT;
+        s[r * RS + q] = TVM_LOAD_STREAM(&y[(u64)r * n2 + q]);
+    }
+    tvm_lds_barrier();
+    lds_ntt_fixed<false, 4, LOGN, 0, RLOG>(s, a.tw_a2, tid, NT);
+    u64 coef[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) coef[e] = s[(e & (ROWS - 1)) * RS + tid + (e >> RLOG) * NT];
+    u64* tw_fwd = s + ROWS * RS;  // the forward twiddles behind the tile (see k_lde_pass2_v2)
+    for (int i = tid; i < (n2 >> 1); i += NT) tw_fwd[i] = a.tw_b1[i];
+    u64 m1[PPT], gh[PPT], gh_step[PPT];
+    bool has_rnd = false;
+#pragma unroll
+    for (int hh = 0; hh < PPT; hh++) {
+        m1[hh] = brev_bits((u32)(tid + hh * NT), LOGN);
+        has_rnd = has_rnd || m1[hh] * n1 < a.h;
+        gh[hh] = a.g_hi[m1[hh]];
+        gh_step[hh] = a.g_hi_step[m1[hh]];
+    }
+    const u64* rnd = a.rnd + (u64)(v / a.fk) * a.h * a.fk + (v % a.fk);
+    // store phase: this work-item writes row b = tid % ROWS, columns j1 = tid / ROWS + i * NT / ROWS, i < 16
+    const int b_out = tid & (ROWS - 1), j1_0 = tid >> RLOG;
+    constexpr int j1_step = NT >> RLOG;
+    const u64 m2_out = brev_bits((u32)(p0 + b_out), a.log_n1);
+    const u64 t_step = pow2_get(a.tw_inter, (m2_out * (u64)j1_step) & (n - 1));
+    u64 t_first = bfe_mul(pow2_get(a.tw_inter, m2_out * (u64)j1_0), a.g_lo[m2_out]);
+    const u64 gl_step = a.g_lo_step[m2_out];
+    for (int k = 0; k < a.n_cosets; k++) {
+        tvm_lds_barrier();
+        const u64 zk = a.zk[k];
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int r = e & (ROWS - 1), hh = e >> RLOG;
+            u64 c = coef[e];
+            if (has_rnd) {
+                const u64 m = m1[hh] * n1 + brev_bits((u32)(p0 + r), a.log_n1);
+                if (m < a.h) c = bfe_add(c, bfe_mul(zk, rnd[m * a.fk]));
+            }
+            s[r * RS + tid + hh * NT] = bfe_mul(c, gh[hh]);
+        }
+        tvm_lds_barrier();
+        lds_ntt_fixed<true, 3, LOGN, 0, RLOG>(s, tw_fwd, tid, NT);
+        u64* z = a.z + ((u64)vl * a.n_cosets + k) * n + p0 + b_out;
+        u64 t = t_first;
+#pragma unroll 4
+        for (int i = 0; i < 16; i++) {
+            const int j1 = j1_0 + i * j1_step;
+            TVM_STORE_STREAM(&z[(u64)j1 * n1], bfe_mul(s[b_out * RS + j1], t));
+            t = bfe_mul(t, t_step);
+        }
+#pragma unroll
+        for (int hh = 0; hh < PPT; hh++) gh[hh] = bfe_mul(gh[hh], gh_step[hh]);
+        t_first = bfe_mul(t_first, gl_step);
+    }
+}
+
+template <int LOGN, int TLOG>
+__global__ void __launch_bounds__(1 << TLOG) k_lde_pass3_v3(LdePass3Args a) {
+    constexpr int NT = 1 << TLOG, RLOG = 4 - (LOGN - TLOG), ROWS = 1 << RLOG;
+    constexpr int n1 = 1 << LOGN, RS = n1 + TVM_ROW_PAD;
+    TVM_DYN_SMEM(u64, s);
+    const int tid = threadIdx.x;
+    const u64 n2 = 1ull << a.log_n2;
+    const u64 X = (u64)a.n_cosets;
+    const int log_x = 31 - __builtin_clz((unsigned)a.n_cosets);
+    const u64 period = X * n2;  // rows per j2, a multiple of 16
+    const int vl = blockIdx.x;
+    const u64* zc = a.z + (u64)vl * X * (n2 << LOGN) + tid;
+    u64* tw_fwd = s + ROWS * RS;
+    for (int i = tid; i < (n1 >> 1); i += NT) tw_fwd[i] = a.tw_b2[i];
+    const int b = tid & (ROWS - 1), j2_0 = tid >> RLOG;
+    constexpr int j2_step = NT >> RLOG;
+    const u64 W = (u64)a.W;
+    const u64 j2_stride = ((period >> TVM_RB_LOG) * W) << TVM_RB_LOG;
+    u64 nxt[16];
+    u64 rho0 = (u64)blockIdx.y * a.tiles * ROWS;  // first local row of the tile
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const u64 rho = rho0 + (e & (ROWS - 1)), j1 = rho >> log_x, k = rho & (X - 1);
+        nxt[e] = TVM_LOAD_STREAM(&zc[((k * n2 + j1) << LOGN) + (u64)(e >> RLOG) * NT]);
+    }
+    for (int it = 0; it < a.tiles; it++, rho0 += ROWS) {
+        if (it) tvm_lds_barrier();
+#pragma unroll
+        for (int e = 0; e < 16; e++) s[(e & (ROWS - 1)) * RS + tid + (e >> RLOG) * NT] = nxt[e];
+        tvm_lds_barrier();
+        if (it + 1 < a.tiles) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const u64 rho = rho0 + ROWS + (e & (ROWS - 1)), j1 = rho >> log_x, k = rho & (X - 1);
+                nxt[e] = TVM_LOAD_STREAM(&zc[((k * n2 + j1) << LOGN) + (u64)(e >> RLOG) * NT]);
+            }
+        }
+        lds_ntt_fixed<true, 4, LOGN, 0, RLOG>(s, tw_fwd, tid, NT);
+        // row period*j2 + rho0 + b of column v; rho0 is a multiple of ROWS, so the ROWS rows stay inside one 16-row block
+        u64* out = a.table + (((rho0 >> TVM_RB_LOG) * W + (u64)(a.col0 + vl)) << TVM_RB_LOG) + (rho0 & (TVM_RB - 1)) + b;
+#pragma unroll 4
+        for (int i = 0; i < 16; i++) {
+            const int j2 = j2_0 + i * j2_step;
+            TVM_STORE_STREAM(&out[(u64)j2 * j2_stride], s[b * RS + j2]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // hipMalloc allocates on the calling thread's CURRENT device, which another context (or the application) may have
 // changed since tvm_ctx_create: every allocating path re-selects the context's device first.
@@ -633,6 +756,8 @@ static void set_lds_attributes() {
     (void)hipFuncSetAttribute((const void*)k_lde_pass3, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_v2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_v2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass2_v3<11, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass3_v3<11, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
 }
 
 // lo[k][i] = scale * gamma_k^i (i < n1), hi[k][i] = gamma_k^(n1*i) (i < n2), gamma_k = offset * gen^k
@@ -841,7 +966,12 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             const int tile = (int)n2 << a.batch_log;
             dim3 grid((unsigned)((n1 + B - 1) / B), (unsigned)nc);
             const size_t lds = (size_t)B * (n2 + TVM_ROW_PAD) * sizeof(u64);
-            if (a.batch_log == 4 && n2 >= 64 && n1 >= 16)  // production shape: one work-item per column of the tile
+            const size_t lds_v3 = (size_t)(8 * (n2 + TVM_ROW_PAD) + n2 / 2) * sizeof(u64);  // 8-row tiles, two positions per work-item
+            if (sp.log_n2 == 11 && n1 % 8 == 0)       // 2^21 / 2^22 rows
+                TVM_LAUNCH((k_lde_pass2_v3<11, 10>), dim3((unsigned)(n1 / 8), (unsigned)nc), dim3(1024), lds_v3, c->stream, a);
+            else if (sp.log_n2 == 7 && n1 % 8 == 0)   // the same shape at 2^13 / 2^14 rows (what the CPU suite can run)
+                TVM_LAUNCH((k_lde_pass2_v3<7, 6>), dim3((unsigned)(n1 / 8), (unsigned)nc), dim3(64), lds_v3, c->stream, a);
+            else if (a.batch_log == 4 && n2 >= 64 && n1 >= 16)  // production shape: one work-item per column of the tile
                 TVM_LAUNCH(k_lde_pass2_v2, grid, dim3((unsigned)n2), lds + (n2 / 2) * sizeof(u64), c->stream, a);
             else
                 TVM_LAUNCH(k_lde_pass2, grid, dim3(threads_for_tile(tile)), lds, c->stream, a);
@@ -854,7 +984,15 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             const int tile = (int)n1 << a.rows_log;
             dim3 grid((unsigned)((X * n2 + RB - 1) / RB), (unsigned)nc);
             const size_t lds = ((size_t)(n1 + TVM_ROW_PAD) << a.rows_log) * sizeof(u64);
-            if (a.rows_log == 4 && n1 >= 64 && (X * n2) % 16 == 0 && X * n2 / 16 < 65536) {
+            const u64 tiles8 = X * n2 / 8;  // 8-row tiles of the two-positions-per-work-item kernels
+            if ((sp.log_n1 == 11 || sp.log_n1 == 7) && (X * n2) % 16 == 0) {
+                a.tiles = tiles8 % 8 == 0 ? 8 : tiles8 % 4 == 0 ? 4 : 1;
+                const dim3 g3((unsigned)nc, (unsigned)(tiles8 / a.tiles));
+                const size_t lds_v3 = (size_t)(8 * (n1 + TVM_ROW_PAD) + n1 / 2) * sizeof(u64);
+                if (g3.y >= 65536) return set_error(c, TVM_ERR_UNSUPPORTED, "lde: too many row tiles");
+                if (sp.log_n1 == 11) TVM_LAUNCH((k_lde_pass3_v3<11, 10>), g3, dim3(1024), lds_v3, c->stream, a);
+                else TVM_LAUNCH((k_lde_pass3_v3<7, 6>), g3, dim3(64), lds_v3, c->stream, a);
+            } else if (a.rows_log == 4 && n1 >= 64 && (X * n2) % 16 == 0 && X * n2 / 16 < 65536) {
                 a.tiles = grid.x % 8 == 0 ? 8 : grid.x % 4 == 0 ? 4 : 1;  // 1 -> 49.2 ms, 2 -> 47.5, 4 -> 47.0, 8 -> 46.3 (2^20 rows)
                 TVM_LAUNCH(k_lde_pass3_v2, dim3(grid.y, grid.x / a.tiles), dim3((unsigned)n1), lds + (n1 / 2) * sizeof(u64), c->stream, a);
             }

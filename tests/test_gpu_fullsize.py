@@ -91,7 +91,7 @@ def test_large_xfe_transform_round_trip_and_point_values(gctx, log_len):
 
 
 
-@pytest.mark.parametrize("log_n,fk,n_cols,sample_cols", [(21, 1, 40, (0, 17, 39)), (22, 1, 24, (0, 23)), (22, 3, 3, (2,)), (21, 3, 7, (6,))])
+@pytest.mark.parametrize("log_n,fk,n_cols,sample_cols", [(21, 1, 40, (0, 17, 39)), (22, 1, 24, (0, 23)), (22, 3, 3, (2,)), (21, 3, 7, (6,)), (23, 1, 6, (5,))])
 def test_lde_of_longer_traces(gctx, orc, log_n, fk, n_cols, sample_cols):
     """2^21 and 2^22 rows (BASELINE config 3's height): 2048-point axes, the kernels with two positions per work-item and
     8-row tiles (k_lde_pass2_v3 / k_lde_pass3_v3).  Sampled columns through the oracle at sampled rows."""

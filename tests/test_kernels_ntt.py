@@ -42,7 +42,9 @@ def test_evaluate_interpolate_match_oracle(ctx, orc, log_len, n_coeffs, fk):
                                                        (4, 1, 3, 5), (12, 1, 2, 7),   # expansion 1: a rank's share at 8 GPUs
                                                        # 2^13 / 2^14 / 2^15 rows: the kernels with two positions per work-item and
                                                        # 8-row tiles (the shape of 2^21 / 2^22-row traces)
-                                                       (13, 8, 3, 198), (14, 8, 2, 198), (14, 4, 17, 5), (15, 2, 2, 9000), (14, 1, 2, 3)])
+                                                       (13, 8, 3, 198), (14, 8, 2, 198), (14, 4, 17, 5), (15, 2, 2, 9000), (14, 1, 2, 3),
+                                                       # ... and four positions per work-item, 4-row tiles (2^23 / 2^24 rows)
+                                                       (15, 8, 2, 20), (16, 4, 2, 198), (16, 1, 1, 3), (17, 2, 1, 70)])
 @pytest.mark.parametrize("fk", [1, 3])
 def test_lde_table_matches_oracle(ctx, orc, log_n, expansion, n_cols, h, fk):
     rng = np.random.default_rng(log_n + 31 * n_cols + fk)

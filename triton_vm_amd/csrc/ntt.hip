@@ -508,8 +508,8 @@ __global__ void __launch_bounds__(1024) k_lde_pass3_v2(LdePass3Args a) {
 // The same two passes for an LDS-resident axis LONGER than a workgroup: 2^LOGN points on 2^TLOG work-items, i.e.
 // PPT = 2^(LOGN - TLOG) positions per work-item and tiles of 16 / PPT rows, so that a work-item still owns 16 elements and
 // the tile still holds 16 * 2^TLOG words (2048-point axes on 1024 work-items with 8-row tiles: traces of 2^21 and 2^22
-// rows, which the production kernels above -- one position per work-item -- cannot take; <7, 6> is the same shape at a
-// size the CPU suite can run).  Element e of a work-item: row e % ROWS, position tid + (e / ROWS) * 2^TLOG.
+// rows, which the production kernels above -- one position per work-item -- cannot take; 4096-point axes with 4-row tiles:
+// 2^23 and 2^24 rows; <7, 6> and <8, 6> are the same shapes at sizes the CPU suite can run).  Element e of a work-item: row e % ROWS, position tid + (e / ROWS) * 2^TLOG.
 template <int LOGN, int TLOG>
 __global__ void __launch_bounds__(1 << TLOG) k_lde_pass2_v3(LdePass2Args a) {
     constexpr int NT = 1 << TLOG, RLOG = 4 - (LOGN - TLOG), ROWS = 1 << RLOG, PPT = 16 / ROWS;
@@ -758,6 +758,8 @@ static void set_lds_attributes() {
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_v2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_v3<11, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_v3<11, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass2_v3<12, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass3_v3<12, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
 }
 
 // lo[k][i] = scale * gamma_k^i (i < n1), hi[k][i] = gamma_k^(n1*i) (i < n2), gamma_k = offset * gen^k
@@ -966,11 +968,18 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             const int tile = (int)n2 << a.batch_log;
             dim3 grid((unsigned)((n1 + B - 1) / B), (unsigned)nc);
             const size_t lds = (size_t)B * (n2 + TVM_ROW_PAD) * sizeof(u64);
-            const size_t lds_v3 = (size_t)(8 * (n2 + TVM_ROW_PAD) + n2 / 2) * sizeof(u64);  // 8-row tiles, two positions per work-item
-            if (sp.log_n2 == 11 && n1 % 8 == 0)       // 2^21 / 2^22 rows
-                TVM_LAUNCH((k_lde_pass2_v3<11, 10>), dim3((unsigned)(n1 / 8), (unsigned)nc), dim3(1024), lds_v3, c->stream, a);
-            else if (sp.log_n2 == 7 && n1 % 8 == 0)   // the same shape at 2^13 / 2^14 rows (what the CPU suite can run)
-                TVM_LAUNCH((k_lde_pass2_v3<7, 6>), dim3((unsigned)(n1 / 8), (unsigned)nc), dim3(64), lds_v3, c->stream, a);
+            // axes longer than a workgroup: 2048 / 4096 points on 1024 work-items (2^21 .. 2^24 rows), and the same shapes at a
+            // size the CPU suite can run (128 / 256 points on 64 work-items); rows per tile = 16 / positions per work-item
+            const int ppt_log = (sp.log_n2 == 11 || sp.log_n2 == 7) ? 1 : (sp.log_n2 == 12 || sp.log_n2 == 8) ? 2 : 0;
+            const u64 rows3 = 16 >> ppt_log;
+            const size_t lds_v3 = (size_t)(rows3 * (n2 + TVM_ROW_PAD) + n2 / 2) * sizeof(u64);
+            const dim3 g2((unsigned)(n1 / rows3), (unsigned)nc);
+            if (ppt_log && n1 % rows3 == 0) {
+                if (sp.log_n2 == 11) TVM_LAUNCH((k_lde_pass2_v3<11, 10>), g2, dim3(1024), lds_v3, c->stream, a);
+                else if (sp.log_n2 == 12) TVM_LAUNCH((k_lde_pass2_v3<12, 10>), g2, dim3(1024), lds_v3, c->stream, a);
+                else if (sp.log_n2 == 7) TVM_LAUNCH((k_lde_pass2_v3<7, 6>), g2, dim3(64), lds_v3, c->stream, a);
+                else TVM_LAUNCH((k_lde_pass2_v3<8, 6>), g2, dim3(64), lds_v3, c->stream, a);
+            }
             else if (a.batch_log == 4 && n2 >= 64 && n1 >= 16)  // production shape: one work-item per column of the tile
                 TVM_LAUNCH(k_lde_pass2_v2, grid, dim3((unsigned)n2), lds + (n2 / 2) * sizeof(u64), c->stream, a);
             else
@@ -984,14 +993,17 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             const int tile = (int)n1 << a.rows_log;
             dim3 grid((unsigned)((X * n2 + RB - 1) / RB), (unsigned)nc);
             const size_t lds = ((size_t)(n1 + TVM_ROW_PAD) << a.rows_log) * sizeof(u64);
-            const u64 tiles8 = X * n2 / 8;  // 8-row tiles of the two-positions-per-work-item kernels
-            if ((sp.log_n1 == 11 || sp.log_n1 == 7) && (X * n2) % 16 == 0) {
-                a.tiles = tiles8 % 8 == 0 ? 8 : tiles8 % 4 == 0 ? 4 : 1;
-                const dim3 g3((unsigned)nc, (unsigned)(tiles8 / a.tiles));
-                const size_t lds_v3 = (size_t)(8 * (n1 + TVM_ROW_PAD) + n1 / 2) * sizeof(u64);
+            const int ppt_log = (sp.log_n1 == 11 || sp.log_n1 == 7) ? 1 : (sp.log_n1 == 12 || sp.log_n1 == 8) ? 2 : 0;
+            const u64 rows3 = 16 >> ppt_log, tiles3 = X * n2 / rows3;  // see pass 2
+            if (ppt_log && (X * n2) % 16 == 0) {
+                a.tiles = tiles3 % 8 == 0 ? 8 : tiles3 % 4 == 0 ? 4 : 1;
+                const dim3 g3((unsigned)nc, (unsigned)(tiles3 / a.tiles));
+                const size_t lds_v3 = (size_t)(rows3 * (n1 + TVM_ROW_PAD) + n1 / 2) * sizeof(u64);
                 if (g3.y >= 65536) return set_error(c, TVM_ERR_UNSUPPORTED, "lde: too many row tiles");
                 if (sp.log_n1 == 11) TVM_LAUNCH((k_lde_pass3_v3<11, 10>), g3, dim3(1024), lds_v3, c->stream, a);
-                else TVM_LAUNCH((k_lde_pass3_v3<7, 6>), g3, dim3(64), lds_v3, c->stream, a);
+                else if (sp.log_n1 == 12) TVM_LAUNCH((k_lde_pass3_v3<12, 10>), g3, dim3(1024), lds_v3, c->stream, a);
+                else if (sp.log_n1 == 7) TVM_LAUNCH((k_lde_pass3_v3<7, 6>), g3, dim3(64), lds_v3, c->stream, a);
+                else TVM_LAUNCH((k_lde_pass3_v3<8, 6>), g3, dim3(64), lds_v3, c->stream, a);
             } else if (a.rows_log == 4 && n1 >= 64 && (X * n2) % 16 == 0 && X * n2 / 16 < 65536) {
                 a.tiles = grid.x % 8 == 0 ? 8 : grid.x % 4 == 0 ? 4 : 1;  // 1 -> 49.2 ms, 2 -> 47.5, 4 -> 47.0, 8 -> 46.3 (2^20 rows)
                 TVM_LAUNCH(k_lde_pass3_v2, dim3(grid.y, grid.x / a.tiles), dim3((unsigned)n1), lds + (n1 / 2) * sizeof(u64), c->stream, a);

@@ -178,8 +178,9 @@ typedef struct {
     uint64_t op_stack_len;
     const uint64_t* ram_trace;                  /* [ram_len][7] (RamTableCall::to_table_row: the last 3 columns are 0) */
     uint64_t ram_len;
-    /* bezout_coefficient_polynomials_coefficients(unique RAM pointers in ascending order) (ram.rs:152-207): computed on
-     * the host (twenty-first polynomial arithmetic), num_ram_pointers words each */
+    /* bezout_coefficient_polynomials_coefficients(unique RAM pointers in ascending order) (ram.rs:152-207), num_ram_pointers
+     * words each, when the host has them (twenty-first polynomial arithmetic); both null and num_ram_pointers 0: they are
+     * computed on the device from the sorted RAM table (tvm_bezout_coefficients' algorithm) */
     const uint64_t* bezout_coefficients_0;
     const uint64_t* bezout_coefficients_1;
     uint64_t num_ram_pointers;
@@ -314,6 +315,11 @@ void tvm_host_stdrng_elements(const uint8_t seed[32], uint64_t n, uint64_t* out)
 /* the same n elements into device memory, generated on the device (one ChaCha block per work-item); when a draw takes the
  * range sampler's rare short path the stream is regenerated sequentially on the host -- the result is always the host's */
 int32_t tvm_stdrng_elements(tvm_ctx* ctx, const uint8_t seed[32], uint64_t n, uint64_t* d_out);
+
+/* The RAM table's Bezout coefficient polynomials: bezout_coefficient_polynomials_coefficients (table/ram.rs:152-207) for n
+ * pairwise distinct roots (the unique RAM pointers, device array): a and b with a * rp + b * rp' = 1, rp = prod (X - r_i),
+ * n coefficients each (device arrays).  TVM_ERR_INVALID_ARGUMENT when two roots coincide. */
+int32_t tvm_bezout_coefficients(tvm_ctx* ctx, const uint64_t* d_roots, uint64_t n, uint64_t* d_a, uint64_t* d_b);
 
 /* ---- verifier batch work --------------------------------------------------------
  * Verifier::verify's work over the num_first_round_queries revealed rows (stark.rs:1388-1763), all host data in / out:

@@ -10,8 +10,9 @@ from tests import vm_fixture as vf
 from triton_vm_amd import master_table as mtab
 
 
-def aet_arrays(orc, aet):
-    """the oracle VM's AET in the layout of AlgebraicExecutionTrace (aet.rs:41-96): Montgomery words, row-major"""
+def aet_arrays(orc, aet, host_bezout=True):
+    """the oracle VM's AET in the layout of AlgebraicExecutionTrace (aet.rs:41-96): Montgomery words, row-major.
+    host_bezout=False leaves the RAM table's Bezout coefficient polynomials to the device."""
     from oracle.vm import tables as T
 
     def M(rows, width):
@@ -24,10 +25,12 @@ def aet_arrays(orc, aet):
         return orc.to_mont(canonical.reshape(-1, width))
 
     hash_rows = lambda trace: [T.hash_table_row(0, ci, rnd, state) for ci, rnd, state in trace]   # Mode is set by fill
-    ram_rows, _ = (T.fill_ram(aet) if aet.ram_trace else ([], []))
-    unique = list(dict.fromkeys(r[T.M["Ram"]["RamPointer"]] for r in ram_rows))
-    b0, b1 = T.bezout_coefficient_polynomials_coefficients(unique)
-    return {
+    b0 = b1 = []
+    if host_bezout:
+        ram_rows, _ = (T.fill_ram(aet) if aet.ram_trace else ([], []))
+        unique = list(dict.fromkeys(r[T.M["Ram"]["RamPointer"]] for r in ram_rows))
+        b0, b1 = T.bezout_coefficient_polynomials_coefficients(unique)
+    arrays = {
         "program_words": orc.to_mont(np.array(aet.program.to_bwords(), dtype=object)),
         "instruction_multiplicities": np.array(aet.instruction_multiplicities, np.uint32),
         "processor_trace": M(aet.processor_trace, 39),
@@ -43,17 +46,20 @@ def aet_arrays(orc, aet):
         "cascade_entries": np.array([[limb, mult] for limb, mult in aet.cascade_multiplicities.items()], np.uint64).reshape(-1, 2),
         "lookup_multiplicities": np.array(aet.lookup_multiplicities, np.uint64),
     }
+    if not host_bezout:
+        del arrays["bezout_coefficients_0"], arrays["bezout_coefficients_1"]
+    return arrays
 
 
-@pytest.mark.parametrize("which", ["tiny", "every"])
-def test_fill_pad_extend_on_the_device_reproduce_the_oracle_tables(ctx, orc, which):
+@pytest.mark.parametrize("which,host_bezout", [("tiny", True), ("every", True), ("every", False)])
+def test_fill_pad_extend_on_the_device_reproduce_the_oracle_tables(ctx, orc, which, host_bezout):
     from oracle.vm import tables as T
 
     main, aux, ch, mt = vf.valid_tables(which)
     _, aet, _, _ = vf.run(which)
     n = main.shape[1]
     d_main = ctx.alloc(379 * n)
-    lengths = mtab.fill(ctx, d_main, n, aet_arrays(orc, aet))
+    lengths = mtab.fill(ctx, d_main, n, aet_arrays(orc, aet, host_bezout))   # without them: the device's Bezout coefficients
     assert lengths == [mt.lengths[t] for t in mtab.TABLE_ORDER]
     # the unpadded fill, table by table
     unpadded = T.MasterMainTable(aet)

@@ -15,6 +15,7 @@ CASES = [
     ("many_u32", 32, 2, "fri", False), ("pick_and_place", 32, 2, "fri", False), (("fib", 100), 32, 2, "fri", False),
     ("every", 32, 2, "fri", False), ("every", 64, 3, "fri", False), (("u32", 100), 32, 2, "fri", False),
     ("halt", 32, 2, "stir", False), ("every", 48, 2, "stir", False), (("fib", 100), 160, 2, "stir", False),
+    (("ram", 3000), 32, 2, "fri", False),   # 3000 distinct RAM pointers: the Bezout coefficient polynomials come from the device
 ]
 
 
@@ -30,7 +31,8 @@ def test_prove_and_verify(ctx, orc, which, security_level, log2_expansion, ldt, 
     if which == "pick_and_place":
         assert output == [1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7]
     claim = snap.claim_of(orc, program, public_input, output)
-    prover = Prover.from_execution(ctx, aet_arrays(orc, aet), aet.padded_height(), claim, snap.prover_seed(len(str(which))),
+    host_bezout = not (isinstance(which, tuple) and which[0] == "ram")
+    prover = Prover.from_execution(ctx, aet_arrays(orc, aet, host_bezout), aet.padded_height(), claim, snap.prover_seed(len(str(which))),
                                    security_level=security_level, log2_expansion=log2_expansion, ldt=ldt)
     proof = prover.prove().proof()
     kw = dict(security_level=security_level, log2_expansion=log2_expansion, ldt_choice=ldt)

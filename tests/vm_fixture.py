@@ -71,6 +71,18 @@ U32_LOOP_PROGRAM = """
         dup 1 xor pop 1
         push -1 add dup 0 skiz recurse return
 """
+# a loop that writes to a fresh RAM address every iteration: as many distinct RAM pointers as iterations (the RAM table's
+# Bezout coefficient polynomials have that many coefficients)
+RAM_LOOP_PROGRAM = """
+    read_io 1
+    call loop
+    pop 1 halt
+    loop:
+        dup 0 dup 0 mul
+        dup 1 push 1000 mul
+        write_mem 1 pop 1
+        push -1 add dup 0 skiz recurse return
+"""
 PROGRAMS = {"halt": ("halt", []), "many_u32": (MANY_U32_PROGRAM, []), "pick_and_place": (PICK_AND_PLACE_PROGRAM, PICK_AND_PLACE_INPUT)}
 
 
@@ -91,15 +103,15 @@ def non_determinism(which):
 
 
 def run(which):
-    """-> (program, aet, public input, public output); which: "tiny", "every", ("fib", index), ("u32", iterations) or a
-    key of PROGRAMS"""
+    """-> (program, aet, public input, public output); which: "tiny", "every", ("fib", index), ("u32", iterations), ("ram", iterations)
+    or a key of PROGRAMS"""
     if which in PROGRAMS:
         text, public_input = PROGRAMS[which]
         program = isa.parse(text)
         aet, output = vm.trace_execution(program, public_input)
         return program, aet, list(public_input), output
-    if isinstance(which, tuple) and which[0] in ("fib", "u32"):
-        program = isa.parse(FIBONACCI_PROGRAM if which[0] == "fib" else U32_LOOP_PROGRAM)
+    if isinstance(which, tuple) and which[0] in ("fib", "u32", "ram"):
+        program = isa.parse({"fib": FIBONACCI_PROGRAM, "u32": U32_LOOP_PROGRAM, "ram": RAM_LOOP_PROGRAM}[which[0]])
         aet, output = vm.trace_execution(program, [which[1]])
         return program, aet, [which[1]], output
     if which == "tiny":

@@ -119,6 +119,7 @@ _SIGNATURES = {
     "tvm_host_xfe_poly_eval": (None, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p]),
     "tvm_host_stdrng_elements": (None, [C.c_char_p, C.c_uint64, C.c_void_p]),
     "tvm_stdrng_elements": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p]),
+    "tvm_bezout_coefficients": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "tvm_host_air_constraints": (C.c_int32, [C.c_void_p] * 6),
 }
 

@@ -540,7 +540,7 @@ int32_t tvm_fill_derived_aux_columns(tvm_ctx* c, const uint64_t* d_main_trace, u
 int32_t tvm_fill_main_table(tvm_ctx* c, const tvm_aet* aet, uint64_t* d_main_trace, uint64_t n_rows, uint64_t* h_table_lengths_out) {
     if (!c || !aet || !d_main_trace || !h_table_lengths_out || !is_pow2(n_rows) || n_rows < 2 || !aet->processor_trace ||
         !aet->lookup_multiplicities || (aet->program_len && (!aet->program_words || !aet->instruction_multiplicities)) ||
-        (aet->op_stack_len && !aet->op_stack_trace) || (aet->ram_len && (!aet->ram_trace || !aet->bezout_coefficients_0 || !aet->bezout_coefficients_1)) ||
+        (aet->op_stack_len && !aet->op_stack_trace) || (aet->ram_len && (!aet->ram_trace || !aet->bezout_coefficients_0 != !aet->bezout_coefficients_1)) ||  // both or neither (device)
         (aet->program_hash_len && !aet->program_hash_trace) || (aet->sponge_len && !aet->sponge_trace) || (aet->hash_len && !aet->hash_trace) ||
         (aet->u32_len && !aet->u32_entries) || (aet->cascade_len && !aet->cascade_entries))
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_fill_main_table arguments");
@@ -927,6 +927,13 @@ int32_t tvm_stdrng_elements(tvm_ctx* c, const uint8_t seed[32], uint64_t n, uint
             rc = set_error(c, TVM_ERR_DEVICE, "stdrng elements (host path)");
     }
     return rc;
+}
+}  // extern "C"
+
+extern "C" {
+int32_t tvm_bezout_coefficients(tvm_ctx* c, const uint64_t* d_roots, uint64_t n, uint64_t* d_a, uint64_t* d_b) {
+    if (!c || (n && (!d_roots || !d_a || !d_b))) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_bezout_coefficients arguments");
+    return tvm::bezout_coefficients(c, d_roots, n, d_a, d_b);
 }
 }  // extern "C"
 

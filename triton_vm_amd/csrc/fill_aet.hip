@@ -126,6 +126,12 @@ __global__ void k_fa_ram_flags(const u64* __restrict__ main, u64 n, u64 len, u64
     if (r >= len) return;
     flags[r] = (r > 0 && main[(u64)MC_RAM_RAM_POINTER * n + r] != main[(u64)MC_RAM_RAM_POINTER * n + r - 1]) ? 1 : 0;
 }
+// the distinct RAM pointers of the sorted table, in table order: row r starts pointer number changes_inclusive[r]
+__global__ void k_fa_distinct_pointers(const u64* __restrict__ main, u64 n, u64 len, const u64* __restrict__ flags,
+                                       const u64* __restrict__ changes_inclusive, u64* __restrict__ out) {
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < len && (r == 0 || flags[r])) out[changes_inclusive[r]] = main[(u64)MC_RAM_RAM_POINTER * n + r];
+}
 // make_ram_table_consistent (ram.rs:214-262): the row's Bezout coefficients are popped from the END of the coefficient
 // vectors, one pair per distinct pointer; the inverse of the pointer difference to the NEXT row
 __global__ void k_fa_ram_consistent(u64* __restrict__ main, u64 n, u64 len, const u64* __restrict__ changes_inclusive,
@@ -311,7 +317,10 @@ int fill_main_table(tvm_ctx* c, const tvm_aet* aet, u64* d_main, u64 n, u64* h_l
         h_lengths[t] = lengths[t];
         if (lengths[t] > n) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "fill: a table is longer than the padded height");
     }
-    if (aet->processor_len < 1 || (aet->ram_len && !aet->num_ram_pointers))
+    // the Bezout coefficient polynomials of the RAM table: given by the host (num_ram_pointers of them) or, when both
+    // pointers are null, computed here from the sorted table's distinct RAM pointers (csrc/bezout.hip)
+    const bool device_bezout = aet->ram_len && !aet->bezout_coefficients_0 && !aet->bezout_coefficients_1;
+    if (aet->processor_len < 1 || (aet->ram_len && !device_bezout && !aet->num_ram_pointers))
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "fill: empty processor trace or missing Bezout coefficients");
     TVM_HIP_CHECK(c, hipMemsetAsync(d_main, 0, (size_t)TVM_NUM_ORIGINAL_MAIN_COLUMNS * n * sizeof(u64), c->stream));
 
@@ -327,6 +336,7 @@ int fill_main_table(tvm_ctx* c, const tvm_aet* aet, u64* d_main, u64 n, u64* h_l
     const u64 max_mem = aet->processor_len > aet->op_stack_len ? (aet->processor_len > aet->ram_len ? aet->processor_len : aet->ram_len)
                                                                : (aet->op_stack_len > aet->ram_len ? aet->op_stack_len : aet->ram_len);
     u64* w = (u64*)pool_alloc(c, (4 * max_mem + aet->processor_len + 8) * sizeof(u64));
+    u64* bz = nullptr;  // device-computed Bezout coefficients (device_bezout)
     const bool ok = program.d && imult.d && proc.d && ops.d && ram.d && bc0.d && bc1.d && ph.d && sp.d && hs.d && u32e.d && u32o.d && casc.d &&
                     lkm.d && w;
     if (!ok) {
@@ -377,7 +387,26 @@ int fill_main_table(tvm_ctx* c, const tvm_aet* aet, u64* d_main, u64 n, u64* h_l
         TVM_LAUNCH(k_fa_gather, fa_grid(len * 4), dim3(256), 0, c->stream, d_ram, order, len, 7, 4, d_main, n, MC_RAM_CLK);
         TVM_LAUNCH(k_fa_ram_flags, fa_grid(len), dim3(256), 0, c->stream, d_main, n, len, keys);
         if ((rc = inclusive_sum(c, keys, keys_out, len)) != TVM_OK) goto done;
-        TVM_LAUNCH(k_fa_ram_consistent, fa_grid(len), dim3(256), 0, c->stream, d_main, n, len, keys_out, d_bc0, d_bc1, aet->num_ram_pointers);
+        if (device_bezout) {
+            u64 changes = 0;  // pointer changes up to the last row: one less than the number of distinct pointers
+            if (hipMemcpyAsync(&changes, keys_out + len - 1, sizeof(u64), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess) {
+                rc = set_error(c, TVM_ERR_DEVICE, "fill: distinct RAM pointers");
+                goto done;
+            }
+            const u64 n_unique = changes + 1;
+            bz = (u64*)pool_alloc(c, 3 * n_unique * sizeof(u64));  // the distinct pointers, then the two coefficient vectors
+            if (!bz) {
+                rc = set_error(c, TVM_ERR_OUT_OF_MEMORY, "fill: Bezout coefficients");
+                goto done;
+            }
+            TVM_LAUNCH(k_fa_distinct_pointers, fa_grid(len), dim3(256), 0, c->stream, (const u64*)d_main, n, len, (const u64*)keys, (const u64*)keys_out, bz);
+            if ((rc = bezout_coefficients(c, bz, n_unique, bz + n_unique, bz + 2 * n_unique)) != TVM_OK) goto done;
+            TVM_LAUNCH(k_fa_ram_consistent, fa_grid(len), dim3(256), 0, c->stream, d_main, n, len, keys_out, (const u64*)(bz + n_unique),
+                       (const u64*)(bz + 2 * n_unique), n_unique);
+        } else {
+            TVM_LAUNCH(k_fa_ram_consistent, fa_grid(len), dim3(256), 0, c->stream, d_main, n, len, keys_out, d_bc0, d_bc1, aet->num_ram_pointers);
+        }
         TVM_LAUNCH(k_fa_clock_jump_differences, fa_grid(len), dim3(256), 0, c->stream, d_main, n, MC_RAM_CLK, MC_RAM_RAM_POINTER, len, hist, aet->processor_len);
     }
     // JumpStack: the processor rows, stable-sorted by jump-stack pointer
@@ -394,6 +423,7 @@ int fill_main_table(tvm_ctx* c, const tvm_aet* aet, u64* d_main, u64 n, u64* h_l
     if (hipGetLastError() != hipSuccess) rc = set_error(c, TVM_ERR_DEVICE, "fill kernels");
 done:
     pool_release(c, w);
+    pool_release(c, bz);
     return rc;
 }
 

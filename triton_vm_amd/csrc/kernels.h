@@ -36,6 +36,8 @@ int stir_quotient(tvm_ctx* c, u64* vals, u64 n, u64 offset, u64 gen, const u64* 
                   u32 kb, const u64* h_r);
 // fill.hip
 int fill_degree_lowering(tvm_ctx* c, int table, u64* d_main, u64* d_aux, const u64* d_challenges, u64 n);
+// bezout.hip
+int bezout_coefficients(tvm_ctx* c, const u64* d_roots, u64 n, u64* d_a, u64* d_b);
 // fill_aet.hip
 int fill_main_table(tvm_ctx* c, const tvm_aet* aet, u64* d_main, u64 n, u64* h_lengths);
 // pad.hip

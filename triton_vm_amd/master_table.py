@@ -161,7 +161,7 @@ def pad(ctx, d_main_trace, n_rows, table_lengths):
 def aet_struct(aet):
     """the C ABI's `tvm_aet` over a dict of numpy arrays shaped like AlgebraicExecutionTrace's fields (aet.rs:41-96):
     program_words [p], instruction_multiplicities [p] (uint32), processor_trace [c][39], op_stack_trace [k][4],
-    ram_trace [k][7], bezout_coefficients_0/1 [u], program_hash_trace / sponge_trace / hash_trace [k][67],
+    ram_trace [k][7], bezout_coefficients_0/1 [u] (optional: computed on the device when absent), program_hash_trace / sponge_trace / hash_trace [k][67],
     u32_entries [k][4], cascade_entries [k][2], lookup_multiplicities [256].  -> (struct, the arrays it points into)"""
     from .capi import Aet
 
@@ -185,10 +185,14 @@ def aet_struct(aet):
         a = arr(name, width=width)
         setattr(s, name, a.ctypes.data)
         setattr(s, len_, a.shape[0])
-    b0, b1 = arr("bezout_coefficients_0"), arr("bezout_coefficients_1")
-    if b0.size != b1.size:
-        raise ValueError("the two Bezout coefficient vectors have the same length")
-    s.bezout_coefficients_0, s.bezout_coefficients_1, s.num_ram_pointers = b0.ctypes.data, b1.ctypes.data, b0.size
+    if "bezout_coefficients_0" in aet or "bezout_coefficients_1" in aet:
+        b0, b1 = arr("bezout_coefficients_0"), arr("bezout_coefficients_1")
+        if b0.size != b1.size:
+            raise ValueError("the two Bezout coefficient vectors have the same length")
+        s.bezout_coefficients_0, s.bezout_coefficients_1, s.num_ram_pointers = b0.ctypes.data, b1.ctypes.data, b0.size
+    else:   # left to the device (csrc/bezout.hip)
+        s.bezout_coefficients_0 = s.bezout_coefficients_1 = None
+        s.num_ram_pointers = 0
     lk = arr("lookup_multiplicities")
     if lk.size != 256:
         raise ValueError("256 lookup multiplicities")

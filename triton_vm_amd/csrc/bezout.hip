@@ -157,11 +157,22 @@ __global__ void k_bz_copy(const u64* __restrict__ src, u64 n_src, u64 n, u64* __
 }
 
 static u64 bz_root_of_unity(u64 order) { return bfe_pow(bfe_from_u64(7), (TVM_P - 1) / order); }
+// `count` transforms of length `len` (input: in_len words at stride in_stride, zero-padded; output at stride out_stride),
+// at most 2^15 per launch (the transform kernels take the column index from the grid's y dimension)
+static int bz_transforms(tvm_ctx* c, const u64* in, u64 in_len, u64 in_stride, u64* out, u64 out_stride, u64 count, u64 len, u64 w,
+                         u64 out_mult) {
+    for (u64 first = 0; first < count; first += 1u << 15) {
+        const u64 batch = count - first < (1u << 15) ? count - first : (1u << 15);
+        TVM_TRY(ntt_columns(c, in + first * in_stride, in_len, 1, in_stride, out + first * out_stride, 1, out_stride, 1, 0, (int)batch, len, w,
+                            TVM_ONE, TVM_ONE, out_mult));
+    }
+    return TVM_OK;
+}
 
 // d_roots: n pairwise distinct field elements; d_a, d_b: n words each
 int bezout_coefficients(tvm_ctx* c, const u64* d_roots, u64 n, u64* d_a, u64* d_b) {
     if (!n) return TVM_OK;
-    if (n > (1ull << 21)) return set_error(c, TVM_ERR_UNSUPPORTED, "bezout: more than 2^21 roots");  // 2^15 chunk columns per transform launch
+    if (n > (1ull << 24)) return set_error(c, TVM_ERR_UNSUPPORTED, "bezout: more than 2^24 roots");  // transforms of up to 2^26 points
     const unsigned bs = 256;
     auto grid = [&](u64 total) { return dim3((unsigned)((total + bs - 1) / bs)); };
     u64 NP = BZ_CHUNK;  // leaves after padding
@@ -207,11 +218,10 @@ int bezout_coefficients(tvm_ctx* c, const u64* d_roots, u64 n, u64* d_a, u64* d_
     TVM_LAUNCH(k_bz_leaves, grid(n_chunks), dim3(bs), 0, c->stream, d_roots, (const u64*)nullptr, n, n_chunks, level(BZ_CHUNK_LOG), (u64*)nullptr);
     for (int l = BZ_CHUNK_LOG; rc == TVM_OK && l < K; l++) {
         const u64 slot = 2ull << l, nodes = NP >> l, len = 2 * slot;  // children; parents have slots of `len` words
-        rc = ntt_columns(c, level(l), slot, 1, slot, FA, 1, len, 1, 0, (int)nodes, len, bz_root_of_unity(len), TVM_ONE, TVM_ONE, TVM_ONE);
+        rc = bz_transforms(c, level(l), slot, slot, FA, len, nodes, len, bz_root_of_unity(len), TVM_ONE);
         if (rc != TVM_OK) break;
         TVM_LAUNCH(k_bz_combine, grid(nodes / 2 * len), dim3(bs), 0, c->stream, (const u64*)FA, (const u64*)nullptr, nodes / 2, len, level(l + 1), (u64*)nullptr);
-        rc = ntt_columns(c, level(l + 1), len, 1, len, level(l + 1), 1, len, 1, 0, (int)(nodes / 2), len, bfe_inv(bz_root_of_unity(len)), TVM_ONE,
-                         TVM_ONE, bfe_inv(bfe_from_u64(len)));
+        rc = bz_transforms(c, level(l + 1), len, len, level(l + 1), len, nodes / 2, len, bfe_inv(bz_root_of_unity(len)), bfe_inv(bfe_from_u64(len)));
     }
     const u64* m_root = level(K);   // X^pad * rp: NP + 1 coefficients, monic
     const u64* rp = m_root + pad;   // n + 1 coefficients
@@ -255,13 +265,13 @@ int bezout_coefficients(tvm_ctx* c, const u64* d_roots, u64 n, u64* d_a, u64* d_
     for (int l = K; rc == TVM_OK && l > BZ_CHUNK_LOG; l--) {
         const u64 D = 1ull << l, parents = NP >> l;
         const u64 wD = bz_root_of_unity(D);
-        rc = ntt_columns(c, T[cur], D, 1, D, FA, 1, D, 1, 0, (int)parents, D, wD, TVM_ONE, TVM_ONE, TVM_ONE);
+        rc = bz_transforms(c, T[cur], D, D, FA, D, parents, D, wD, TVM_ONE);
         if (rc != TVM_OK) break;
         TVM_LAUNCH(k_bz_reverse_children, grid(2 * parents * D), dim3(bs), 0, c->stream, (const u64*)level(l - 1), 2 * parents, D, FB);
-        rc = ntt_columns(c, FB, D, 1, D, FB, 1, D, 1, 0, (int)(2 * parents), D, wD, TVM_ONE, TVM_ONE, TVM_ONE);
+        rc = bz_transforms(c, FB, D, D, FB, D, 2 * parents, D, wD, TVM_ONE);
         if (rc != TVM_OK) break;
         TVM_LAUNCH(k_bz_middle, grid(parents * D), dim3(bs), 0, c->stream, (const u64*)FA, parents, D, FB);
-        rc = ntt_columns(c, FB, D, 1, D, FB, 1, D, 1, 0, (int)(2 * parents), D, bfe_inv(wD), TVM_ONE, TVM_ONE, bfe_inv(bfe_from_u64(D)));
+        rc = bz_transforms(c, FB, D, D, FB, D, 2 * parents, D, bfe_inv(wD), bfe_inv(bfe_from_u64(D)));
         if (rc != TVM_OK) break;
         TVM_LAUNCH(k_bz_take_middle, grid(NP), dim3(bs), 0, c->stream, (const u64*)FB, 2 * parents, D, T[1 - cur]);
         cur = 1 - cur;
@@ -280,11 +290,11 @@ int bezout_coefficients(tvm_ctx* c, const u64* d_roots, u64 n, u64* d_a, u64* d_
     for (int l = BZ_CHUNK_LOG; rc == TVM_OK && l < K; l++) {
         const u64 slot = 2ull << l, nodes = NP >> l, len = 2 * slot;
         const u64 wl = bz_root_of_unity(len);
-        rc = ntt_columns(c, level(l), slot, 1, slot, FA, 1, len, 1, 0, (int)nodes, len, wl, TVM_ONE, TVM_ONE, TVM_ONE);
-        if (rc == TVM_OK) rc = ntt_columns(c, N[cur], slot, 1, slot, FB, 1, len, 1, 0, (int)nodes, len, wl, TVM_ONE, TVM_ONE, TVM_ONE);
+        rc = bz_transforms(c, level(l), slot, slot, FA, len, nodes, len, wl, TVM_ONE);
+        if (rc == TVM_OK) rc = bz_transforms(c, N[cur], slot, slot, FB, len, nodes, len, wl, TVM_ONE);
         if (rc != TVM_OK) break;
         TVM_LAUNCH(k_bz_combine, grid(nodes / 2 * len), dim3(bs), 0, c->stream, (const u64*)FA, (const u64*)FB, nodes / 2, len, (u64*)nullptr, N[1 - cur]);
-        rc = ntt_columns(c, N[1 - cur], len, 1, len, N[1 - cur], 1, len, 1, 0, (int)(nodes / 2), len, bfe_inv(wl), TVM_ONE, TVM_ONE, bfe_inv(bfe_from_u64(len)));
+        rc = bz_transforms(c, N[1 - cur], len, len, N[1 - cur], len, nodes / 2, len, bfe_inv(wl), bfe_inv(bfe_from_u64(len)));
         cur = 1 - cur;
     }
 

@@ -1,6 +1,8 @@
 """One proof split over 2, 4 and 8 ranks (triton_vm_amd/sharded.py: coset sharding, gloo on CPU, the kernels on the
 TEST-ONLY fiber emulation) must commit to the same roots, sample the same challenges and hand FRI the same
-combination codeword as the single-process prover on the same traces.  World size 8 is the full node: with the
+combination codeword as the single-process prover on the same traces, and produce the same proof word for word --
+with the Merkle trees built redundantly and with the trees split over the ranks (subtree per rank, exchanged roots,
+authentication nodes fetched from their owners).  World size 8 is the full node: with the
 default expansion factor every rank then owns exactly one coset of the trace domain."""
 import os
 import socket
@@ -23,14 +25,15 @@ def _traces():
 
 def _capture(prover):
     prover.capture = {}
-    prover.prove()
+    proof = prover.prove().proof().words
     c = prover.capture
     keys = ("main_root", "aux_root", "quot_root", "challenges", "alpha", "ood_main", "ood_aux", "combination")
     return {k: np.array(c[k]) for k in keys} | {"last_polynomial": prover.last_polynomial,
-                                                "main rows": prover.opened["main"], "aux rows": prover.opened["aux"]}
+                                                "main rows": prover.opened["main"], "aux rows": prover.opened["aux"],
+                                                "proof": np.array(proof)}
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, split_trees):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -45,14 +48,18 @@ def _worker(rank, world, port, out):
     p = StarkParameters(LOG2_ROWS, num_trace_randomizers=H, num_collinearity_checks=QUERIES)
     main_trace, aux_trace = _traces()
     prover = ShardedProver(ctx, p, dist, torch.device("cpu"), main_trace, aux_trace, seed=SEED)
+    if split_trees:
+        prover.split_tree_min_leaves = 0   # every tree with at least two leaves per rank is built split (production: >= 2^21 leaves)
     got = _capture(prover)
+    # three table trees and the FRI rounds with at least two leaves per rank
+    assert getattr(prover, "split_trees_built", 0) >= (4 if split_trees else 0) and (split_trees or not hasattr(prover, "split_trees_built"))
     out.put((rank, got))
     dist.destroy_process_group()
     ctx.close()
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_sharded_proof_equals_single_process_proof(world):
+@pytest.mark.parametrize("world,split_trees", [(2, True), (4, False), (8, True)])
+def test_sharded_proof_equals_single_process_proof(world, split_trees):
     import torch.multiprocessing as mp
 
     from tests.emu_fixture import emu_context
@@ -63,7 +70,7 @@ def test_sharded_proof_equals_single_process_proof(world):
         port = s.getsockname()[1]
     mpctx = mp.get_context("spawn")
     out = mpctx.Queue()
-    procs = [mpctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
+    procs = [mpctx.Process(target=_worker, args=(r, world, port, out, split_trees)) for r in range(world)]
     for pr in procs:
         pr.start()
 
@@ -115,9 +122,14 @@ def test_sharded_prover_on_one_gpu_matches_plain_prover():
         ctx = Context(0)
         p = StarkParameters(10)
         want = _capture(Prover(ctx, p, seed=9))
-        got = _capture(ShardedProver(ctx, p, dist, torch.device("cuda", 0), seed=9))
-        for key, value in want.items():
-            assert (got[key] == value).all(), key
+        for split_trees in (False, True):
+            prover = ShardedProver(ctx, p, dist, torch.device("cuda", 0), seed=9)
+            if split_trees:  # one rank: the "subtree" is the whole tree, the exchanges run through RCCL all the same
+                prover.split_tree_min_leaves = 0
+            got = _capture(prover)
+            assert bool(getattr(prover, "split_trees_built", 0)) == split_trees
+            for key, value in want.items():
+                assert (got[key] == value).all(), (split_trees, key)
         ctx.close()
     finally:
         dist.destroy_process_group()

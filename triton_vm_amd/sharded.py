@@ -12,9 +12,13 @@ The trace (5 GiB at 2^20 rows) is replicated.  Exchanges (RCCL all-gather over x
     the opened rows (173 x 652 words)   all-gather of each owner's rows, put back into query order
     the out-of-domain rows              columns split over the ranks, all-gather of the shares (2 x 470 XFE)
 
-Everything after the quotient codeword (segments, out-of-domain rows, combination, DEEP, FRI: ~55 ms of a
-411 ms proof at 2^20 rows) is computed redundantly on every rank from identical inputs, so every rank derives
-the same transcript and no broadcast is needed.  Splitting that tail is the next step for strong scaling.
+    Merkle subtree roots and authentication nodes      a few KB (the trees are built split, see _SplitTree)
+
+Everything after the quotient codeword (segments, combination, DEEP, the FRI folds: ~25 ms of a 263 ms proof at
+2^20 rows) is computed redundantly on every rank from identical inputs, so every rank derives the same transcript
+and no broadcast is needed.  The large Merkle trees (the three table trees, the first FRI rounds) are not built
+redundantly: every rank has all the leaves, builds the subtree over its contiguous 1/R of them, and the R subtree
+roots are exchanged; authentication nodes are fetched from the rank that holds them.
 
 Process set-up order matters: import torch (and select the device) BEFORE creating the Context -- torch brings
 its own HIP runtime, and a process that has already initialised the system runtime through libtriton_hip.so
@@ -41,6 +45,60 @@ class _TensorBuffer:
         return a.reshape(shape) if shape is not None else a
 
 
+class _SplitTree:
+    """A Merkle tree over n leaves whose lower levels are split over the R ranks by contiguous leaf ranges: this rank
+    holds the node array of subtree `rank` (device, heap order, [2 n/R][5]), every rank the top tree over the R subtree
+    roots (host, heap order, [2R][5]).  Same nodes as MerkleTree::par_new over all the leaves."""
+
+    def __init__(self, prover, sub_nodes, n_leaves):
+        from .verifier import hash_pair
+
+        self.prover, self.sub, self.n = prover, sub_nodes, n_leaves
+        prover.split_trees_built = getattr(prover, "split_trees_built", 0) + 1
+        ctx, R = prover.ctx, prover.world
+        mine = np.empty((1, 5), np.uint64)
+        ctx._check(ctx.lib.tvm_memcpy_d2h(ctx.handle, mine.ctypes.data, sub_nodes.ptr + 40, 40), "subtree root")
+        self.top = np.zeros((2 * R, 5), np.uint64)
+        self.top[R:] = prover._all_gather_host(mine, 1).reshape(R, 5)
+        for k in range(R - 1, 0, -1):
+            self.top[k] = hash_pair(ctx.lib, self.top[2 * k], self.top[2 * k + 1])
+
+    def root(self):
+        return self.top[1].copy()
+
+    def authentication_nodes(self, indices):
+        """stark.auth_nodes for the split tree: node k of the whole tree at depth d >= log2 R is node
+        2^(d - log2 R) + (its position within the subtree's level) of subtree (position >> (d - log2 R))"""
+        prover, R = self.prover, self.prover.world
+        ctx, log_r = prover.ctx, self.prover.world.bit_length() - 1
+        idx = stark.auth_node_indices(self.n, indices).astype(np.int64)
+        out = np.empty((idx.size, 5), np.uint64)
+        if not idx.size:
+            return out
+        depth = np.floor(np.log2(idx.astype(np.float64))).astype(np.int64)      # node k sits at depth floor(log2 k)
+        depth -= (np.int64(1) << depth) > idx                                     # (guards the float rounding)
+        depth += (np.int64(2) << depth) <= idx
+        in_top = idx < 2 * R
+        out[in_top] = self.top[idx[in_top]]
+        low = np.nonzero(~in_top)[0]
+        dd = depth[low] - log_r
+        pos = idx[low] - (np.int64(1) << depth[low])
+        owner = pos >> dd
+        local = (np.int64(1) << dd) + (pos & ((np.int64(1) << dd) - 1))
+        mine = low[owner == prover.rank]
+        got = np.zeros((mine.size, 5), np.uint64)
+        if mine.size:
+            lix = np.ascontiguousarray(local[owner == prover.rank].astype(np.uint64))
+            ctx._check(ctx.lib.tvm_gather_elements(ctx.handle, self.sub.ptr, 5, lix.ctypes.data, lix.size, got.ctypes.data),
+                       "auth nodes")
+        cap = max(int(np.bincount(owner, minlength=R).max()) if low.size else 0, 1)
+        gathered = prover._all_gather_host(got, cap)                              # [R, cap, 5]
+        for r in range(R):
+            sel = low[owner == r]
+            out[sel] = gathered[r, :sel.size]
+        return out
+
+
 def local_domain(domain, rank, world):
     """rows i = rank (mod world) of `domain`, as a domain"""
     return ArithmeticDomain(field.mont_mul(domain.offset, field.mont_pow(domain.generator, rank)),
@@ -60,6 +118,9 @@ class ShardedProver(Prover):
             raise ValueError("coset sharding needs |quotient| == |LDT| and a world size dividing |LDT| / |trace|")
         super().__init__(ctx, params, main_trace, aux_trace, seed)  # every rank holds the same traces (same seed)
         self.ldt_local = local_domain(params.ldt, self.rank, self.world)
+        # trees of at least this many leaves are built split (_SplitTree); below it the two small exchanges cost
+        # more than the redundant hashing saves
+        self.split_tree_min_leaves = (1 << 21) if self.world > 1 else (1 << 62)
         for mt in (self.main, self.aux):
             mt.quotient_domain = mt.ldt_domain = self.ldt_local
 
@@ -88,10 +149,57 @@ class ShardedProver(Prover):
         digests = self._empty(5 * self.ldt_local.length)
         ctx._check(ctx.lib.tvm_hash_rows(ctx.handle, mt._need_table(), self.ldt_local.length, digests.data_ptr()), "hash_rows")
         leaves = self._all_gather_rows(digests, 5)
-        nodes = ctx.alloc(10 * L)
-        ctx._check(ctx.lib.tvm_merkle_tree(ctx.handle, leaves.data_ptr(), L, nodes.ptr), "merkle_tree")
         self._keep = leaves  # until the stream has consumed it
-        return nodes
+        return self._tree_of_leaf_digests(leaves.data_ptr(), L)
+
+    def _splits(self, n_leaves):
+        return n_leaves >= max(self.split_tree_min_leaves, 2 * self.world)
+
+    def _tree_of_leaf_digests(self, leaves_ptr, n_leaves):
+        """leaf digests on the device (all of them, on every rank) -> node array, or a _SplitTree"""
+        ctx = self.ctx
+        if not self._splits(n_leaves):
+            nodes = ctx.alloc(10 * n_leaves)
+            ctx._check(ctx.lib.tvm_merkle_tree(ctx.handle, leaves_ptr, n_leaves, nodes.ptr), "merkle_tree")
+            return nodes
+        per = n_leaves // self.world
+        sub = ctx.alloc(10 * per)
+        ctx._check(ctx.lib.tvm_merkle_tree(ctx.handle, leaves_ptr + self.rank * per * 40, per, sub.ptr), "merkle_tree")
+        return _SplitTree(self, sub, n_leaves)
+
+    def _table_tree(self, table_handle, n):
+        """the quotient-segment table's tree: rows hashed on every rank (the table is replicated), the tree split"""
+        if not self._splits(n):
+            return super()._table_tree(table_handle, n)
+        ctx = self.ctx
+        digests = ctx.alloc(5 * n)
+        ctx._check(ctx.lib.tvm_hash_rows(ctx.handle, table_handle, n, digests.ptr), "hash_rows")
+        tree = self._tree_of_leaf_digests(digests.ptr, n)
+        ctx.sync()  # the digests are read by the stream until here
+        return tree
+
+    def _codeword_tree(self, ctx, d_codeword, length):
+        """merkle_tree_from_codeword (fri.rs:343-347) for the FRI rounds"""
+        if not self._splits(length):
+            return stark.merkle_tree_from_codeword(ctx, d_codeword, length)
+        per = length // self.world
+        sub = ctx.alloc(10 * per)
+        ctx._check(ctx.lib.tvm_codeword_merkle_tree(ctx.handle, d_codeword.ptr + self.rank * per * 24, per, sub.ptr), "codeword tree")
+        return _SplitTree(self, sub, length)
+
+    def _root(self, nodes):
+        return nodes.root() if isinstance(nodes, _SplitTree) else super()._root(nodes)
+
+    def _auth_nodes(self, nodes, n_leaves, indices):
+        if isinstance(nodes, _SplitTree):
+            return nodes.authentication_nodes(indices)
+        return super()._auth_nodes(nodes, n_leaves, indices)
+
+    def _fri(self, combination, ps):
+        p = self.p
+        a_indices, self.last_codeword, self.last_polynomial, self.last_domain = stark.fri_prove(
+            self.ctx, p.ldt, p.fri_rounds, p.num_collinearity_checks, combination, ps, trees=self)
+        return a_indices
 
     def _quotient_codeword(self, challenges, quotient_weights):
         ctx = self.ctx

@@ -144,17 +144,21 @@ def merkle_root(ctx, d_nodes):
     return out
 
 
-def fri_prove(ctx, ldt_domain, num_rounds, num_collinearity_checks, d_codeword, ps):
+def fri_prove(ctx, ldt_domain, num_rounds, num_collinearity_checks, d_codeword, ps, trees=None):
     """Fri::prove (fri.rs:212-319, 754-772): commit and fold round by round, send the last codeword and polynomial,
-    answer the queries.  ps: the transcript (enqueue / sample_scalars / sample_indices).
+    answer the queries.  ps: the transcript (enqueue / sample_scalars / sample_indices).  trees: optional provider
+    of `_codeword_tree(ctx, codeword, length)`, `_root(nodes)`, `_auth_nodes(nodes, n_leaves, indices)`.
     -> (first-round indices, last codeword, last polynomial, last domain)"""
     from .arithmetic_domain import ArithmeticDomain
 
     lib = ctx.lib
+    tree_of = trees._codeword_tree if trees is not None else merkle_tree_from_codeword
+    root_of = trees._root if trees is not None else (lambda nodes: merkle_root(ctx, nodes))
+    auth_of = trees._auth_nodes if trees is not None else (lambda nodes, n, ix: auth_nodes(ctx, nodes, n, ix))
     dom, cw, rounds = ldt_domain, d_codeword, []
     for r in range(num_rounds + 1):
-        nodes = merkle_tree_from_codeword(ctx, cw, dom.length)
-        ps.enqueue(f"fri root {r}", merkle_root(ctx, nodes))
+        nodes = tree_of(ctx, cw, dom.length)
+        ps.enqueue(f"fri root {r}", root_of(nodes))
         rounds.append((dom, cw, nodes))
         if r == num_rounds:
             break
@@ -177,6 +181,6 @@ def fri_prove(ctx, ldt_domain, num_rounds, num_collinearity_checks, d_codeword, 
             leaves = np.empty((ix.size, 3), np.uint64)
             ctx._check(lib.tvm_gather_elements(ctx.handle, rcw.ptr, 3, ix.ctypes.data, ix.size, leaves.ctypes.data), "leaves")
             ps.enqueue(f"fri response {r}", leaves, fiat_shamir=False)
-            ps.enqueue(f"fri auth {r}", auth_nodes(ctx, rnodes, rdom.length, which), fiat_shamir=False)
+            ps.enqueue(f"fri auth {r}", auth_of(rnodes, rdom.length, which), fiat_shamir=False)
     ps.sample_scalars(1)
     return a_indices, last, last_poly, dom

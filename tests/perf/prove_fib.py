@@ -2,8 +2,10 @@
 oracle-side VM up to 2^k cycles, hand the algebraic execution trace to Prover.from_execution -- fill, pad, extend and the
 hot path on the device, the reference's transcript on the host -- and put the proof through the restated Verifier::verify.
 The VM run stands in for the reference's Rust VM (host work there too); everything after it is the product.
-With `u32` instead: a loop of u32 operations whose U32 table fills the padded height (BASELINE.json's many-u32-ops shape).
-usage: python tests/perf/prove_fib.py [log2_padded_height=20] [fri|stir] [u32] [--no-verify]"""
+With `u32` instead: a loop of u32 operations whose U32 table fills the padded height (BASELINE.json's many-u32-ops shape);
+with `ram`: a loop that writes a fresh RAM address per iteration (the RAM table's Bezout coefficient polynomials, one
+coefficient per distinct pointer, are then computed on the device: tvm_bezout_coefficients inside tvm_fill_main_table).
+usage: python tests/perf/prove_fib.py [log2_padded_height=20] [fri|stir] [u32|ram] [--no-verify]"""
 import json
 import os
 import sys
@@ -20,17 +22,17 @@ from triton_vm_amd.prover import Prover  # noqa: E402
 
 log2 = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 20
 ldt = "stir" if "stir" in sys.argv else "fri"
-u32 = "u32" in sys.argv
-# fib: ten instructions per iteration, a dozen around the loop; u32: 33 rows of the U32 table per iteration
-index = (1 << log2) // 33 if u32 else ((1 << log2) - 20) // 10
+u32, ram = "u32" in sys.argv, "ram" in sys.argv
+# fib: ten instructions per iteration, a dozen around the loop; u32: 33 rows of the U32 table per iteration; ram: 14 cycles
+index = (1 << log2) // 33 if u32 else ((1 << log2) - 20) // 14 if ram else ((1 << log2) - 20) // 10
 t = {}
 t0 = time.perf_counter()
-program, aet, public_input, output = vf.run(("u32" if u32 else "fib", index))
+program, aet, public_input, output = vf.run(("u32" if u32 else "ram" if ram else "fib", index))
 t["vm_s"] = time.perf_counter() - t0
 padded_height = aet.padded_height()      # (the oracle-side AET recomputes its table heights on every call: not in the timed regions)
 assert padded_height == 1 << log2, padded_height
 t0 = time.perf_counter()
-arrays = aet_arrays(orc, aet)
+arrays = aet_arrays(orc, aet, host_bezout=not ram)
 t["aet_arrays_s"] = time.perf_counter() - t0
 claim = snap.claim_of(orc, program, public_input, output)
 ctx = Context(device=0)
@@ -51,8 +53,9 @@ for attempt in range(2):                    # the second pass is the warm one
     result = {"fill_pad_randomizers_ms": 1e3 * (t1 - t0), "extend_and_hot_path_ms": 1e3 * (t2 - t1), "proof_words": int(proof.words.size)}
     prover.release()
     del prover
-out = {"program": f"u32 loop, {index} iterations" if u32 else f"fibonacci_sequence, index {index}",
-       "table_heights": {name: aet.height_of_table(name) for name in ("Processor", "OpStack", "U32", "Hash")},
+out = {"program": f"u32 loop, {index} iterations" if u32 else f"RAM loop, {index} distinct pointers (Bezout coefficients on the device)" if ram
+       else f"fibonacci_sequence, index {index}",
+       "table_heights": {name: aet.height_of_table(name) for name in ("Processor", "OpStack", "Ram", "U32", "Hash")},
        "cycles": aet.height_of_table("Processor"), "padded_height": padded_height,
        "ldt": ldt, **{k: round(v, 2) for k, v in t.items()}, **{k: round(v, 1) if isinstance(v, float) else v for k, v in result.items()},
        "proof_digest": proof.digest(ctx.lib)}

@@ -16,6 +16,7 @@ CASES = [
     ("every", 32, 2, "fri", False), ("every", 64, 3, "fri", False), (("u32", 100), 32, 2, "fri", False),
     ("halt", 32, 2, "stir", False), ("every", 48, 2, "stir", False), (("fib", 100), 160, 2, "stir", False),
     (("ram", 3000), 32, 2, "fri", False),   # 3000 distinct RAM pointers: the Bezout coefficient polynomials come from the device
+    (("sponge", 60), 32, 4, "fri", False),  # sponge loop (hash and cascade tables), the recursive-verifier config's FRI log-blowup
 ]
 
 

@@ -206,7 +206,7 @@ int bezout_coefficients(tvm_ctx* c, const u64* d_roots, u64 n, u64* d_a, u64* d_
             hipStreamSynchronize(c->stream) != hipSuccess)
             rc = set_error(c, TVM_ERR_DEVICE, "bezout flag");
     };
-    // out[0 .. lo) = (a[0 .. la) * b[0 .. lb)) mod X^lo, on transforms of length len >= la + lb - 1 (through FA, FB)
+    // single transforms of length `len` (the first l_src words of src, zero-padded) and back, for the series products
     auto forward = [&](const u64* src, u64 l_src, u64 len, u64* dst) {
         return ntt_columns(c, src, l_src, 1, 0, dst, 1, 0, 1, 0, 1, len, bz_root_of_unity(len), TVM_ONE, TVM_ONE, TVM_ONE);
     };

@@ -15,12 +15,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LOG2_ROWS, H, QUERIES, SEED = 3, 3, 2, 5
 
 
-def _traces():
+def _traces(n):
     from oracle import oracle as orc
 
     rng = np.random.default_rng(77)
-    n = 1 << (LOG2_ROWS + 1)
     return orc.random_elements(rng, (379, n)), orc.random_elements(rng, (91, n, 3))
+
+
+def _params(ldt):
+    from triton_vm_amd.prover import StarkParameters
+
+    if ldt == "fri":
+        return StarkParameters(LOG2_ROWS, num_trace_randomizers=H, num_collinearity_checks=QUERIES)
+    from triton_vm_amd import low_degree_test as ldt_module   # STIR at a security level that still has a quotienting round at this size
+
+    stir = ldt_module.stark_stir(1 << LOG2_ROWS, security_level=8)
+    p = StarkParameters(LOG2_ROWS, num_trace_randomizers=stir.num_trace_randomizers(), num_collinearity_checks=QUERIES)
+    p.stir = stir
+    return p
 
 
 def _capture(prover):
@@ -33,7 +45,7 @@ def _capture(prover):
                                                 "proof": np.array(proof)}
 
 
-def _worker(rank, world, port, out, split_trees):
+def _worker(rank, world, port, out, split_trees, ldt):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -45,21 +57,21 @@ def _worker(rank, world, port, out, split_trees):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     ctx = emu_context()
-    p = StarkParameters(LOG2_ROWS, num_trace_randomizers=H, num_collinearity_checks=QUERIES)
-    main_trace, aux_trace = _traces()
+    p = _params(ldt)
+    main_trace, aux_trace = _traces(p.trace.length)
     prover = ShardedProver(ctx, p, dist, torch.device("cpu"), main_trace, aux_trace, seed=SEED)
     if split_trees:
         prover.split_tree_min_leaves = 0   # every tree with at least two leaves per rank is built split (production: >= 2^21 leaves)
     got = _capture(prover)
     # three table trees and the FRI rounds with at least two leaves per rank
-    assert getattr(prover, "split_trees_built", 0) >= (4 if split_trees else 0) and (split_trees or not hasattr(prover, "split_trees_built"))
+    assert getattr(prover, "split_trees_built", 0) >= ((4 if ldt == "fri" else 3) if split_trees else 0) and (split_trees or not hasattr(prover, "split_trees_built"))
     out.put((rank, got))
     dist.destroy_process_group()
     ctx.close()
 
 
-@pytest.mark.parametrize("world,split_trees", [(2, True), (4, False), (8, True)])
-def test_sharded_proof_equals_single_process_proof(world, split_trees):
+@pytest.mark.parametrize("world,split_trees,ldt", [(2, True, "fri"), (4, False, "fri"), (8, True, "fri"), (2, True, "stir")])
+def test_sharded_proof_equals_single_process_proof(world, split_trees, ldt):
     import torch.multiprocessing as mp
 
     from tests.emu_fixture import emu_context
@@ -70,13 +82,13 @@ def test_sharded_proof_equals_single_process_proof(world, split_trees):
         port = s.getsockname()[1]
     mpctx = mp.get_context("spawn")
     out = mpctx.Queue()
-    procs = [mpctx.Process(target=_worker, args=(r, world, port, out, split_trees)) for r in range(world)]
+    procs = [mpctx.Process(target=_worker, args=(r, world, port, out, split_trees, ldt)) for r in range(world)]
     for pr in procs:
         pr.start()
 
     ctx = emu_context()
-    p = StarkParameters(LOG2_ROWS, num_trace_randomizers=H, num_collinearity_checks=QUERIES)
-    main_trace, aux_trace = _traces()
+    p = _params(ldt)
+    main_trace, aux_trace = _traces(p.trace.length)
     single = Prover(ctx, p, main_trace, aux_trace, seed=SEED)
     want = _capture(single)
     ctx.close()

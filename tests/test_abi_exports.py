@@ -36,3 +36,17 @@ def test_host_library_exports_its_entry_points():
     assert declared, "the host header declares its C entry points"
     for name in set(declared):
         assert hasattr(host, name), name
+
+
+def test_there_is_no_cpu_fallback(tmp_path):
+    """a missing library and a missing GPU are errors, never a silent CPU path"""
+    import pytest
+    import torch
+
+    from triton_vm_amd import capi
+
+    with pytest.raises(FileNotFoundError, match="no CPU fallback"):
+        capi.load_library(str(tmp_path / "libtriton_hip.so"))
+    if not torch.cuda.is_available():   # the GPU-less container: the product library loads, a context cannot be created
+        with pytest.raises(capi.TritonHipError):
+            capi.Context(device=0)

@@ -736,8 +736,8 @@ static int threads_for_tile(int tile) {
 }
 // Tile = 2^log_axis points x 2^batch transforms, at most 2^14 words = 128 KiB of LDS (one 1024-thread workgroup per
 // CU).  Measured alternative: 64 KiB tiles with two 512-thread workgroups per CU, so that one workgroup's global
-// traffic overlaps the other's butterflies -- no gain (24.9 vs 25.5 ms for 128 columns): the passes are bound by
-// VALU issue, not by exposed memory latency.
+// traffic overlaps the other's butterflies -- no gain for the generic passes in round 1 (24.9 vs 25.5 ms for 128
+// columns), but worth 4 % for the LDE's pass 3 once its arithmetic had been trimmed (lde_table: k_lde_pass3_v3<10, 9>).
 static int tile_words_log() { return 14; }
 static int batch_log_for(int log_axis) {
     int b = tile_words_log() - log_axis;
@@ -756,6 +756,7 @@ static void set_lds_attributes() {
     (void)hipFuncSetAttribute((const void*)k_lde_pass3, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_v2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_v2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass3_v3<10, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_v3<11, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_v3<11, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_v3<12, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -995,6 +996,17 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             const size_t lds = ((size_t)(n1 + TVM_ROW_PAD) << a.rows_log) * sizeof(u64);
             const int ppt_log = (sp.log_n1 == 11 || sp.log_n1 == 7) ? 1 : (sp.log_n1 == 12 || sp.log_n1 == 8) ? 2 : 0;
             const u64 rows3 = 16 >> ppt_log, tiles3 = X * n2 / rows3;  // see pass 2
+            if (sp.log_n1 == 10 && (X * n2) % 16 == 0 && X * n2 / 8 < 65536) {
+                // 1024-point axis (2^19 and 2^20 rows): 8-row tiles on 512 work-items, 70 KB of LDS -- TWO workgroups per CU, so
+                // that one's loads and stores run under the other's butterflies.  Pass 3 is the sum of ~9 ms of arithmetic
+                // and ~9 ms of memory time per 379 columns with one resident workgroup; main table 44.8 -> 42.8 ms
+                // (tiles per workgroup: 8 -> 43.1 ms, 16 -> 42.8 ms).  The 64-byte store runs of an 8-row tile pair up in L2.
+                const u64 tiles_h = X * n2 / 8;
+                a.tiles = tiles_h % 16 == 0 ? 16 : tiles_h % 8 == 0 ? 8 : tiles_h % 4 == 0 ? 4 : 1;
+                const dim3 g3((unsigned)nc, (unsigned)(tiles_h / a.tiles));
+                const size_t lds_h = (size_t)(8 * (n1 + TVM_ROW_PAD) + n1 / 2) * sizeof(u64);
+                TVM_LAUNCH((k_lde_pass3_v3<10, 9>), g3, dim3(512), lds_h, c->stream, a);
+            } else
             if (ppt_log && (X * n2) % 16 == 0) {
                 a.tiles = tiles3 % 8 == 0 ? 8 : tiles3 % 4 == 0 ? 4 : 1;
                 const dim3 g3((unsigned)nc, (unsigned)(tiles3 / a.tiles));

@@ -112,6 +112,31 @@ def test_lde_of_longer_traces(gctx, orc, log_n, fk, n_cols, sample_cols):
     mt.clear_cache()
 
 
+@pytest.mark.parametrize("log_n,world,rank,fk,n_cols,sample_cols", [(20, 8, 3, 1, 100, (0, 57, 99)), (20, 2, 1, 3, 5, (4,)),
+                                                                      (19, 4, 2, 1, 20, (0, 19)), (19, 1, 0, 1, 12, (11,))])
+def test_lde_onto_a_ranks_share_of_the_domain(gctx, orc, log_n, world, rank, fk, n_cols, sample_cols):
+    """What a rank of the sharded proof extends onto (triton_vm_amd/sharded.py): the rows i = rank (mod world) of the LDT
+    domain -- 8 / world cosets of the trace domain, down to a single one -- at the heights whose pass 3 runs as 8-row tiles
+    with two workgroups per CU (1024-point axes: 2^19 and 2^20 rows)."""
+    from triton_vm_amd.sharded import local_domain
+
+    ctx, n = gctx, 1 << log_n
+    trace_dom = ArithmeticDomain.of_length(n)
+    ev = local_domain(ArithmeticDomain.of_length(8 * n).with_offset(field.generator()), rank, world)
+    mt = MasterTable.from_device(ctx, ctx.synthetic(n_cols * n * fk, seed=31 + fk), ctx.synthetic(n_cols * H * fk, seed=33 + fk), n_cols, n, H,
+                                 trace_dom, ev, ev, fk)
+    mt.maybe_low_degree_extend_all_columns()
+    rng = np.random.default_rng(log_n + world)
+    rows = np.unique(np.concatenate([[0, 1, 7, 8, 15, 16, len(ev) - 1], rng.integers(0, len(ev), 300)])).astype(np.uint64)
+    revealed = mt.reveal_rows(rows)
+    trace_host = mt.d_trace.download().reshape((n_cols, n) + ((3,) if fk == 3 else ()))
+    rnd_host = mt.d_randomizers.download().reshape((n_cols, H) + ((3,) if fk == 3 else ()))
+    for c in sample_cols:
+        want = orc.lde_table(trace_host[c:c + 1], rnd_host[c:c + 1], odom(orc, ev), fk)
+        assert (revealed[:, c] == want[rows.astype(np.int64), 0]).all(), f"column {c}"
+    mt.clear_cache()
+
+
 @pytest.mark.parametrize("log_n,log_ldt_expansion", [(20, 3), (18, 5)])
 def test_full_size_air_sampled_rows(gctx, orc, log_n, log_ldt_expansion):
     """all_quotients_combined at BASELINE config 1's size (2^20 rows: quotient = LDT domain 2^23, tables of 23.7 +

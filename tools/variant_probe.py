@@ -4,11 +4,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa
 from triton_vm_amd.capi import Context, load_library
 from triton_vm_amd.prover import Prover, StarkParameters
-variant = sys.argv[1] if len(sys.argv) > 1 else None
+variant = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] != "-" else None
 here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "triton_vm_amd")
 lib = load_library(os.path.join(here, f"libtriton_hip_{variant}.so")) if variant else load_library()
 ctx = Context(device=0, lib=lib)
-p = Prover(ctx, StarkParameters(20), seed=1)
+p = Prover(ctx, StarkParameters(int(sys.argv[2]) if len(sys.argv) > 2 else 20), seed=1)
 for _ in range(2):
     p.prove(profile=False)
 p.timings = {}

@@ -544,7 +544,10 @@ __global__ void __launch_bounds__(1 << TLOG) k_lde_pass2_v3(LdePass2Args a) {
     }
     const u64* rnd = a.rnd + (u64)(v / a.fk) * a.h * a.fk + (v % a.fk);
     // store phase: this work-item writes row b = tid % ROWS, columns j1 = tid / ROWS + i * NT / ROWS, i < 16
-    const int b_out = tid & (ROWS - 1), j1_0 = tid >> RLOG;
+    // (the column slots of a wavefront are ROWS apart: LDS bank conflicts, see k_lde_pass3_v3)
+    constexpr int LPW = 64 >> RLOG;
+    const int b_out = tid & (ROWS - 1), q_ = tid >> RLOG;
+    const int j1_0 = (NT >> RLOG) >= 64 ? ((q_ & ~63) | ((q_ & (LPW - 1)) << RLOG) | ((q_ & 63) >> (6 - RLOG))) : q_;
     constexpr int j1_step = NT >> RLOG;
     const u64 m2_out = brev_bits((u32)(p0 + b_out), a.log_n1);
     const u64 t_step = pow2_get(a.tw_inter, (m2_out * (u64)j1_step) & (n - 1));
@@ -593,7 +596,15 @@ __global__ void __launch_bounds__(1 << TLOG) k_lde_pass3_v3(LdePass3Args a) {
     const u64* zc = a.z + (u64)vl * X * (n2 << LOGN) + tid;
     u64* tw_fwd = s + ROWS * RS;
     for (int i = tid; i < (n1 >> 1); i += NT) tw_fwd[i] = a.tw_b2[i];
-    const int b = tid & (ROWS - 1), j2_0 = tid >> RLOG;
+    // store phase: row b = tid % ROWS, columns j2 = j2_0 + i * NT / ROWS.  The 64 / ROWS column slots of a wavefront are
+    // ROWS apart (slot q of a block of 64 -> column (q % LPW) * ROWS + q / LPW): with the odd row pitch the LDS words
+    // b * RS + j2 of its 64 lanes then fall into 64 different banks -- consecutive columns collide ROWS-fold (8-row tiles:
+    // 44 % of the LDS cycles of this kernel were bank conflicts; worth 1.7 % of the LDE at 2^22 rows, nothing at 2^20,
+    // where the second resident workgroup hides them).  Every (row run, column) is its own line in the table
+    // anyway, so the order within a wavefront does not matter to the global stores.
+    constexpr int LPW = 64 >> RLOG;
+    const int b = tid & (ROWS - 1), q_ = tid >> RLOG;
+    const int j2_0 = (NT >> RLOG) >= 64 ? ((q_ & ~63) | ((q_ & (LPW - 1)) << RLOG) | ((q_ & 63) >> (6 - RLOG))) : q_;
     constexpr int j2_step = NT >> RLOG;
     const u64 W = (u64)a.W;
     const u64 j2_stride = ((period >> TVM_RB_LOG) * W) << TVM_RB_LOG;

@@ -145,3 +145,31 @@ def test_sharded_prover_on_one_gpu_matches_plain_prover():
         ctx.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+@pytest.mark.parametrize("log_leaves", [4, 11, 23, 40])
+def test_split_tree_locations_against_the_heap_layout(world, log_leaves):
+    """where a node of the whole tree lives once the lowest levels are split into `world` subtrees by contiguous leaf
+    ranges: brute force -- walk down from each subtree root and number its nodes in heap order"""
+    from triton_vm_amd.sharded import split_tree_locations
+
+    rng = np.random.default_rng(world * 100 + log_leaves)
+    n = 1 << log_leaves
+    picks = np.unique(np.concatenate([[1, 2, 3, world, 2 * world - 1, min(2 * world, 2 * n - 1), n, 2 * n - 1, n - 1],
+                                      rng.integers(1, 2 * n, 500)]))
+    in_top, owner, local = split_tree_locations(picks, world)
+    for k, top, r, loc in zip(picks.tolist(), in_top.tolist(), owner.tolist(), local.tolist()):
+        if k < 2 * world:
+            assert top and loc == k
+            continue
+        # climb from k to its ancestor at the depth of the subtree roots, recording the path
+        path, a = [], k
+        while a >= 2 * world:
+            path.append(a & 1)
+            a >>= 1
+        assert not top and r == a - world                 # the a-th node of that depth is subtree a - world
+        node = 1
+        for bit in reversed(path):
+            node = 2 * node + bit
+        assert loc == node, (k, world)

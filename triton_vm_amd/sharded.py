@@ -45,6 +45,24 @@ class _TensorBuffer:
         return a.reshape(shape) if shape is not None else a
 
 
+def split_tree_locations(node_indices, world):
+    """heap indices of a Merkle tree whose lowest levels are split into `world` subtrees by contiguous leaf ranges ->
+    (in the top tree?, owning rank, heap index within that rank's subtree).  Node k sits at depth d = floor(log2 k); at
+    depths >= log2(world) its position p = k - 2^d within the level selects subtree p >> (d - log2 world), where it is node
+    2^(d - log2 world) + (p mod 2^(d - log2 world)).  The subtree roots themselves (depth log2 world) count as top-tree nodes."""
+    idx = np.asarray(node_indices, dtype=np.int64)
+    log_r = int(world).bit_length() - 1
+    depth = np.floor(np.log2(np.maximum(idx, 1).astype(np.float64))).astype(np.int64)
+    depth -= (np.int64(1) << depth) > idx                                         # (guards the float rounding)
+    depth += (np.int64(2) << depth) <= idx
+    in_top = idx < 2 * world
+    dd = np.maximum(depth - log_r, 0)
+    pos = idx - (np.int64(1) << depth)
+    owner = np.where(in_top, -1, pos >> dd)
+    local = np.where(in_top, idx, (np.int64(1) << dd) + (pos & ((np.int64(1) << dd) - 1)))
+    return in_top, owner, local
+
+
 class _SplitTree:
     """A Merkle tree over n leaves whose lower levels are split over the R ranks by contiguous leaf ranges: this rank
     holds the node array of subtree `rank` (device, heap order, [2 n/R][5]), every rank the top tree over the R subtree
@@ -75,16 +93,10 @@ class _SplitTree:
         out = np.empty((idx.size, 5), np.uint64)
         if not idx.size:
             return out
-        depth = np.floor(np.log2(idx.astype(np.float64))).astype(np.int64)      # node k sits at depth floor(log2 k)
-        depth -= (np.int64(1) << depth) > idx                                     # (guards the float rounding)
-        depth += (np.int64(2) << depth) <= idx
-        in_top = idx < 2 * R
+        in_top, owner_all, local_all = split_tree_locations(idx, R)
         out[in_top] = self.top[idx[in_top]]
         low = np.nonzero(~in_top)[0]
-        dd = depth[low] - log_r
-        pos = idx[low] - (np.int64(1) << depth[low])
-        owner = pos >> dd
-        local = (np.int64(1) << dd) + (pos & ((np.int64(1) << dd) - 1))
+        owner, local = owner_all[low], local_all[low]
         mine = low[owner == prover.rank]
         got = np.zeros((mine.size, 5), np.uint64)
         if mine.size:

@@ -110,8 +110,12 @@ def timed_steps(step, steps, warmup, device_sync, dist=None, device="cuda"):
     `dist` is torch.distributed (initialised) or None; ranks run independent proofs, so the barrier and the
     max-reduction are the only collectives of the N > 1 path (tests/test_bench_distributed.py, gloo)."""
     def barrier():
-        device_sync()
+        device_sync()                            # the context's stream (the kernels of the step run there)
         if dist is not None:
+            if device == "cuda":
+                import torch
+
+                torch.cuda.synchronize()         # ... and torch's streams (the all-gathers of the sharded proof)
             dist.barrier()
             device_sync()
 

@@ -166,8 +166,11 @@ int32_t tvm_fill_derived_aux_columns(tvm_ctx* ctx, const uint64_t* d_main_trace,
 
 /* ---- main-table fill from the AET (the `fill` half) ----------------------------------
  * MasterMainTable::new's table fills (master_table.rs:881-931; table/{op_stack,ram,jump_stack,processor,program,hash,
- * cascade,lookup,u32}.rs `fill`).  The AET is handed over as AlgebraicExecutionTrace holds it (aet.rs:41-96), all HOST
- * pointers: trace arrays row-major in Montgomery words, multiplicities as plain integers. */
+ * cascade,lookup,u32}.rs `fill`).  The AET is handed over as AlgebraicExecutionTrace holds it (aet.rs:41-96): trace arrays
+ * row-major in Montgomery words, multiplicities as plain integers.  Every array may live in HOST memory (it is staged
+ * through the context's pool: 327 MB of processor trace at 2^20 cycles, ~6 ms over PCIe) or in DEVICE memory of the
+ * context's GPU (a host that keeps the trace resident next to the prover: the library reads it where it lies); the
+ * library tells the two apart per pointer (hipPointerGetAttributes). */
 typedef struct {
     const uint64_t* program_words;              /* Program::to_bwords(), program_len words */
     const uint32_t* instruction_multiplicities; /* [program_len] */

@@ -72,7 +72,7 @@ if ldt == "fri":   # the same through the C++ host (triton_vm::prove_execution):
     for attempt in range(2):
         ctx.sync()
         t0 = time.perf_counter()
-        words = native_host.prove_execution(ctx, host_lib, arrays, padded_height, claim, seed, log2_expansion=log2_expansion)
+        words = native_host.prove_execution(ctx, host_lib, arrays, padded_height, claim, seed, log2_expansion=log2_expansion, ldt="fri")
         out["cpp_host_whole_prove_ms"] = round(1e3 * (time.perf_counter() - t0), 1)
     out["cpp_host_proof_equals_python_host_proof"] = bool(words.size == proof.words.size and (words == proof.words).all())
 if "--no-verify" not in sys.argv:

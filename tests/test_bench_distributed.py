@@ -64,7 +64,8 @@ def test_single_process_needs_no_collective():
 @pytest.mark.parametrize("mode", ["sharded"])   # "replicas" runs in test_bench_script_spawns_its_own_ranks
 def test_bench_script_runs_under_torchrun_with_two_ranks(mode):
     """bench.py itself, launched the way the driver launches it for N = 2 (torch.distributed.run, one process per
-    rank), on CPU: gloo instead of RCCL and the test-only emulation of the kernels (TVM_BENCH_TEST_EMU=1).  The
+    rank), on CPU: gloo instead of RCCL and the test-only emulation of the kernels (tests/bench_on_emulation.py replaces
+    bench.py's process set-up hooks; bench.py itself carries no test switch).  The
     sharded mode runs collectives inside prove(); a rank that skips one of them would hang this test."""
     import json
     import subprocess
@@ -72,10 +73,10 @@ def test_bench_script_runs_under_torchrun_with_two_ranks(mode):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, TVM_BENCH_TEST_EMU="1", OMP_NUM_THREADS="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-           "--log2-rows", "3", "--trace-randomizers", "3", "--queries", "2", "--no-cpu-baseline"] + (["--replicas"] if mode == "replicas" else [])
+           "--master-port", str(port), os.path.join(ROOT, "tests", "bench_on_emulation.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--data", "synthetic", "--log2-rows", "3", "--trace-randomizers", "3", "--queries", "2", "--no-cpu-baseline"] + (["--replicas"] if mode == "replicas" else [])
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -92,11 +93,11 @@ def test_bench_script_spawns_its_own_ranks():
     import json
     import subprocess
 
-    env = dict(os.environ, TVM_BENCH_TEST_EMU="1", OMP_NUM_THREADS="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--log2-rows", "3",
-           "--trace-randomizers", "3", "--queries", "2", "--no-cpu-baseline", "--replicas"]
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_on_emulation.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--data", "synthetic",
+           "--log2-rows", "3", "--trace-randomizers", "3", "--queries", "2", "--no-cpu-baseline", "--replicas"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]

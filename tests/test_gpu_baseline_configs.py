@@ -1,0 +1,121 @@
+"""BASELINE.json's configurations FOR REAL, at their full sizes, on the MI355X: the programs are run in the oracle-side VM
+(the stand-in for the reference's Rust VM: host work there too), the algebraic execution trace goes through the whole of
+`Prover::prove(claim, aet)` on the device (/root/reference/triton-vm/src/stark.rs:331-719: fill, pad, extend, LDE, hashing,
+AIR, quotient segments, DEEP, low-degree test, openings), and the proof is put through BOTH verifiers: the restated
+`Verifier::verify` of the oracle (oracle/real_verifier.py, anchored to the reference-pinned proofs in
+tests/test_verify_proof.py) and the product's own (triton_vm_amd/verifier.py).
+
+    configs[1]  prove_fib (triton-dev-util/src/example_programs.rs:6-38) at 2^20 padded rows -- with LdtChoice::Fri and with
+                the STIR that Stark::default() picks at this size (stark.rs:1944-1951)
+    configs[2]  prove_fib at 2^22 padded rows (that configuration's height; here on ONE GPU: 163 GiB of extended tables)
+    configs[3]  the many-u32-operations shape at 2^20 rows (a loop over the operations of example_programs.rs:70-99: the U32
+                table sets the padded height)
+    configs[4]  a hash-heavy program at 2^20 rows with FRI log-blowup 4, Stark::new(160, 4) (the recursive verifier itself
+                lives outside the reference repository: a sponge loop fills the hash and cascade tables instead)
+
+Size-independent properties checked besides acceptance: the C++ host's proof equals the Python host's word for word, a
+second run with the same seed reproduces the proof (stark.rs:2434-2460's derandomization property), the exact row-by-row
+AIR gives the proof of the valid-trace mode, and the same proof is rejected under a different claim.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+# (program, log2 padded height, low-degree test, log2 expansion, restated verifier too?)
+# The restated STIR verifier is pure Python (~2.5 minutes per proof): it runs on ONE STIR proof.
+CASES = [
+    (("fib", None), 20, "fri", 2, True),
+    (("fib", None), 20, "stir", 2, True),
+    (("u32", None), 20, "fri", 2, True),
+    (("sponge", None), 20, "fri", 4, True),
+    (("fib", None), 22, "fri", 2, True),
+    (("fib", None), 22, None, 2, False),     # Stark::default() at this height: STIR by the automatic rule
+]
+
+
+@pytest.fixture(scope="module")
+def gctx():
+    from triton_vm_amd import Context
+
+    c = Context(device=0)
+    yield c
+    c.close()
+
+
+_TRACES = {}
+
+
+def execution(kind, log2):
+    """one VM run per (program, height) for the whole module; one trace at a time (a 2^22-row AET is 1.3 GB of host arrays)"""
+    from oracle.vm import workload
+    from triton_vm_amd.proof_stream import Claim
+
+    if (kind, log2) not in _TRACES:
+        _TRACES.clear()
+        e = workload.execution(kind, log2)
+        e["claim"] = Claim(e["program_digest"], e["public_input"], e["public_output"])
+        _TRACES[(kind, log2)] = e
+    return _TRACES[(kind, log2)]
+
+
+@pytest.mark.parametrize("which,log2,ldt,log2_expansion,restated", CASES)
+def test_baseline_config_proves_and_verifies(gctx, orc, which, log2, ldt, log2_expansion, restated):
+    from oracle import real_verifier
+    from tests import test_proof_snapshot as snap
+    from triton_vm_amd import native_host, verifier as product
+    from triton_vm_amd.proof_stream import ProofStream
+    from triton_vm_amd.prover import Prover
+
+    ctx, kind = gctx, which[0]
+    if ldt == "stir" and os.environ.get("TVM_SKIP_SLOW_VERIFIER") == "1":
+        restated = False
+    e = execution(kind, log2)
+    arrays, claim, padded_height, heights = e["aet"], e["claim"], e["padded_height"], e["table_heights"]
+    if kind == "u32":
+        assert heights["U32"] > heights["Processor"]          # the co-processor table sets the height
+    if kind == "sponge":
+        assert heights["Hash"] > heights["Processor"]
+    seed = snap.prover_seed(7)
+    effective_ldt = ldt or ("fri" if log2 < 16 else "stir")
+
+    prover = Prover.from_execution(ctx, arrays, padded_height, claim, seed, ldt=ldt, log2_expansion=log2_expansion)
+    assert (prover.p.stir is not None) == (effective_ldt == "stir")
+    assert prover.p.ldt.length == (1 << (log2 + 1 + log2_expansion))
+    proof = prover.prove().proof()
+    prover.release()
+    del prover
+
+    # Verifier::verify, twice over
+    kw = dict(log2_expansion=log2_expansion)
+    accepted_at = product.Verifier(ctx, ldt=ldt, **kw).verify(claim, proof.words)
+    assert len(accepted_at) >= 160 // 2
+    if restated:
+        view = ProofStream.from_proof(ctx.lib, proof.words).verifier_view()
+        assert real_verifier.verify(view, claim, ldt_choice=effective_ldt, **kw) == accepted_at
+    from triton_vm_amd.proof_stream import Claim
+
+    wrong = Claim(e["program_digest"], e["public_input"], list(e["public_output"]) + [1])
+    with pytest.raises(product.VerificationError):
+        product.Verifier(ctx, ldt=ldt, **kw).verify(wrong, proof.words)
+
+    # the C++ host's Prover::prove(claim, aet) yields the same words, from host arrays and from a device-resident trace
+    host_lib = native_host.load_host_library()
+    words = native_host.prove_execution(ctx, host_lib, arrays, padded_height, claim, seed, log2_expansion=log2_expansion, ldt=ldt)
+    assert words.size == proof.words.size and (words == proof.words).all()
+    if log2 == 20 and ldt == "fri" and kind == "fib":
+        from triton_vm_amd.master_table import aet_to_device
+
+        resident = aet_to_device(ctx, arrays)
+        again = native_host.prove_execution(ctx, host_lib, resident, padded_height, claim, seed, log2_expansion=log2_expansion, ldt=ldt)
+        assert (again == proof.words).all()
+        del resident
+        # the exact row-by-row AIR (what the reference computes) instead of valid-trace mode: the same proof
+        exact = Prover.from_execution(ctx, arrays, padded_height, claim, seed, ldt=ldt, log2_expansion=log2_expansion,
+                                      assume_valid_trace=False)
+        exact_proof = exact.prove().proof()
+        exact.release()
+        assert (exact_proof.words == proof.words).all()
+    ctx.trim()

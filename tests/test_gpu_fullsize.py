@@ -27,7 +27,11 @@ def gctx():
     c.close()
 
 
-@pytest.mark.parametrize("fk,n_cols,sample_cols", [(1, 379, (0, 200, 378)), (3, 91, (0, 90))])
+# Sampled columns: the table is extended in launches of 96 base-field columns (csrc/ntt.hip: lde_table's chunks), so there is one
+# column inside every launch and one on either side of every launch boundary -- main words 95|96, 191|192, 287|288; the
+# auxiliary table's words 95|96 and 191|192 are the XFE columns 31|32 and 63|64 (words 93-95|96-98, 189-191|192-194).
+@pytest.mark.parametrize("fk,n_cols,sample_cols", [(1, 379, (0, 50, 95, 96, 150, 191, 192, 250, 287, 288, 378)),
+                                                    (3, 91, (0, 31, 32, 50, 63, 64, 90))])
 def test_full_size_table(gctx, orc, fk, n_cols, sample_cols):
     ctx = gctx
     n = 1 << LOG_N
@@ -182,3 +186,115 @@ def test_full_size_extend_satisfies_the_transition_constraints(gctx, orc):
                                       np.ascontiguousarray(got[:, i]), np.ascontiguousarray(got[:, i + 1]), ch)
         assert not v[81:178].any(), f"consistency constraints, row {i}"
         assert not v[178:581].any(), f"transition constraints, rows {i}, {i + 1}"
+
+
+# ---- csrc/poly.hip at BASELINE config 1's size: the streaming stages against the oracle on sampled columns / indices ----------
+def _sampled_indices(rng, n, k=200):
+    return np.unique(np.concatenate([[0, 1, n // 2 - 1, n // 2, n - 1], rng.integers(0, n, k)])).astype(np.int64)
+
+
+def _gather(ctx, buf, idx, words=3):
+    idx = np.ascontiguousarray(idx, dtype=np.uint64)
+    got = np.empty((idx.size, words), np.uint64)
+    ctx._check(ctx.lib.tvm_gather_elements(ctx.handle, buf.ptr, words, idx.ctypes.data, idx.size, got.ctypes.data), "gather")
+    return got
+
+
+@pytest.mark.parametrize("fk,n_cols", [(1, 379), (3, 91)])
+def test_full_size_out_of_domain_rows_and_weighted_sums(gctx, orc, fk, n_cols):
+    """out_of_domain_row (master_table.rs:348-390) and weighted_sum_of_columns (:512-542) over the whole 2^20-row trace table:
+    the out-of-domain values of sampled columns against the oracle's barycentric evaluation of those columns; the weighted
+    sum with weights that are zero outside a sampled set of columns against the oracle's sum over that set (every column
+    still passes through the kernel's accumulation)."""
+    ctx, n = gctx, 1 << LOG_N
+    rng = np.random.default_rng(fk + 40)
+    trace_dom = ArithmeticDomain.of_length(n)
+    ev = ArithmeticDomain.of_length(8 * n).with_offset(field.generator())
+    mt = MasterTable.from_device(ctx, ctx.synthetic(n_cols * n * fk, seed=41 + fk), ctx.synthetic(n_cols * H * fk, seed=43 + fk), n_cols, n, H,
+                                 trace_dom, ev, ev, fk)
+    shape = lambda k: (n_cols, k) + ((3,) if fk == 3 else ())
+    trace_host, rnd_host = mt.d_trace.download(shape(n)), mt.d_randomizers.download(shape(H))
+    cols = sorted({0, 1, n_cols // 2, n_cols - 1} | {int(c) for c in rng.integers(0, n_cols, 4)})
+    pts = orc.random_elements(rng, (2, 3))
+    got = mt.out_of_domain_rows(pts)                                               # [2][n_cols][3]
+    for p in range(2):
+        want = orc.out_of_domain_row(np.ascontiguousarray(trace_host[cols]), np.ascontiguousarray(rnd_host[cols]), pts[p], fk)
+        assert (got[p][cols] == want).all(), f"point {p}"
+    w = np.zeros((n_cols, 3), np.uint64)
+    w[cols] = orc.random_elements(rng, (len(cols), 3))
+    got = mt.weighted_sum_of_columns(w).download((2 * n, 3))
+    want = orc.weighted_sum_of_columns(np.ascontiguousarray(trace_host[cols]), np.ascontiguousarray(rnd_host[cols]), w[cols], fk)
+    assert (got == want).all()
+    for buf in (mt.d_trace, mt.d_randomizers):
+        buf.free()
+
+
+def test_full_size_quotient_segments(gctx, orc):
+    """interpolate_quotient_segments + ldt_domain_segment_polynomials + randomize_quotient_segments (stark.rs:1224-1356) on a
+    2^23-point quotient codeword: all five randomized segment polynomials coefficient by coefficient against the oracle's
+    (its 2^23-point interpolation), and the [L][5] codeword table at sampled rows against Horner evaluations of those
+    polynomials at the domain points."""
+    from triton_vm_amd import stark
+
+    ctx = gctx
+    rng = np.random.default_rng(77)
+    L = 8 << LOG_N
+    g = field.generator()
+    dom = ArithmeticDomain.of_length(L).with_offset(g)
+    n_rand = (H + 1) * 5
+    d_cw = ctx.synthetic(3 * L, seed=91)
+    rnd = orc.random_elements(rng, (n_rand, 3))
+    qs = stark.quotient_segments(ctx, d_cw, dom, dom, rnd)
+    seg = orc.interpolate_quotient_segments(d_cw.download((L, 3)), odom(orc, dom))   # [4][L/4][3]
+    polys = qs.polys.download((5, qs.poly_len, 3))
+    # s_4 = the randomizer; s_i = q_i - zeta^i * s_{i+1}(zeta^4 X), zeta = 3 (stark.rs:1338-1352), checked through point values
+    idx = _sampled_indices(rng, L, 40)
+    rows = np.empty((idx.size, 15), np.uint64)
+    ix = idx.astype(np.uint64)
+    ctx._check(ctx.lib.tvm_table_reveal_rows(ctx.handle, qs.table, L, ix.ctypes.data, ix.size, rows.ctypes.data), "rows")
+    zeta = field.to_mont(3)
+    for j, i in enumerate(idx):
+        x = dom.value(int(i))
+        xp = np.array([x, 0, 0], np.uint64)
+        for k in range(5):                                            # the table is the polynomials evaluated on the LDT domain
+            assert (rows[j].reshape(5, 3)[k] == orc.poly_eval_xfe(polys[k], xp)).all(), (i, k)
+    assert (polys[4][:n_rand] == rnd).all() and not polys[4][n_rand:].any()
+    for _ in range(3):                                               # the recursion at random points
+        x = orc.random_elements(rng, 3)
+        z4x = x.copy()
+        for _k in range(4):
+            z4x = np.array([field.mont_mul(int(c), zeta) for c in z4x], np.uint64)
+        for i in range(4):
+            zi = np.array([field.mont_pow(zeta, i), 0, 0], np.uint64)
+            want = orc.xfe_sub(orc.poly_eval_xfe(seg[i], x), orc.xfe_mul(zi, orc.poly_eval_xfe(polys[i + 1], z4x)))
+            assert (orc.poly_eval_xfe(polys[i], x) == want).all(), i
+    qs.free()
+
+
+def test_full_size_deep_codeword_and_fri_fold(gctx, orc):
+    """deep_codeword with its weighted sum (stark.rs:566-625, 1360-1379) over four 2^23-point codewords at sampled indices
+    (one extension-field inversion per component and index through the oracle's scalar arithmetic), and the whole first FRI
+    fold 2^23 -> 2^22 (fri.rs:349-366) against the oracle."""
+    from triton_vm_amd import stark
+
+    ctx = gctx
+    rng = np.random.default_rng(78)
+    L = 8 << LOG_N
+    dom = ArithmeticDomain.of_length(L).with_offset(field.generator())
+    bufs = [ctx.synthetic(3 * L, seed=101 + k) for k in range(4)]
+    pts, vals, ws = (orc.random_elements(rng, (4, 3)) for _ in range(3))
+    deep = stark.deep_codeword(ctx, bufs, dom, pts, vals, ws)
+    idx = _sampled_indices(rng, L)
+    got = _gather(ctx, deep, idx)
+    at = [_gather(ctx, b, idx) for b in bufs]
+    for j, i in enumerate(idx):
+        x = np.array([dom.value(int(i)), 0, 0], np.uint64)
+        acc = np.zeros(3, np.uint64)
+        for k in range(4):
+            comp = orc.xfe_mul(orc.xfe_sub(at[k][j], vals[k]), orc.xfe_inv(orc.xfe_sub(x, pts[k])))
+            acc = orc.xfe_add(acc, orc.xfe_mul(comp, ws[k]))
+        assert (got[j] == acc).all(), i
+    ch = orc.random_elements(rng, 3)
+    folded = stark.split_and_fold(ctx, bufs[0], dom, ch)
+    want = orc.fri_split_and_fold(bufs[0].download((L, 3)), odom(orc, dom), ch)
+    assert (folded.download((L // 2, 3)) == want).all()

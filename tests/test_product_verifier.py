@@ -94,3 +94,52 @@ def test_product_stir_verifier_agrees_with_the_oracle_restatement(ctx, orc):
         bad.log[k][1].reshape(-1)[0] ^= np.uint64(1)
         with pytest.raises(VerificationError):
             run(bad, stir)
+
+
+def test_statically_sized_items_of_the_wrong_length_do_not_decode(ctx):
+    """BFieldCodec rejects a MerkleRoot, Log2PaddedHeight or out-of-domain row whose payload is not exactly the type's static
+    length; so must ProofStream::try_from(&Proof) here -- as ProofDecodingError, never a numpy error, and never an
+    acceptance (a decoder that takes any length makes proofs malleable).  Items are re-encoded with one word appended /
+    removed and the enclosing length prefixes fixed up."""
+    from triton_vm_amd import field
+    from triton_vm_amd.proof_stream import PROOF_ITEMS, STATIC_WORDS, Proof, ProofDecodingError, ProofStream
+    from triton_vm_amd.verifier import Verifier
+
+    words, claim, indices = oracle_proof("tiny", snap.SEED_U64, 160)
+    assert Verifier(ctx).verify(claim, words) == indices
+    w = [field.from_mont(int(x)) for x in words]
+    items, pos = [], 2
+    for _ in range(w[1]):
+        size = w[pos]
+        items.append(np.array(words[pos + 1:pos + 1 + size]))
+        pos += 1 + size
+
+    def proof_of(item_list):
+        parts = [np.array([field.to_mont(len(item_list))], np.uint64)]
+        for it in item_list:
+            parts += [np.array([field.to_mont(it.size)], np.uint64), it]
+        body = np.concatenate(parts)
+        return np.concatenate([[np.uint64(field.to_mont(body.size))], body])
+
+    assert (proof_of(items) == words).all()
+    seen = set()
+    for k, it in enumerate(items):
+        name, kind, _ = PROOF_ITEMS[field.from_mont(int(it[0]))]
+        if kind != "static" or name in seen:
+            continue
+        seen.add(name)
+        assert it.size - 1 == STATIC_WORDS[name]
+        for mutated in (np.concatenate([it, it[-1:]]), it[:-1]):
+            bad = proof_of(items[:k] + [mutated] + items[k + 1:])
+            with pytest.raises(ProofDecodingError):
+                ProofStream.from_proof(ctx.lib, bad)
+            with pytest.raises(ProofDecodingError):
+                Verifier(ctx).verify(claim, bad)
+    assert seen == set(STATIC_WORDS)
+    # a u32 that is not one
+    k = next(i for i, it in enumerate(items) if PROOF_ITEMS[field.from_mont(int(it[0]))][0] == "Log2PaddedHeight")
+    big = items[k].copy()
+    big[1] = np.uint64(field.to_mont(1 << 32))
+    with pytest.raises(ProofDecodingError):
+        ProofStream.from_proof(ctx.lib, proof_of(items[:k] + [big] + items[k + 1:]))
+    del Proof

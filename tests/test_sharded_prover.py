@@ -113,6 +113,112 @@ def test_sharded_proof_equals_single_process_proof(world, split_trees, ldt):
             assert (results[rank][key] == value).all(), (rank, key)
 
 
+def _execution_worker(rank, world, port, out, backend):
+    """Prover::prove(claim, aet) over the ranks (ShardedProver.from_execution): `halt` at security level 32"""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from oracle import oracle as orc
+    from tests import test_proof_snapshot as snap, vm_fixture as vf
+    from tests.test_fill import aet_arrays
+    from triton_vm_amd.sharded import ShardedProver
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        device = torch.device("cuda", rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        from triton_vm_amd import Context
+
+        ctx = Context(device=rank)
+        which, level = ("fib", 100), 160
+    else:
+        device = torch.device("cpu")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        from tests.emu_fixture import emu_context
+
+        ctx = emu_context()
+        which, level = "halt", 32
+    program, aet, public_input, output = vf.run(which)
+    claim = snap.claim_of(orc, program, public_input, output)
+    prover = ShardedProver.from_execution(ctx, dist, device, aet_arrays(orc, aet), aet.padded_height(), claim, snap.prover_seed(3),
+                                          security_level=level, ldt="fri")
+    prover.split_tree_min_leaves = 0
+    words = prover.prove().proof().words
+    out.put((rank, np.array(words), prover.leaf_exchange))
+    dist.destroy_process_group()
+    ctx.close()
+
+
+def _run_execution_ranks(world, backend, single_ctx, which, level):
+    import queue
+    import time
+
+    import torch.multiprocessing as mp
+
+    from oracle import oracle as orc
+    from tests import test_proof_snapshot as snap, vm_fixture as vf
+    from tests.test_fill import aet_arrays
+    from triton_vm_amd.prover import Prover
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mpctx = mp.get_context("spawn")
+    out = mpctx.Queue()
+    procs = [mpctx.Process(target=_execution_worker, args=(r, world, port, out, backend)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    program, aet, public_input, output = vf.run(which)
+    claim = snap.claim_of(orc, program, public_input, output)
+    want = Prover.from_execution(single_ctx, aet_arrays(orc, aet), aet.padded_height(), claim, snap.prover_seed(3), security_level=level,
+                                 ldt="fri").prove().proof().words
+    results, deadline = {}, time.time() + 900
+    while len(results) < world:
+        try:
+            rank, words, exchange = out.get(timeout=5)
+            results[rank] = (words, exchange)
+        except queue.Empty:
+            assert all(pr.exitcode in (None, 0) for pr in procs), "a rank died"
+            assert time.time() < deadline, "timed out"
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    for rank in range(world):
+        words, exchange = results[rank]
+        assert exchange == "all_to_all"                       # the leaf digests travelled once, to the rank that builds on them
+        assert words.size == want.size and (words == want).all(), rank
+
+
+def test_sharded_prove_execution_equals_single_process_proof():
+    """fill, pad, extend replicated on two gloo ranks, the extended tables split: the reference-shaped proof, word for word"""
+    from tests.emu_fixture import emu_context
+
+    ctx = emu_context()
+    try:
+        _run_execution_ranks(2, "gloo", ctx, "halt", 32)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_sharded_prove_execution_over_rccl_on_two_gpus():
+    """the same over RCCL with one rank per GPU -- skipped on a single-GPU box, so the first multi-GPU node exercises the
+    all-to-all of leaf digests, the all-gather of the quotient codeword and the split trees for real"""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    from triton_vm_amd import Context
+
+    ctx = Context(device=0)
+    try:
+        _run_execution_ranks(2, "nccl", ctx, ("fib", 100), 160)
+    finally:
+        ctx.close()
+
+
 @pytest.mark.gpu
 def test_sharded_prover_on_one_gpu_matches_plain_prover():
     """The torch-tensor / RCCL plumbing of ShardedProver on the real device (a one-rank nccl group: the

@@ -12,17 +12,6 @@ from oracle.vm import isa, tables as T, vm
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TINY_PROGRAM = "pick 11 pick 12 pick 13 pick 14 pick 15 read_io 5 assert_vector halt"
-# the program of the reference's headline benchmark, prove_fib (benches/prove_fib.rs:8-24 runs it with index 100;
-# triton-dev-util/src/example_programs.rs:6-38): ten instructions per iteration
-FIBONACCI_PROGRAM = """
-    push 0 push 1 read_io 1
-    dup 0 skiz call fib_loop
-    pop 1 write_io 1 halt
-    fib_loop:
-        push -1 add swap 2 dup 1 add swap 1 swap 2 dup 0 skiz recurse return
-"""
-
-
 # more of the programs the reference proves and verifies (stark.rs:4257-4317, triton-dev-util/src/example_programs.rs:70-96)
 MANY_U32_PROGRAM = """
     push 1311768464867721216 split
@@ -60,41 +49,7 @@ PICK_AND_PLACE_PROGRAM = """
     halt
 """
 PICK_AND_PLACE_INPUT = [6, 3, 7, 5, 1, 2, 4, 4, 7, 3, 6, 1, 5, 2]
-# a loop of u32 operations on fresh operand pairs: every iteration adds a 33-row section to the U32 table (BASELINE.json's
-# "many_u32_ops at 2^20 rows": 31775 iterations fill 1 048 575 rows)
-U32_LOOP_PROGRAM = """
-    read_io 1
-    call loop
-    pop 1 halt
-    loop:
-        dup 0 push 2147483648 add
-        dup 1 xor pop 1
-        push -1 add dup 0 skiz recurse return
-"""
-# a loop that writes to a fresh RAM address every iteration: as many distinct RAM pointers as iterations (the RAM table's
-# Bezout coefficient polynomials have that many coefficients)
-RAM_LOOP_PROGRAM = """
-    read_io 1
-    call loop
-    pop 1 halt
-    loop:
-        dup 0 dup 0 mul
-        dup 1 push 1000 mul
-        write_mem 1 pop 1
-        push -1 add dup 0 skiz recurse return
-"""
-# a loop of sponge operations: every iteration squeezes and absorbs (two Tip5 permutations = 12 rows of the hash table
-# against 8 processor cycles), so the hash table sets the padded height -- the hash-heavy shape that stands in for
-# BASELINE.json's recursive-verifier program (which lives outside the reference repository)
-SPONGE_LOOP_PROGRAM = """
-    read_io 1
-    sponge_init
-    call loop
-    pop 1 halt
-    loop:
-        sponge_squeeze sponge_absorb
-        push -1 add dup 0 skiz recurse return
-"""
+from oracle.vm.workload import FIBONACCI_PROGRAM, RAM_LOOP_PROGRAM, SPONGE_LOOP_PROGRAM, U32_LOOP_PROGRAM  # noqa: E402,F401
 PROGRAMS = {"halt": ("halt", []), "many_u32": (MANY_U32_PROGRAM, []), "pick_and_place": (PICK_AND_PLACE_PROGRAM, PICK_AND_PLACE_INPUT)}
 
 

@@ -53,6 +53,20 @@ int set_error(tvm_ctx* c, int code, const char* what);
 void* pool_alloc(tvm_ctx* c, size_t bytes);
 void pool_release(tvm_ctx* c, void* p);   // back to the cache (stream-ordered reuse)
 void pool_trim(tvm_ctx* c);               // cached blocks back to the driver (synchronises the stream)
+// a pool block that goes back to the cache on every exit path of the function that holds it
+struct PoolBlock {
+    tvm_ctx* c;
+    void* p = nullptr;
+    explicit PoolBlock(tvm_ctx* c_) : c(c_) {}
+    PoolBlock(tvm_ctx* c_, size_t bytes) : c(c_), p(pool_alloc(c_, bytes)) {}
+    void* alloc(size_t bytes) {
+        pool_release(c, p);
+        return p = pool_alloc(c, bytes);
+    }
+    ~PoolBlock() { pool_release(c, p); }
+    PoolBlock(const PoolBlock&) = delete;
+    PoolBlock& operator=(const PoolBlock&) = delete;
+};
 inline int ilog2(u64 n) {
     int l = 0;
     while ((1ull << l) < n) l++;

@@ -283,17 +283,41 @@ static int inclusive_sum(tvm_ctx* c, u64* d_in, u64* d_out, u64 len) {
 }
 
 static inline dim3 fa_grid(u64 count) { return dim3((unsigned)((count + 255) / 256)); }
-struct FaUpload {  // host array -> device copy from the pool, released on scope exit
+// The AET's arrays may live in host memory (the reference's AlgebraicExecutionTrace) or already on the device (a host that
+// runs the VM next to the GPU and keeps the trace resident: nothing crosses PCIe inside the call).
+static bool fa_on_device(const void* p) {
+#ifdef TVM_EMU
+    (void)p;
+    return false;
+#else
+    if (!p) return false;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();  // plain (unregistered) host memory on runtimes that report it as an error
+        return false;
+    }
+    return at.type == hipMemoryTypeDevice;
+#endif
+}
+struct FaUpload {  // host array -> device copy from the pool, released on scope exit; a device array is used where it lies
     tvm_ctx* c;
     u64* d = nullptr;
+    bool owned = true;
     FaUpload(tvm_ctx* c_, const void* h, size_t bytes) : c(c_) {
+        if (bytes && fa_on_device(h)) {
+            d = (u64*)h;
+            owned = false;
+            return;
+        }
         d = (u64*)pool_alloc(c, bytes ? bytes : 8);
         if (d && bytes && hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
             pool_release(c, d);
             d = nullptr;
         }
     }
-    ~FaUpload() { pool_release(c, d); }
+    ~FaUpload() {
+        if (owned) pool_release(c, d);
+    }
     FaUpload(const FaUpload&) = delete;   // (the emulation's launch macro captures its arguments by value)
     FaUpload& operator=(const FaUpload&) = delete;
 };
@@ -303,10 +327,18 @@ int fill_main_table(tvm_ctx* c, const tvm_aet* aet, u64* d_main, u64 n, u64* h_l
     const u64 hash_len = aet->program_hash_len + aet->sponge_len + aet->hash_len;
     u64 u32_len = 0;
     std::vector<u64> u32_offsets(aet->u32_len ? aet->u32_len : 1);
+    std::vector<u64> u32_host;                 // the section offsets are computed on the host: a device-resident entry list comes back
+    const u64* u32_entries = aet->u32_entries;
+    if (aet->u32_len && fa_on_device(aet->u32_entries)) {
+        u32_host.resize(aet->u32_len * 4);
+        TVM_HIP_CHECK(c, hipMemcpyAsync(u32_host.data(), aet->u32_entries, u32_host.size() * 8, hipMemcpyDeviceToHost, c->stream));
+        TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+        u32_entries = u32_host.data();
+    }
     for (u64 e = 0; e < aet->u32_len; e++) {   // U32TableEntry::table_height_contribution (u32.rs:53-64)
-        const u64 op = aet->u32_entries[4 * e];
+        const u64 op = u32_entries[4 * e];
         auto value = [](u64 w) { return bfe_mul(w, 1); };
-        const u64 lhs = value(aet->u32_entries[4 * e + 1]), rhs = value(aet->u32_entries[4 * e + 2]);
+        const u64 lhs = value(u32_entries[4 * e + 1]), rhs = value(u32_entries[4 * e + 2]);
         const u64 dominant = op == OP_POW ? rhs : (lhs > rhs ? lhs : rhs);
         u32_offsets[e] = u32_len;
         u32_len += dominant ? 2 + (63 - __builtin_clzll(dominant)) : 1;
@@ -335,14 +367,12 @@ int fill_main_table(tvm_ctx* c, const tvm_aet* aet, u64* d_main, u64 n, u64* h_l
     FaUpload casc(c, aet->cascade_entries, aet->cascade_len * 2 * 8), lkm(c, aet->lookup_multiplicities, 256 * 8);
     const u64 max_mem = aet->processor_len > aet->op_stack_len ? (aet->processor_len > aet->ram_len ? aet->processor_len : aet->ram_len)
                                                                : (aet->op_stack_len > aet->ram_len ? aet->op_stack_len : aet->ram_len);
-    u64* w = (u64*)pool_alloc(c, (4 * max_mem + aet->processor_len + 8) * sizeof(u64));
+    PoolBlock w_block(c, (4 * max_mem + aet->processor_len + 8) * sizeof(u64)), bz_block(c);  // released on every exit path
+    u64* w = (u64*)w_block.p;
     u64* bz = nullptr;  // device-computed Bezout coefficients (device_bezout)
     const bool ok = program.d && imult.d && proc.d && ops.d && ram.d && bc0.d && bc1.d && ph.d && sp.d && hs.d && u32e.d && u32o.d && casc.d &&
                     lkm.d && w;
-    if (!ok) {
-        pool_release(c, w);
-        return set_error(c, TVM_ERR_OUT_OF_MEMORY, "fill: device staging");
-    }
+    if (!ok) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "fill: device staging");
     TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));   // the host arrays may be caller temporaries
     const u64 *d_program = program.d, *d_proc = proc.d, *d_ops = ops.d, *d_ram = ram.d, *d_bc0 = bc0.d, *d_bc1 = bc1.d, *d_u32e = u32e.d,
               *d_u32o = u32o.d, *d_casc = casc.d, *d_lkm = lkm.d;
@@ -395,7 +425,7 @@ int fill_main_table(tvm_ctx* c, const tvm_aet* aet, u64* d_main, u64 n, u64* h_l
                 goto done;
             }
             const u64 n_unique = changes + 1;
-            bz = (u64*)pool_alloc(c, 3 * n_unique * sizeof(u64));  // the distinct pointers, then the two coefficient vectors
+            bz = (u64*)bz_block.alloc(3 * n_unique * sizeof(u64));  // the distinct pointers, then the two coefficient vectors
             if (!bz) {
                 rc = set_error(c, TVM_ERR_OUT_OF_MEMORY, "fill: Bezout coefficients");
                 goto done;
@@ -422,8 +452,6 @@ int fill_main_table(tvm_ctx* c, const tvm_aet* aet, u64* d_main, u64 n, u64* h_l
     }
     if (hipGetLastError() != hipSuccess) rc = set_error(c, TVM_ERR_DEVICE, "fill kernels");
 done:
-    pool_release(c, w);
-    pool_release(c, bz);
     return rc;
 }
 

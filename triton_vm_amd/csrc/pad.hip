@@ -148,17 +148,23 @@ int pad_main_table(tvm_ctx* c, u64* d_main, u64 n, const u64* lengths) {
     const int bs = 256;
     u64* d_pivot = (u64*)scratch(c, 22, sizeof(u64));
     if (!d_pivot) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "pad scratch");
+    // the pivot is only written by the row that holds the largest clock: start from a sentinel, so that a malformed or
+    // unsorted trace (no such row) is an error instead of stale scratch contents
+    TVM_HIP_CHECK(c, hipMemsetAsync(d_pivot, 0xFF, sizeof(u64), c->stream));
     TVM_LAUNCH(k_pad_find_js_pivot, dim3((unsigned)((a.len[4] + bs - 1) / bs)), dim3(bs), 0, c->stream, a, d_pivot);
     TVM_HIP_CHECK(c, hipMemcpyAsync(&a.js_pivot, d_pivot, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (a.js_pivot >= a.len[4])
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "pad: no jump-stack row carries the last clock value (malformed execution trace)");
     const u64 n_tail = a.len[4] - a.js_pivot - 1;
-    u64* tail = (u64*)pool_alloc(c, (size_t)(5 * n_tail + 1) * sizeof(u64));
+    PoolBlock tail_block(c, (size_t)(5 * n_tail + 1) * sizeof(u64));  // released on every exit path
+    u64* tail = (u64*)tail_block.p;
     if (!tail) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "pad scratch");
     a.js_tail = tail;
     if (n_tail) TVM_LAUNCH(k_pad_save_js_tail, dim3((unsigned)((n_tail + bs - 1) / bs)), dim3(bs), 0, c->stream, a, tail);
     TVM_LAUNCH(k_pad_main_table, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, c->stream, a);
     TVM_LAUNCH(k_pad_processor_row1, dim3(1), dim3(64), 0, c->stream, a);
-    pool_release(c, tail);
+    TVM_HIP_CHECK(c, hipGetLastError());
     return TVM_OK;
 }
 

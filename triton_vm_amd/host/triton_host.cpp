@@ -898,7 +898,10 @@ extern "C" int32_t tvmh_prove_execution(tvm_ctx* ctx, const tvm_aet* aet, uint32
     try {
         if (!aet || !randomness_seed) throw Error(TVM_ERR_INVALID_ARGUMENT, "tvmh_prove_execution: null execution trace or seed");
         const Context c(ctx);
-        const StarkParameters p = stark_parameters(log2_padded_height, security_level, log2_expansion, use_stir != 0);
+        // use_stir: 0 = LdtChoice::Fri, 1 = LdtChoice::Stir, 2 = Stark::ldt's rule (STIR from 2^16 padded rows on, stark.rs:1944-1951)
+        if (use_stir > 2) throw Error(TVM_ERR_INVALID_ARGUMENT, "tvmh_prove_execution: use_stir is 0 (FRI), 1 (STIR) or 2 (automatic)");
+        const bool stir = use_stir == 2 ? log2_padded_height >= 16 : use_stir == 1;
+        const StarkParameters p = stark_parameters(log2_padded_height, security_level, log2_expansion, stir);
         Claim claim;
         if (h_program_digest) std::memcpy(claim.program_digest, h_program_digest, sizeof(claim.program_digest));
         if (n_public_input) claim.input.assign(h_public_input, h_public_input + n_public_input);

@@ -217,7 +217,9 @@ extern "C" int32_t tvmh_prove(tvm_ctx* ctx, uint32_t log2_padded_height, uint64_
                               const uint64_t* h_public_output, uint64_t n_public_output, uint32_t use_stir, uint64_t* h_proof,
                               uint64_t proof_capacity_words, uint64_t* proof_words, char* error, uint64_t error_capacity);
 
-// Prover::prove(claim, aet) -- triton_vm::prove_execution -- for hosts without a C++ ABI.
+// Prover::prove(claim, aet) -- triton_vm::prove_execution -- for hosts without a C++ ABI.  use_stir: 0 = LdtChoice::Fri,
+// 1 = LdtChoice::Stir, 2 = Stark::ldt's rule, what Stark::default() does (STIR from 2^16 padded rows on, stark.rs:1944-1951).
+// The arrays of `aet` may be host or device memory (include/triton_hip.h: tvm_fill_main_table).
 extern "C" int32_t tvmh_prove_execution(tvm_ctx* ctx, const tvm_aet* aet, uint32_t log2_padded_height, uint32_t security_level,
                                         uint32_t log2_expansion, uint32_t use_stir, const uint8_t randomness_seed[32],
                                         const uint64_t* h_program_digest, const uint64_t* h_public_input,

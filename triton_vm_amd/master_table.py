@@ -158,6 +158,29 @@ def pad(ctx, d_main_trace, n_rows, table_lengths):
     degree_lowering.fill_derived_main_columns(ctx, d_main_trace, n_rows)
 
 
+class DeviceAet:
+    """An algebraic execution trace whose arrays are resident on the device (aet_to_device): tvm_fill_main_table reads
+    them where they lie, so nothing crosses PCIe inside Prover::prove.  Accepted wherever the dict of numpy arrays is."""
+
+    def __init__(self, struct, buffers):
+        self.struct, self.buffers = struct, buffers
+
+
+def aet_to_device(ctx, aet):
+    """upload the arrays of `aet` (see aet_struct) once -> DeviceAet.  instruction_multiplicities (uint32) travel padded to
+    whole words."""
+    s, keep = aet_struct(aet)
+    buffers = {}
+    for name, a in keep.items():
+        if a.size == 0:
+            continue
+        raw = np.frombuffer(a.tobytes() + b"\0" * (-a.nbytes % 8), np.uint64)
+        buffers[name] = ctx.to_device(raw)
+        setattr(s, name, buffers[name].ptr)
+    ctx.sync()
+    return DeviceAet(s, buffers)
+
+
 def aet_struct(aet):
     """the C ABI's `tvm_aet` over a dict of numpy arrays shaped like AlgebraicExecutionTrace's fields (aet.rs:41-96):
     program_words [p], instruction_multiplicities [p] (uint32), processor_trace [c][39], op_stack_trace [k][4],
@@ -165,6 +188,8 @@ def aet_struct(aet):
     u32_entries [k][4], cascade_entries [k][2], lookup_multiplicities [256].  -> (struct, the arrays it points into)"""
     from .capi import Aet
 
+    if isinstance(aet, DeviceAet):
+        return aet.struct, aet.buffers
     keep = {}
 
     def arr(name, dtype=np.uint64, width=None):

@@ -54,9 +54,11 @@ def stir_prove(ctx, host_lib, stir, d_codeword):
     return [int(i) for i in first], out[:n.value].copy()
 
 
-def prove_execution(ctx, host_lib, aet, padded_height, claim, randomness_seed, security_level=160, log2_expansion=2, ldt="fri"):
+def prove_execution(ctx, host_lib, aet, padded_height, claim, randomness_seed, security_level=160, log2_expansion=2, ldt=None):
     """The C++ host's Prover::prove(claim, aet) (triton_vm::prove_execution): fill, pad, extend and the hot path on the
-    device, the seeded randomness and the transcript in C++.  aet: the arrays master_table.fill takes.  -> the proof words"""
+    device, the seeded randomness and the transcript in C++.  aet: the arrays master_table.fill takes (host arrays, or
+    master_table.aet_to_device's device-resident copy).  ldt: "fri", "stir" or None = Stark::ldt's rule (STIR from 2^16 padded
+    rows on, stark.rs:1944-1951).  -> the proof words"""
     from .master_table import aet_struct
 
     s, keep = aet_struct(aet)
@@ -64,7 +66,7 @@ def prove_execution(ctx, host_lib, aet, padded_height, claim, randomness_seed, s
     err, n = C.create_string_buffer(512), C.c_uint64(0)
     out = np.empty(1 << 20, np.uint64)   # a 2^20-row proof is ~0.3 M words
     while True:
-        rc = host_lib.tvmh_prove_execution(ctx.handle, C.addressof(s), log2, security_level, log2_expansion, 1 if ldt == "stir" else 0,
+        rc = host_lib.tvmh_prove_execution(ctx.handle, C.addressof(s), log2, security_level, log2_expansion, {"fri": 0, "stir": 1, None: 2}[ldt],
                                            bytes(randomness_seed),
                                            claim.program_digest.ctypes.data, claim.input.ctypes.data, claim.input.size,
                                            claim.output.ctypes.data, claim.output.size, out.ctypes.data, out.size, C.byref(n), err, len(err))

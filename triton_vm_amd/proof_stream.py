@@ -27,6 +27,10 @@ PROOF_ITEMS = [
     ("FriResponse", "response", False), ("StirResponse", "response", False),
 ]
 VARIANT = {name: (k, kind, fs) for k, (name, kind, fs) in enumerate(PROOF_ITEMS)}
+# the statically sized payloads (BFieldCodec::static_length): Digest, u32, [XFieldElement; 379], [XFieldElement; 91],
+# [XFieldElement; 4] -- a decoder that takes whatever length the proof offers accepts proofs the reference rejects
+STATIC_WORDS = {"MerkleRoot": 5, "Log2PaddedHeight": 1, "OutOfDomainMainRow": 379 * 3, "OutOfDomainAuxRow": 91 * 3,
+                "OutOfDomainQuotientSegments": 4 * 3}
 
 # the labels the provers in this package enqueue under (longest prefix wins) -> proof item
 LABELS = [
@@ -262,6 +266,10 @@ class ProofStream:
                 raise ProofDecodingError("unknown proof item")
             name, kind, fs = PROOF_ITEMS[w[start]]
             if kind == "static":
+                if size - 1 != STATIC_WORDS[name]:
+                    raise ProofDecodingError(f"{name}: {size - 1} payload words, the type has {STATIC_WORDS[name]}")
+                if name == "Log2PaddedHeight" and w[start + 1] >= 1 << 32:
+                    raise ProofDecodingError("Log2PaddedHeight: not a u32")
                 self.log.append((name, words[start + 1:start + size].copy(), fs))
                 continue
             if size < 2 or w[start + 1] != size - 2:
@@ -292,7 +300,9 @@ class ProofStream:
                         q += 1 + w[q]
                     if q != leaves_at + 1 + leaves_len:
                         raise ProofDecodingError("StirResponse: the stacks do not span the field")
-                    leaves = np.array(stacks, np.uint64)
+                    if len({len(st) for st in stacks}) > 1:   # (the verifier rejects ragged stacks; never a numpy error)
+                        raise ProofDecodingError("StirResponse: stacks of different heights")
+                    leaves = np.array(stacks, np.uint64).reshape(len(stacks), -1, 3)
                 self.log.append((DECODED_LABELS[name][0], leaves.copy(), fs))
                 self.log.append((DECODED_LABELS[name][1], auth.copy(), fs))
         if take(0) != len(w):

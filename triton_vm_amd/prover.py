@@ -102,6 +102,21 @@ class StarkParameters:
             self.quotient = ArithmeticDomain.of_length(max(quotient_len, 1)).with_offset(g)
 
 
+def stark_parameters(log2_padded_height, security_level=160, log2_expansion=2, ldt=None):
+    """Stark::new(security_level, log2_expansion) for a padded height (stark.rs:1815-1830, 1944-2089): ldt "fri", "stir" or None
+    = Stark::ldt's rule (STIR from 2^16 padded rows on).  fri.rs:832-836: the number of collinearity checks;
+    stark.rs:2083-2089: the number of trace randomizers."""
+    import math
+
+    from .low_degree_test import ReedSolomonCode
+
+    if ldt is None:
+        ldt = "fri" if log2_padded_height < 16 else "stir"
+    checks = math.ceil(-security_level / math.log2(1.0 - ReedSolomonCode(log2_expansion).proximity_parameter()))
+    return StarkParameters(log2_padded_height, num_trace_randomizers=checks + 4 * 3 * 2 + 1, num_collinearity_checks=checks,
+                           log2_expansion=log2_expansion, ldt=ldt, security_level=security_level)
+
+
 class Prover:
     """Runs the prover's hot path on synthetic or caller-provided padded trace tables, or -- `from_execution` -- the
     whole of Prover::prove from an algebraic execution trace."""
@@ -127,7 +142,7 @@ class Prover:
         self.capture = None
 
     @classmethod
-    def from_execution(cls, ctx, aet, padded_height, claim, randomness_seed, log2_expansion=2, ldt="fri", security_level=160,
+    def from_execution(cls, ctx, aet, padded_height, claim, randomness_seed, log2_expansion=2, ldt=None, security_level=160,
                        assume_valid_trace=True):
         """Prover::prove from the start (stark.rs:331-400): the master main table is filled from the algebraic
         execution trace and padded on the device (MasterMainTable::new + pad, master_table.rs:881-983), all randomness
@@ -135,25 +150,16 @@ class Prover:
         the device once the challenges are sampled (MasterMainTable::extend, master_table.rs:1006-1075).
         aet: the arrays master_table.fill takes; padded_height: AlgebraicExecutionTrace::padded_height (aet.rs:141-146);
         security_level, log2_expansion: Stark::new's (stark.rs:1815-1830; Stark::default() is 160, 2); ldt: "fri", "stir" or
-        None for the reference's automatic choice (STIR from 2^16 padded rows on);
+        None (the default, like Stark::default()) for the reference's automatic choice (STIR from 2^16 padded rows on);
         assume_valid_trace: the tables come from an execution trace, so the quotient evaluation may use the degree
         bounds of the constraint quotients (TVM_OPTION_AIR_VALID_TRACE) -- the same proof, word for word, as
         long as the trace satisfies the AIR (both reference snapshots are reproduced this way); an invalid trace gives a
         proof that differs from the reference's equally unverifiable one."""
-        import math
-
-        from .low_degree_test import ReedSolomonCode
-
         self = cls.__new__(cls)
         log2 = padded_height.bit_length() - 1
         if padded_height != 1 << log2:
             raise ValueError("the padded height is a power of two")
-        if ldt is None:      # Stark::ldt's heuristic for proven soundness (stark.rs:1944-1951)
-            ldt = "fri" if log2 < 16 else "stir"
-        # fri.rs:832-836: the number of collinearity checks; stark.rs:2083-2089: the number of trace randomizers
-        checks = math.ceil(-security_level / math.log2(1.0 - ReedSolomonCode(log2_expansion).proximity_parameter()))
-        p = StarkParameters(log2, num_trace_randomizers=checks + 4 * 3 * 2 + 1, num_collinearity_checks=checks,
-                            log2_expansion=log2_expansion, ldt=ldt, security_level=security_level)
+        p = stark_parameters(log2, security_level, log2_expansion, ldt)
         self.ctx, self.p, self.claim, self.randomness_seed = ctx, p, claim, bytes(randomness_seed)
         self.assume_valid_trace = assume_valid_trace
         n, h, lib = p.trace.length, p.h, ctx.lib

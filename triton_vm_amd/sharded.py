@@ -7,7 +7,8 @@ domain -- offset g*w_L^r, generator w_L^R, length L/R -- so a rank's share of
 i + L/N stays on the same rank) are the *same* C-ABI calls on that local domain: no kernel knows about ranks.
 The trace (5 GiB at 2^20 rows) is replicated.  Exchanges (RCCL all-gather over xGMI; gloo in the CPU tests):
 
-    leaf digests of each master table   L x 40 B  (336 MB at 2^20), interleaved back into row order
+    leaf digests of each master table   all-to-all: rank t receives the digests of ITS contiguous leaf range (L/R x 40 B:
+                                        42 MB per rank at 2^20 rows and 8 ranks), interleaved into row order
     the quotient codeword               L x 24 B  (201 MB), likewise
     the opened rows (173 x 652 words)   all-gather of each owner's rows, put back into query order
     the out-of-domain rows              columns split over the ranks, all-gather of the shares (2 x 470 XFE)
@@ -121,20 +122,43 @@ class ShardedProver(Prover):
     """Prover whose extended master tables are split by cosets over the ranks of a torch.distributed group."""
 
     def __init__(self, ctx, params, dist, device, main_trace=None, aux_trace=None, seed=1):
+        self._check_sharding(params, dist)
+        super().__init__(ctx, params, main_trace, aux_trace, seed)  # every rank holds the same traces (same seed)
+        self._init_sharding(dist, device)
+
+    @classmethod
+    def from_execution(cls, ctx, dist, device, aet, padded_height, claim, randomness_seed, **kw):
+        """Prover::prove(claim, aet) over the ranks: every rank fills, pads and (after the challenges) extends the SAME trace
+        tables from the same execution trace and the same seed (replicated: 16 ms at 2^20 rows), then owns its cosets of
+        the extended tables.  Arguments as Prover.from_execution."""
+        self = super().from_execution(ctx, aet, padded_height, claim, randomness_seed, **kw)
+        self._check_sharding(self.p, dist)
+        self._init_sharding(dist, device)
+        return self
+
+    @staticmethod
+    def _check_sharding(params, dist):
+        expansion = params.ldt.length // params.trace.length
+        if params.quotient.length != params.ldt.length or expansion % dist.get_world_size():
+            raise ValueError("coset sharding needs |quotient| == |LDT| and a world size dividing |LDT| / |trace|")
+
+    def _init_sharding(self, dist, device):
         import torch
 
         self.torch, self.dist, self.device = torch, dist, device
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        expansion = params.ldt.length // params.trace.length
-        if params.quotient.length != params.ldt.length or expansion % self.world:
-            raise ValueError("coset sharding needs |quotient| == |LDT| and a world size dividing |LDT| / |trace|")
-        super().__init__(ctx, params, main_trace, aux_trace, seed)  # every rank holds the same traces (same seed)
-        self.ldt_local = local_domain(params.ldt, self.rank, self.world)
+        self.ldt_local = local_domain(self.p.ldt, self.rank, self.world)
         # trees of at least this many leaves are built split (_SplitTree); below it the two small exchanges cost
         # more than the redundant hashing saves
         self.split_tree_min_leaves = (1 << 21) if self.world > 1 else (1 << 62)
         for mt in (self.main, self.aux):
-            mt.quotient_domain = mt.ldt_domain = self.ldt_local
+            if mt is not None:
+                mt.quotient_domain = mt.ldt_domain = self.ldt_local
+
+    def _extend(self, challenges):
+        aux = super()._extend(challenges)       # MasterMainTable::extend, replicated; this rank extends it onto its cosets
+        aux.quotient_domain = aux.ldt_domain = self.ldt_local
+        return aux
 
     # -- collectives ---------------------------------------------------------------------------------
     def _empty(self, n_words):
@@ -157,11 +181,29 @@ class ShardedProver(Prover):
 
     # -- the sharded steps -----------------------------------------------------------------------------
     def _commit_master_table(self, mt):
-        ctx, L = self.ctx, self.p.ldt.length
-        digests = self._empty(5 * self.ldt_local.length)
-        ctx._check(ctx.lib.tvm_hash_rows(ctx.handle, mt._need_table(), self.ldt_local.length, digests.data_ptr()), "hash_rows")
+        ctx, L, R = self.ctx, self.p.ldt.length, self.world
+        local_rows = self.ldt_local.length
+        digests = self._empty(5 * local_rows)
+        ctx._check(ctx.lib.tvm_hash_rows(ctx.handle, mt._need_table(), local_rows, digests.data_ptr()), "hash_rows")
+        if self._splits(L) and local_rows % R == 0:
+            # The tree is built split: rank t needs the leaves of ITS contiguous range [t L/R, (t+1) L/R) only.  Of this
+            # rank's rows (global row rank + R a) those are the local rows a in [t L/R^2, (t+1) L/R^2): one all-to-all
+            # moves every digest once (1/R of what an all-gather of all leaves moves), then the R received blocks are
+            # interleaved into row order.
+            self._sync_device()
+            received = self._empty(5 * local_rows)
+            self.dist.all_to_all_single(received, digests)
+            mine = received.view(R, local_rows // R, 5).permute(1, 0, 2).contiguous().view(-1)
+            self._sync_device()
+            self._keep = mine  # until the stream has consumed it
+            self.leaf_exchange = "all_to_all"
+            per = L // R
+            sub = ctx.alloc(10 * per)
+            ctx._check(ctx.lib.tvm_merkle_tree(ctx.handle, mine.data_ptr(), per, sub.ptr), "merkle_tree")
+            return _SplitTree(self, sub, L)
         leaves = self._all_gather_rows(digests, 5)
         self._keep = leaves  # until the stream has consumed it
+        self.leaf_exchange = "all_gather"
         return self._tree_of_leaf_digests(leaves.data_ptr(), L)
 
     def _splits(self, n_leaves):

@@ -118,7 +118,7 @@ def verify_inclusion(lib, root, n_leaves, leaf_indices, leaf_digests, authentica
     for i, d in zip(leaf_indices, leaf_digests):
         key = int(i) + n_leaves
         d = _h(d)
-        if key in known and not (known[key] == d).all():
+        if d.shape != (5,) or (key in known and not np.array_equal(known[key], d)):
             raise VerificationError(error)
         known[key] = d
     sent = auth_node_indices(n_leaves, leaf_indices)
@@ -136,7 +136,8 @@ def verify_inclusion(lib, root, n_leaves, leaf_indices, leaf_digests, authentica
             parents[k >> 1] = hash_pair(lib, left, right)
         known.update(parents)
         level = sorted(parents)
-    if not (known.get(1) == _h(root)).all():
+    root = _h(root)
+    if root.shape != (5,) or not np.array_equal(known.get(1), root):   # (never an elementwise broadcast against a short root)
         raise VerificationError(error)
 
 
@@ -145,9 +146,9 @@ class Verifier:
     the host sequences the Fiat-Shamir schedule and the decisions; the row hashing and the per-row combination values run
     on the device (tvm_verifier_row_digests, tvm_verifier_deep_values), the AIR at the out-of-domain rows through
     tvm_host_air_constraints.  ldt: "fri" or "stir" (stir.rs:995-1340) -- Stark::ldt picks by padded height
-    (stark.rs:1944-1951: STIR from 2^16 on); None applies that rule."""
+    (stark.rs:1944-1951: STIR from 2^16 on); None (the default, like Stark::default()) applies that rule."""
 
-    def __init__(self, ctx, security_level=160, log2_expansion=2, ldt="fri"):
+    def __init__(self, ctx, security_level=160, log2_expansion=2, ldt=None):
         self.ctx, self.security_level, self.log2_expansion, self.ldt = ctx, security_level, log2_expansion, ldt
 
     def verify(self, claim, proof_words):

@@ -19,6 +19,15 @@ namespace tvm {
 #ifndef AIR_BLOCK
 #define AIR_BLOCK 256
 #endif
+#if AIR_BLOCK == 128
+#define TVM_AIR_BLOCK_LOG 7
+#elif AIR_BLOCK == 256
+#define TVM_AIR_BLOCK_LOG 8
+#elif AIR_BLOCK == 512
+#define TVM_AIR_BLOCK_LOG 9
+#else
+#error "AIR_BLOCK is 128, 256 or 512"
+#endif
 // AIR_MIN_WAVES: wavefronts per SIMD the register allocation must leave room for.  Two (256 registers per lane):
 // with the table cells of the next segment in flight some parts would otherwise take > 256 and run alone.
 #ifndef AIR_MIN_WAVES
@@ -34,17 +43,57 @@ namespace tvm {
 #endif
 
 struct AirArgs {
-    const u64* main_table;   // row-block-major [rows][main_w]
-    const u64* aux_table;    // row-block-major [rows][aux_w]
+    const u64* main_table;   // row-block-major over storage rows, main_w words per row
+    const u64* aux_table;    // likewise, aux_w words per row
     u64 main_w, aux_w;       // words per table row
-    u64 stride;              // table rows per quotient-domain row
-    u64 q_len, unit;         // |quotient domain|, |quotient domain| / |trace domain|
+    u64 q_len;               // |quotient domain|
+    // Where the quotient domain's rows are (context.h: TabLayout): the quotient domain is X' = q_len / N cosets of the trace
+    // domain, coset kq of it = coset kq * (X / X') of the table; row j = j1 + n2*j2 of a coset is storage row
+    // coset base + j1*n1 + j2 and its successor j + 1 is n1 storage rows further (successor blocks).
+    u64 n1;                  // rows per block
+    int log_n1, log_n2, log_n;  // n1, n2 = blocks per coset, N = n1 * n2 = |trace domain|
+    int log_xq;              // X' = 2^log_xq
+    u64 coset_rows;          // storage rows from one coset of the quotient domain to the next
+    int tiled;               // a workgroup is (AIR_BLOCK / 64 blocks) x (64 rows) of one coset, one block per wavefront
     const u64* challenges;   // 63 XFE
     const u64* weights;      // 604 XFE
-    const u64* zinv;         // [4][q_len] zerofier inverses (k_zerofier_inverses)
-    u64* out;                // q_len XFE
+    const u64* zinv;         // [4][q_len] zerofier inverses in WORK order (k_zerofier_inverses)
+    u64* out;                // q_len XFE in WORK order (k_air_scatter puts them into domain order)
     int accumulate;          // 0: this part stores its share of the quotient, 1: it adds to what is there
 };
+
+// Work item t = workgroup * AIR_BLOCK + lane of the workgroup  ->  its row: `s_base` (uniform over the workgroup, a multiple
+// of 16) + `rel` storage rows, and the row's index in the quotient domain.
+// Tiled form (tables with n1 >= 64): wavefront w of a workgroup takes 64 consecutive rows of block g*WPB + w -- every
+// column it reads is four full 128-byte lines, and the successor rows of wavefront w are the current rows of wavefront
+// w + 1: WPB + 1 blocks of cells are fetched for WPB blocks of work (the successors of the last block come from the next
+// workgroup's lines, which consecutive workgroups g, g + 1 have in flight together).
+TVM_D void air_locate(const AirArgs& a, u64 block, int tid, u64& t, bool& active, u64& s_base, u32& rel, u64& index) {
+    constexpr int WPB_LOG = TVM_AIR_BLOCK_LOG - 6;
+    t = block * AIR_BLOCK + (u64)tid;
+    active = t < a.q_len;
+    u64 kq, j1, j2;
+    if (a.tiled) {  // (q_len is a multiple of AIR_BLOCK: every lane is active)
+        const int log_tiles = a.log_n - TVM_AIR_BLOCK_LOG;     // tiles per coset
+        const int log_groups = a.log_n2 - WPB_LOG;             // groups of WPB blocks per coset
+        kq = block >> log_tiles;
+        const u64 tile = block & ((1ull << log_tiles) - 1);
+        const u64 g = tile & ((1ull << log_groups) - 1), jb = tile >> log_groups;
+        j1 = (g << WPB_LOG) + (u64)(tid >> 6);
+        j2 = jb * 64 + (u64)(tid & 63);
+        s_base = kq * a.coset_rows + (g << WPB_LOG) * a.n1 + jb * 64;
+        rel = (u32)((u64)(tid >> 6) * a.n1) + (u32)(tid & 63);
+    } else {
+        const u64 tt = active ? t : a.q_len - 1;  // keep every lane on the common path
+        kq = tt >> a.log_n;
+        const u64 r = tt & ((1ull << a.log_n) - 1);
+        j1 = r >> a.log_n1;
+        j2 = r & (a.n1 - 1);
+        s_base = 0;
+        rel = (u32)(kq * a.coset_rows + r);
+    }
+    index = ((j1 + (j2 << a.log_n2)) << a.log_xq) + kq;
+}
 
 // The accumulator of  sum_k w_k * c_k  for one group of constraints.
 #ifdef TVM_FIELD_ASM
@@ -133,24 +182,24 @@ TVM_D xfe air_acc_value(const AirAcc& a) { return a.v; }
 #endif
 TVM_D xfe xfe_bfe_sub(u64 b, xfe x) { return xfe_bfe_minus(b, x); }
 
-// Addressing: a workgroup covers AIR_BLOCK consecutive quotient-domain rows, so every table cell it reads
-// is  (uniform block base + column offset)  +  (a 32-bit per-lane byte offset): the first term lives in
-// SGPRs (scalar adds, free), the second in ONE VGPR per row kind -- global_load's saddr + voffset form --
-// instead of a 64-bit VGPR pointer per 8 KiB window of columns (~50 VGPRs in the transition constraints).
-// The "next" row of the last rows of the domain is read from the table's wrap rows (kernels.h: tvm_table).
+// Addressing: every table cell a workgroup reads is  (uniform row-block base + column offset)  +  (a 32-bit per-lane byte
+// offset): the first term lives in SGPRs (scalar adds, free), the second in ONE VGPR per row kind -- global_load's saddr +
+// voffset form -- instead of a 64-bit VGPR pointer per 8 KiB window of columns (~50 VGPRs in the transition constraints).
+// The "next" row is n1 storage rows behind the current one (context.h: successor blocks), never a wrap-around.
 #define AIR_PROLOGUE()                                                                                          \
-    const u64 first_ = (u64)blockIdx.x * AIR_BLOCK;                                                             \
-    const u64 i_raw_ = first_ + threadIdx.x;                                                                    \
-    const bool active_ = i_raw_ < a.q_len;                                                                      \
-    const u64 i_ = active_ ? i_raw_ : a.q_len - 1; /* keep every lane on the barrier path */                    \
-    const u64 blk_row_ = first_ * a.stride; /* a multiple of TVM_RB */                                          \
-    const u32 loc_cur_ = (u32)((i_ - first_) * a.stride), loc_next_ = loc_cur_ + (u32)(a.unit * a.stride);      \
-    const char* mb_ = (const char*)(a.main_table + (blk_row_ >> TVM_RB_LOG) * a.main_w * TVM_RB);               \
-    const char* ab_ = (const char*)(a.aux_table + (blk_row_ >> TVM_RB_LOG) * a.aux_w * TVM_RB);                 \
+    bool active_;                                                                                               \
+    u64 t_, s_base_, dom_index_;                                                                                \
+    u32 loc_cur_;                                                                                               \
+    air_locate(a, (u64)blockIdx.x, (int)threadIdx.x, t_, active_, s_base_, loc_cur_, dom_index_);               \
+    (void)dom_index_;                                                                                           \
+    const u32 loc_next_ = loc_cur_ + (u32)a.n1;                                                                 \
+    const char* mb_ = (const char*)(a.main_table + (s_base_ >> TVM_RB_LOG) * a.main_w * TVM_RB);                \
+    const char* ab_ = (const char*)(a.aux_table + (s_base_ >> TVM_RB_LOG) * a.aux_w * TVM_RB);                  \
     const u32 mc_ = 8u * ((loc_cur_ >> TVM_RB_LOG) * (u32)a.main_w * TVM_RB + (loc_cur_ & (TVM_RB - 1)));       \
     const u32 mn_ = 8u * ((loc_next_ >> TVM_RB_LOG) * (u32)a.main_w * TVM_RB + (loc_next_ & (TVM_RB - 1)));     \
     const u32 ac_ = 8u * ((loc_cur_ >> TVM_RB_LOG) * (u32)a.aux_w * TVM_RB + (loc_cur_ & (TVM_RB - 1)));        \
     const u32 an_ = 8u * ((loc_next_ >> TVM_RB_LOG) * (u32)a.aux_w * TVM_RB + (loc_next_ & (TVM_RB - 1)));      \
+    const u64 w_ = active_ ? t_ : a.q_len - 1; /* work-order slot of this lane's row */                         \
     const AIR_UNIFORM u64* ch_ = (const AIR_UNIFORM u64*)a.challenges;                                          \
     const AIR_UNIFORM u64* wt_ = (const AIR_UNIFORM u64*)a.weights;                                             \
     xfe quot = xfe_zero()
@@ -163,7 +212,7 @@ TVM_D xfe xfe_bfe_sub(u64 b, xfe x) { return xfe_bfe_minus(b, x); }
 #define AN(c) xfe_make(AIR_CELL(ab_, an_, 3 * (c)), AIR_CELL(ab_, an_, 3 * (c) + 1), AIR_CELL(ab_, an_, 3 * (c) + 2))
 #define CH(k) xfe_make(ch_[3 * (k)], ch_[3 * (k) + 1], ch_[3 * (k) + 2])
 #define W(k) xfe_make(wt_[3 * (k)], wt_[3 * (k) + 1], wt_[3 * (k) + 2])
-#define ZINV(s) (a.zinv[(u64)(s) * a.q_len + i_])
+#define ZINV(s) (a.zinv[(u64)(s) * a.q_len + w_])
 // AIR_SYNC: a compiler-level memory barrier -- loads of table cells are neither merged nor moved across
 // it, which bounds the live range of every loaded value to one segment.
 // AIR_PIN_*: an empty asm that "modifies" a value, so its computation cannot sink below this point.
@@ -199,7 +248,7 @@ TVM_D xfe xfe_bfe_sub(u64 b, xfe x) { return xfe_bfe_minus(b, x); }
 
 #define AIR_EPILOGUE(accumulate)                                        \
     if (active_) {                                                      \
-        u64* o_ = a.out + 3 * i_;                                       \
+        u64* o_ = a.out + 3 * w_;                                       \
         if (accumulate) {                                               \
             o_[0] = bfe_add(o_[0], quot.c0);                            \
             o_[1] = bfe_add(o_[1], quot.c1);                            \

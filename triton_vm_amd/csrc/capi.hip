@@ -277,7 +277,8 @@ int32_t tvm_lde_table(tvm_ctx* c, int32_t fk, const uint64_t* d_trace, uint64_t 
     tvm_table* t = new (std::nothrow) tvm_table();
     if (!t) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "table handle");
     t->rows = eval_dom.length;
-    t->wrap_rows = eval_dom.length / n_rows;  // one trace-domain step in table rows
+    t->layout = lde_table_layout(n_rows, eval_dom.length);  // coset-major, one successor block per coset (context.h)
+    t->has_successor_blocks = true;
     t->n_cols = n_cols;
     t->fk = fk;
     t->W = (int)(n_cols * fk);
@@ -287,13 +288,13 @@ int32_t tvm_lde_table(tvm_ctx* c, int32_t fk, const uint64_t* d_trace, uint64_t 
         delete t;
         return set_error(c, TVM_ERR_OUT_OF_MEMORY, "LDE table allocation");
     }
-    if ((t->rows + t->wrap_rows) % TVM_RB) {  // zero the padding rows of the last (partial) row block
-        const u64 full = (t->rows + t->wrap_rows) / TVM_RB * TVM_RB * (u64)t->W;
+    if (t->layout.storage_rows() % TVM_RB) {  // zero the padding rows of the last (partial) row block
+        const u64 full = t->layout.storage_rows() / TVM_RB * TVM_RB * (u64)t->W;
         (void)hipMemsetAsync(t->data + full, 0, t->bytes() - full * sizeof(u64), c->stream);
     }
     int rc = lde_table(c, fk, d_trace, n_rows, n_cols, d_rnd, h, trace_dom.generator, eval_dom.offset, eval_dom.generator,
                        eval_dom.length, t->data, 0);
-    if (rc == TVM_OK) rc = copy_rows(c, t->data, t->W, 0, t->rows, t->wrap_rows);
+    if (rc == TVM_OK) rc = fill_successor_blocks(c, t->data, t->layout, t->W);
     if (rc != TVM_OK) {
         pool_release(c, t->data);
         delete t;
@@ -314,7 +315,7 @@ int32_t tvm_table_field_kind(const tvm_table* t) { return t ? t->fk : 0; }
 
 int32_t tvm_table_export_row_major(tvm_ctx* c, const tvm_table* t, uint64_t* d_out) {
     if (!c || !t || !d_out) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "export arguments");
-    return table_to_row_major(c, t->data, t->rows, t->W, d_out);
+    return table_to_row_major(c, t->data, t->layout, t->W, d_out);
 }
 
 int32_t tvm_table_reveal_rows(tvm_ctx* c, const tvm_table* t, uint64_t ldt_length, const uint64_t* h_idx, uint64_t n,
@@ -333,7 +334,7 @@ int32_t tvm_table_reveal_rows(tvm_ctx* c, const tvm_table* t, uint64_t ldt_lengt
     if (!d_idx || !d_out) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "reveal scratch");
     TVM_HIP_CHECK(c, hipMemcpyAsync(d_idx, idx.data(), n * sizeof(u64), hipMemcpyHostToDevice, c->stream));
     TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));  // idx is a local
-    TVM_TRY(gather_rows(c, t->data, t->rows, t->W, d_idx, n, d_out));
+    TVM_TRY(gather_rows(c, t->data, t->layout, t->W, d_idx, n, d_out));
     TVM_HIP_CHECK(c, hipMemcpyAsync(h_out, d_out, n * t->W * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     return TVM_OK;
@@ -343,7 +344,7 @@ int32_t tvm_table_reveal_rows(tvm_ctx* c, const tvm_table* t, uint64_t ldt_lengt
 int32_t tvm_hash_rows(tvm_ctx* c, const tvm_table* t, uint64_t ldt_length, uint64_t* d_digests) {
     if (!c || !t || !d_digests || !is_pow2(ldt_length) || ldt_length > t->rows)
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "hash_rows arguments");
-    return hash_rows(c, t->data, t->rows, t->W, t->rows / ldt_length, d_digests);
+    return hash_rows(c, t->data, t->layout, t->W, t->rows / ldt_length, d_digests);
 }
 int32_t tvm_merkle_tree(tvm_ctx* c, const uint64_t* d_leaves, uint64_t n, uint64_t* d_nodes) {
     if (!c || !d_leaves || !d_nodes || !is_pow2(n)) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "merkle arguments");
@@ -353,7 +354,7 @@ int32_t tvm_merkle_tree(tvm_ctx* c, const uint64_t* d_leaves, uint64_t n, uint64
 int32_t tvm_table_merkle_tree(tvm_ctx* c, const tvm_table* t, uint64_t ldt_length, uint64_t* d_nodes) {
     if (!c || !t || !d_nodes || !is_pow2(ldt_length) || ldt_length > t->rows)
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "table_merkle_tree arguments");
-    TVM_TRY(hash_rows(c, t->data, t->rows, t->W, t->rows / ldt_length, d_nodes + 5 * ldt_length));
+    TVM_TRY(hash_rows(c, t->data, t->layout, t->W, t->rows / ldt_length, d_nodes + 5 * ldt_length));
     return merkle_tree_from_leaves(c, d_nodes, ldt_length);
 }
 }  // extern "C"
@@ -464,6 +465,7 @@ int32_t tvm_quotient_segments(tvm_ctx* c, const uint64_t* d_cw, tvm_domain qd, t
     tvm_table* t = new (std::nothrow) tvm_table();
     if (!t) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "table handle");
     t->rows = L;
+    t->layout = tab_layout_natural(L);
     t->n_cols = 5;
     t->fk = 3;
     t->W = 15;
@@ -503,7 +505,7 @@ int32_t tvm_table_linear_combination(tvm_ctx* c, const tvm_table* t, uint64_t ld
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "table_linear_combination arguments");
     const u64* d_w = stage_small(c, 9, h_w, 3 * (size_t)t->n_cols);
     if (!d_w) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "weights staging");
-    return table_lincomb(c, t->data, t->rows, t->fk, t->n_cols, t->rows / ldt_length, d_w, d_out);
+    return table_lincomb(c, t->data, t->layout, t->fk, t->n_cols, t->rows / ldt_length, d_w, d_out);
 }
 
 int32_t tvm_deep_codeword(tvm_ctx* c, uint32_t n_comp, const uint64_t* const* d_cw, tvm_domain dom, const uint64_t* h_points,
@@ -570,8 +572,9 @@ int32_t tvm_all_quotients_combined(tvm_ctx* c, const tvm_table* mt, const tvm_ta
     if (!c || !mt || !at || !h_challenges || !h_weights || !d_out || !valid_domain(td) || !valid_domain(qd))
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "all_quotients_combined arguments");
     if (mt->fk != 1 || mt->n_cols != TVM_NUM_MAIN_COLUMNS || at->fk != 3 || at->n_cols != TVM_NUM_AUX_COLUMNS ||
-        mt->rows != at->rows || qd.length > mt->rows || mt->wrap_rows != at->wrap_rows)
-        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "all_quotients_combined: tables must be 379 BFE / 91 XFE columns wide");
+        mt->rows != at->rows || qd.length > mt->rows || !mt->has_successor_blocks || !at->has_successor_blocks ||
+        mt->layout.X != at->layout.X || mt->layout.n1 != at->layout.n1 || mt->layout.n2 != at->layout.n2 || mt->layout.pitch != at->layout.pitch)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "all_quotients_combined: tables must be 379 BFE / 91 XFE columns wide, made by tvm_lde_table over one domain");
     u64* staged = (u64*)scratch(c, 13, (size_t)3 * (TVM_NUM_CHALLENGES + TVM_NUM_QUOTIENT_WEIGHTS) * sizeof(u64));
     if (!staged) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "challenge staging");
     TVM_HIP_CHECK(c, hipMemcpyAsync(staged, h_challenges, 3 * TVM_NUM_CHALLENGES * sizeof(u64), hipMemcpyHostToDevice, c->stream));
@@ -595,20 +598,20 @@ int32_t tvm_all_quotients_combined(tvm_ctx* c, const tvm_table* mt, const tvm_ta
     const bool split = c->air_valid_trace && mt->interpolant_len && at->interpolant_len && half >= 2 * td.length && half % td.length == 0 &&
                        4 * (m - 1) + 2 <= half + td.length && mt->rows % half == 0;
     if (!split)
-        return all_quotients_combined(c, mt->data, mt->rows, mt->wrap_rows, (u64)mt->W, at->data, (u64)at->W, td.length, td.generator,
+        return all_quotients_combined(c, mt->data, mt->layout, (u64)mt->W, at->data, (u64)at->W, td.length, td.generator,
                                       qd.offset, qd.generator, qd.length, d_ch, d_w, d_out);
-    u64* low = (u64*)pool_alloc(c, (size_t)2 * 3 * half * sizeof(u64));
+    PoolBlock low_block(c, (size_t)2 * 3 * half * sizeof(u64));  // released on every exit path
+    u64* low = (u64*)low_block.p;
     if (!low) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "quotient scratch");
     u64* coeffs = low + 3 * half;
     const tvm_domain half_dom = {qd.offset, bfe_mul(qd.generator, qd.generator), half};
-    int rc = all_quotients_combined(c, mt->data, mt->rows, mt->wrap_rows, (u64)mt->W, at->data, (u64)at->W, td.length, td.generator,
+    int rc = all_quotients_combined(c, mt->data, mt->layout, (u64)mt->W, at->data, (u64)at->W, td.length, td.generator,
                                     half_dom.offset, half_dom.generator, half, d_ch, d_w, low, 1, 0);
     if (rc == TVM_OK) rc = tvm_interpolate(c, 3, low, half_dom, coeffs);
     if (rc == TVM_OK) rc = tvm_evaluate(c, 3, coeffs, half, qd, d_out);
     if (rc == TVM_OK)
-        rc = all_quotients_combined(c, mt->data, mt->rows, mt->wrap_rows, (u64)mt->W, at->data, (u64)at->W, td.length, td.generator,
+        rc = all_quotients_combined(c, mt->data, mt->layout, (u64)mt->W, at->data, (u64)at->W, td.length, td.generator,
                                     qd.offset, qd.generator, qd.length, d_ch, d_w, d_out, 2, 1);
-    pool_release(c, low);
     return rc;
 }
 

@@ -13,15 +13,80 @@
 #include "field.h"
 #include "triton_hip.h"  // status codes and the public C ABI (include/)
 
-// Device tables are "row-block-major" (DESIGN.md section 2): blocks of TVM_RB = 16 consecutive rows,
-// column-major inside a block, i.e. element (row, v) of a table with W base-field words per row is at
-// ((row / 16) * W + v) * 16 + row % 16.  Sixteen consecutive rows of one column form one 128-byte line,
-// so a wavefront whose lanes are consecutive rows reads any column as four full lines (row hashing,
+// Device tables are "row-block-major" (DESIGN.md section 2): blocks of TVM_RB = 16 consecutive STORAGE rows,
+// column-major inside a block, i.e. element (s, v) of a table with W base-field words per row is at
+// ((s / 16) * W + v) * 16 + s % 16.  Sixteen consecutive storage rows of one column form one 128-byte line,
+// so a wavefront whose lanes are consecutive storage rows reads any column as four full lines (row hashing,
 // AIR evaluation, linear combinations), and the last LDE pass writes full lines.
 #define TVM_RB 16
 #define TVM_RB_LOG 4
 TVM_HD u64 tvm_tab_idx(u64 row, u64 v, u64 W) { return ((row >> TVM_RB_LOG) * W + v) * TVM_RB + (row & (TVM_RB - 1)); }
 TVM_HD u64 tvm_tab_words(u64 rows, u64 W) { return ((rows + TVM_RB - 1) / TVM_RB) * TVM_RB * W; }
+
+// Which storage row holds which row of the domain.  A table made by tvm_lde_table over the evaluation domain
+// g*<w_L>, L = X*N, N = n1*n2 (the two axes of the transform, csrc/ntt.hip) is stored COSET-MAJOR and, inside a coset of
+// the trace domain, in the order the last LDE pass produces it:
+//     domain row  i = X*j + k,  j = j1 + n2*j2  (k < X the coset, j1 < n2, j2 < n1)   <->   storage row  k*pitch + j1*n1 + j2.
+//   * one transform of the last pass (fixed k, j1; all j2) owns n1 CONSECUTIVE storage rows: it writes full lines whatever the
+//     number of transforms a workgroup holds;
+//   * the rows of a coset -- of a stride view (every s-th domain row = the cosets k = 0 mod s: the quotient domain inside a
+//     longer LDT domain, a rank's or a coset-wise pass's share, the half domain of valid-trace mode) -- are contiguous;
+//   * the successor row j + 1 of the AIR (domain row i + X) is storage row + n1; tables the AIR reads carry one more block of
+//     n1 rows per coset behind the n2 blocks (`pitch` = (n2 + 1)*n1): block n2 = block 0 shifted by one row, the successors of
+//     block n2 - 1.
+// Tables in natural row order (the quotient-segment table, the verifier's row packs) are the case X = 1, n2 = 1, n1 = rows.
+struct TabLayout {
+    u64 X = 1, n1 = 0, n2 = 1, pitch = 0;   // X, n2 and -- unless n2 == 1 -- n1 are powers of two
+    int log_x = 0, log_n1 = 0, log_n2 = 0;
+    TVM_HD u64 rows() const { return X * n1 * n2; }
+    TVM_HD u64 storage_rows() const { return X * pitch; }
+    // position r = j1*n1 + j2 inside a coset -> j = j1 + n2*j2
+    TVM_HD u64 coset_index(u64 r) const { return n2 == 1 ? r : (r >> log_n1) + ((r & (n1 - 1)) << log_n2); }
+    TVM_HD u64 storage_row(u64 i) const {
+        const u64 k = i & (X - 1), j = i >> log_x;
+        return n2 == 1 ? k * pitch + j : k * pitch + (j & (n2 - 1)) * n1 + (j >> log_n2);
+    }
+};
+inline TabLayout tab_layout_natural(u64 rows) {
+    TabLayout l;
+    l.n1 = l.pitch = rows;
+    return l;
+}
+// The rows of a stride view in an order that walks storage contiguously: view row index t < rows/stride, in "coset-major"
+// order when the stride selects whole cosets, in domain order otherwise.  -> storage row, and the view's domain index of it.
+struct TabView {
+    TabLayout l;
+    u64 stride = 1, n_out = 0;
+    bool by_coset = false;   // stride divides X: the view is the cosets k = stride*k', k' < X/stride
+    int log_n = 0, log_xv = 0;
+    TVM_HD void locate(u64 t, u64& s, u64& out_index) const {
+        if (by_coset) {
+            const u64 kv = t >> log_n, r = t & ((1ull << log_n) - 1);
+            s = kv * stride * l.pitch + r;
+            out_index = (l.coset_index(r) << log_xv) + kv;
+        } else {
+            s = l.storage_row(t * stride);
+            out_index = t;
+        }
+    }
+};
+inline int tab_ilog2(u64 n) {
+    int k = 0;
+    while ((1ull << k) < n) k++;
+    return k;
+}
+inline TabView tab_view(const TabLayout& l, u64 stride) {
+    TabView v;
+    v.l = l;
+    v.stride = stride;
+    v.n_out = l.rows() / stride;
+    v.by_coset = l.X > 1 && stride <= l.X && l.X % stride == 0 && l.n2 > 1;
+    if (v.by_coset) {
+        v.log_n = l.log_n1 + l.log_n2;
+        v.log_xv = tab_ilog2(l.X / stride);
+    }
+    return v;
+}
 
 struct tvm_ctx {
     int device = 0;

@@ -20,31 +20,34 @@ namespace tvm {
 #define TVM_HASH_BLOCK 256
 #endif
 
-// digests[r] = Tip5::hash_varlen(row r*stride of the table), W words per row, with the permutation's MDS layer on
+// digests[r] = Tip5::hash_varlen(domain row r*stride of the table), W words per row, with the permutation's MDS layer on
 // the matrix cores (tip5_permute_mfma): four lanes per row, sixteen rows per wavefront.  Lane (n, g) absorbs the
 // words g, g + 4 (and g + 8 for g < 2) of each block of ten: with consecutive rows in a wavefront (stride 1) every
 // load instruction touches four full 128-byte lines of the row-block-major table.
-__global__ void __launch_bounds__(TVM_HASH_BLOCK) k_hash_rows_mfma(const u64* __restrict__ table, u64 L, int W, u64 stride,
-                                                                    u64 n_out, u64* __restrict__ digests) {
+__global__ void __launch_bounds__(TVM_HASH_BLOCK) k_hash_rows_mfma(const u64* __restrict__ table, TabView view, int W,
+                                                                    u64* __restrict__ digests) {
     __shared__ unsigned char lut[256];
     __shared__ int ctab[TIP5_ROUNDS * TIP5_MFMA_POSITIONS * 16];
     const int tid = threadIdx.x;
     for (int i = tid; i < TIP5_ROUNDS * TIP5_MFMA_POSITIONS * 16; i += blockDim.x) ctab[i] = d_tip5_mfma_table.v[i];
     tip5_stage_lut(lut, tid, blockDim.x);
     const int lane = tid & 63, n = lane & 15, g = lane >> 4;
-    const u64 r = ((u64)blockIdx.x * (TVM_HASH_BLOCK / 64) + (tid >> 6)) * 16 + n;
-    const bool live = r < n_out;  // every lane of a wavefront takes part in the matrix instructions
-    const u64 row = (live ? r : n_out - 1) * stride;
+    // the view's rows in the order that walks storage contiguously (context.h: TabView); digest r goes to the row's index
+    // in the domain
+    const u64 t = ((u64)blockIdx.x * (TVM_HASH_BLOCK / 64) + (tid >> 6)) * 16 + n;
+    const bool live = t < view.n_out;  // every lane of a wavefront takes part in the matrix instructions
+    u64 row, r;
+    view.locate(live ? t : view.n_out - 1, row, r);
     const u64* base = table + (row >> TVM_RB_LOG) * (u64)W * TVM_RB + (row & (TVM_RB - 1));
     const tvm_v4i a = tip5_mfma_matrix_operand(lane);
     u64 st[4] = {0, 0, 0, 0};
     const int n_perms = W / TIP5_RATE + 1;
     for (int perm = 0; perm < n_perms; perm++) {
 #pragma unroll
-        for (int t = 0; t < 3; t++) {
-            const int q = g + 4 * t;  // word of the state, overwritten if it is in the rate part
+        for (int t3 = 0; t3 < 3; t3++) {
+            const int q = g + 4 * t3;  // word of the state, overwritten if it is in the rate part
             const int wi = perm * TIP5_RATE + q;
-            if (q < TIP5_RATE) st[t] = wi < W ? TVM_LOAD_STREAM(&base[(u64)wi * TVM_RB]) : (wi == W ? TVM_ONE : 0);  // padding: 1 then 0s
+            if (q < TIP5_RATE) st[t3] = wi < W ? TVM_LOAD_STREAM(&base[(u64)wi * TVM_RB]) : (wi == W ? TVM_ONE : 0);  // padding: 1 then 0s
         }
         tip5_permute_mfma(st, a, g, lut, ctab);
     }
@@ -129,26 +132,35 @@ __global__ void k_xfe_leaves(const u64* __restrict__ cw, u64 plane, u64 n, u64* 
     leaves[5 * i + 4] = 0;
 }
 
-// rows[j][0..W) = table row idx[j], row-major out (reveal_rows, master_table.rs:548-555)
-__global__ void k_gather_rows(const u64* __restrict__ table, u64 L, int W, const u64* __restrict__ idx, u64 n,
+// rows[j][0..W) = table row idx[j] (a row of the domain), row-major out (reveal_rows, master_table.rs:548-555)
+__global__ void k_gather_rows(const u64* __restrict__ table, TabLayout l, int W, const u64* __restrict__ idx, u64 n,
                               u64* __restrict__ out) {
     const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n * (u64)W) return;
     const u64 j = e / W;
     const int v = (int)(e % W);
-    out[e] = table[tvm_tab_idx(idx[j], (u64)v, (u64)W)];
+    out[e] = table[tvm_tab_idx(l.storage_row(idx[j]), (u64)v, (u64)W)];
 }
 
-// whole table to the reference's row-major [L][W] layout (tests, and hosts that want the cache)
-__global__ void k_table_to_row_major(const u64* __restrict__ table, u64 L, int W, u64* __restrict__ out) {
+// whole table to the reference's row-major [L][W] layout in domain order (tests, and hosts that want the cache)
+__global__ void k_table_to_row_major(const u64* __restrict__ table, TabLayout l, int W, u64* __restrict__ out) {
     const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= L * (u64)W) return;
+    if (e >= l.rows() * (u64)W) return;
     const u64 row = e / W;
     const int v = (int)(e % W);
-    out[e] = table[tvm_tab_idx(row, (u64)v, (u64)W)];
+    out[e] = table[tvm_tab_idx(l.storage_row(row), (u64)v, (u64)W)];
 }
 
-// planar columns [W][L] -> row-block-major table (used for the quotient-segment table)
+// the successor block of every coset (context.h): row j2 of block n2 = row (j2 + 1) mod n1 of block 0
+__global__ void k_successor_blocks(u64* __restrict__ table, TabLayout l, int W) {
+    const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= l.X * l.n1 * (u64)W) return;
+    const u64 j2 = e % l.n1, v = (e / l.n1) % (u64)W, k = e / (l.n1 * (u64)W);
+    const u64 src = k * l.pitch + (j2 + 1 == l.n1 ? 0 : j2 + 1), dst = k * l.pitch + l.n2 * l.n1 + j2;
+    table[tvm_tab_idx(dst, v, (u64)W)] = table[tvm_tab_idx(src, v, (u64)W)];
+}
+
+// planar columns [W][L] -> row-block-major table in natural row order (used for the quotient-segment table)
 __global__ void k_columns_to_table(const u64* __restrict__ cols, u64 col_stride, u64 L, int W, u64* __restrict__ table) {
     const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 total = tvm_tab_words(L, (u64)W);
@@ -160,12 +172,12 @@ __global__ void k_columns_to_table(const u64* __restrict__ cols, u64 col_stride,
 }
 
 // ------------------------------------------------------------------------------------------------
-int hash_rows(tvm_ctx* c, const u64* table, u64 L, int W, u64 stride, u64* digests) {
-    if (!stride || L % stride) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "hash_rows: stride must divide L");
-    const u64 n = L / stride;
+int hash_rows(tvm_ctx* c, const u64* table, const TabLayout& layout, int W, u64 stride, u64* digests) {
+    if (!stride || layout.rows() % stride) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "hash_rows: stride must divide the number of rows");
+    const TabView view = tab_view(layout, stride);
     const u64 rows_per_block = TVM_HASH_BLOCK / 4;
-    TVM_LAUNCH(k_hash_rows_mfma, dim3((unsigned)((n + rows_per_block - 1) / rows_per_block)), dim3(TVM_HASH_BLOCK), 0, c->stream,
-               table, L, W, stride, n, digests);
+    TVM_LAUNCH(k_hash_rows_mfma, dim3((unsigned)((view.n_out + rows_per_block - 1) / rows_per_block)), dim3(TVM_HASH_BLOCK), 0, c->stream,
+               table, view, W, digests);
     TVM_HIP_CHECK(c, hipGetLastError());
     return TVM_OK;
 }
@@ -190,32 +202,25 @@ int xfe_leaves(tvm_ctx* c, const u64* cw, u64 plane, u64 n, u64* leaves) {
     return TVM_OK;
 }
 
-int gather_rows(tvm_ctx* c, const u64* table, u64 L, int W, const u64* d_idx, u64 n, u64* d_out) {
+int gather_rows(tvm_ctx* c, const u64* table, const TabLayout& layout, int W, const u64* d_idx, u64 n, u64* d_out) {
     const u64 total = n * (u64)W;
     if (!total) return TVM_OK;
-    TVM_LAUNCH(k_gather_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, table, L, W, d_idx, n, d_out);
+    TVM_LAUNCH(k_gather_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, table, layout, W, d_idx, n, d_out);
     TVM_HIP_CHECK(c, hipGetLastError());
     return TVM_OK;
 }
 
-// rows [dst_row, dst_row + n_rows) := rows [src_row, src_row + n_rows) of a row-block-major table
-__global__ void k_copy_rows(u64* __restrict__ table, int W, u64 src_row, u64 dst_row, u64 n_rows) {
-    const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_rows * (u64)W) return;
-    const u64 v = e / n_rows, r = e % n_rows;
-    table[tvm_tab_idx(dst_row + r, v, (u64)W)] = table[tvm_tab_idx(src_row + r, v, (u64)W)];
-}
-int copy_rows(tvm_ctx* c, u64* table, int W, u64 src_row, u64 dst_row, u64 n_rows) {
-    const u64 total = n_rows * (u64)W;
-    if (!total) return TVM_OK;
-    TVM_LAUNCH(k_copy_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, table, W, src_row, dst_row, n_rows);
+int fill_successor_blocks(tvm_ctx* c, u64* table, const TabLayout& layout, int W) {
+    const u64 total = layout.X * layout.n1 * (u64)W;
+    if (layout.pitch < (layout.n2 + 1) * layout.n1) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "the table has no successor blocks");
+    TVM_LAUNCH(k_successor_blocks, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, table, layout, W);
     TVM_HIP_CHECK(c, hipGetLastError());
     return TVM_OK;
 }
 
-int table_to_row_major(tvm_ctx* c, const u64* table, u64 L, int W, u64* d_out) {
-    const u64 total = L * (u64)W;
-    TVM_LAUNCH(k_table_to_row_major, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, table, L, W, d_out);
+int table_to_row_major(tvm_ctx* c, const u64* table, const TabLayout& layout, int W, u64* d_out) {
+    const u64 total = layout.rows() * (u64)W;
+    TVM_LAUNCH(k_table_to_row_major, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, table, layout, W, d_out);
     TVM_HIP_CHECK(c, hipGetLastError());
     return TVM_OK;
 }

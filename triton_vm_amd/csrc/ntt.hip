@@ -315,18 +315,20 @@ __global__ void __launch_bounds__(1024) k_lde_pass2(LdePass2Args a) {
     }
 }
 
-// Pass 3 writes the row-block-major table (context.h).  A workgroup owns one virtual column and
-// 2^rows_log (<= 16) consecutive rows rho = X*j1 + k of every row period X*N2: it transforms the
-// corresponding (k, j1) rows of Z over m2 and stores, for each j2, one run of consecutive rows.
+// Pass 3 writes the table (context.h: coset-major, inside a coset in the order of this pass).  A workgroup owns one virtual
+// column and 2^rows_log (<= 16) of the (k, j1) rows of Z, enumerated rho = X*j1 + k: it transforms them over m2 and stores, for
+// every row, its n1 results j2 = 0 .. n1-1 into the n1 CONSECUTIVE storage rows k*pitch + j1*n1 + j2 -- consecutive lanes
+// write consecutive rows, i.e. full 128-byte lines of the row-block-major table whatever the number of rows in the tile.
 struct LdePass3Args {
     const u64* z;        // [cols][X][N2 (j1)][N1 positions p]
-    u64* table;          // row-block-major [L][W]
+    u64* table;          // row-block-major over storage rows, W words per row
     int log_n1, log_n2;
     int n_cosets;
     int col0;            // first virtual column of the chunk
-    int tiles;           // k_lde_pass3_v2: consecutive row tiles per workgroup
+    int tiles;           // k_lde_pass3_v2 / _v3: consecutive row tiles per workgroup
     int W;               // words per table row
     u64 L;
+    u64 pitch;           // storage rows per coset
     const u64* tw_b2;    // w_N1^e
     int rows_log;        // rows per workgroup tile
 };
@@ -358,10 +360,11 @@ __global__ void __launch_bounds__(1024) k_lde_pass3(LdePass3Args a) {
     lds_ntt<true>(s, a.log_n1, a.rows_log, 1, RS, a.tw_b2, tid, nt);
     const u64 v = (u64)(a.col0 + vl);
     for (int idx = tid; idx < tile; idx += nt) {
-        const int b = idx & (RB - 1), j2 = idx >> a.rows_log;
+        const int j2 = idx & (n1 - 1), b = idx >> a.log_n1;
         const u64 rho = rho0 + b;
         if (rho >= period) continue;
-        a.table[tvm_tab_idx(period * (u64)j2 + rho, v, (u64)a.W)] = s[b * RS + j2];
+        const u64 j1 = rho / X, k = rho % X;
+        a.table[tvm_tab_idx(k * a.pitch + j1 * (u64)n1 + (u64)j2, v, (u64)a.W)] = s[b * RS + j2];
     }
 }
 
@@ -461,17 +464,15 @@ __global__ void __launch_bounds__(1024) k_lde_pass3_v2(LdePass3Args a) {
     const int RS = n1 + TVM_ROW_PAD;
     const u64 X = (u64)a.n_cosets;
     const int log_x = 31 - __builtin_clz((unsigned)a.n_cosets);
-    const u64 period = X * n2;                  // rows per j2, a multiple of 16
     // adjacent workgroups = adjacent table columns of the same 16 rows: together they write runs of
     // chunk_cols * 128 contiguous bytes of the row-block-major table instead of lines 48 KiB apart
     const int vl = blockIdx.x;
     const u64* zc = a.z + (u64)vl * X * (n2 << a.log_n1) + tid;
     u64* tw_fwd = s + 16 * RS;  // twiddles in LDS (see k_lde_pass2_v2)
     if (tid < (n1 >> 1)) tw_fwd[tid] = a.tw_b2[tid];
-    const int b = tid & 15, j2_0 = tid >> 4;
+    // store phase: work-item tid writes position j2 = tid of all 16 rows (consecutive lanes = consecutive storage rows)
     const u64 W = (u64)a.W;
-    const u64 j2_stride = ((period >> TVM_RB_LOG) * W) << TVM_RB_LOG;
-    const int j2_step = n1 >> 4;
+    u64* const out_t = a.table + ((((u64)(tid >> TVM_RB_LOG)) * W + (u64)(a.col0 + vl)) << TVM_RB_LOG) + (tid & (TVM_RB - 1));
     u64 nxt[16];
     u64 rho0 = (u64)blockIdx.y * a.tiles * 16;  // first local row of the tile
 #pragma unroll
@@ -494,12 +495,12 @@ __global__ void __launch_bounds__(1024) k_lde_pass3_v2(LdePass3Args a) {
         if (a.log_n1 == 10) lds_ntt_fixed<true, 4, 10>(s, tw_fwd, tid, nt);
         else if (a.log_n1 == 6) lds_ntt_fixed<true, 4, 6>(s, tw_fwd, tid, nt);
         else lds_ntt<true>(s, a.log_n1, 4, 1, RS, tw_fwd, tid, nt);
-        // row period*j2 + rho0 + b of column v: ((row / 16) * W + v) * 16 + b, row / 16 = (period / 16) * j2 + rho0 / 16
-        u64* out = a.table + (((rho0 >> TVM_RB_LOG) * W + (u64)(a.col0 + vl)) << TVM_RB_LOG) + b;
+        // row e of the tile is (k, j1): its storage rows start at k*pitch + j1*n1 (a multiple of 16)
 #pragma unroll 4
-        for (int i = 0; i < 16; i++) {
-            const int j2 = j2_0 + i * j2_step;
-            TVM_STORE_STREAM(&out[(u64)j2 * j2_stride], s[b * RS + j2]);
+        for (int e = 0; e < 16; e++) {
+            const u64 rho = rho0 + e, j1 = rho >> log_x, k = rho & (X - 1);
+            const u64 blk = (k * a.pitch + (j1 << a.log_n1)) >> TVM_RB_LOG;
+            TVM_STORE_STREAM(&out_t[(blk * W) << TVM_RB_LOG], s[e * RS + tid]);
         }
     }
 }
@@ -591,23 +592,14 @@ __global__ void __launch_bounds__(1 << TLOG) k_lde_pass3_v3(LdePass3Args a) {
     const u64 n2 = 1ull << a.log_n2;
     const u64 X = (u64)a.n_cosets;
     const int log_x = 31 - __builtin_clz((unsigned)a.n_cosets);
-    const u64 period = X * n2;  // rows per j2, a multiple of 16
     const int vl = blockIdx.x;
     const u64* zc = a.z + (u64)vl * X * (n2 << LOGN) + tid;
     u64* tw_fwd = s + ROWS * RS;
     for (int i = tid; i < (n1 >> 1); i += NT) tw_fwd[i] = a.tw_b2[i];
-    // store phase: row b = tid % ROWS, columns j2 = j2_0 + i * NT / ROWS.  The 64 / ROWS column slots of a wavefront are
-    // ROWS apart (slot q of a block of 64 -> column (q % LPW) * ROWS + q / LPW): with the odd row pitch the LDS words
-    // b * RS + j2 of its 64 lanes then fall into 64 different banks -- consecutive columns collide ROWS-fold (8-row tiles:
-    // 44 % of the LDS cycles of this kernel were bank conflicts; worth 1.7 % of the LDE at 2^22 rows, nothing at 2^20,
-    // where the second resident workgroup hides them).  Every (row run, column) is its own line in the table
-    // anyway, so the order within a wavefront does not matter to the global stores.
-    constexpr int LPW = 64 >> RLOG;
-    const int b = tid & (ROWS - 1), q_ = tid >> RLOG;
-    const int j2_0 = (NT >> RLOG) >= 64 ? ((q_ & ~63) | ((q_ & (LPW - 1)) << RLOG) | ((q_ & 63) >> (6 - RLOG))) : q_;
-    constexpr int j2_step = NT >> RLOG;
+    // store phase: work-item tid writes positions j2 = tid + hh * NT of every row of the tile (consecutive lanes =
+    // consecutive storage rows and consecutive LDS words: full lines, no bank conflicts)
     const u64 W = (u64)a.W;
-    const u64 j2_stride = ((period >> TVM_RB_LOG) * W) << TVM_RB_LOG;
+    u64* const out_t = a.table + ((((u64)(tid >> TVM_RB_LOG)) * W + (u64)(a.col0 + vl)) << TVM_RB_LOG) + (tid & (TVM_RB - 1));
     u64 nxt[16];
     u64 rho0 = (u64)blockIdx.y * a.tiles * ROWS;  // first local row of the tile
 #pragma unroll
@@ -628,12 +620,12 @@ __global__ void __launch_bounds__(1 << TLOG) k_lde_pass3_v3(LdePass3Args a) {
             }
         }
         lds_ntt_fixed<true, 4, LOGN, 0, RLOG>(s, tw_fwd, tid, NT);
-        // row period*j2 + rho0 + b of column v; rho0 is a multiple of ROWS, so the ROWS rows stay inside one 16-row block
-        u64* out = a.table + (((rho0 >> TVM_RB_LOG) * W + (u64)(a.col0 + vl)) << TVM_RB_LOG) + (rho0 & (TVM_RB - 1)) + b;
 #pragma unroll 4
-        for (int i = 0; i < 16; i++) {
-            const int j2 = j2_0 + i * j2_step;
-            TVM_STORE_STREAM(&out[(u64)j2 * j2_stride], s[b * RS + j2]);
+        for (int e = 0; e < 16; e++) {
+            const int r = e & (ROWS - 1), hh = e >> RLOG;
+            const u64 rho = rho0 + r, j1 = rho >> log_x, k = rho & (X - 1);
+            const u64 blk = ((k * a.pitch + (j1 << LOGN)) >> TVM_RB_LOG) + (u64)(hh * (NT >> TVM_RB_LOG));
+            TVM_STORE_STREAM(&out_t[(blk * W) << TVM_RB_LOG], s[r * RS + tid + hh * NT]);
         }
     }
 }
@@ -813,6 +805,19 @@ static Split split_for(u64 n) {
     s.shift = (s.log_n + 1) / 2;
     return s;
 }
+// the layout lde_table writes (context.h): X cosets of n2 blocks of n1 rows, plus one successor block per coset
+TabLayout lde_table_layout(u64 n_rows, u64 L) {
+    const Split sp = split_for(n_rows);
+    TabLayout l;
+    l.X = L / n_rows;
+    l.log_x = ilog2(l.X);
+    l.n1 = 1ull << sp.log_n1;
+    l.n2 = 1ull << sp.log_n2;
+    l.log_n1 = sp.log_n1;
+    l.log_n2 = sp.log_n2;
+    l.pitch = (l.n2 + 1) * l.n1;
+    return l;
+}
 static int make_inter(tvm_ctx* c, u64 w, const Split& sp, Pow2* out) {
     out->shift = sp.shift;
     out->lo = pow_table(c, w, 1ull << sp.shift);
@@ -881,7 +886,8 @@ int ntt_columns(tvm_ctx* c, const u64* in, u64 in_len, int in_fk, u64 in_col_str
 }
 
 // master_table.rs:258-322.  trace: column-major [n_cols][n_rows][fk]; rnd: [n_cols][h][fk];
-// table: row-block-major [L][n_cols*fk] (context.h).
+// table: row-block-major over the storage rows of lde_table_layout(n_rows, L), n_cols*fk words per row (context.h); the
+// successor blocks are the caller's (fill_successor_blocks).
 int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, const u64* rnd, u64 h, u64 trace_gen,
               u64 eval_offset, u64 eval_gen, u64 L, u64* table, int chunk_cols) {
     if (!is_pow2(n_rows) || !is_pow2(L) || n_rows < 2 || L < n_rows || (fk != 1 && fk != 3))
@@ -951,6 +957,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     p3.n_cosets = (int)X;
     p3.L = L;
     p3.W = W;
+    p3.pitch = lde_table_layout(N, L).pitch;
     p3.tw_b2 = pow_table(c, bfe_pow(w, n2), n1 > 1 ? n1 / 2 : 1);
     if (!p1.tw1 || !p2.tw_a2 || !p2.tw_b1 || !p2.g_lo || !p2.g_hi || !p2.g_lo_step || !p2.g_hi_step || !p3.tw_b2)
         return set_error(c, TVM_ERR_OUT_OF_MEMORY, "lde tables");

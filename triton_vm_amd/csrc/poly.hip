@@ -188,13 +188,14 @@ __global__ void k_randomized_segments(const u64* __restrict__ q_coeffs, u64 q_le
     }
 }
 
-// out[i] = sum_v w_v * table_cell(row i*stride, element v): linear combination of the columns of a
+// out[i] = sum_v w_v * table_cell(domain row i*stride, element v): linear combination of the columns of a
 // device table (used for the P and R combinations of the randomized quotient segments, stark.rs:520-540)
-__global__ void k_table_lincomb(const u64* __restrict__ table, u64 L, int fk, u64 n_cols, u64 stride, u64 n_out,
+__global__ void k_table_lincomb(const u64* __restrict__ table, TabView view, int fk, u64 n_cols,
                                 const u64* __restrict__ w, u64* __restrict__ out) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_out) return;
-    const u64 row = i * stride;
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= view.n_out) return;
+    u64 row, i;
+    view.locate(t, row, i);
     xfe acc = xfe_zero();
     for (u64 c = 0; c < n_cols; c++) {
         const xfe wc = ld_xfe(w + 3 * c);
@@ -345,9 +346,9 @@ int randomized_segments(tvm_ctx* c, const u64* d_q_coeffs, u64 q_len, const u64*
     TVM_HIP_CHECK(c, hipGetLastError());
     return TVM_OK;
 }
-int table_lincomb(tvm_ctx* c, const u64* table, u64 L, int fk, u64 n_cols, u64 stride, const u64* d_w, u64* d_out) {
-    const u64 n_out = L / stride;
-    TVM_LAUNCH(k_table_lincomb, TVM_GRID(n_out, 256), dim3(256), 0, c->stream, table, L, fk, n_cols, stride, n_out, d_w, d_out);
+int table_lincomb(tvm_ctx* c, const u64* table, const TabLayout& layout, int fk, u64 n_cols, u64 stride, const u64* d_w, u64* d_out) {
+    const TabView view = tab_view(layout, stride);
+    TVM_LAUNCH(k_table_lincomb, TVM_GRID(view.n_out, 256), dim3(256), 0, c->stream, table, view, fk, n_cols, d_w, d_out);
     TVM_HIP_CHECK(c, hipGetLastError());
     return TVM_OK;
 }

@@ -81,14 +81,13 @@ __global__ void k_rows_to_table(const u64* __restrict__ rows, u64 n, int W, u64*
 
 int hash_varlen_rows(tvm_ctx* c, const u64* d_rows, u64 n, int W, u64* d_digests) {
     const u64 padded = (n + TVM_RB - 1) / TVM_RB * TVM_RB;
-    u64* table = (u64*)pool_alloc(c, (size_t)tvm_tab_words(padded, (u64)W) * sizeof(u64));
+    PoolBlock block(c, (size_t)tvm_tab_words(padded, (u64)W) * sizeof(u64));  // released on every exit path
+    u64* table = (u64*)block.p;
     if (!table) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "hash_varlen_rows scratch");
     TVM_HIP_CHECK(c, hipMemsetAsync(table, 0, (size_t)tvm_tab_words(padded, (u64)W) * sizeof(u64), c->stream));
     const u64 total = n * (u64)W;
     TVM_LAUNCH(k_rows_to_table, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_rows, n, W, table);
-    const int rc = hash_rows(c, table, n, W, 1, d_digests);
-    pool_release(c, table);
-    return rc;
+    return hash_rows(c, table, tab_layout_natural(n), W, 1, d_digests);
 }
 
 int verifier_deep_values(tvm_ctx* c, const u64* d_main_rows, int n_main, const u64* d_aux_rows, int n_aux, const u64* d_quot_rows,

@@ -76,8 +76,8 @@ def cpu_baseline(log2_rows, log2_expansion=2):
     """The oracle ("port" of the reference's algorithms: oracle/tvm_oracle.c, OpenMP) on a bounded sample of the same
     workload, stage by stage, each stage scaled to the full prove():
       LDE            C main-table columns at the full height (2^log2_rows -> x expansion*2 rows)      x 652 / C
-      row hashing    Tip5 hash_varlen over the rows of that C-column table                              x permutations(full) / permutations(C)
-      Merkle         one tree over all its leaf digests                                                 x (3 table trees + the FRI round trees ~ 1) = 4
+      row hashing    Tip5 hash_varlen over the first 2^20 rows of that C-column table                   x permutations(full) / permutations(C) x L / 2^20
+      Merkle         one tree over those 2^20 leaf digests                                              x (3 table trees + the FRI round trees ~ 1) = 4, x L / 2^20
       AIR            all 604 constraints + zerofiers on 2^15 full-width quotient-domain rows            x |quotient domain| / 2^15
       DEEP, FRI      4 DEEP components and one fold on 2^18-point codewords                             x |LDT domain| / 2^18 (folds: x 2, the geometric series)
     -> a prove()-shaped estimate in trace-cells/s.  It is a textbook restatement on all host cores, NOT the Rust prover."""
@@ -106,8 +106,9 @@ def cpu_baseline(log2_rows, log2_expansion=2):
     ev = orc.domain_of_length(L, offset=g)
     table = timed("lde", MASTER_WORDS / cols, lambda: orc.lde_table(trace, rnd, ev, 1))
     perms = lambda w: w // 10 + 1
-    digests = timed("hash_rows", (perms(379) + perms(273) + perms(15)) / perms(cols), lambda: orc.hash_rows(table))
-    timed("merkle", 4.0, lambda: orc.merkle_tree(digests))
+    hs = min(L, 1 << 20)                          # rows hashed / leaves of the sampled tree
+    digests = timed("hash_rows", (perms(379) + perms(273) + perms(15)) / perms(cols) * L / hs, lambda: orc.hash_rows(table[:hs]))
+    timed("merkle", 4.0 * L / hs, lambda: orc.merkle_tree(digests))
     del table, digests, trace
     q_s, n_s = 1 << 15, 1 << 12
     main_rows = orc.random_elements(rng, (q_s, 379))
@@ -124,7 +125,7 @@ def cpu_baseline(log2_rows, log2_expansion=2):
             "estimated_prove_seconds": round(est, 1), "sample_seconds": {k: round(v, 2) for k, v in t.items()},
             "scaled_seconds": {k: round(v, 1) for k, v in scaled.items()},
             "sample": f"oracle (C, OpenMP, {cores} host threads; the LDE parallelises over its {cols} sampled columns only): LDE of {cols} "
-                      f"main columns at 2^{log2_rows} rows onto the {X}x domain, Tip5 hashing of that table's rows, one Merkle tree, the "
+                      f"main columns at 2^{log2_rows} rows onto the {X}x domain, Tip5 hashing of 2^20 of that table's rows, one Merkle tree over them, the "
                       "AIR on 2^15 full-width quotient rows, DEEP (4 components) and one FRI fold on 2^18-point codewords; every stage "
                       f"scaled to the full prove() ({sum(t.values()):.1f} s measured -> {est:.0f} s estimated).  A textbook restatement, "
                       "NOT the Rust prover (no cargo in this image): do not read value/cpu as a speed-up over the reference"}

@@ -84,8 +84,11 @@ int32_t tvm_timer_stop(tvm_ctx* ctx, float* h_elapsed_ms); /* synchronises the s
 int32_t tvm_synthetic_fill(tvm_ctx* ctx, uint64_t* d_data, uint64_t n_words, uint64_t seed);
 
 /* Elementwise d_out[i] = d_a[i] op d_b[i] on Montgomery words through the device's field arithmetic
- * (op 0: +, 1: -, 2: *, 3: a^7): the known-answer hook for the hand-scheduled carry chains in csrc/field.h
- * (BFieldElement's Add/Sub/Mul, twenty-first; KAT triton-constraint-builder/src/codegen.rs:926-944). */
+ * (op 0: +, 1: -, 2: *, 3: a^7, 4: a * 2^b for a plain integer b < 192): the known-answer hook for the hand-scheduled carry
+ * chains in csrc/field.h (BFieldElement's Add/Sub/Mul, twenty-first; KAT triton-constraint-builder/src/codegen.rs:926-944)
+ * and for the shift forms of csrc/ntt_shift.h.  op 32 + 4K + 2*dit + inverse (K = 1..4): the in-register transforms of
+ * 2^K points with power-of-two twiddles on consecutive groups of 2^K words of d_a (d_b unused): dit = bit-reversed in /
+ * natural out, else natural in / bit-reversed out; inverse = with the inverse root (no scaling by 2^-K). */
 int32_t tvm_field_op(tvm_ctx* ctx, int32_t op, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, uint64_t n);
 
 /* ---- L2 / L3: ArithmeticDomain::{evaluate, interpolate} (arithmetic_domain.rs:141-189) -------

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "ntt_shift.h"
 
 using namespace tvm;
 
@@ -161,7 +162,13 @@ int32_t tvm_synthetic_fill(tvm_ctx* c, uint64_t* d, uint64_t n, uint64_t seed) {
 // ---------------------------------------------------------------------------------- field self-check
 }  // extern "C"
 namespace tvm {
-// out[i] = a[i] op b[i] through the device arithmetic of field.h (op: 0 add, 1 sub, 2 mul, 3 a^7)
+// out[i] = a[i] op b[i] through the device arithmetic of field.h (op: 0 add, 1 sub, 2 mul, 3 a^7, 4: a * 2^b for a plain
+// exponent b < 192 through the shift forms of ntt_shift.h)
+template <int S>
+TVM_D u64 mul_pow2_dispatch(u64 x, int s) {
+    if constexpr (S < 0) return 0;
+    else return s == S ? bfe_mul_pow2<S>(x) : mul_pow2_dispatch<S - 1>(x, s);
+}
 __global__ void k_field_op(int op, const u64* __restrict__ a, const u64* __restrict__ b, u64* __restrict__ out, u64 n) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -170,14 +177,50 @@ __global__ void k_field_op(int op, const u64* __restrict__ a, const u64* __restr
     if (op == 0) r = bfe_add(x, y);
     else if (op == 1) r = bfe_sub(x, y);
     else if (op == 2) r = bfe_mul(x, y);
-    else r = bfe_mul(bfe_mul(bfe_sqr(bfe_sqr(x)), bfe_sqr(x)), x);
+    else if (op == 3) r = bfe_mul(bfe_mul(bfe_sqr(bfe_sqr(x)), bfe_sqr(x)), x);
+    else {
+        const int s = (int)(y % 192);
+        r = mul_pow2_dispatch<95>(x, s % 96);
+        if (s >= 96) r = bfe_neg(r);
+    }
     out[i] = r;
+}
+// the in-register power-of-two-twiddle transforms of ntt_shift.h on consecutive groups of 2^K words
+template <int K, bool DIT, bool INVERSE>
+__global__ void k_pow2_points(const u64* __restrict__ a, u64* __restrict__ out, u64 n_groups) {
+    const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    u64 x[1 << K];
+#pragma unroll
+    for (int e = 0; e < (1 << K); e++) x[e] = a[(g << K) + e];
+    ntt_pow2_points<K, DIT, INVERSE>(x);
+#pragma unroll
+    for (int e = 0; e < (1 << K); e++) out[(g << K) + e] = x[e];
+}
+template <int K>
+static void launch_pow2_points(tvm_ctx* c, int dit, int inverse, const u64* a, u64* out, u64 n_groups) {
+    const dim3 grid((unsigned)((n_groups + 63) / 64)), block(64);
+    if (dit && inverse) TVM_LAUNCH((k_pow2_points<K, true, true>), grid, block, 0, c->stream, a, out, n_groups);
+    else if (dit) TVM_LAUNCH((k_pow2_points<K, true, false>), grid, block, 0, c->stream, a, out, n_groups);
+    else if (inverse) TVM_LAUNCH((k_pow2_points<K, false, true>), grid, block, 0, c->stream, a, out, n_groups);
+    else TVM_LAUNCH((k_pow2_points<K, false, false>), grid, block, 0, c->stream, a, out, n_groups);
 }
 }  // namespace tvm
 extern "C" {
 int32_t tvm_field_op(tvm_ctx* c, int32_t op, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, uint64_t n) {
-    if (!c || op < 0 || op > 3 || (n && (!d_a || !d_b || !d_out))) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_field_op arguments");
+    const bool points = op >= 32 && op < 32 + 5 * 4;  // 32 + 4 K + 2 dit + inverse: transforms of 2^K points, K = 1 .. 4
+    if (!c || op < 0 || (op > 4 && !points) || (n && (!d_a || !d_b || !d_out))) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_field_op arguments");
     if (!n) return TVM_OK;
+    if (points) {
+        const int K = (op - 32) >> 2, dit = (op >> 1) & 1, inverse = op & 1;
+        if (K < 1 || K > 4 || n % (1ull << K)) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_field_op: whole groups of 2^K words");
+        if (K == 1) tvm::launch_pow2_points<1>(c, dit, inverse, d_a, d_out, n >> 1);
+        else if (K == 2) tvm::launch_pow2_points<2>(c, dit, inverse, d_a, d_out, n >> 2);
+        else if (K == 3) tvm::launch_pow2_points<3>(c, dit, inverse, d_a, d_out, n >> 3);
+        else tvm::launch_pow2_points<4>(c, dit, inverse, d_a, d_out, n >> 4);
+        TVM_HIP_CHECK(c, hipGetLastError());
+        return TVM_OK;
+    }
     TVM_LAUNCH(tvm::k_field_op, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (int)op, d_a, d_b, d_out, n);
     TVM_HIP_CHECK(c, hipGetLastError());
     return TVM_OK;

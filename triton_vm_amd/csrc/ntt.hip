@@ -24,7 +24,10 @@
 //   pass3  forward rows step (DIT) for 16 table columns at once  reads Z,       writes the table
 // Algorithmic HBM bytes per base-field trace cell: 8 (read) + 8*X (write) = 72 at X = 8; the
 // scheme moves 8*(1+1+1+X+X+X) = 216.
+#include <cstdlib>
+
 #include "context.h"
+#include "ntt_shift.h"
 
 namespace tvm {
 
@@ -58,7 +61,10 @@ __global__ void k_pow_table(u64 base, u64 count, u64 scale, u64* out) {
 // production tile (16 transforms side by side, element (a, b) at s[a + b * (n + TVM_ROW_PAD)]): every LDS address
 // of the group is then the work-item's base plus an immediate offset, and the twiddle indices are shifts by
 // constants -- the generic form spends ~190 of its ~1050 instructions per group on that arithmetic.
-template <bool DIT, int K, bool L0, int CL = -1, int CLOGN = -1, int CB = 4>
+// ROOT: 0 = any root of unity (every twiddle from tw); 1 / 2 = the n-th root is the domains' own (ntt_shift.h) / its
+// inverse, all of whose 16th roots are powers of two: the group of the lowest four layers (l == 0) is then a transform with
+// shift twiddles, no table access and 9-12-instruction multiplications instead of 16-instruction ones.
+template <bool DIT, int K, bool L0, int CL = -1, int CLOGN = -1, int CB = 4, int ROOT = 0>
 TVM_D void lds_ntt_group(u64* s, int log_n_rt, int batch_log_rt, int SA_rt, int SB_rt, const u64* __restrict__ tw, int l_rt, int tid, int nt) {
     constexpr int R = 1 << K;
     const int log_n = CLOGN >= 0 ? CLOGN : log_n_rt, batch_log = CLOGN >= 0 ? CB : batch_log_rt, l = CL >= 0 ? CL : l_rt;
@@ -73,6 +79,9 @@ TVM_D void lds_ntt_group(u64* s, int log_n_rt, int batch_log_rt, int SA_rt, int 
         u64 x[R];
 #pragma unroll
         for (int e = 0; e < R; e++) x[e] = p[e * stride];
+        if constexpr (L0 && ROOT != 0) {
+            ntt_pow2_points<K, DIT, ROOT == 2>(x);
+        } else {
 #pragma unroll
         for (int tt = 0; tt < K; tt++) {
             const int t = DIT ? tt : (K - 1 - tt);  // layer l + t: butterfly span 2^(l+t)
@@ -100,13 +109,14 @@ TVM_D void lds_ntt_group(u64* s, int log_n_rt, int batch_log_rt, int SA_rt, int 
                 }
             }
         }
+        }
 #pragma unroll
         for (int e = 0; e < R; e++) p[e * stride] = x[e];
     }
     tvm_lds_barrier();
 }
 
-template <bool DIT, int MAXK = 4>
+template <bool DIT, int MAXK = 4, int ROOT = 0>
 TVM_D void lds_ntt(u64* s, int log_n, int batch_log, int SA, int SB, const u64* __restrict__ tw, int tid, int nt) {
     // DIT runs the layers upwards from span 1, DIF downwards from span n/2; groups of MAXK layers (4, or 3
     // where the caller keeps other per-thread state in VGPRs), the remainder as the last group
@@ -115,10 +125,10 @@ TVM_D void lds_ntt(u64* s, int log_n, int batch_log, int SA, int SB, const u64* 
         const int k = (log_n - done) >= MAXK ? MAXK : (log_n - done);
         const int l = DIT ? done : (log_n - done - k);
         if (l == 0) {
-            if (MAXK >= 4 && k == 4) lds_ntt_group<DIT, 4, true>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
-            else if (k == 3) lds_ntt_group<DIT, 3, true>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
-            else if (k == 2) lds_ntt_group<DIT, 2, true>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
-            else lds_ntt_group<DIT, 1, true>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
+            if (MAXK >= 4 && k == 4) lds_ntt_group<DIT, 4, true, -1, -1, 4, ROOT>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
+            else if (k == 3) lds_ntt_group<DIT, 3, true, -1, -1, 4, ROOT>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
+            else if (k == 2) lds_ntt_group<DIT, 2, true, -1, -1, 4, ROOT>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
+            else lds_ntt_group<DIT, 1, true, -1, -1, 4, ROOT>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
         } else {
             if (MAXK >= 4 && k == 4) lds_ntt_group<DIT, 4, false>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
             else if (k == 3) lds_ntt_group<DIT, 3, false>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
@@ -128,15 +138,22 @@ TVM_D void lds_ntt(u64* s, int log_n, int batch_log, int SA, int SB, const u64* 
         done += k;
     }
 }
+// the same with the kind of root known only at run time (generic kernels: both forms are compiled)
+template <bool DIT, int MAXK = 4>
+TVM_D void lds_ntt_rt(int root, u64* s, int log_n, int batch_log, int SA, int SB, const u64* __restrict__ tw, int tid, int nt) {
+    if (root == 1) lds_ntt<DIT, MAXK, 1>(s, log_n, batch_log, SA, SB, tw, tid, nt);
+    else if (root == 2) lds_ntt<DIT, MAXK, 2>(s, log_n, batch_log, SA, SB, tw, tid, nt);
+    else lds_ntt<DIT, MAXK, 0>(s, log_n, batch_log, SA, SB, tw, tid, nt);
+}
 
 // The same sequence of groups with everything known at compile time (see lds_ntt_group).
-template <bool DIT, int MAXK, int LOGN, int DONE = 0, int CB = 4>
+template <bool DIT, int MAXK, int LOGN, int DONE = 0, int CB = 4, int ROOT = 0>
 TVM_D void lds_ntt_fixed(u64* s, const u64* __restrict__ tw, int tid, int nt) {
     if constexpr (DONE < LOGN) {
         constexpr int k = (LOGN - DONE) >= MAXK ? MAXK : (LOGN - DONE);
         constexpr int l = DIT ? DONE : (LOGN - DONE - k);
-        lds_ntt_group<DIT, k, l == 0, l, LOGN, CB>(s, LOGN, CB, 1, (1 << LOGN) + TVM_ROW_PAD, tw, l, tid, nt);
-        lds_ntt_fixed<DIT, MAXK, LOGN, DONE + k, CB>(s, tw, tid, nt);
+        lds_ntt_group<DIT, k, l == 0, l, LOGN, CB, ROOT>(s, LOGN, CB, 1, (1 << LOGN) + TVM_ROW_PAD, tw, l, tid, nt);
+        lds_ntt_fixed<DIT, MAXK, LOGN, DONE + k, CB, ROOT>(s, tw, tid, nt);
     }
 }
 
@@ -162,6 +179,7 @@ struct Ntt2Args {
     const u64* post_hi;
     u64 out_mul, out_add;        // output element k is stored at index k*out_mul + out_add
     int col0;                    // first virtual column (in/out use col0 + blockIdx.y, tmp uses blockIdx.y)
+    int root;                    // 1 / 2: w is the domains' own N-th root of unity / its inverse (shift twiddles, lds_ntt_group)
 };
 
 
@@ -184,7 +202,7 @@ __global__ void __launch_bounds__(1024) k_ntt2_pass1(Ntt2Args a) {
         s[idx] = x;
     }
     tvm_lds_barrier();
-    lds_ntt<false>(s, a.log_n1, a.batch_log, B, 1, a.tw1, tid, nt);
+    lds_ntt_rt<false>(a.root, s, a.log_n1, a.batch_log, B, 1, a.tw1, tid, nt);
     u64* tmp = a.tmp + (u64)vl * a.tmp_col_stride;
     for (int idx = tid; idx < tile; idx += nt) {
         const int b = idx & (B - 1), p = idx >> a.batch_log;
@@ -214,7 +232,7 @@ __global__ void __launch_bounds__(1024) k_ntt2_pass2(Ntt2Args a) {
         s[b * RS + i2] = x;
     }
     tvm_lds_barrier();
-    lds_ntt<false>(s, a.log_n2, a.batch_log, 1, RS, a.tw2, tid, nt);
+    lds_ntt_rt<false>(a.root, s, a.log_n2, a.batch_log, 1, RS, a.tw2, tid, nt);
     u64* out = a.out + (u64)(v / a.out_fk) * a.out_col_stride + (v % a.out_fk);
     for (int idx = tid; idx < tile; idx += nt) {
         const int b = idx & (B - 1), q = idx >> a.batch_log;
@@ -250,6 +268,7 @@ struct LdePass2Args {
     const u64* g_lo_step;  // [N1]: (gamma_{k+1} / gamma_k)^m2       (k_lde_pass2_v2 walks the cosets with running
     const u64* g_hi_step;  // [N2]: (gamma_{k+1} / gamma_k)^(N1*m1)    products: no table load inside its coset loop)
     u64 zk[TVM_LDE_MAX_COSETS];  // N * (gamma_k^N - 1)
+    int std_roots;       // the trace domain's generator is the domains' own root of unity (shift twiddles, lds_ntt_group)
 };
 
 __global__ void __launch_bounds__(1024) k_lde_pass2(LdePass2Args a) {
@@ -272,7 +291,7 @@ __global__ void __launch_bounds__(1024) k_lde_pass2(LdePass2Args a) {
     }
     tvm_lds_barrier();
     // inverse rows step: position q of row b now holds N * t[k1 + N1*k2], k2 = brev(q)
-    lds_ntt<false>(s, a.log_n2, a.batch_log, 1, RS, a.tw_a2, tid, nt);
+    lds_ntt_rt<false>(a.std_roots ? 2 : 0, s, a.log_n2, a.batch_log, 1, RS, a.tw_a2, tid, nt);
 
     // The N coefficients of this tile stay in VGPRs for the whole coset loop (the only per-thread
     // state: 16 words); coset factors come from two small L2-resident tables per coset.
@@ -304,7 +323,7 @@ __global__ void __launch_bounds__(1024) k_lde_pass2(LdePass2Args a) {
         }
         tvm_lds_barrier();
         // forward columns step over m1 (bit-reversed in position q): natural j1 out
-        lds_ntt<true, 3>(s, a.log_n2, a.batch_log, 1, RS, a.tw_b1, tid, nt);  // coef[] stays live: 8-element groups
+        lds_ntt_rt<true, 3>(a.std_roots ? 1 : 0, s, a.log_n2, a.batch_log, 1, RS, a.tw_b1, tid, nt);  // coef[] stays live: 8-element groups
         u64* z = a.z + ((u64)vl * a.n_cosets + k) * n;
         for (int idx = tid; idx < tile; idx += nt) {
             const int b = idx & (B - 1), j1 = idx >> a.batch_log;
@@ -331,6 +350,7 @@ struct LdePass3Args {
     u64 pitch;           // storage rows per coset
     const u64* tw_b2;    // w_N1^e
     int rows_log;        // rows per workgroup tile
+    int std_roots;       // see LdePass2Args
 };
 
 __global__ void __launch_bounds__(1024) k_lde_pass3(LdePass3Args a) {
@@ -357,7 +377,7 @@ __global__ void __launch_bounds__(1024) k_lde_pass3(LdePass3Args a) {
         s[b * RS + p] = x;
     }
     tvm_lds_barrier();
-    lds_ntt<true>(s, a.log_n1, a.rows_log, 1, RS, a.tw_b2, tid, nt);
+    lds_ntt_rt<true>(a.std_roots ? 1 : 0, s, a.log_n1, a.rows_log, 1, RS, a.tw_b2, tid, nt);
     const u64 v = (u64)(a.col0 + vl);
     for (int idx = tid; idx < tile; idx += nt) {
         const int j2 = idx & (n1 - 1), b = idx >> a.log_n1;
@@ -393,9 +413,10 @@ __global__ void __launch_bounds__(1024) k_lde_pass2_v2(LdePass2Args a) {
     for (int e = 0; e < 16; e++) s[e * RS + tid] = TVM_LOAD_STREAM(&y[(u64)e * n2 + tid]);
     tvm_lds_barrier();
     // position q of row e: N * t[m1*n1 + m2], m1 = brev(q)
-    if (a.log_n2 == 10) lds_ntt_fixed<false, 4, 10>(s, a.tw_a2, tid, nt);
-    else if (a.log_n2 == 6) lds_ntt_fixed<false, 4, 6>(s, a.tw_a2, tid, nt);  // 2^12 rows: the size the CPU suite runs
-    else lds_ntt<false>(s, a.log_n2, 4, 1, RS, a.tw_a2, tid, nt);
+    // (the production kernels are launched for the domains' own roots of unity only: shift twiddles, ROOT = 2 / 1)
+    if (a.log_n2 == 10) lds_ntt_fixed<false, 4, 10, 0, 4, 2>(s, a.tw_a2, tid, nt);
+    else if (a.log_n2 == 6) lds_ntt_fixed<false, 4, 6, 0, 4, 2>(s, a.tw_a2, tid, nt);  // 2^12 rows: the size the CPU suite runs
+    else lds_ntt<false, 4, 2>(s, a.log_n2, 4, 1, RS, a.tw_a2, tid, nt);
 
     u64 coef[16];
 #pragma unroll
@@ -437,9 +458,9 @@ __global__ void __launch_bounds__(1024) k_lde_pass2_v2(LdePass2Args a) {
         }
         tvm_lds_barrier();
         // coef[] stays live: 8-element groups
-        if (a.log_n2 == 10) lds_ntt_fixed<true, 3, 10>(s, tw_fwd, tid, nt);
-        else if (a.log_n2 == 6) lds_ntt_fixed<true, 3, 6>(s, tw_fwd, tid, nt);
-        else lds_ntt<true, 3>(s, a.log_n2, 4, 1, RS, tw_fwd, tid, nt);
+        if (a.log_n2 == 10) lds_ntt_fixed<true, 3, 10, 0, 4, 1>(s, tw_fwd, tid, nt);
+        else if (a.log_n2 == 6) lds_ntt_fixed<true, 3, 6, 0, 4, 1>(s, tw_fwd, tid, nt);
+        else lds_ntt<true, 3, 1>(s, a.log_n2, 4, 1, RS, tw_fwd, tid, nt);
         u64* z = a.z + ((u64)vl * a.n_cosets + k) * n + p0 + b_out;
         u64 t = t_first;  // w_N^(m2*j1) * gamma_k^m2 / N at j1 = j1_0
 #pragma unroll 4
@@ -492,9 +513,9 @@ __global__ void __launch_bounds__(1024) k_lde_pass3_v2(LdePass3Args a) {
                 nxt[e] = TVM_LOAD_STREAM(&zc[(k * n2 + j1) << a.log_n1]);
             }
         }
-        if (a.log_n1 == 10) lds_ntt_fixed<true, 4, 10>(s, tw_fwd, tid, nt);
-        else if (a.log_n1 == 6) lds_ntt_fixed<true, 4, 6>(s, tw_fwd, tid, nt);
-        else lds_ntt<true>(s, a.log_n1, 4, 1, RS, tw_fwd, tid, nt);
+        if (a.log_n1 == 10) lds_ntt_fixed<true, 4, 10, 0, 4, 1>(s, tw_fwd, tid, nt);
+        else if (a.log_n1 == 6) lds_ntt_fixed<true, 4, 6, 0, 4, 1>(s, tw_fwd, tid, nt);
+        else lds_ntt<true, 4, 1>(s, a.log_n1, 4, 1, RS, tw_fwd, tid, nt);
         // row e of the tile is (k, j1): its storage rows start at k*pitch + j1*n1 (a multiple of 16)
 #pragma unroll 4
         for (int e = 0; e < 16; e++) {
@@ -528,7 +549,7 @@ __global__ void __launch_bounds__(1 << TLOG) k_lde_pass2_v3(LdePass2Args a) {
         s[r * RS + q] = TVM_LOAD_STREAM(&y[(u64)r * n2 + q]);
     }
     tvm_lds_barrier();
-    lds_ntt_fixed<false, 4, LOGN, 0, RLOG>(s, a.tw_a2, tid, NT);
+    lds_ntt_fixed<false, 4, LOGN, 0, RLOG, 2>(s, a.tw_a2, tid, NT);
     u64 coef[16];
 #pragma unroll
     for (int e = 0; e < 16; e++) coef[e] = s[(e & (ROWS - 1)) * RS + tid + (e >> RLOG) * NT];
@@ -568,7 +589,7 @@ __global__ void __launch_bounds__(1 << TLOG) k_lde_pass2_v3(LdePass2Args a) {
             s[r * RS + tid + hh * NT] = bfe_mul(c, gh[hh]);
         }
         tvm_lds_barrier();
-        lds_ntt_fixed<true, 3, LOGN, 0, RLOG>(s, tw_fwd, tid, NT);
+        lds_ntt_fixed<true, 3, LOGN, 0, RLOG, 1>(s, tw_fwd, tid, NT);
         u64* z = a.z + ((u64)vl * a.n_cosets + k) * n + p0 + b_out;
         u64 t = t_first;
 #pragma unroll 4
@@ -619,7 +640,7 @@ __global__ void __launch_bounds__(1 << TLOG) k_lde_pass3_v3(LdePass3Args a) {
                 nxt[e] = TVM_LOAD_STREAM(&zc[((k * n2 + j1) << LOGN) + (u64)(e >> RLOG) * NT]);
             }
         }
-        lds_ntt_fixed<true, 4, LOGN, 0, RLOG>(s, tw_fwd, tid, NT);
+        lds_ntt_fixed<true, 4, LOGN, 0, RLOG, 1>(s, tw_fwd, tid, NT);
 #pragma unroll 4
         for (int e = 0; e < 16; e++) {
             const int r = e & (ROWS - 1), hh = e >> RLOG;
@@ -760,6 +781,7 @@ static void set_lds_attributes() {
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_v2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_v2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_v3<10, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass3_v3<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_v3<11, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_v3<11, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_v3<12, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -825,6 +847,17 @@ static int make_inter(tvm_ctx* c, u64 w, const Split& sp, Pow2* out) {
     return (out->lo && out->hi) ? TVM_OK : TVM_ERR_OUT_OF_MEMORY;
 }
 
+// Is w (w^n = 1, n >= 2 a power of two) the domains' own n-th root of unity [twenty-first primitive_root_of_unity:
+// 1753635133440165772^(2^32 / n)] (-> 1), its inverse (-> 2), or some other root (-> 0)?  Decided on its power of order
+// min(n, 16), which must be 2^156 = w_16 (2^36 for the inverse) or the corresponding root of lower order (ntt_shift.h).
+static int classify_root(u64 w, u64 n) {
+    const int k = ilog2(n) < 4 ? ilog2(n) : 4;
+    const u64 r = bfe_pow(w, n >> k), two = bfe_from_u64(2);
+    if (r == bfe_pow(two, (u64)((156 << (4 - k)) % 192))) return 1;
+    if (r == bfe_pow(two, (u64)((36 << (4 - k)) % 192))) return 2;
+    return 0;
+}
+
 // Transform `ncols` columns of length n with root `w` (w^n = 1; pass the inverse root for an
 // inverse transform).  in_scale/out_scale: optional x[i] *= in_scale^i and X[k] *= out_mult*out_scale^k.
 int ntt_columns(tvm_ctx* c, const u64* in, u64 in_len, int in_fk, u64 in_col_stride, u64* out, int out_fk,
@@ -866,6 +899,7 @@ int ntt_columns(tvm_ctx* c, const u64* in, u64 in_len, int in_fk, u64 in_col_str
     a.out_mul = out_mul;
     a.out_add = out_add;
     a.col0 = 0;
+    a.root = classify_root(w, n);
     {
         a.batch_log = batch_log_for(sp.log_n1);
         const int B = 1 << a.batch_log;
@@ -928,6 +962,8 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     p1.out_mul = 1;
     p1.out_add = 0;
     p1.col0 = 0;
+    const bool std_roots = classify_root(w, N) == 1;  // every ArithmeticDomain's generator is; any other root takes the generic kernels
+    p1.root = std_roots ? 2 : 0;
 
     LdePass2Args p2;
     p2.rnd = rnd;
@@ -937,6 +973,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     p2.fk = fk;
     p2.h = h;
     p2.n_cosets = (int)X;
+    p2.std_roots = std_roots ? 1 : 0;
     p2.tw_a2 = pow_table(c, bfe_pow(wi, n1), n2 / 2);
     p2.tw_b1 = pow_table(c, bfe_pow(w, n1), n2 / 2);
     TVM_TRY(make_inter(c, w, sp, &p2.tw_inter));
@@ -958,6 +995,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     p3.L = L;
     p3.W = W;
     p3.pitch = lde_table_layout(N, L).pitch;
+    p3.std_roots = std_roots ? 1 : 0;
     p3.tw_b2 = pow_table(c, bfe_pow(w, n2), n1 > 1 ? n1 / 2 : 1);
     if (!p1.tw1 || !p2.tw_a2 || !p2.tw_b1 || !p2.g_lo || !p2.g_hi || !p2.g_lo_step || !p2.g_hi_step || !p3.tw_b2)
         return set_error(c, TVM_ERR_OUT_OF_MEMORY, "lde tables");
@@ -993,13 +1031,13 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             const u64 rows3 = 16 >> ppt_log;
             const size_t lds_v3 = (size_t)(rows3 * (n2 + TVM_ROW_PAD) + n2 / 2) * sizeof(u64);
             const dim3 g2((unsigned)(n1 / rows3), (unsigned)nc);
-            if (ppt_log && n1 % rows3 == 0) {
+            if (std_roots && ppt_log && n1 % rows3 == 0) {
                 if (sp.log_n2 == 11) TVM_LAUNCH((k_lde_pass2_v3<11, 10>), g2, dim3(1024), lds_v3, c->stream, a);
                 else if (sp.log_n2 == 12) TVM_LAUNCH((k_lde_pass2_v3<12, 10>), g2, dim3(1024), lds_v3, c->stream, a);
                 else if (sp.log_n2 == 7) TVM_LAUNCH((k_lde_pass2_v3<7, 6>), g2, dim3(64), lds_v3, c->stream, a);
                 else TVM_LAUNCH((k_lde_pass2_v3<8, 6>), g2, dim3(64), lds_v3, c->stream, a);
             }
-            else if (a.batch_log == 4 && n2 >= 64 && n1 >= 16)  // production shape: one work-item per column of the tile
+            else if (std_roots && a.batch_log == 4 && n2 >= 64 && n1 >= 16)  // production shape: one work-item per column of the tile
                 TVM_LAUNCH(k_lde_pass2_v2, grid, dim3((unsigned)n2), lds + (n2 / 2) * sizeof(u64), c->stream, a);
             else
                 TVM_LAUNCH(k_lde_pass2, grid, dim3(threads_for_tile(tile)), lds, c->stream, a);
@@ -1014,7 +1052,18 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             const size_t lds = ((size_t)(n1 + TVM_ROW_PAD) << a.rows_log) * sizeof(u64);
             const int ppt_log = (sp.log_n1 == 11 || sp.log_n1 == 7) ? 1 : (sp.log_n1 == 12 || sp.log_n1 == 8) ? 2 : 0;
             const u64 rows3 = 16 >> ppt_log, tiles3 = X * n2 / rows3;  // see pass 2
-            if (sp.log_n1 == 10 && (X * n2) % 16 == 0 && X * n2 / 8 < 65536) {
+            static const int p3_rows = std::getenv("TVM_LDE_PASS3_ROWS") ? std::atoi(std::getenv("TVM_LDE_PASS3_ROWS")) : 8;  // experiment knob
+            if (std_roots && sp.log_n1 == 10 && p3_rows == 4 && (X * n2) % 16 == 0) {
+                // 4-row tiles on 256 work-items, 37 KB of LDS: FOUR workgroups per CU.  Every row of a tile owns 1024 consecutive
+                // storage rows of the table (context.h), so the stores are full lines whatever the tile height.
+                const u64 tiles_q = X * n2 / 4;
+                a.tiles = tiles_q % 32 == 0 ? 32 : tiles_q % 8 == 0 ? 8 : 1;
+                if (tiles_q / a.tiles >= 65536) return set_error(c, TVM_ERR_UNSUPPORTED, "lde: too many row tiles");
+                const dim3 g3((unsigned)nc, (unsigned)(tiles_q / a.tiles));
+                const size_t lds_q = (size_t)(4 * (n1 + TVM_ROW_PAD) + n1 / 2) * sizeof(u64);
+                TVM_LAUNCH((k_lde_pass3_v3<10, 8>), g3, dim3(256), lds_q, c->stream, a);
+            } else
+            if (std_roots && sp.log_n1 == 10 && (X * n2) % 16 == 0 && X * n2 / 8 < 65536) {
                 // 1024-point axis (2^19 and 2^20 rows): 8-row tiles on 512 work-items, 70 KB of LDS -- TWO workgroups per CU, so
                 // that one's loads and stores run under the other's butterflies.  Pass 3 is the sum of ~9 ms of arithmetic
                 // and ~9 ms of memory time per 379 columns with one resident workgroup; main table 44.8 -> 42.8 ms
@@ -1025,7 +1074,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
                 const size_t lds_h = (size_t)(8 * (n1 + TVM_ROW_PAD) + n1 / 2) * sizeof(u64);
                 TVM_LAUNCH((k_lde_pass3_v3<10, 9>), g3, dim3(512), lds_h, c->stream, a);
             } else
-            if (ppt_log && (X * n2) % 16 == 0) {
+            if (std_roots && ppt_log && (X * n2) % 16 == 0) {
                 a.tiles = tiles3 % 8 == 0 ? 8 : tiles3 % 4 == 0 ? 4 : 1;
                 const dim3 g3((unsigned)nc, (unsigned)(tiles3 / a.tiles));
                 const size_t lds_v3 = (size_t)(rows3 * (n1 + TVM_ROW_PAD) + n1 / 2) * sizeof(u64);
@@ -1034,7 +1083,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
                 else if (sp.log_n1 == 12) TVM_LAUNCH((k_lde_pass3_v3<12, 10>), g3, dim3(1024), lds_v3, c->stream, a);
                 else if (sp.log_n1 == 7) TVM_LAUNCH((k_lde_pass3_v3<7, 6>), g3, dim3(64), lds_v3, c->stream, a);
                 else TVM_LAUNCH((k_lde_pass3_v3<8, 6>), g3, dim3(64), lds_v3, c->stream, a);
-            } else if (a.rows_log == 4 && n1 >= 64 && (X * n2) % 16 == 0 && X * n2 / 16 < 65536) {
+            } else if (std_roots && a.rows_log == 4 && n1 >= 64 && (X * n2) % 16 == 0 && X * n2 / 16 < 65536) {
                 a.tiles = grid.x % 8 == 0 ? 8 : grid.x % 4 == 0 ? 4 : 1;  // 1 -> 49.2 ms, 2 -> 47.5, 4 -> 47.0, 8 -> 46.3 (2^20 rows)
                 TVM_LAUNCH(k_lde_pass3_v2, dim3(grid.y, grid.x / a.tiles), dim3((unsigned)n1), lds + (n1 / 2) * sizeof(u64), c->stream, a);
             }

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Light GPU visit for LDE work: field / NTT / full-size LDE parity, bench without extras, kernel trace.
+# usage: bash tools/gpu_visit3.sh <tag> [env assignments for extra bench runs]
+TAG=${1:-visit}; shift
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+( timeout 900 python -m pytest tests/test_kernels_field.py tests/test_kernels_ntt.py tests/test_gpu_fullsize.py tests/test_proof_snapshot.py -m gpu -x -q -k "not quotient_segments and not deep and not air and not extend" 2>&1 | tail -8 ) > gpurun_out/${TAG}_pytest_gpu.log
+( timeout 600 python bench.py --steps 5 --warmup 2 --no-extras --no-cpu-baseline 2>gpurun_out/${TAG}_bench.err | tail -1 ) > gpurun_out/${TAG}_bench.json
+for E in "$@"; do
+  ( env $E timeout 300 python bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline 2>&1 | tail -1 ) > gpurun_out/${TAG}_bench_${E}.json
+done
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras 2>&1 | tail -3 ) > gpurun_out/${TAG}_rocprof.log
+DB=$(find gpurun_out/${TAG}_prof -name '*.db' | head -1)
+[ -n "$DB" ] && python tools/rocprof_summary.py $DB > gpurun_out/${TAG}_kernels.txt
+rm -rf gpurun_out/${TAG}_prof
+cat gpurun_out/${TAG}_pytest_gpu.log
+python - <<P
+import json,glob
+for f in sorted(glob.glob("gpurun_out/${TAG}_bench*.json")):
+    try:
+        d=json.load(open(f))
+        print(f, d["ms_per_step"], d["roofline"]["launch_ms"], d["roofline"]["frac"], json.dumps(d["stage_ms"]))
+    except Exception as e:
+        print(f, "unreadable", e)
+P
+tail -3 gpurun_out/${TAG}_bench.err
+head -12 gpurun_out/${TAG}_kernels.txt

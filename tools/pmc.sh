@@ -5,7 +5,7 @@ TAG=$1; shift
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-cd /tmp
+cd /tmp  # (rocprofv3 wants a writable cwd; commands must use absolute paths: $GRAFT_REPO_ROOT/...)
 run() {  # name, counters... (the command is in "${CMD[@]}")
   local name=$1; shift
   timeout 900 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $ROOT/gpurun_out/${TAG}_$name -o r -- "${CMD[@]}" > $ROOT/gpurun_out/${TAG}_$name.log 2>&1

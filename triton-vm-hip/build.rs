@@ -1,5 +1,6 @@
-// Link against libtriton_hip.so.  TRITON_HIP_LIB_DIR = the directory that holds it (…/triton_vm_amd after
-// `python -m triton_vm_amd.build`, which runs hipcc --offload-arch=gfx950 over csrc/*.hip).
+// Link against libtriton_hip.so (the C ABI) and libtriton_host.so (the C++ mirror of Prover::prove above it, stage 2).
+// TRITON_HIP_LIB_DIR = the directory that holds both (…/triton_vm_amd after `python -m triton_vm_amd.build`, which runs
+// hipcc --offload-arch=gfx950 over csrc/*.hip and g++ over host/triton_host.cpp).
 use std::env;
 use std::path::PathBuf;
 
@@ -10,5 +11,6 @@ fn main() {
     });
     println!("cargo:rustc-link-search=native={}", dir.display());
     println!("cargo:rustc-link-lib=dylib=triton_hip");
+    println!("cargo:rustc-link-lib=dylib=triton_host");
     println!("cargo:rustc-link-arg=-Wl,-rpath,{}", dir.display());
 }

@@ -300,9 +300,189 @@ pub fn codeword_merkle_nodes(ctx: &Context, codeword: &[XFieldElement]) -> Resul
 pub fn extend_aux_table(ctx: &Context, main_trace_words: &[u64], aux_trace_words: &mut [u64], n_rows: usize, challenges: &[XFieldElement]) -> Result<()> {
     let d_main = ctx.upload(main_trace_words)?;
     let d_aux = ctx.upload(aux_trace_words)?;
+    assert_eq!(TVM_NUM_CHALLENGES, challenges.len());   // the C side reads 63 * 3 words and n_rows-sized columns unconditionally
+    assert_eq!(379 * n_rows, main_trace_words.len());
+    assert_eq!(91 * n_rows * 3, aux_trace_words.len());
     let ch = xfe_words(challenges);
     ctx.check(unsafe { tvm_extend_aux_table(ctx.raw, d_main.ptr, d_aux.ptr, n_rows as u64, ch.as_ptr()) })?;
     ctx.check(unsafe { tvm_fill_derived_aux_columns(ctx.raw, d_main.ptr, d_aux.ptr, n_rows as u64, ch.as_ptr()) })?;
     aux_trace_words.copy_from_slice(&d_aux.download()?);
     Ok(())
+}
+
+// ---- stage 2: the whole of Prover::prove(claim, aet) behind one call ---------------------------------------------
+/// The algebraic execution trace as plain words, field by field as `AlgebraicExecutionTrace` holds it (aet.rs:41-96):
+/// trace arrays row-major in `raw_u64` Montgomery words, multiplicities as plain integers.  `u32_entries`:
+/// `[opcode, left operand, right operand, multiplicity]` per entry in `IndexMap` order; `cascade_entries`:
+/// `[16-bit limb, multiplicity]`.
+pub struct ExecutionTrace {
+    pub program_words: Vec<u64>,
+    pub instruction_multiplicities: Vec<u32>,
+    pub processor_trace: Vec<u64>,
+    pub op_stack_trace: Vec<u64>,
+    pub ram_trace: Vec<u64>,
+    pub program_hash_trace: Vec<u64>,
+    pub sponge_trace: Vec<u64>,
+    pub hash_trace: Vec<u64>,
+    pub u32_entries: Vec<u64>,
+    pub cascade_entries: Vec<u64>,
+    pub lookup_multiplicities: Vec<u64>,
+}
+
+/// `Stark::ldt_choice`: `Auto` = the reference's heuristic (STIR from 2^16 padded rows on, stark.rs:1944-1951).
+#[derive(Debug, Copy, Clone, PartialEq, Eq)]
+pub enum Ldt {
+    Fri = 0,
+    Stir = 1,
+    Auto = 2,
+}
+
+/// `tvm_aet` of include/triton_hip.h (the arrays may be host or device memory; here: host).
+#[repr(C)]
+struct TvmAet {
+    program_words: *const u64,
+    instruction_multiplicities: *const u32,
+    program_len: u64,
+    processor_trace: *const u64,
+    processor_len: u64,
+    op_stack_trace: *const u64,
+    op_stack_len: u64,
+    ram_trace: *const u64,
+    ram_len: u64,
+    bezout_coefficients_0: *const u64,
+    bezout_coefficients_1: *const u64,
+    num_ram_pointers: u64,
+    program_hash_trace: *const u64,
+    program_hash_len: u64,
+    sponge_trace: *const u64,
+    sponge_len: u64,
+    hash_trace: *const u64,
+    hash_len: u64,
+    u32_entries: *const u64,
+    u32_len: u64,
+    cascade_entries: *const u64,
+    cascade_len: u64,
+    lookup_multiplicities: *const u64,
+}
+
+// libtriton_host.so (triton_vm_amd/host/triton_host.hpp): the C++ mirror of Prover::prove above the C ABI
+#[link(name = "triton_host")]
+unsafe extern "C" {
+    fn tvmh_prove_execution(
+        ctx: *mut TvmCtx,
+        aet: *const TvmAet,
+        log2_padded_height: u32,
+        security_level: u32,
+        log2_expansion: u32,
+        use_stir: u32,
+        randomness_seed: *const u8,
+        h_program_digest: *const u64,
+        h_public_input: *const u64,
+        n_public_input: u64,
+        h_public_output: *const u64,
+        n_public_output: u64,
+        h_proof: *mut u64,
+        capacity: u64,
+        proof_words: *mut u64,
+        error: *mut std::ffi::c_char,
+        error_capacity: u64,
+    ) -> i32;
+}
+
+/// `Prover::prove(claim, aet)` (stark.rs:331-719) on the device: fill, pad, randomizers, extend, LDE, Merkle trees, AIR,
+/// quotient segments, DEEP, the low-degree test and the openings with the master tables resident in HBM throughout;
+/// the RAM table's Bezout coefficient polynomials are computed on the device.  Returns the `raw_u64` words of the
+/// reference's `Proof` -- for the same seed, the words the CPU prover emits.
+#[allow(clippy::too_many_arguments)]
+pub fn prove_execution(
+    ctx: &Context,
+    aet: &ExecutionTrace,
+    padded_height: usize,
+    security_level: usize,
+    log2_expansion: usize,
+    ldt: Ldt,
+    randomness_seed: &[u8; 32],
+    program_digest: &[u64],
+    public_input: &[u64],
+    public_output: &[u64],
+) -> Result<Vec<u64>> {
+    assert!(padded_height.is_power_of_two());
+    assert_eq!(5, program_digest.len());
+    assert_eq!(aet.program_words.len(), aet.instruction_multiplicities.len());
+    assert_eq!(256, aet.lookup_multiplicities.len());
+    for (words, width) in [
+        (&aet.processor_trace, 39),
+        (&aet.op_stack_trace, 4),
+        (&aet.ram_trace, 7),
+        (&aet.program_hash_trace, 67),
+        (&aet.sponge_trace, 67),
+        (&aet.hash_trace, 67),
+        (&aet.u32_entries, 4),
+        (&aet.cascade_entries, 2),
+    ] {
+        assert_eq!(0, words.len() % width);
+    }
+    let raw = TvmAet {
+        program_words: aet.program_words.as_ptr(),
+        instruction_multiplicities: aet.instruction_multiplicities.as_ptr(),
+        program_len: aet.program_words.len() as u64,
+        processor_trace: aet.processor_trace.as_ptr(),
+        processor_len: (aet.processor_trace.len() / 39) as u64,
+        op_stack_trace: aet.op_stack_trace.as_ptr(),
+        op_stack_len: (aet.op_stack_trace.len() / 4) as u64,
+        ram_trace: aet.ram_trace.as_ptr(),
+        ram_len: (aet.ram_trace.len() / 7) as u64,
+        bezout_coefficients_0: ptr::null(),   // both null: computed on the device from the sorted RAM table
+        bezout_coefficients_1: ptr::null(),
+        num_ram_pointers: 0,
+        program_hash_trace: aet.program_hash_trace.as_ptr(),
+        program_hash_len: (aet.program_hash_trace.len() / 67) as u64,
+        sponge_trace: aet.sponge_trace.as_ptr(),
+        sponge_len: (aet.sponge_trace.len() / 67) as u64,
+        hash_trace: aet.hash_trace.as_ptr(),
+        hash_len: (aet.hash_trace.len() / 67) as u64,
+        u32_entries: aet.u32_entries.as_ptr(),
+        u32_len: (aet.u32_entries.len() / 4) as u64,
+        cascade_entries: aet.cascade_entries.as_ptr(),
+        cascade_len: (aet.cascade_entries.len() / 2) as u64,
+        lookup_multiplicities: aet.lookup_multiplicities.as_ptr(),
+    };
+    let mut proof = vec![0_u64; 1 << 20];
+    let mut error = [0 as std::ffi::c_char; 512];
+    loop {
+        let mut n = 0_u64;
+        let status = unsafe {
+            tvmh_prove_execution(
+                ctx.raw,
+                &raw,
+                padded_height.trailing_zeros(),
+                security_level as u32,
+                log2_expansion as u32,
+                ldt as u32,
+                randomness_seed.as_ptr(),
+                program_digest.as_ptr(),
+                public_input.as_ptr(),
+                public_input.len() as u64,
+                public_output.as_ptr(),
+                public_output.len() as u64,
+                proof.as_mut_ptr(),
+                proof.len() as u64,
+                &mut n,
+                error.as_mut_ptr(),
+                error.len() as u64,
+            )
+        };
+        match status {
+            TVM_OK if n as usize <= proof.len() => {
+                proof.truncate(n as usize);
+                return Ok(proof);
+            }
+            TVM_OK => proof = vec![0_u64; n as usize],   // the proof did not fit: grow and run again
+            TVM_ERR_OUT_OF_MEMORY => return Err(HipError::OutOfMemory),
+            TVM_ERR_INVALID_ARGUMENT => {
+                return Err(HipError::InvalidArgument(unsafe { CStr::from_ptr(error.as_ptr()) }.to_string_lossy().into_owned()))
+            }
+            _ => return Err(HipError::Device(unsafe { CStr::from_ptr(error.as_ptr()) }.to_string_lossy().into_owned())),
+        }
+    }
 }

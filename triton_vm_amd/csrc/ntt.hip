@@ -46,7 +46,8 @@ __global__ void k_pow_table(u64 base, u64 count, u64 scale, u64* out) {
 }
 
 // In-LDS transform of a tile: element (a, b) at s[a*SA + b*SB], a < 2^log_n the transform axis,
-// b < 2^batch_log independent transforms.  tw[e] = w^e, e < n/2, w the n-th root to use.
+// b < 2^batch_log independent transforms.  tw[e] = w^e, e < n (all n powers: the twiddle steps of lds_ntt_group use the
+// upper half too), w the n-th root to use.
 // DIT = false: decimation in frequency, natural order in, bit-reversed order out.
 // DIT = true : decimation in time, bit-reversed order in, natural order out.
 //
@@ -81,6 +82,22 @@ TVM_D void lds_ntt_group(u64* s, int log_n_rt, int batch_log_rt, int SA_rt, int 
         for (int e = 0; e < R; e++) x[e] = p[e * stride];
         if constexpr (L0 && ROOT != 0) {
             ntt_pow2_points<K, DIT, ROOT == 2>(x);
+        } else if constexpr (ROOT != 0) {
+            // Layers l .. l+K-1 of the transform = a twiddle step and a 2^K-point transform with shift twiddles: the
+            // twiddle of layer l+t, w_{2^(l+t+1)}^((m << l) | j0), is w_{2^(t+1)}^m -- a power of two -- times a factor
+            // that depends on j0 and t alone, and those factors collect on element e as  w_{2^(l+K)}^(j0 * brev_K(e))
+            // (decimation in time: before the butterflies; in frequency: after them).  R - 1 general multiplications
+            // and the shifts instead of R/2 * K general ones; tw holds all n powers of the root here.
+            const int shift = log_n - l - K;
+            if constexpr (DIT) {
+#pragma unroll
+                for (int e = 1; e < R; e++) x[e] = bfe_mul(x[e], tw[(j0 * brev_k(e, K)) << shift]);
+            }
+            ntt_pow2_points<K, DIT, ROOT == 2>(x);
+            if constexpr (!DIT) {
+#pragma unroll
+                for (int e = 1; e < R; e++) x[e] = bfe_mul(x[e], tw[(j0 * brev_k(e, K)) << shift]);
+            }
         } else {
 #pragma unroll
         for (int tt = 0; tt < K; tt++) {
@@ -130,10 +147,10 @@ TVM_D void lds_ntt(u64* s, int log_n, int batch_log, int SA, int SB, const u64* 
             else if (k == 2) lds_ntt_group<DIT, 2, true, -1, -1, 4, ROOT>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
             else lds_ntt_group<DIT, 1, true, -1, -1, 4, ROOT>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
         } else {
-            if (MAXK >= 4 && k == 4) lds_ntt_group<DIT, 4, false>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
-            else if (k == 3) lds_ntt_group<DIT, 3, false>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
-            else if (k == 2) lds_ntt_group<DIT, 2, false>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
-            else lds_ntt_group<DIT, 1, false>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
+            if (MAXK >= 4 && k == 4) lds_ntt_group<DIT, 4, false, -1, -1, 4, ROOT>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
+            else if (k == 3) lds_ntt_group<DIT, 3, false, -1, -1, 4, ROOT>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
+            else if (k == 2) lds_ntt_group<DIT, 2, false, -1, -1, 4, ROOT>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
+            else lds_ntt_group<DIT, 1, false, -1, -1, 4, ROOT>(s, log_n, batch_log, SA, SB, tw, l, tid, nt);
         }
         done += k;
     }
@@ -424,7 +441,7 @@ __global__ void __launch_bounds__(1024) k_lde_pass2_v2(LdePass2Args a) {
     // the forward twiddles w_N2^e (n2/2 words) live in LDS behind the tile for the X column steps that follow:
     // an LDS read costs a fraction of the L1-hit latency of the same table in global memory
     u64* tw_fwd = s + 16 * RS;
-    if (tid < (n2 >> 1)) tw_fwd[tid] = a.tw_b1[tid];
+    tw_fwd[tid] = a.tw_b1[tid];   // all n2 powers (nt == n2)
     const u64 m1 = brev_bits((u32)tid, a.log_n2);
     const bool has_rnd = m1 * n1 < a.h;  // a wavefront-uniform "no" for all but the first work-items
     const u64* rnd = a.rnd + (u64)(v / a.fk) * a.h * a.fk + (v % a.fk);
@@ -490,7 +507,7 @@ __global__ void __launch_bounds__(1024) k_lde_pass3_v2(LdePass3Args a) {
     const int vl = blockIdx.x;
     const u64* zc = a.z + (u64)vl * X * (n2 << a.log_n1) + tid;
     u64* tw_fwd = s + 16 * RS;  // twiddles in LDS (see k_lde_pass2_v2)
-    if (tid < (n1 >> 1)) tw_fwd[tid] = a.tw_b2[tid];
+    tw_fwd[tid] = a.tw_b2[tid];   // all n1 powers (nt == n1)
     // store phase: work-item tid writes position j2 = tid of all 16 rows (consecutive lanes = consecutive storage rows)
     const u64 W = (u64)a.W;
     u64* const out_t = a.table + ((((u64)(tid >> TVM_RB_LOG)) * W + (u64)(a.col0 + vl)) << TVM_RB_LOG) + (tid & (TVM_RB - 1));
@@ -553,8 +570,13 @@ __global__ void __launch_bounds__(1 << TLOG) k_lde_pass2_v3(LdePass2Args a) {
     u64 coef[16];
 #pragma unroll
     for (int e = 0; e < 16; e++) coef[e] = s[(e & (ROWS - 1)) * RS + tid + (e >> RLOG) * NT];
-    u64* tw_fwd = s + ROWS * RS;  // the forward twiddles behind the tile (see k_lde_pass2_v2)
-    for (int i = tid; i < (n2 >> 1); i += NT) tw_fwd[i] = a.tw_b1[i];
+    // the forward twiddles (all n2 powers) behind the tile (see k_lde_pass2_v2); a 4096-point axis leaves no room: global
+    const u64* tw_fwd = a.tw_b1;
+    if constexpr (LOGN < 12) {
+        u64* tw_lds = s + ROWS * RS;
+        for (int i = tid; i < n2; i += NT) tw_lds[i] = a.tw_b1[i];
+        tw_fwd = tw_lds;
+    }
     u64 m1[PPT], gh[PPT], gh_step[PPT];
     bool has_rnd = false;
 #pragma unroll
@@ -615,8 +637,12 @@ __global__ void __launch_bounds__(1 << TLOG) k_lde_pass3_v3(LdePass3Args a) {
     const int log_x = 31 - __builtin_clz((unsigned)a.n_cosets);
     const int vl = blockIdx.x;
     const u64* zc = a.z + (u64)vl * X * (n2 << LOGN) + tid;
-    u64* tw_fwd = s + ROWS * RS;
-    for (int i = tid; i < (n1 >> 1); i += NT) tw_fwd[i] = a.tw_b2[i];
+    const u64* tw_fwd = a.tw_b2;
+    if constexpr (LOGN < 12) {
+        u64* tw_lds = s + ROWS * RS;
+        for (int i = tid; i < n1; i += NT) tw_lds[i] = a.tw_b2[i];
+        tw_fwd = tw_lds;
+    }
     // store phase: work-item tid writes positions j2 = tid + hh * NT of every row of the tile (consecutive lanes =
     // consecutive storage rows and consecutive LDS words: full lines, no bank conflicts)
     const u64 W = (u64)a.W;
@@ -881,8 +907,8 @@ int ntt_columns(tvm_ctx* c, const u64* in, u64 in_len, int in_fk, u64 in_col_str
     a.in_col_stride = in_col_stride;
     a.tmp_col_stride = n;
     a.out_col_stride = out_col_stride;
-    a.tw1 = pow_table(c, bfe_pow(w, n2), n1 > 1 ? n1 / 2 : 1);
-    a.tw2 = pow_table(c, bfe_pow(w, n1), n2 / 2);
+    a.tw1 = pow_table(c, bfe_pow(w, n2), n1);
+    a.tw2 = pow_table(c, bfe_pow(w, n1), n2);
     TVM_TRY(make_inter(c, w, sp, &a.tw_inter));
     a.pre_hi = a.pre_lo = a.post_lo = a.post_hi = nullptr;
     if (in_scale != TVM_ONE) {
@@ -955,7 +981,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     p1.in_col_stride = N * fk;
     p1.tmp_col_stride = N;
     p1.out_col_stride = 0;
-    p1.tw1 = pow_table(c, bfe_pow(wi, n2), n1 > 1 ? n1 / 2 : 1);
+    p1.tw1 = pow_table(c, bfe_pow(wi, n2), n1);
     p1.tw2 = nullptr;
     TVM_TRY(make_inter(c, wi, sp, &p1.tw_inter));
     p1.pre_hi = p1.pre_lo = p1.post_lo = p1.post_hi = nullptr;
@@ -974,8 +1000,8 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     p2.h = h;
     p2.n_cosets = (int)X;
     p2.std_roots = std_roots ? 1 : 0;
-    p2.tw_a2 = pow_table(c, bfe_pow(wi, n1), n2 / 2);
-    p2.tw_b1 = pow_table(c, bfe_pow(w, n1), n2 / 2);
+    p2.tw_a2 = pow_table(c, bfe_pow(wi, n1), n2);
+    p2.tw_b1 = pow_table(c, bfe_pow(w, n1), n2);
     TVM_TRY(make_inter(c, w, sp, &p2.tw_inter));
     TVM_TRY(coset_tables(c, eval_offset, eval_gen, X, n1, n2, n_inv, &p2.g_lo, &p2.g_hi));
     p2.g_lo_step = pow_table(c, eval_gen, n1);
@@ -996,7 +1022,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     p3.W = W;
     p3.pitch = lde_table_layout(N, L).pitch;
     p3.std_roots = std_roots ? 1 : 0;
-    p3.tw_b2 = pow_table(c, bfe_pow(w, n2), n1 > 1 ? n1 / 2 : 1);
+    p3.tw_b2 = pow_table(c, bfe_pow(w, n2), n1);
     if (!p1.tw1 || !p2.tw_a2 || !p2.tw_b1 || !p2.g_lo || !p2.g_hi || !p2.g_lo_step || !p2.g_hi_step || !p3.tw_b2)
         return set_error(c, TVM_ERR_OUT_OF_MEMORY, "lde tables");
 
@@ -1029,7 +1055,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             // size the CPU suite can run (128 / 256 points on 64 work-items); rows per tile = 16 / positions per work-item
             const int ppt_log = (sp.log_n2 == 11 || sp.log_n2 == 7) ? 1 : (sp.log_n2 == 12 || sp.log_n2 == 8) ? 2 : 0;
             const u64 rows3 = 16 >> ppt_log;
-            const size_t lds_v3 = (size_t)(rows3 * (n2 + TVM_ROW_PAD) + n2 / 2) * sizeof(u64);
+            const size_t lds_v3 = (size_t)(rows3 * (n2 + TVM_ROW_PAD) + (sp.log_n2 < 12 ? n2 : 0)) * sizeof(u64);
             const dim3 g2((unsigned)(n1 / rows3), (unsigned)nc);
             if (std_roots && ppt_log && n1 % rows3 == 0) {
                 if (sp.log_n2 == 11) TVM_LAUNCH((k_lde_pass2_v3<11, 10>), g2, dim3(1024), lds_v3, c->stream, a);
@@ -1038,7 +1064,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
                 else TVM_LAUNCH((k_lde_pass2_v3<8, 6>), g2, dim3(64), lds_v3, c->stream, a);
             }
             else if (std_roots && a.batch_log == 4 && n2 >= 64 && n1 >= 16)  // production shape: one work-item per column of the tile
-                TVM_LAUNCH(k_lde_pass2_v2, grid, dim3((unsigned)n2), lds + (n2 / 2) * sizeof(u64), c->stream, a);
+                TVM_LAUNCH(k_lde_pass2_v2, grid, dim3((unsigned)n2), lds + n2 * sizeof(u64), c->stream, a);
             else
                 TVM_LAUNCH(k_lde_pass2, grid, dim3(threads_for_tile(tile)), lds, c->stream, a);
         }
@@ -1060,7 +1086,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
                 a.tiles = tiles_q % 32 == 0 ? 32 : tiles_q % 8 == 0 ? 8 : 1;
                 if (tiles_q / a.tiles >= 65536) return set_error(c, TVM_ERR_UNSUPPORTED, "lde: too many row tiles");
                 const dim3 g3((unsigned)nc, (unsigned)(tiles_q / a.tiles));
-                const size_t lds_q = (size_t)(4 * (n1 + TVM_ROW_PAD) + n1 / 2) * sizeof(u64);
+                const size_t lds_q = (size_t)(4 * (n1 + TVM_ROW_PAD) + n1) * sizeof(u64);
                 TVM_LAUNCH((k_lde_pass3_v3<10, 8>), g3, dim3(256), lds_q, c->stream, a);
             } else
             if (std_roots && sp.log_n1 == 10 && (X * n2) % 16 == 0 && X * n2 / 8 < 65536) {
@@ -1071,13 +1097,13 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
                 const u64 tiles_h = X * n2 / 8;
                 a.tiles = tiles_h % 16 == 0 ? 16 : tiles_h % 8 == 0 ? 8 : tiles_h % 4 == 0 ? 4 : 1;
                 const dim3 g3((unsigned)nc, (unsigned)(tiles_h / a.tiles));
-                const size_t lds_h = (size_t)(8 * (n1 + TVM_ROW_PAD) + n1 / 2) * sizeof(u64);
+                const size_t lds_h = (size_t)(8 * (n1 + TVM_ROW_PAD) + n1) * sizeof(u64);
                 TVM_LAUNCH((k_lde_pass3_v3<10, 9>), g3, dim3(512), lds_h, c->stream, a);
             } else
             if (std_roots && ppt_log && (X * n2) % 16 == 0) {
                 a.tiles = tiles3 % 8 == 0 ? 8 : tiles3 % 4 == 0 ? 4 : 1;
                 const dim3 g3((unsigned)nc, (unsigned)(tiles3 / a.tiles));
-                const size_t lds_v3 = (size_t)(rows3 * (n1 + TVM_ROW_PAD) + n1 / 2) * sizeof(u64);
+                const size_t lds_v3 = (size_t)(rows3 * (n1 + TVM_ROW_PAD) + (sp.log_n1 < 12 ? n1 : 0)) * sizeof(u64);
                 if (g3.y >= 65536) return set_error(c, TVM_ERR_UNSUPPORTED, "lde: too many row tiles");
                 if (sp.log_n1 == 11) TVM_LAUNCH((k_lde_pass3_v3<11, 10>), g3, dim3(1024), lds_v3, c->stream, a);
                 else if (sp.log_n1 == 12) TVM_LAUNCH((k_lde_pass3_v3<12, 10>), g3, dim3(1024), lds_v3, c->stream, a);
@@ -1085,7 +1111,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
                 else TVM_LAUNCH((k_lde_pass3_v3<8, 6>), g3, dim3(64), lds_v3, c->stream, a);
             } else if (std_roots && a.rows_log == 4 && n1 >= 64 && (X * n2) % 16 == 0 && X * n2 / 16 < 65536) {
                 a.tiles = grid.x % 8 == 0 ? 8 : grid.x % 4 == 0 ? 4 : 1;  // 1 -> 49.2 ms, 2 -> 47.5, 4 -> 47.0, 8 -> 46.3 (2^20 rows)
-                TVM_LAUNCH(k_lde_pass3_v2, dim3(grid.y, grid.x / a.tiles), dim3((unsigned)n1), lds + (n1 / 2) * sizeof(u64), c->stream, a);
+                TVM_LAUNCH(k_lde_pass3_v2, dim3(grid.y, grid.x / a.tiles), dim3((unsigned)n1), lds + n1 * sizeof(u64), c->stream, a);
             }
             else
                 TVM_LAUNCH(k_lde_pass3, grid, dim3(threads_for_tile(tile)), lds, c->stream, a);

@@ -69,6 +69,13 @@ TVM_HD void bfe_butterfly_dif_pow2(u64& lo, u64& hi) {
     else hi = bfe_mul_pow2<EE - 96>(bfe_sub(v, u));
 }
 
+// bit reversal of a K-bit index, usable in constant expressions
+TVM_HD constexpr int brev_k(int e, int k) {
+    int r = 0;
+    for (int i = 0; i < k; i++) r |= ((e >> i) & 1) << (k - 1 - i);
+    return r;
+}
+
 // log2 of the primitive 2^K-th root of unity the domains use (K <= 4), forward and inverse
 template <int K, bool INVERSE>
 struct Pow2Root {

@@ -34,13 +34,21 @@ def _powers(x, n, first=0):
 
 
 def verify(view, claim, security_level=160, log2_expansion=2, ldt_choice="fri"):
-    """view: ProofStream.verifier_view() of the decoded proof; claim: triton_vm_amd.proof_stream.Claim; ldt_choice: "fri" or
+    """view: oracle/proof_decode.py's VerifierView of the proof (or any object with its four methods); claim: an object with
+    program_digest / input / output (Montgomery words) and version; ldt_choice: "fri" or
     "stir" (Stark::ldt picks by padded height, stark.rs:1944-1951; the caller says which the prover used).
     Raises VerificationError; returns the first-round indices on acceptance."""
     from .real_prover import fri_num_collinearity_checks
 
     values = lambda a: [int(v) for v in orc.from_mont(np.asarray(a, np.uint64).reshape(-1))]
-    view.alter_fiat_shamir_state_with(claim.encode())
+    # Claim (proof.rs:62-120) in the oracle's own BFieldCodec: the struct's fields last field first, a dynamically sized
+    # one prefixed with its length (only the plain data of `claim` is read: digest, version, input, output)
+    from .real_prover import Variant, enc_bfe_words, enc_struct, enc_vec_static
+
+    encoded = enc_struct([enc_bfe_words(values(claim.program_digest)), enc_bfe_words([int(getattr(claim, "version", 6))]),
+                          enc_vec_static(values(claim.input), len(claim.input)), enc_vec_static(values(claim.output), len(claim.output))],
+                         Variant())
+    view.alter_fiat_shamir_state_with(orc.to_mont(np.array(encoded.words, dtype=object)) if encoded.words else np.zeros(0, np.uint64))
     log2_padded_height = values(view.dequeue("Log2PaddedHeight"))[0]
     if log2_padded_height >= 32:
         raise VerificationError("Log2PaddedHeightTooLarge")

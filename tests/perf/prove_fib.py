@@ -76,11 +76,10 @@ if ldt == "fri":   # the same through the C++ host (triton_vm::prove_execution):
         out["cpp_host_whole_prove_ms"] = round(1e3 * (time.perf_counter() - t0), 1)
     out["cpp_host_proof_equals_python_host_proof"] = bool(words.size == proof.words.size and (words == proof.words).all())
 if "--no-verify" not in sys.argv:
-    from oracle import real_verifier
-    from triton_vm_amd.proof_stream import ProofStream
+    from oracle import proof_decode, real_verifier
 
     t0 = time.perf_counter()
-    indices = real_verifier.verify(ProofStream.from_proof(ctx.lib, proof.words).verifier_view(), claim, log2_expansion=log2_expansion, ldt_choice=ldt)
+    indices = real_verifier.verify(proof_decode.VerifierView(proof.words), claim, log2_expansion=log2_expansion, ldt_choice=ldt)
     out["verified"] = True
     out["verifier_s"] = round(time.perf_counter() - t0, 1)
     out["revealed_rows"] = len(indices)

@@ -63,10 +63,9 @@ def execution(kind, log2):
 
 @pytest.mark.parametrize("which,log2,ldt,log2_expansion,restated", CASES)
 def test_baseline_config_proves_and_verifies(gctx, orc, which, log2, ldt, log2_expansion, restated):
-    from oracle import real_verifier
+    from oracle import proof_decode, real_verifier
     from tests import test_proof_snapshot as snap
     from triton_vm_amd import native_host, verifier as product
-    from triton_vm_amd.proof_stream import ProofStream
     from triton_vm_amd.prover import Prover
 
     ctx, kind = gctx, which[0]
@@ -93,7 +92,7 @@ def test_baseline_config_proves_and_verifies(gctx, orc, which, log2, ldt, log2_e
     accepted_at = product.Verifier(ctx, ldt=ldt, **kw).verify(claim, proof.words)
     assert len(accepted_at) >= 160 // 2
     if restated:
-        view = ProofStream.from_proof(ctx.lib, proof.words).verifier_view()
+        view = proof_decode.VerifierView(proof.words)      # the oracle's own decoder and sponge: nothing of the product
         assert real_verifier.verify(view, claim, ldt_choice=effective_ldt, **kw) == accepted_at
     from triton_vm_amd.proof_stream import Claim
 

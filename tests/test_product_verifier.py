@@ -19,8 +19,8 @@ def test_air_constraints_at_one_row_pair_equal_the_oracle_circuit(ctx, orc):
 
 
 def test_product_verifier_accepts_the_reference_pinned_proof_and_agrees_with_the_oracle_on_rejections(ctx):
-    from oracle import real_verifier
-    from triton_vm_amd.proof_stream import Claim, ProofDecodingError, ProofStream
+    from oracle import proof_decode, real_verifier
+    from triton_vm_amd.proof_stream import Claim, ProofDecodingError
     from triton_vm_amd.verifier import VerificationError, Verifier
 
     words, claim, indices = oracle_proof("tiny", snap.SEED_U64, 160)
@@ -30,11 +30,11 @@ def test_product_verifier_accepts_the_reference_pinned_proof_and_agrees_with_the
     def verdicts(bad_words, bad_claim, **kw):
         out = []
         for run in (lambda: (Verifier(ctx, **kw) if kw else verifier).verify(bad_claim, bad_words),
-                    lambda: real_verifier.verify(ProofStream.from_proof(ctx.lib, bad_words).verifier_view(), bad_claim, **kw)):
+                    lambda: real_verifier.verify(proof_decode.VerifierView(bad_words), bad_claim, **kw)):
             try:
                 run()
                 out.append("accepted")
-            except (VerificationError, real_verifier.VerificationError, ProofDecodingError, ValueError):
+            except (VerificationError, real_verifier.VerificationError, ProofDecodingError, proof_decode.DecodingError, ValueError):
                 out.append("rejected")
         return out
 

@@ -27,6 +27,8 @@ def _params(ldt):
 
     if ldt == "fri":
         return StarkParameters(LOG2_ROWS, num_trace_randomizers=H, num_collinearity_checks=QUERIES)
+    if ldt == "fri16":   # LDT expansion 16 (BASELINE config 5's FRI log-blowup 4): the quotient domain is a quarter of the LDT domain
+        return StarkParameters(LOG2_ROWS, num_trace_randomizers=H, num_collinearity_checks=QUERIES, log2_expansion=4)
     from triton_vm_amd import low_degree_test as ldt_module   # STIR at a security level that still has a quotienting round at this size
 
     stir = ldt_module.stark_stir(1 << LOG2_ROWS, security_level=8)
@@ -64,13 +66,14 @@ def _worker(rank, world, port, out, split_trees, ldt):
         prover.split_tree_min_leaves = 0   # every tree with at least two leaves per rank is built split (production: >= 2^21 leaves)
     got = _capture(prover)
     # three table trees and the FRI rounds with at least two leaves per rank
-    assert getattr(prover, "split_trees_built", 0) >= ((4 if ldt == "fri" else 3) if split_trees else 0) and (split_trees or not hasattr(prover, "split_trees_built"))
+    assert getattr(prover, "split_trees_built", 0) >= ((4 if ldt.startswith("fri") else 3) if split_trees else 0) and (split_trees or not hasattr(prover, "split_trees_built"))
     out.put((rank, got))
     dist.destroy_process_group()
     ctx.close()
 
 
-@pytest.mark.parametrize("world,split_trees,ldt", [(2, True, "fri"), (4, False, "fri"), (8, True, "fri"), (2, True, "stir")])
+@pytest.mark.parametrize("world,split_trees,ldt", [(2, True, "fri"), (4, False, "fri"), (8, True, "fri"), (2, True, "stir"), (2, True, "fri16"),
+                                                   (8, False, "fri16")])
 def test_sharded_proof_equals_single_process_proof(world, split_trees, ldt):
     import torch.multiprocessing as mp
 

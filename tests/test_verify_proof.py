@@ -36,10 +36,22 @@ def host_lib():
 
 
 def verify(host_lib, words, claim, **kw):
-    from oracle import real_verifier
-    from triton_vm_amd.proof_stream import ProofStream
+    """the restated Verifier::verify over the oracle's OWN decoding of the proof and its own sponge (oracle/proof_decode.py:
+    nothing of the product's proof_stream.py or host-side Tip5 takes part); the product's decoder must read the same items"""
+    from oracle import proof_decode, real_verifier
+    from triton_vm_amd.proof_stream import ProofDecodingError, ProofStream
 
-    return real_verifier.verify(ProofStream.from_proof(host_lib, words).verifier_view(), claim, **kw)
+    try:
+        view = proof_decode.VerifierView(words)
+    except proof_decode.DecodingError as e:
+        with pytest.raises(ProofDecodingError):       # both decoders refuse the same proofs
+            ProofStream.from_proof(host_lib, words)
+        raise ProofDecodingError(str(e))
+    theirs = ProofStream.from_proof(host_lib, words).log
+    assert len(theirs) == len(view.pending)
+    for (name, _enc, _k, payload), (label, other, _fs) in zip(view.pending, theirs):
+        assert np.array_equal(np.asarray(payload).reshape(-1), np.asarray(other).reshape(-1)), (name, label)
+    return real_verifier.verify(view, claim, **kw)
 
 
 def test_verifier_accepts_the_reference_pinned_proof(host_lib):

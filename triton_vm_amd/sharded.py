@@ -138,9 +138,10 @@ class ShardedProver(Prover):
 
     @staticmethod
     def _check_sharding(params, dist):
-        expansion = params.ldt.length // params.trace.length
-        if params.quotient.length != params.ldt.length or expansion % dist.get_world_size():
-            raise ValueError("coset sharding needs |quotient| == |LDT| and a world size dividing |LDT| / |trace|")
+        world = dist.get_world_size()
+        if (params.ldt.length // params.trace.length) % world or (params.quotient.length // params.trace.length) % world \
+                or params.quotient.length > params.ldt.length:
+            raise ValueError("coset sharding needs a world size that divides |LDT| / |trace| and |quotient| / |trace|")
 
     def _init_sharding(self, dist, device):
         import torch
@@ -256,13 +257,36 @@ class ShardedProver(Prover):
         return a_indices
 
     def _quotient_codeword(self, challenges, quotient_weights):
-        ctx = self.ctx
+        """this rank's rows q = rank (mod world) of the quotient domain, all-gathered into row order.  With |quotient| ==
+        |LDT| (Stark::default()) those are rows of the cached tables; with a shorter quotient domain (LDT expansion 16:
+        the quotient domain is the stride-4 view of the LDT domain, whose cosets k = 0 (mod 4) sit on a quarter of the
+        ranks) every rank extends the traces once more onto ITS share of the quotient domain -- 1/4 of its LDT share --
+        so that the AIR, the one stage that reads the quotient rows, stays spread evenly over the ranks."""
+        ctx, p = self.ctx, self.p
         ch = np.ascontiguousarray(challenges, dtype=np.uint64).reshape(63, 3)
         w = np.ascontiguousarray(quotient_weights, dtype=np.uint64).reshape(604, 3)
-        local = self._empty(3 * self.ldt_local.length)
-        ctx._check(ctx.lib.tvm_all_quotients_combined(ctx.handle, self.main._need_table(), self.aux._need_table(),
-                                                      self.p.trace.c(), self.ldt_local.c(), ch.ctypes.data, w.ctypes.data,
-                                                      local.data_ptr()), "all_quotients_combined")
+        valid = getattr(self, "assume_valid_trace", False)
+        if valid:
+            ctx.assume_valid_trace(True)
+        try:
+            if p.quotient.length == p.ldt.length:
+                q_local, tables = self.ldt_local, (self.main, self.aux)
+            else:
+                q_local = local_domain(p.quotient, self.rank, self.world)
+                tables = tuple(MasterTable.from_device(ctx, mt.d_trace, mt.d_randomizers, mt.n_cols, mt.n_rows, mt.num_trace_randomizers,
+                                                       mt.trace_domain, q_local, q_local, mt.fk) for mt in (self.main, self.aux))
+                for t in tables:
+                    t.maybe_low_degree_extend_all_columns()
+            local = self._empty(3 * q_local.length)
+            ctx._check(ctx.lib.tvm_all_quotients_combined(ctx.handle, tables[0]._need_table(), tables[1]._need_table(),
+                                                          p.trace.c(), q_local.c(), ch.ctypes.data, w.ctypes.data,
+                                                          local.data_ptr()), "all_quotients_combined")
+            if tables[0] is not self.main:
+                for t in tables:
+                    t.clear_cache()
+        finally:
+            if valid:
+                ctx.assume_valid_trace(False)
         return _TensorBuffer(self._all_gather_rows(local, 3))
 
     def _all_gather_host(self, mine, cap):

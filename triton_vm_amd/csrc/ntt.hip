@@ -445,6 +445,24 @@ __global__ void __launch_bounds__(1024) k_lde_pass2_v2(LdePass2Args a) {
     const u64 m1 = brev_bits((u32)tid, a.log_n2);
     const bool has_rnd = m1 * n1 < a.h;  // a wavefront-uniform "no" for all but the first work-items
     const u64* rnd = a.rnd + (u64)(v / a.fk) * a.h * a.fk + (v % a.fk);
+    // h <= n1 (every production shape): only the coefficients m < n1, i.e. m1 = 0 = position 0 of each row, see a randomizer.
+    // Work-item 0 parks its 16 coefficients in LDS, work-items 0..15 fetch the randomizer word of "their" row once, and in
+    // every coset work-item e writes  s[e][0] = t[m] + zk * r[m]  (gamma_k^(n1*0) = 1) instead of work-item 0: no global
+    // load and no divergent 16-element branch inside the coset loop -- the wavefront that ran it used to arrive last at
+    // every barrier of every coset.
+    const bool single = a.h <= n1;
+    u64* c0 = tw_fwd + n2;
+    u64* r0 = c0 + 16;
+    if (single) {
+        if (tid == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) c0[e] = coef[e];
+        }
+        if (tid < 16) {
+            const u64 m = brev_bits((u32)(p0 + tid), a.log_n1);
+            r0[tid] = m < a.h ? rnd[m * a.fk] : 0;
+        }
+    }
     // store phase: this work-item writes row b = tid % 16, columns j1 = tid / 16 + i * n2/16, i < 16
     const int b_out = tid & 15, j1_0 = tid >> 4;
     const u64 m2_out = brev_bits((u32)(p0 + b_out), a.log_n1);
@@ -460,7 +478,13 @@ __global__ void __launch_bounds__(1024) k_lde_pass2_v2(LdePass2Args a) {
     const u64 gl_step = a.g_lo_step[m2_out];
     for (int k = 0; k < a.n_cosets; k++) {
         tvm_lds_barrier();
-        if (has_rnd) {
+        if (single) {
+            if (tid != 0) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) s[e * RS + tid] = bfe_mul(coef[e], gh);
+            }
+            if (tid < 16) s[tid * RS] = bfe_add(c0[tid], bfe_mul(a.zk[k], r0[tid]));
+        } else if (has_rnd) {
             const u64 zk = a.zk[k];
 #pragma unroll
             for (int e = 0; e < 16; e++) {
@@ -1064,7 +1088,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
                 else TVM_LAUNCH((k_lde_pass2_v3<8, 6>), g2, dim3(64), lds_v3, c->stream, a);
             }
             else if (std_roots && a.batch_log == 4 && n2 >= 64 && n1 >= 16)  // production shape: one work-item per column of the tile
-                TVM_LAUNCH(k_lde_pass2_v2, grid, dim3((unsigned)n2), lds + n2 * sizeof(u64), c->stream, a);
+                TVM_LAUNCH(k_lde_pass2_v2, grid, dim3((unsigned)n2), lds + (n2 + 32) * sizeof(u64), c->stream, a);
             else
                 TVM_LAUNCH(k_lde_pass2, grid, dim3(threads_for_tile(tile)), lds, c->stream, a);
         }

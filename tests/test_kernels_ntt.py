@@ -63,3 +63,23 @@ def test_lde_table_matches_oracle(ctx, orc, log_n, expansion, n_cols, h, fk):
     # reveal_rows is a gather of the same table
     idx = [0, 3, len(ev) - 1]
     assert (mt.reveal_rows(idx) == want[idx]).all()
+
+
+@pytest.mark.parametrize("log_n,fk,n_cols", [(20, 1, 2), (19, 3, 1)])
+def test_lde_with_1024_point_axes(ctx, orc, log_n, fk, n_cols):
+    """The production kernels of tvm_lde_table (one transform row per wavefront, csrc/ntt.hip: k_lde_pass2_rows /
+    k_lde_pass3_rows, taken for 1024-point axes: traces of 2^19 and 2^20 rows -- BASELINE config 1's height) on a few
+    columns at full height, sampled rows against the oracle's extension of the same columns.  (On the emulation too: its
+    wavefront-level synchronisation models the wavefront-private LDS exchange of these kernels.)"""
+    rng = np.random.default_rng(log_n + fk)
+    n, h = 1 << log_n, 198
+    shape = lambda k: (n_cols, k) + ((3,) if fk == 3 else ())
+    trace, rnd = orc.random_elements(rng, shape(n)), orc.random_elements(rng, shape(h))
+    ev = ArithmeticDomain.of_length(8 * n).with_offset(field.generator())
+    mt = MasterTable(ctx, trace, rnd, ArithmeticDomain.of_length(n), ev, ev, fk)
+    mt.maybe_low_degree_extend_all_columns()
+    rows = np.unique(np.concatenate([[0, 1, 7, 8, 15, 16, 8 * n - 1], rng.integers(0, 8 * n, 3000)])).astype(np.uint64)
+    got = mt.reveal_rows(rows)
+    want = orc.lde_table(trace, rnd, orc.Domain(ev.offset, ev.generator, ev.length), fk)
+    assert (got == want[rows.astype(np.int64)]).all()
+    mt.clear_cache()

@@ -175,6 +175,55 @@ TVM_D void lds_ntt_fixed(u64* s, const u64* __restrict__ tw, int tid, int nt) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// One transform row per WAVEFRONT.  A row of n = 2^LOGN points lives in LDS words only its wavefront touches, element p at
+// row[p + (p >> 4)] (one pad word per 16: the stride-16 accesses of the lowest group and the consecutive accesses of the
+// others all fall into distinct banks), and the butterfly groups of lds_ntt_group run with the wavefront's 64 lanes taking
+// groups lane, lane + 64, ...: between groups the data crosses lanes of the SAME wavefront only, so there is no workgroup
+// barrier inside a transform -- the wavefronts of a workgroup drift apart and one's LDS / memory phases run under another's
+// butterflies.  Roots: the domains' own (ROOT = 1) or their inverses (2); tw = all n powers of the root.
+#define TVM_ROW_SKEW(p) ((p) + ((p) >> 4))
+#define TVM_ROW_WORDS(n) ((n) + ((n) >> 4) + 1)   // odd pitch: position p of the 16 rows of a tile falls into 16 different banks
+template <bool DIT, int K, int L, int LOGN, int ROOT>
+TVM_D void row_ntt_group(u64* row, const u64* __restrict__ tw, int lane) {
+    static_assert(ROOT == 1 || ROOT == 2, "the domains' own roots of unity only");
+    constexpr int R = 1 << K, NG = 1 << (LOGN - K);
+#pragma unroll 1
+    for (int g = lane; g < NG; g += 64) {
+        const int j0 = g & ((1 << L) - 1);
+        const int base = ((g >> L) << (L + K)) | j0;
+        // skew(base + (e << L)) = skew(base) + skew(e << L): no carry into bit 4 -- for L >= 4 the second term is a multiple
+        // of 16, below that base mod 16 = j0 < 2^L and (e << L) mod 16 <= 16 - 2^L.  Every LDS address of the group is the
+        // lane's base plus an immediate.
+        static_assert(L == 0 || L + K >= 4, "no carry into bit 4 of the skewed index");
+        u64* const p = row + TVM_ROW_SKEW(base);
+        u64 x[R];
+#pragma unroll
+        for (int e = 0; e < R; e++) x[e] = p[TVM_ROW_SKEW(e << L)];
+        if constexpr (L > 0 && DIT) {
+#pragma unroll
+            for (int e = 1; e < R; e++) x[e] = bfe_mul(x[e], tw[(j0 * brev_k(e, K)) << (LOGN - L - K)]);
+        }
+        ntt_pow2_points<K, DIT, ROOT == 2>(x);
+        if constexpr (L > 0 && !DIT) {
+#pragma unroll
+            for (int e = 1; e < R; e++) x[e] = bfe_mul(x[e], tw[(j0 * brev_k(e, K)) << (LOGN - L - K)]);
+        }
+#pragma unroll
+        for (int e = 0; e < R; e++) p[TVM_ROW_SKEW(e << L)] = x[e];
+    }
+    tvm_wave_sync();
+}
+template <bool DIT, int MAXK, int LOGN, int ROOT, int DONE = 0>
+TVM_D void row_ntt(u64* row, const u64* __restrict__ tw, int lane) {
+    if constexpr (DONE < LOGN) {
+        constexpr int k = (LOGN - DONE) >= MAXK ? MAXK : (LOGN - DONE);
+        constexpr int l = DIT ? DONE : (LOGN - DONE - k);
+        row_ntt_group<DIT, k, l, LOGN, ROOT>(row, tw, lane);
+        row_ntt<DIT, MAXK, LOGN, ROOT, DONE + k>(row, tw, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Generic two-pass transform of `ncols` columns (grid.y), natural order in and out.
 //   X[k1 + N1*k2] = sum_{i2} w_N^(i2 k1) w_N2^(i2 k2) sum_{i1} x[i1*N2 + i2] w_N1^(i1 k1)
 // Input column v starts at in + (v / fk) * in_col_stride + v % fk with element stride fk, so an
@@ -702,6 +751,144 @@ __global__ void __launch_bounds__(1 << TLOG) k_lde_pass3_v3(LdePass3Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Passes 2 and 3 with one row per wavefront (row_ntt), for 1024-point axes (traces of 2^19 and 2^20 rows).
+//
+// Pass 3: a wavefront owns one (k, j1) row of Z at a time -- loads its 1024 words (16 coalesced loads per lane), transforms
+// them in its own LDS words and stores the 1024 results into 1024 consecutive storage rows of the table (context.h): NO
+// workgroup barrier after the twiddle table is staged.  Work-item = lane of wavefront w of WAVES; the workgroup walks a.tiles
+// tiles of WAVES rows, every wavefront with the loads of its next row in flight under the butterflies of the current one.
+template <int LOGN, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, 4) k_lde_pass3_rows(LdePass3Args a) {   // room for 4 wavefronts per SIMD: 128 VGPRs
+    constexpr int n1 = 1 << LOGN, ROWW = TVM_ROW_WORDS(n1), E = n1 / 64;
+    static_assert(E == 16, "16 elements per lane");
+    TVM_DYN_SMEM(u64, s);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const u64 n2 = 1ull << a.log_n2;
+    const u64 X = (u64)a.n_cosets;
+    const int log_x = 31 - __builtin_clz((unsigned)a.n_cosets);
+    const int vl = blockIdx.x;
+    const u64* zc = a.z + (u64)vl * X * (n2 << LOGN) + lane;
+    u64* row = s + w * ROWW;
+    u64* const rowl = row + TVM_ROW_SKEW(lane);
+    u64* tw_lds = s + WAVES * ROWW;
+    for (int i = tid; i < n1; i += 64 * WAVES) tw_lds[i] = a.tw_b2[i];
+    __syncthreads();   // the only workgroup barrier: the twiddles are read-only from here on
+    const u64 W = (u64)a.W;
+    u64* const out_l = a.table + ((((u64)(lane >> TVM_RB_LOG)) * W + (u64)(a.col0 + vl)) << TVM_RB_LOG) + (lane & (TVM_RB - 1));
+    u64 rho = ((u64)blockIdx.y * a.tiles) * WAVES + w;   // this wavefront's row of the first tile
+    u64 nxt[E];
+    {
+        const u64 j1 = rho >> log_x, k = rho & (X - 1);
+#pragma unroll
+        for (int e = 0; e < E; e++) nxt[e] = TVM_LOAD_STREAM(&zc[((k * n2 + j1) << LOGN) + 64 * e]);
+    }
+    for (int it = 0; it < a.tiles; it++, rho += WAVES) {
+#pragma unroll
+        for (int e = 0; e < E; e++) rowl[68 * e] = nxt[e];   // position lane + 64 e (skew: + 4 e)
+        tvm_wave_sync();
+        if (it + 1 < a.tiles) {
+            const u64 r2 = rho + WAVES, j1 = r2 >> log_x, k = r2 & (X - 1);
+#pragma unroll
+            for (int e = 0; e < E; e++) nxt[e] = TVM_LOAD_STREAM(&zc[((k * n2 + j1) << LOGN) + 64 * e]);
+        }
+        row_ntt<true, 4, LOGN, 1>(row, tw_lds, lane);
+        const u64 j1 = rho >> log_x, k = rho & (X - 1);
+        const u64 blk = (k * a.pitch + (j1 << LOGN)) >> TVM_RB_LOG;   // the row's first 16-row block of the table
+#pragma unroll 4
+        for (int e = 0; e < E; e++)   // j2 = lane + 64 e: consecutive lanes = consecutive storage rows, 4 full lines per store
+            TVM_STORE_STREAM(&out_l[((blk + 4 * e) * W) << TVM_RB_LOG], rowl[68 * e]);
+        tvm_wave_sync();   // (the next tile overwrites the row)
+    }
+}
+
+// Pass 2: as k_lde_pass2_v2 (work-item tid owns position tid of all 16 rows of the tile across the coset loop), but both
+// LDS-resident transforms run one row per wavefront (16 wavefronts, 16 rows): three workgroup barriers per coset -- around
+// the scale phase and before the store phase, where data changes wavefronts -- instead of six.
+template <int LOGN>
+__global__ void __launch_bounds__(1 << LOGN) k_lde_pass2_rows(LdePass2Args a) {
+    constexpr int n2 = 1 << LOGN, ROWW = TVM_ROW_WORDS(n2);
+    static_assert(LOGN == 10, "16 wavefronts for 16 rows");
+    TVM_DYN_SMEM(u64, s);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const u64 n1 = 1ull << a.log_n1;
+    const int vl = blockIdx.y, v = a.col0 + vl;
+    const u64 p0 = (u64)blockIdx.x * 16;
+    const u64 n = n1 << LOGN;
+    const u64* y = a.y + (u64)vl * n + p0 * n2;
+    const int me = TVM_ROW_SKEW(tid);
+#pragma unroll
+    for (int e = 0; e < 16; e++) s[e * ROWW + me] = TVM_LOAD_STREAM(&y[(u64)e * n2 + tid]);
+    u64* tw_fwd = s + 16 * ROWW;   // all n2 powers of the forward root, behind the tile
+    tw_fwd[tid] = a.tw_b1[tid];
+    tvm_lds_barrier();
+    // inverse rows step, row w by wavefront w: position q of row e then holds N * t[m1*n1 + m2], m1 = brev(q)
+    row_ntt<false, 4, LOGN, 2>(s + w * ROWW, a.tw_a2, lane);
+    tvm_lds_barrier();
+    u64 coef[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) coef[e] = s[e * ROWW + me];
+    const u64 m1 = brev_bits((u32)tid, LOGN);
+    const bool has_rnd = m1 * n1 < a.h;
+    const u64* rnd = a.rnd + (u64)(v / a.fk) * a.h * a.fk + (v % a.fk);
+    const bool single = a.h <= n1;   // see k_lde_pass2_v2
+    u64* c0 = tw_fwd + n2;
+    u64* r0 = c0 + 16;
+    if (single) {
+        if (tid == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) c0[e] = coef[e];
+        }
+        if (tid < 16) {
+            const u64 m = brev_bits((u32)(p0 + tid), a.log_n1);
+            r0[tid] = m < a.h ? rnd[m * a.fk] : 0;
+        }
+    }
+    const int b_out = tid & 15, j1_0 = tid >> 4;
+    const u64 m2_out = brev_bits((u32)(p0 + b_out), a.log_n1);
+    constexpr int j1_step = n2 >> 4;
+    const u64 t_step = pow2_get(a.tw_inter, (m2_out * (u64)j1_step) & (n - 1));
+    u64 gh = a.g_hi[m1];
+    const u64 gh_step = a.g_hi_step[m1];
+    u64 t_first = bfe_mul(pow2_get(a.tw_inter, m2_out * (u64)j1_0), a.g_lo[m2_out]);
+    const u64 gl_step = a.g_lo_step[m2_out];
+    for (int k = 0; k < a.n_cosets; k++) {
+        tvm_lds_barrier();   // the store phase of the previous coset has read the tile
+        if (single) {
+            if (tid != 0) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) s[e * ROWW + me] = bfe_mul(coef[e], gh);
+            }
+            if (tid < 16) s[tid * ROWW] = bfe_add(c0[tid], bfe_mul(a.zk[k], r0[tid]));
+        } else if (has_rnd) {
+            const u64 zk = a.zk[k];
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const u64 m = m1 * n1 + brev_bits((u32)(p0 + e), a.log_n1);
+                u64 c = coef[e];
+                if (m < a.h) c = bfe_add(c, bfe_mul(zk, rnd[m * a.fk]));
+                s[e * ROWW + me] = bfe_mul(c, gh);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; e++) s[e * ROWW + me] = bfe_mul(coef[e], gh);
+        }
+        tvm_lds_barrier();
+        row_ntt<true, 3, LOGN, 1>(s + w * ROWW, tw_fwd, lane);   // forward columns step of row w (coef[] stays live: 8-element groups)
+        tvm_lds_barrier();
+        u64* z = a.z + ((u64)vl * a.n_cosets + k) * n + p0 + b_out;
+        u64 t = t_first;
+#pragma unroll 4
+        for (int i = 0; i < 16; i++) {
+            const int j1 = j1_0 + i * j1_step;
+            TVM_STORE_STREAM(&z[(u64)j1 * n1], bfe_mul(s[b_out * ROWW + TVM_ROW_SKEW(j1)], t));
+            t = bfe_mul(t, t_step);
+        }
+        gh = bfe_mul(gh, gh_step);
+        t_first = bfe_mul(t_first, gl_step);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // hipMalloc allocates on the calling thread's CURRENT device, which another context (or the application) may have
 // changed since tvm_ctx_create: every allocating path re-selects the context's device first.
@@ -832,6 +1019,8 @@ static void set_lds_attributes() {
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_v2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_v3<10, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_v3<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass2_rows<10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_v3<11, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_v3<11, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_v3<12, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -1013,6 +1202,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     p1.out_add = 0;
     p1.col0 = 0;
     const bool std_roots = classify_root(w, N) == 1;  // every ArithmeticDomain's generator is; any other root takes the generic kernels
+    static const bool lde_rows = !(std::getenv("TVM_LDE_ROWS") && std::atoi(std::getenv("TVM_LDE_ROWS")) == 0);  // experiment knob
     p1.root = std_roots ? 2 : 0;
 
     LdePass2Args p2;
@@ -1087,6 +1277,11 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
                 else if (sp.log_n2 == 7) TVM_LAUNCH((k_lde_pass2_v3<7, 6>), g2, dim3(64), lds_v3, c->stream, a);
                 else TVM_LAUNCH((k_lde_pass2_v3<8, 6>), g2, dim3(64), lds_v3, c->stream, a);
             }
+            else if (std_roots && lde_rows && sp.log_n2 == 10 && n1 % 16 == 0) {
+                // 1024-point axis: one row per wavefront inside the LDS-resident transforms (k_lde_pass2_rows)
+                const size_t lds_r = (size_t)(16 * TVM_ROW_WORDS(n2) + n2 + 32) * sizeof(u64);
+                TVM_LAUNCH((k_lde_pass2_rows<10>), dim3((unsigned)(n1 / 16), (unsigned)nc), dim3(1024), lds_r, c->stream, a);
+            }
             else if (std_roots && a.batch_log == 4 && n2 >= 64 && n1 >= 16)  // production shape: one work-item per column of the tile
                 TVM_LAUNCH(k_lde_pass2_v2, grid, dim3((unsigned)n2), lds + (n2 + 32) * sizeof(u64), c->stream, a);
             else
@@ -1103,6 +1298,15 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             const int ppt_log = (sp.log_n1 == 11 || sp.log_n1 == 7) ? 1 : (sp.log_n1 == 12 || sp.log_n1 == 8) ? 2 : 0;
             const u64 rows3 = 16 >> ppt_log, tiles3 = X * n2 / rows3;  // see pass 2
             static const int p3_rows = std::getenv("TVM_LDE_PASS3_ROWS") ? std::atoi(std::getenv("TVM_LDE_PASS3_ROWS")) : 8;  // experiment knob
+            if (std_roots && lde_rows && sp.log_n1 == 10 && (X * n2) % 8 == 0) {
+                // 1024-point axis: one (k, j1) row per wavefront, no workgroup barrier (k_lde_pass3_rows): 8 wavefronts per
+                // workgroup, 78 KB of LDS -- two workgroups per CU
+                const u64 tiles_w = X * n2 / 8;
+                a.tiles = tiles_w % 16 == 0 ? 16 : tiles_w % 8 == 0 ? 8 : tiles_w % 4 == 0 ? 4 : 1;
+                if (tiles_w / a.tiles >= 65536) return set_error(c, TVM_ERR_UNSUPPORTED, "lde: too many row tiles");
+                const size_t lds_w = (size_t)(8 * TVM_ROW_WORDS(n1) + n1) * sizeof(u64);
+                TVM_LAUNCH((k_lde_pass3_rows<10, 8>), dim3((unsigned)nc, (unsigned)(tiles_w / a.tiles)), dim3(512), lds_w, c->stream, a);
+            } else
             if (std_roots && sp.log_n1 == 10 && p3_rows == 4 && (X * n2) % 16 == 0) {
                 // 4-row tiles on 256 work-items, 37 KB of LDS: FOUR workgroups per CU.  Every row of a tile owns 1024 consecutive
                 // storage rows of the table (context.h), so the stores are full lines whatever the tile height.

@@ -26,6 +26,16 @@ static inline void tvm_lds_barrier() { __syncthreads(); }
 static __device__ __forceinline__ void tvm_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #endif
 
+// tvm_wave_sync(): orders the LDS traffic of ONE wavefront -- the lanes of a wavefront exchange data through LDS words that
+// only this wavefront touches (ntt.hip: one transform row per wavefront), so no workgroup barrier is needed: the LDS unit
+// serves a wavefront's instructions in order; the wait makes the writes visible before the reads that follow are issued and
+// keeps the compiler from moving LDS accesses across.
+#ifdef TVM_EMU
+static inline void tvm_wave_sync() { emu::sync_wave(); }
+#else
+static __device__ __forceinline__ void tvm_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#endif
+
 // Streaming accesses (non-temporal: the LDE's intermediates and table, written once and read a whole pass later, or read
 // once): measured -3 % on the LDE at 2^20 rows (main table 46.8 -> 45.2 ms); nothing for the VALU-bound row hashing.
 #if defined(TVM_EMU)

@@ -181,6 +181,9 @@ TVM_D void lds_ntt_fixed(u64* s, const u64* __restrict__ tw, int tid, int nt) {
 // groups lane, lane + 64, ...: between groups the data crosses lanes of the SAME wavefront only, so there is no workgroup
 // barrier inside a transform -- the wavefronts of a workgroup drift apart and one's LDS / memory phases run under another's
 // butterflies.  Roots: the domains' own (ROOT = 1) or their inverses (2); tw = all n powers of the root.
+#ifndef TVM_P2_MAXK
+#define TVM_P2_MAXK 4   // butterfly layers per LDS round trip in the forward columns step of k_lde_pass2_rows
+#endif
 #define TVM_ROW_SKEW(p) ((p) + ((p) >> 4))
 #define TVM_ROW_WORDS(n) ((n) + ((n) >> 4) + 1)   // odd pitch: position p of the 16 rows of a tile falls into 16 different banks
 template <bool DIT, int K, int L, int LOGN, int ROOT>
@@ -873,7 +876,7 @@ __global__ void __launch_bounds__(1 << LOGN) k_lde_pass2_rows(LdePass2Args a) {
             for (int e = 0; e < 16; e++) s[e * ROWW + me] = bfe_mul(coef[e], gh);
         }
         tvm_lds_barrier();
-        row_ntt<true, 3, LOGN, 1>(s + w * ROWW, tw_fwd, lane);   // forward columns step of row w (coef[] stays live: 8-element groups)
+        row_ntt<true, TVM_P2_MAXK, LOGN, 1>(s + w * ROWW, tw_fwd, lane);   // forward columns step of row w
         tvm_lds_barrier();
         u64* z = a.z + ((u64)vl * a.n_cosets + k) * n + p0 + b_out;
         u64 t = t_first;
@@ -1020,6 +1023,8 @@ static void set_lds_attributes() {
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_v3<10, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_v3<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<10, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<10, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_rows<10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_v3<11, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_v3<11, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -1179,6 +1184,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     // columns per chunk: 96 while the chunk's intermediate (96 * L words) stays below 8 GiB, else 32.  Measured at 2^20 rows
     // (main table, with 8 row tiles per pass-3 workgroup): 16 -> 48.0 ms, 32 -> 47.0, 96 -> 45.6, 192 -> 45.5, 379 -> 45.1
     if (chunk_cols <= 0) chunk_cols = ((size_t)96 * X * n_rows * sizeof(u64) <= ((size_t)8 << 30)) ? 96 : 32;
+    if (std::getenv("TVM_LDE_CHUNK") && std::atoi(std::getenv("TVM_LDE_CHUNK")) > 0) chunk_cols = std::atoi(std::getenv("TVM_LDE_CHUNK"));  // experiment knob
 
     const u64 w = trace_gen, wi = bfe_inv(trace_gen);
     const u64 n_inv = bfe_inv(bfe_from_u64(N));
@@ -1301,11 +1307,16 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             if (std_roots && lde_rows && sp.log_n1 == 10 && (X * n2) % 8 == 0) {
                 // 1024-point axis: one (k, j1) row per wavefront, no workgroup barrier (k_lde_pass3_rows): 8 wavefronts per
                 // workgroup, 78 KB of LDS -- two workgroups per CU
-                const u64 tiles_w = X * n2 / 8;
+                static const int p3_waves = std::getenv("TVM_LDE_PASS3_WAVES") ? std::atoi(std::getenv("TVM_LDE_PASS3_WAVES")) : 8;  // experiment knob
+                const u64 waves = (p3_waves == 4 || p3_waves == 16) && (X * n2) % (u64)p3_waves == 0 ? (u64)p3_waves : 8;
+                const u64 tiles_w = X * n2 / waves;
                 a.tiles = tiles_w % 16 == 0 ? 16 : tiles_w % 8 == 0 ? 8 : tiles_w % 4 == 0 ? 4 : 1;
                 if (tiles_w / a.tiles >= 65536) return set_error(c, TVM_ERR_UNSUPPORTED, "lde: too many row tiles");
-                const size_t lds_w = (size_t)(8 * TVM_ROW_WORDS(n1) + n1) * sizeof(u64);
-                TVM_LAUNCH((k_lde_pass3_rows<10, 8>), dim3((unsigned)nc, (unsigned)(tiles_w / a.tiles)), dim3(512), lds_w, c->stream, a);
+                const size_t lds_w = (size_t)(waves * TVM_ROW_WORDS(n1) + n1) * sizeof(u64);
+                const dim3 g3((unsigned)nc, (unsigned)(tiles_w / a.tiles));
+                if (waves == 4) TVM_LAUNCH((k_lde_pass3_rows<10, 4>), g3, dim3(256), lds_w, c->stream, a);
+                else if (waves == 16) TVM_LAUNCH((k_lde_pass3_rows<10, 16>), g3, dim3(1024), lds_w, c->stream, a);
+                else TVM_LAUNCH((k_lde_pass3_rows<10, 8>), g3, dim3(512), lds_w, c->stream, a);
             } else
             if (std_roots && sp.log_n1 == 10 && p3_rows == 4 && (X * n2) % 16 == 0) {
                 // 4-row tiles on 256 work-items, 37 KB of LDS: FOUR workgroups per CU.  Every row of a tile owns 1024 consecutive

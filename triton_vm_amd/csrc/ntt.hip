@@ -181,6 +181,9 @@ TVM_D void lds_ntt_fixed(u64* s, const u64* __restrict__ tw, int tid, int nt) {
 // groups lane, lane + 64, ...: between groups the data crosses lanes of the SAME wavefront only, so there is no workgroup
 // barrier inside a transform -- the wavefronts of a workgroup drift apart and one's LDS / memory phases run under another's
 // butterflies.  Roots: the domains' own (ROOT = 1) or their inverses (2); tw = all n powers of the root.
+#ifndef TVM_TW_BATCH
+#define TVM_TW_BATCH 0   // twiddle loads in flight per batch in row_ntt_group (0: let the compiler schedule them)
+#endif
 #ifndef TVM_P2_MAXK
 #define TVM_P2_MAXK 4   // butterfly layers per LDS round trip in the forward columns step of k_lde_pass2_rows
 #endif
@@ -202,14 +205,26 @@ TVM_D void row_ntt_group(u64* row, const u64* __restrict__ tw, int lane) {
         u64 x[R];
 #pragma unroll
         for (int e = 0; e < R; e++) x[e] = p[TVM_ROW_SKEW(e << L)];
+        // (the twiddles are fetched TVM_TW_BATCH at a time: left alone, hipcc hoists all 2^K - 1 loads above the
+        // multiplications -- 30 VGPRs that the coset loop of pass 2 does not have)
         if constexpr (L > 0 && DIT) {
 #pragma unroll
-            for (int e = 1; e < R; e++) x[e] = bfe_mul(x[e], tw[(j0 * brev_k(e, K)) << (LOGN - L - K)]);
+            for (int e = 1; e < R; e++) {
+                x[e] = bfe_mul(x[e], tw[(j0 * brev_k(e, K)) << (LOGN - L - K)]);
+                if constexpr (TVM_TW_BATCH > 0) {
+                    if (e % TVM_TW_BATCH == 0) asm volatile("" ::: "memory");
+                }
+            }
         }
         ntt_pow2_points<K, DIT, ROOT == 2>(x);
         if constexpr (L > 0 && !DIT) {
 #pragma unroll
-            for (int e = 1; e < R; e++) x[e] = bfe_mul(x[e], tw[(j0 * brev_k(e, K)) << (LOGN - L - K)]);
+            for (int e = 1; e < R; e++) {
+                x[e] = bfe_mul(x[e], tw[(j0 * brev_k(e, K)) << (LOGN - L - K)]);
+                if constexpr (TVM_TW_BATCH > 0) {
+                    if (e % TVM_TW_BATCH == 0) asm volatile("" ::: "memory");
+                }
+            }
         }
 #pragma unroll
         for (int e = 0; e < R; e++) p[TVM_ROW_SKEW(e << L)] = x[e];
@@ -663,6 +678,21 @@ __global__ void __launch_bounds__(1 << TLOG) k_lde_pass2_v3(LdePass2Args a) {
         gh_step[hh] = a.g_hi_step[m1[hh]];
     }
     const u64* rnd = a.rnd + (u64)(v / a.fk) * a.h * a.fk + (v % a.fk);
+    // h <= n1: only position 0 of each row (work-item 0's first ROWS coefficients) sees a randomizer -- parked in LDS, written
+    // into the tile by work-items 0 .. ROWS-1 in every coset (see k_lde_pass2_v2): no global load in the coset loop
+    const bool single = a.h <= n1;
+    u64* c0 = s + ROWS * RS + (LOGN < 12 ? n2 : 0);
+    u64* r0 = c0 + 16;
+    if (single) {
+        if (tid == 0) {
+#pragma unroll
+            for (int e = 0; e < ROWS; e++) c0[e] = coef[e];
+        }
+        if (tid < ROWS) {
+            const u64 m = brev_bits((u32)(p0 + tid), a.log_n1);
+            r0[tid] = m < a.h ? rnd[m * a.fk] : 0;
+        }
+    }
     // store phase: this work-item writes row b = tid % ROWS, columns j1 = tid / ROWS + i * NT / ROWS, i < 16
     // (the column slots of a wavefront are ROWS apart: LDS bank conflicts, see k_lde_pass3_v3)
     constexpr int LPW = 64 >> RLOG;
@@ -676,15 +706,24 @@ __global__ void __launch_bounds__(1 << TLOG) k_lde_pass2_v3(LdePass2Args a) {
     for (int k = 0; k < a.n_cosets; k++) {
         tvm_lds_barrier();
         const u64 zk = a.zk[k];
+        if (single) {
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const int r = e & (ROWS - 1), hh = e >> RLOG;
-            u64 c = coef[e];
-            if (has_rnd) {
-                const u64 m = m1[hh] * n1 + brev_bits((u32)(p0 + r), a.log_n1);
-                if (m < a.h) c = bfe_add(c, bfe_mul(zk, rnd[m * a.fk]));
+            for (int e = 0; e < 16; e++) {
+                const int r = e & (ROWS - 1), hh = e >> RLOG;
+                if (hh || tid) s[r * RS + tid + hh * NT] = bfe_mul(coef[e], gh[hh]);
             }
-            s[r * RS + tid + hh * NT] = bfe_mul(c, gh[hh]);
+            if (tid < ROWS) s[tid * RS] = bfe_add(c0[tid], bfe_mul(zk, r0[tid]));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int r = e & (ROWS - 1), hh = e >> RLOG;
+                u64 c = coef[e];
+                if (has_rnd) {
+                    const u64 m = m1[hh] * n1 + brev_bits((u32)(p0 + r), a.log_n1);
+                    if (m < a.h) c = bfe_add(c, bfe_mul(zk, rnd[m * a.fk]));
+                }
+                s[r * RS + tid + hh * NT] = bfe_mul(c, gh[hh]);
+            }
         }
         tvm_lds_barrier();
         lds_ntt_fixed<true, 3, LOGN, 0, RLOG, 1>(s, tw_fwd, tid, NT);
@@ -801,6 +840,45 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_lde_pass3_rows(LdePass3Args a
         for (int e = 0; e < E; e++)   // j2 = lane + 64 e: consecutive lanes = consecutive storage rows, 4 full lines per store
             TVM_STORE_STREAM(&out_l[((blk + 4 * e) * W) << TVM_RB_LOG], rowl[68 * e]);
         tvm_wave_sync();   // (the next tile overwrites the row)
+    }
+}
+
+// Pass 1 (the inverse transform's column step) in the same form: a tile is 16 adjacent columns i2 of the N1 x N2 view, i.e.
+// 16 rows of 1024 points i1 (128-byte runs in memory); wavefront w transforms row w (decimation in frequency, inverse roots),
+// and the store applies the inter-pass twiddle w_N^-(i2 * k1) as a running product over k1 = brev(position) -- the positions
+// of a work-item are visited in bit-reversed order so that k1 advances by one -- instead of two table loads per element.
+template <int LOGN>
+__global__ void __launch_bounds__(1 << LOGN) k_lde_pass1_rows(Ntt2Args a) {
+    constexpr int n1 = 1 << LOGN, ROWW = TVM_ROW_WORDS(n1);
+    static_assert(LOGN == 10, "16 wavefronts for 16 rows");
+    TVM_DYN_SMEM(u64, s);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const u64 n2 = 1ull << a.log_n2;
+    const int vl = blockIdx.y, v = a.col0 + vl;
+    const u64 i2_0 = (u64)blockIdx.x * 16;
+    const int b = tid & 15, q0 = tid >> 4;   // this work-item loads / stores row b, positions q0 + 64 * it
+    const u64* in = a.in + (u64)(v / a.in_fk) * a.in_col_stride + (v % a.in_fk) + (i2_0 + b) * a.in_fk;
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+        const int i1 = q0 + 64 * it;
+        s[b * ROWW + TVM_ROW_SKEW(i1)] = TVM_LOAD_STREAM(&in[(u64)i1 * n2 * a.in_fk]);
+    }
+    u64* tw_lds = s + 16 * ROWW;
+    tw_lds[tid] = a.tw1[tid];   // all n1 powers of the inverse root (blockDim.x == n1)
+    tvm_lds_barrier();
+    row_ntt<false, 4, LOGN, 2>(s + w * ROWW, tw_lds, lane);
+    tvm_lds_barrier();
+    // position p = q0 + 64 * brev4(c) holds index k1 = brev(p) = brev6(q0) * 16 + c
+    const u64 i2 = i2_0 + b;
+    const u64 k1_0 = (u64)brev_bits((u32)q0, 6) << 4;
+    u64 t = pow2_get(a.tw_inter, (i2 * k1_0) & ((n2 << LOGN) - 1));
+    const u64 t_step = pow2_get(a.tw_inter, i2);
+    u64* tmp = a.tmp + (u64)vl * a.tmp_col_stride + i2;
+#pragma unroll 4
+    for (int c = 0; c < 16; c++) {
+        const int p = q0 + 64 * (int)brev_bits((u32)c, 4);
+        TVM_STORE_STREAM(&tmp[(u64)p * n2], bfe_mul(s[b * ROWW + TVM_ROW_SKEW(p)], t));
+        t = bfe_mul(t, t_step);
     }
 }
 
@@ -1026,6 +1104,7 @@ static void set_lds_attributes() {
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<10, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<10, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_rows<10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass1_rows<10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_v3<11, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_v3<11, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_v3<12, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -1262,7 +1341,11 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             const int B = 1 << a.batch_log;
             const int tile = (int)n1 << a.batch_log;
             dim3 grid((unsigned)((n2 + B - 1) / B), (unsigned)nc);
-            TVM_LAUNCH(k_ntt2_pass1, grid, dim3(threads_for_tile(tile)), (size_t)tile * sizeof(u64), c->stream, a);
+            if (std_roots && lde_rows && sp.log_n1 == 10 && n2 % 16 == 0)   // 1024-point axis: one row per wavefront
+                TVM_LAUNCH((k_lde_pass1_rows<10>), dim3((unsigned)(n2 / 16), (unsigned)nc), dim3(1024),
+                           (size_t)(16 * TVM_ROW_WORDS(n1) + n1) * sizeof(u64), c->stream, a);
+            else
+                TVM_LAUNCH(k_ntt2_pass1, grid, dim3(threads_for_tile(tile)), (size_t)tile * sizeof(u64), c->stream, a);
         }
         {
             LdePass2Args a = p2;
@@ -1275,7 +1358,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             // size the CPU suite can run (128 / 256 points on 64 work-items); rows per tile = 16 / positions per work-item
             const int ppt_log = (sp.log_n2 == 11 || sp.log_n2 == 7) ? 1 : (sp.log_n2 == 12 || sp.log_n2 == 8) ? 2 : 0;
             const u64 rows3 = 16 >> ppt_log;
-            const size_t lds_v3 = (size_t)(rows3 * (n2 + TVM_ROW_PAD) + (sp.log_n2 < 12 ? n2 : 0)) * sizeof(u64);
+            const size_t lds_v3 = (size_t)(rows3 * (n2 + TVM_ROW_PAD) + (sp.log_n2 < 12 ? n2 : 0) + 32) * sizeof(u64);
             const dim3 g2((unsigned)(n1 / rows3), (unsigned)nc);
             if (std_roots && ppt_log && n1 % rows3 == 0) {
                 if (sp.log_n2 == 11) TVM_LAUNCH((k_lde_pass2_v3<11, 10>), g2, dim3(1024), lds_v3, c->stream, a);

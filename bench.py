@@ -271,6 +271,8 @@ def main():
     ap.add_argument("--jit-passes", type=int, default=0, help="synthetic data, single GPU: evaluate the extended tables coset-wise in this "
                     "many passes (triton_vm_amd/jit.py, the reference's JIT path) instead of caching them")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent proofs per GPU instead of one sharded proof")
+    ap.add_argument("--sharded", action="store_true", help="run the sharded prover (process group, collectives) even with ONE rank: the "
+                    "code path of the N > 1 runs on a single-GPU box (plumbing check; the collectives are identities)")
     ap.add_argument("--host", choices=["cpp", "python"], default="cpp",
                     help="host side that sequences the C-ABI calls of the timed step: the C++ mirror of Prover::prove "
                          "(triton_vm_amd/host/, the default where it applies: cached tables, one proof per GPU) or the "
@@ -288,14 +290,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist, device = None, None
-    if world > 1:
+    if world > 1 or args.sharded:
+        if "RANK" not in os.environ:   # --sharded without a launcher: a one-rank group on this process
+            import socket
+
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                port = sock.getsockname()[1]
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         dist, device = init_distributed(local_rank)
     dev_kind = "cuda" if device is None or device.type == "cuda" else "cpu"
 
     from triton_vm_amd.prover import Prover, StarkParameters, stark_parameters
 
     ctx = make_context(local_rank)
-    sharded = world > 1 and not args.replicas
+    sharded = (world > 1 or args.sharded) and not args.replicas
     ldt = None if args.ldt == "auto" else args.ldt
     effective_ldt = ldt or ("fri" if args.log2_rows < 16 else "stir")
     host_lib = None
@@ -328,6 +337,8 @@ def main():
                 from triton_vm_amd.sharded import ShardedProver
 
                 prover = ShardedProver.from_execution(ctx, dist, device, aet, padded_height, claim, PROVER_SEED, **kw)
+                if args.sharded:
+                    prover.split_tree_min_leaves = 0   # one rank: still build the trees split (all-to-all, subtree roots, remote nodes)
                 last["proof"] = prover.prove().proof().words
                 prover.release()
             elif host_lib is not None:
@@ -476,7 +487,7 @@ def main():
         if stage_ms.get("AIR quotients", 0.0) > (80.0 if args.log2_rows == 20 and world == 1 else 1e9):
             # the unexplained slow mode of the AIR kernels seen on 2 of ~40 boxes in round 2: leave evidence
             out["air_slow_mode"] = {"stage_ms": stage_ms["AIR quotients"], "smi": smi_snapshot()}
-        extras = world == 1 and not args.jit_passes and not args.no_extras
+        extras = world == 1 and not sharded and not args.jit_passes and not args.no_extras
         if extras and args.data == "real":
             # (1) the same step with the execution trace in host memory (what a host that keeps the AET in RAM pays)
             t = timed_steps(lambda: prove_from(e["aet"]), 3, 1, ctx.sync)

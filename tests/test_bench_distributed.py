@@ -104,3 +104,23 @@ def test_bench_script_spawns_its_own_ranks():
     assert len(lines) == 1
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak"
+
+
+@pytest.mark.gpu
+def test_bench_sharded_code_path_over_rccl_with_one_rank():
+    """`bench.py --sharded`: the code path of the driver's N > 1 runs -- process group over RCCL, ShardedProver.from_execution
+    on the real prove_fib trace, leaf digests through the all-to-all, split Merkle trees, all-gather of the quotient codeword,
+    the proof verified -- with a single rank on the single-GPU box (the collectives are identities, the plumbing is not)."""
+    import json
+    import subprocess
+
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--sharded", "--steps", "1", "--warmup", "0", "--log2-rows", "16",
+           "--no-cpu-baseline", "--no-extras"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["data"] == "real" and rec["verified"]["accepted"] and rec["n_gpus"] == 1
+    assert "one proof over" in rec["config"]["parallelism"]

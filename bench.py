@@ -469,7 +469,7 @@ def main():
                                        "digests, all-gather of the quotient codeword" if sharded else f"{world} independent proofs, one per GPU" if world > 1
                                        else f"single GPU, tables evaluated coset-wise in {args.jit_passes} passes (nothing cached)"
                                        if args.jit_passes else "single GPU")},
-            "roofline": {"bound": "hbm", "kernel": "main-table LDE: tvm_lde_table of 379 columns (k_ntt2_pass1 + k_lde_pass2* + k_lde_pass3*, column chunks of 96)",
+            "roofline": {"bound": "hbm", "kernel": "main-table LDE: tvm_lde_table of 379 columns (k_lde_pass1_rows + k_lde_pass2_rows + k_lde_pass3_rows at 2^20 rows, column chunks of 96)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_from,
                          "launch_ms": round(lde_avg_ms, 3),

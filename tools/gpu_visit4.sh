@@ -25,4 +25,4 @@ for k in ("pcie_inclusive","reference_default_ldt","synthetic_hot_path","cpu_bas
 P
 tail -3 gpurun_out/${TAG}_bench.err
 head -16 gpurun_out/${TAG}_kernels.txt
-grep -A20 "k_lde_pass2_v2\|k_lde_pass3_v3" gpurun_out/${TAG}_pmc_lde_summary.txt | head -50
+grep -A20 "k_lde_pass[123]_rows" gpurun_out/${TAG}_pmc_lde_summary.txt | head -50

@@ -12,7 +12,7 @@ import sys
 def main(path, cols=32):
     txt = open(path).read()
     total, per_kernel = 0.0, {}
-    for head, kernel in re.findall(r"^((?:void )?tvm::(k_ntt2_pass1|k_lde_pass2\w*|k_lde_pass3\w*)(?:<[^>\n]*>)?)$", txt, re.M):
+    for head, kernel in re.findall(r"^((?:void )?tvm::(k_ntt2_pass1|k_lde_pass1\w*|k_lde_pass2\w*|k_lde_pass3\w*)(?:<[^>\n]*>)?)$", txt, re.M):
         block = txt.split(head + "\n", 1)[1]
         kernel = head.replace("void ", "").replace("tvm::", "")
         get = lambda c: float(re.search(r"^\s+" + c + r"\s+avg\s+([0-9.]+)", block, re.M).group(1))  # noqa: E731

@@ -88,11 +88,13 @@ TVM_HD void mul64wide(u64 a, u64 b, u64& lo, u64& hi) {
     lo = (m2 << 32) | (u32)p00;
     hi = (u64)a1 * b1 + (m1 >> 32) + (m2 >> 32);
 }
-// Device multiplication: the four 32x32 partial products are C (v_mad_u64_u32), the carry chain is asm.
-// With t = a0*b0, u = a0*b1 + t1, v = a1*b0 + u0, w = a1*b1 + u1 the 128-bit product is
-// x = (w + v1) : v0 : t0; the asm adds v1 into w and performs bfe_montyred on 32-bit limbs with the
-// carries kept in VCC -- nine VALU instructions and one scalar one, where the compiler's rendering of the 64-bit C
-// form takes fourteen plus re-pairing moves and a zero-extended register pair per partial sum:
+// Device multiplication.  With t = a0*b0, u = a0*b1 + t1 and the 65-bit sum (c : v) = a1*b0 + u the 128-bit product is
+// x = (a1*b1 + (c : v1)) : v0 : t0 -- every addend but t1 is a FULL 64-bit register pair, so only t1 (and v1, next to the
+// carry c) has to be moved into the low half of an aligned pair: v_mad_u64_u32 takes its addend as an even-aligned VGPR
+// pair and the high half of a product always lands in an odd register.  (The textbook form u, v = a1*b0 + u0,
+// w = a1*b1 + u1, x3:x2 = w + v1 costs three such moves and two more additions per product: 16 VALU instructions where
+// this takes 14.)  The carry c is the mad's own carry-out (asm: C has no name for it); the tail is bfe_montyred on 32-bit
+// limbs with the carries kept in VCC -- seven VALU instructions and one scalar one:
 //   a1 = x1 + x0 (carry e);  b = (a1:x0) - a1 - e;  r = (x3:x2) - b;  if that borrowed (B), r -= 2^32 - 1.
 // The last step is r0 += B (carry c), r1 -= B & ~c: the borrow goes to an SGPR pair, the AND-NOT is an s_andn2
 // on the scalar unit, so the conditional correction costs two vector instructions instead of three.
@@ -101,22 +103,25 @@ TVM_HD u64 bfe_mul(u64 a, u64 b) {
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     const u64 t = (u64)a0 * b0;
     const u64 u = (u64)a0 * b1 + (t >> 32);
-    const u64 v = (u64)a1 * b0 + (u32)u;
-    const u64 w = (u64)a1 * b1 + (u >> 32);
+    u64 v, sc;
+    u32 c;
+    asm("v_mad_u64_u32 %[v], %[sc], %[a1], %[b0], %[u]\n\t" TVM_VCC_WAIT
+        "v_cndmask_b32_e64 %[c], 0, 1, %[sc]"
+        : [v] "=&v"(v), [sc] "=&s"(sc), [c] "=&v"(c)
+        : [a1] "v"(a1), [b0] "v"(b0), [u] "v"(u));
+    const u64 w = (u64)a1 * b1 + (((u64)c << 32) | (v >> 32));
     u32 r0, r1, s1, s0;
     u64 bw;
-    asm("v_add_co_u32 %[r0], vcc, %[w0], %[v1]\n\t" TVM_VCC_WAIT
-        "v_addc_co_u32 %[r1], vcc, 0, %[w1], vcc\n\t"
-        "v_add_co_u32 %[s1], vcc, %[x1], %[x0]\n\t" TVM_VCC_WAIT
+    asm("v_add_co_u32 %[s1], vcc, %[x1], %[x0]\n\t" TVM_VCC_WAIT
         "v_subb_co_u32 %[s0], vcc, %[x0], %[s1], vcc\n\t" TVM_VCC_WAIT
         "v_subbrev_co_u32 %[s1], vcc, 0, %[s1], vcc\n\t"
-        "v_sub_co_u32 %[r0], vcc, %[r0], %[s0]\n\t" TVM_VCC_WAIT
-        "v_subb_co_u32_e64 %[r1], %[bw], %[r1], %[s1], vcc\n\t" TVM_VCC_WAIT
+        "v_sub_co_u32 %[r0], vcc, %[w0], %[s0]\n\t" TVM_VCC_WAIT
+        "v_subb_co_u32_e64 %[r1], %[bw], %[w1], %[s1], vcc\n\t" TVM_VCC_WAIT
         "v_addc_co_u32_e64 %[r0], vcc, %[r0], 0, %[bw]\n\t"
         "s_andn2_b64 vcc, %[bw], vcc\n\t"
         "v_subbrev_co_u32 %[r1], vcc, 0, %[r1], vcc"
         : [r0] "=&v"(r0), [r1] "=&v"(r1), [s1] "=&v"(s1), [s0] "=&v"(s0), [bw] "=&s"(bw)
-        : [x0] "v"((u32)t), [x1] "v"((u32)v), [w0] "v"((u32)w), [w1] "v"((u32)(w >> 32)), [v1] "v"((u32)(v >> 32))
+        : [x0] "v"((u32)t), [x1] "v"((u32)v), [w0] "v"((u32)w), [w1] "v"((u32)(w >> 32))
         : "vcc", "scc");
     return ((u64)r1 << 32) | r0;
 #else
@@ -137,24 +142,25 @@ TVM_HD u64 bfe_mul(u64 a, u64 b) {
 #define TVM_CB "%[cb]"
 #define TVM_CC "%[cc]"
 // steps of the multiplication tail (see bfe_mul): S = operand suffix of the chain, C = its carry register
-#define TVM_M1(S, C) "v_add_co_u32_e64 %[r0" #S "], " C ", %[w0" #S "], %[v1" #S "]\n\t"
-#define TVM_M2(S, C) "v_addc_co_u32_e64 %[r1" #S "], " C ", 0, %[w1" #S "], " C "\n\t"
+// the middle partial product with its carry-out, and the carry as a 0/1 word (see bfe_mul)
+#define TVM_MV(S, C) "v_mad_u64_u32 %[v" #S "], " C ", %[a1" #S "], %[b0" #S "], %[u" #S "]\n\t"
+#define TVM_MC(S, C) "v_cndmask_b32_e64 %[k" #S "], 0, 1, " C "\n\t"
+#define TVM_MID_OUT(S, v, c) [v##S] "=&v"(v), [k##S] "=&v"(c)
+#define TVM_MID_IN(S, a, b, u) [a1##S] "v"((u32)((a) >> 32)), [b0##S] "v"((u32)(b)), [u##S] "v"(u)
 #define TVM_M3(S, C) "v_add_co_u32_e64 %[s1" #S "], " C ", %[x1" #S "], %[x0" #S "]\n\t"
 #define TVM_M4(S, C) "v_subb_co_u32_e64 %[s0" #S "], " C ", %[x0" #S "], %[s1" #S "], " C "\n\t"
 #define TVM_M5(S, C) "v_subbrev_co_u32_e64 %[s1" #S "], " C ", 0, %[s1" #S "], " C "\n\t"
-#define TVM_M6(S, C) "v_sub_co_u32_e64 %[r0" #S "], " C ", %[r0" #S "], %[s0" #S "]\n\t"
-#define TVM_M7(S, C) "v_subb_co_u32_e64 %[r1" #S "], %[bw" #S "], %[r1" #S "], %[s1" #S "], " C "\n\t"
+#define TVM_M6(S, C) "v_sub_co_u32_e64 %[r0" #S "], " C ", %[w0" #S "], %[s0" #S "]\n\t"
+#define TVM_M7(S, C) "v_subb_co_u32_e64 %[r1" #S "], %[bw" #S "], %[w1" #S "], %[s1" #S "], " C "\n\t"
 #define TVM_M8(S, C) "v_addc_co_u32_e64 %[r0" #S "], " C ", %[r0" #S "], 0, %[bw" #S "]\n\t"
 #define TVM_M9(S, C) "s_andn2_b64 " C ", %[bw" #S "], " C "\n\t"
 #define TVM_M10(S, C) "v_subbrev_co_u32_e64 %[r1" #S "], " C ", 0, %[r1" #S "], " C "\n\t"
 #define TVM_MUL_OUT(S, p, q, x, y, k) [r0##S] "=&v"(p), [r1##S] "=&v"(q), [s0##S] "=&v"(x), [s1##S] "=&v"(y), [bw##S] "=&s"(k)
-#define TVM_MUL_IN(S, t, v, w) \
-    [x0##S] "v"((u32)(t)), [x1##S] "v"((u32)(v)), [w0##S] "v"((u32)(w)), [w1##S] "v"((u32)((w) >> 32)), [v1##S] "v"((u32)((v) >> 32))
-#define TVM_MUL_PARTIALS(a, b, t, u, v, w)                                                        \
-    const u64 t = (u64)(u32)(a) * (u32)(b);                                                       \
-    const u64 u = (u64)(u32)(a) * (u32)((b) >> 32) + (t >> 32);                                   \
-    const u64 v = (u64)(u32)((a) >> 32) * (u32)(b) + (u32)u;                                      \
-    const u64 w = (u64)(u32)((a) >> 32) * (u32)((b) >> 32) + (u >> 32)
+#define TVM_MUL_IN(S, t, v, w) [x0##S] "v"((u32)(t)), [x1##S] "v"((u32)(v)), [w0##S] "v"((u32)(w)), [w1##S] "v"((u32)((w) >> 32))
+#define TVM_MUL_LOW(a, b, t, u)                         \
+    const u64 t = (u64)(u32)(a) * (u32)(b);             \
+    const u64 u = (u64)(u32)(a) * (u32)((b) >> 32) + (t >> 32)
+#define TVM_MUL_HIGH(a, b, v, c, w) const u64 w = (u64)(u32)((a) >> 32) * (u32)((b) >> 32) + (((u64)(c) << 32) | ((v) >> 32))
 #define TVM_3WAY(STEP) STEP(a, TVM_CA) STEP(b, TVM_CB) STEP(c, TVM_CC)
 #define TVM_2WAY(STEP) STEP(a, TVM_CA) STEP(b, TVM_CB) "s_nop 0\n\t"
 #endif
@@ -162,15 +168,24 @@ TVM_HD u64 bfe_mul(u64 a, u64 b) {
 // three independent products
 TVM_HD void bfe_mul3(u64 a0, u64 b0, u64 a1, u64 b1, u64 a2, u64 b2, u64& p0, u64& p1, u64& p2) {
 #ifdef TVM_FIELD_ASM
-    TVM_MUL_PARTIALS(a0, b0, ta, ua, va, wa);
-    TVM_MUL_PARTIALS(a1, b1, tb, ub, vb, wb);
-    TVM_MUL_PARTIALS(a2, b2, tc, uc, vc, wc);
+    TVM_MUL_LOW(a0, b0, ta, ua);
+    TVM_MUL_LOW(a1, b1, tb, ub);
+    TVM_MUL_LOW(a2, b2, tc, uc);
+    u64 va, vb, vc, cb, cc;
+    u32 ca, cb_, cc_;
+    asm(TVM_3WAY(TVM_MV) TVM_3WAY(TVM_MC)
+        : TVM_MID_OUT(a, va, ca), TVM_MID_OUT(b, vb, cb_), TVM_MID_OUT(c, vc, cc_), [cb] "=&s"(cb), [cc] "=&s"(cc)
+        : TVM_MID_IN(a, a0, b0, ua), TVM_MID_IN(b, a1, b1, ub), TVM_MID_IN(c, a2, b2, uc)
+        : "vcc");
+    TVM_MUL_HIGH(a0, b0, va, ca, wa);
+    TVM_MUL_HIGH(a1, b1, vb, cb_, wb);
+    TVM_MUL_HIGH(a2, b2, vc, cc_, wc);
     u32 r0a, r1a, s0a, s1a, r0b, r1b, s0b, s1b, r0c, r1c, s0c, s1c;
-    u64 cb, cc, ba, bb, bc;
-    asm(TVM_3WAY(TVM_M1) TVM_3WAY(TVM_M2) TVM_3WAY(TVM_M3) TVM_3WAY(TVM_M4) TVM_3WAY(TVM_M5) TVM_3WAY(TVM_M6)
+    u64 db, dc, ba, bb, bc;
+    asm(TVM_3WAY(TVM_M3) TVM_3WAY(TVM_M4) TVM_3WAY(TVM_M5) TVM_3WAY(TVM_M6)
         TVM_3WAY(TVM_M7) TVM_3WAY(TVM_M8) TVM_3WAY(TVM_M9) TVM_3WAY(TVM_M10)
         : TVM_MUL_OUT(a, r0a, r1a, s0a, s1a, ba), TVM_MUL_OUT(b, r0b, r1b, s0b, s1b, bb), TVM_MUL_OUT(c, r0c, r1c, s0c, s1c, bc),
-          [cb] "=&s"(cb), [cc] "=&s"(cc)
+          [cb] "=&s"(db), [cc] "=&s"(dc)
         : TVM_MUL_IN(a, ta, va, wa), TVM_MUL_IN(b, tb, vb, wb), TVM_MUL_IN(c, tc, vc, wc)
         : "vcc", "scc");
     p0 = ((u64)r1a << 32) | r0a;
@@ -185,13 +200,21 @@ TVM_HD void bfe_mul3(u64 a0, u64 b0, u64 a1, u64 b1, u64 a2, u64 b2, u64& p0, u6
 // two independent products
 TVM_HD void bfe_mul2(u64 a0, u64 b0, u64 a1, u64 b1, u64& p0, u64& p1) {
 #ifdef TVM_FIELD_ASM
-    TVM_MUL_PARTIALS(a0, b0, ta, ua, va, wa);
-    TVM_MUL_PARTIALS(a1, b1, tb, ub, vb, wb);
+    TVM_MUL_LOW(a0, b0, ta, ua);
+    TVM_MUL_LOW(a1, b1, tb, ub);
+    u64 va, vb, cb;
+    u32 ca, cb_;
+    asm(TVM_2WAY(TVM_MV) TVM_MC(a, TVM_CA) TVM_MC(b, TVM_CB)
+        : TVM_MID_OUT(a, va, ca), TVM_MID_OUT(b, vb, cb_), [cb] "=&s"(cb)
+        : TVM_MID_IN(a, a0, b0, ua), TVM_MID_IN(b, a1, b1, ub)
+        : "vcc");
+    TVM_MUL_HIGH(a0, b0, va, ca, wa);
+    TVM_MUL_HIGH(a1, b1, vb, cb_, wb);
     u32 r0a, r1a, s0a, s1a, r0b, r1b, s0b, s1b;
-    u64 cb, ba, bb;
-    asm(TVM_2WAY(TVM_M1) TVM_2WAY(TVM_M2) TVM_2WAY(TVM_M3) TVM_2WAY(TVM_M4) TVM_2WAY(TVM_M5) TVM_2WAY(TVM_M6)
+    u64 db, ba, bb;
+    asm(TVM_2WAY(TVM_M3) TVM_2WAY(TVM_M4) TVM_2WAY(TVM_M5) TVM_2WAY(TVM_M6)
         TVM_2WAY(TVM_M7) TVM_2WAY(TVM_M8) TVM_M9(a, TVM_CA) TVM_M9(b, TVM_CB) TVM_M10(a, TVM_CA) TVM_M10(b, TVM_CB)
-        : TVM_MUL_OUT(a, r0a, r1a, s0a, s1a, ba), TVM_MUL_OUT(b, r0b, r1b, s0b, s1b, bb), [cb] "=&s"(cb)
+        : TVM_MUL_OUT(a, r0a, r1a, s0a, s1a, ba), TVM_MUL_OUT(b, r0b, r1b, s0b, s1b, bb), [cb] "=&s"(db)
         : TVM_MUL_IN(a, ta, va, wa), TVM_MUL_IN(b, tb, vb, wb)
         : "vcc", "scc");
     p0 = ((u64)r1a << 32) | r0a;

@@ -27,6 +27,9 @@
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(TVM_EMU)
 #define TVM_FIELD_ASM 1
 #endif
+#ifndef TVM_MUL_CARRY_FORM
+#define TVM_MUL_CARRY_FORM 1   // 0: the textbook form of the partial products (see bfe_mul), for A/B timings
+#endif
 
 TVM_HD u64 bfe_add(u64 a, u64 b) {
 #ifdef TVM_FIELD_ASM
@@ -100,6 +103,7 @@ TVM_HD void mul64wide(u64 a, u64 b, u64& lo, u64& hi) {
 // on the scalar unit, so the conditional correction costs two vector instructions instead of three.
 TVM_HD u64 bfe_mul(u64 a, u64 b) {
 #ifdef TVM_FIELD_ASM
+#if TVM_MUL_CARRY_FORM
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     const u64 t = (u64)a0 * b0;
     const u64 u = (u64)a0 * b1 + (t >> 32);
@@ -107,7 +111,7 @@ TVM_HD u64 bfe_mul(u64 a, u64 b) {
     u32 c;
     asm("v_mad_u64_u32 %[v], %[sc], %[a1], %[b0], %[u]\n\t" TVM_VCC_WAIT
         "v_cndmask_b32_e64 %[c], 0, 1, %[sc]"
-        : [v] "=&v"(v), [sc] "=&s"(sc), [c] "=&v"(c)
+        : [v] "=v"(v), [sc] "=&s"(sc), [c] "=v"(c)
         : [a1] "v"(a1), [b0] "v"(b0), [u] "v"(u));
     const u64 w = (u64)a1 * b1 + (((u64)c << 32) | (v >> 32));
     u32 r0, r1, s1, s0;
@@ -124,6 +128,29 @@ TVM_HD u64 bfe_mul(u64 a, u64 b) {
         : [x0] "v"((u32)t), [x1] "v"((u32)v), [w0] "v"((u32)w), [w1] "v"((u32)(w >> 32))
         : "vcc", "scc");
     return ((u64)r1 << 32) | r0;
+#else  // the textbook form
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 t = (u64)a0 * b0;
+    const u64 u = (u64)a0 * b1 + (t >> 32);
+    const u64 v = (u64)a1 * b0 + (u32)u;
+    const u64 w = (u64)a1 * b1 + (u >> 32);
+    u32 r0, r1, s1, s0;
+    u64 bw;
+    asm("v_add_co_u32 %[r0], vcc, %[w0], %[v1]\n\t" TVM_VCC_WAIT
+        "v_addc_co_u32 %[r1], vcc, 0, %[w1], vcc\n\t"
+        "v_add_co_u32 %[s1], vcc, %[x1], %[x0]\n\t" TVM_VCC_WAIT
+        "v_subb_co_u32 %[s0], vcc, %[x0], %[s1], vcc\n\t" TVM_VCC_WAIT
+        "v_subbrev_co_u32 %[s1], vcc, 0, %[s1], vcc\n\t"
+        "v_sub_co_u32 %[r0], vcc, %[r0], %[s0]\n\t" TVM_VCC_WAIT
+        "v_subb_co_u32_e64 %[r1], %[bw], %[r1], %[s1], vcc\n\t" TVM_VCC_WAIT
+        "v_addc_co_u32_e64 %[r0], vcc, %[r0], 0, %[bw]\n\t"
+        "s_andn2_b64 vcc, %[bw], vcc\n\t"
+        "v_subbrev_co_u32 %[r1], vcc, 0, %[r1], vcc"
+        : [r0] "=&v"(r0), [r1] "=&v"(r1), [s1] "=&v"(s1), [s0] "=&v"(s0), [bw] "=&s"(bw)
+        : [x0] "v"((u32)t), [x1] "v"((u32)v), [w0] "v"((u32)w), [w1] "v"((u32)(w >> 32)), [v1] "v"((u32)(v >> 32))
+        : "vcc", "scc");
+    return ((u64)r1 << 32) | r0;
+#endif
 #else
     u64 lo, hi;
     mul64wide(a, b, lo, hi);
@@ -141,12 +168,12 @@ TVM_HD u64 bfe_mul(u64 a, u64 b) {
 #define TVM_CA "vcc"
 #define TVM_CB "%[cb]"
 #define TVM_CC "%[cc]"
-// steps of the multiplication tail (see bfe_mul): S = operand suffix of the chain, C = its carry register
+// S = operand suffix of the chain, C = its carry register
 // the middle partial product with its carry-out, and the carry as a 0/1 word (see bfe_mul)
 #define TVM_MV(S, C) "v_mad_u64_u32 %[v" #S "], " C ", %[a1" #S "], %[b0" #S "], %[u" #S "]\n\t"
 #define TVM_MC(S, C) "v_cndmask_b32_e64 %[k" #S "], 0, 1, " C "\n\t"
-#define TVM_MID_OUT(S, v, c) [v##S] "=&v"(v), [k##S] "=&v"(c)
-#define TVM_MID_IN(S, a, b, u) [a1##S] "v"((u32)((a) >> 32)), [b0##S] "v"((u32)(b)), [u##S] "v"(u)
+#define TVM_MID_OUT(S, mid, carry) [v##S] "=&v"(mid), [k##S] "=&v"(carry)
+#define TVM_MID_IN(S, fa, fb, low) [a1##S] "v"((u32)((fa) >> 32)), [b0##S] "v"((u32)(fb)), [u##S] "v"(low)
 #define TVM_M3(S, C) "v_add_co_u32_e64 %[s1" #S "], " C ", %[x1" #S "], %[x0" #S "]\n\t"
 #define TVM_M4(S, C) "v_subb_co_u32_e64 %[s0" #S "], " C ", %[x0" #S "], %[s1" #S "], " C "\n\t"
 #define TVM_M5(S, C) "v_subbrev_co_u32_e64 %[s1" #S "], " C ", 0, %[s1" #S "], " C "\n\t"
@@ -161,6 +188,25 @@ TVM_HD u64 bfe_mul(u64 a, u64 b) {
     const u64 t = (u64)(u32)(a) * (u32)(b);             \
     const u64 u = (u64)(u32)(a) * (u32)((b) >> 32) + (t >> 32)
 #define TVM_MUL_HIGH(a, b, v, c, w) const u64 w = (u64)(u32)((a) >> 32) * (u32)((b) >> 32) + (((u64)(c) << 32) | ((v) >> 32))
+// the textbook form (TVM_MUL_CARRY_FORM 0): steps of its tail
+#define TVM_M1_T(S, C) "v_add_co_u32_e64 %[r0" #S "], " C ", %[w0" #S "], %[v1" #S "]\n\t"
+#define TVM_M2_T(S, C) "v_addc_co_u32_e64 %[r1" #S "], " C ", 0, %[w1" #S "], " C "\n\t"
+#define TVM_M3_T(S, C) "v_add_co_u32_e64 %[s1" #S "], " C ", %[x1" #S "], %[x0" #S "]\n\t"
+#define TVM_M4_T(S, C) "v_subb_co_u32_e64 %[s0" #S "], " C ", %[x0" #S "], %[s1" #S "], " C "\n\t"
+#define TVM_M5_T(S, C) "v_subbrev_co_u32_e64 %[s1" #S "], " C ", 0, %[s1" #S "], " C "\n\t"
+#define TVM_M6_T(S, C) "v_sub_co_u32_e64 %[r0" #S "], " C ", %[r0" #S "], %[s0" #S "]\n\t"
+#define TVM_M7_T(S, C) "v_subb_co_u32_e64 %[r1" #S "], %[bw" #S "], %[r1" #S "], %[s1" #S "], " C "\n\t"
+#define TVM_M8_T(S, C) "v_addc_co_u32_e64 %[r0" #S "], " C ", %[r0" #S "], 0, %[bw" #S "]\n\t"
+#define TVM_M9_T(S, C) "s_andn2_b64 " C ", %[bw" #S "], " C "\n\t"
+#define TVM_M10_T(S, C) "v_subbrev_co_u32_e64 %[r1" #S "], " C ", 0, %[r1" #S "], " C "\n\t"
+#define TVM_MUL_OUT_T(S, p, q, x, y, k) [r0##S] "=&v"(p), [r1##S] "=&v"(q), [s0##S] "=&v"(x), [s1##S] "=&v"(y), [bw##S] "=&s"(k)
+#define TVM_MUL_IN_T(S, t, v, w) \
+    [x0##S] "v"((u32)(t)), [x1##S] "v"((u32)(v)), [w0##S] "v"((u32)(w)), [w1##S] "v"((u32)((w) >> 32)), [v1##S] "v"((u32)((v) >> 32))
+#define TVM_MUL_PARTIALS_T(a, b, t, u, v, w)                                                        \
+    const u64 t = (u64)(u32)(a) * (u32)(b);                                                       \
+    const u64 u = (u64)(u32)(a) * (u32)((b) >> 32) + (t >> 32);                                   \
+    const u64 v = (u64)(u32)((a) >> 32) * (u32)(b) + (u32)u;                                      \
+    const u64 w = (u64)(u32)((a) >> 32) * (u32)((b) >> 32) + (u >> 32)
 #define TVM_3WAY(STEP) STEP(a, TVM_CA) STEP(b, TVM_CB) STEP(c, TVM_CC)
 #define TVM_2WAY(STEP) STEP(a, TVM_CA) STEP(b, TVM_CB) "s_nop 0\n\t"
 #endif
@@ -168,6 +214,7 @@ TVM_HD u64 bfe_mul(u64 a, u64 b) {
 // three independent products
 TVM_HD void bfe_mul3(u64 a0, u64 b0, u64 a1, u64 b1, u64 a2, u64 b2, u64& p0, u64& p1, u64& p2) {
 #ifdef TVM_FIELD_ASM
+#if TVM_MUL_CARRY_FORM
     TVM_MUL_LOW(a0, b0, ta, ua);
     TVM_MUL_LOW(a1, b1, tb, ub);
     TVM_MUL_LOW(a2, b2, tc, uc);
@@ -192,6 +239,22 @@ TVM_HD void bfe_mul3(u64 a0, u64 b0, u64 a1, u64 b1, u64 a2, u64 b2, u64& p0, u6
     p1 = ((u64)r1b << 32) | r0b;
     p2 = ((u64)r1c << 32) | r0c;
 #else
+    TVM_MUL_PARTIALS_T(a0, b0, ta, ua, va, wa);
+    TVM_MUL_PARTIALS_T(a1, b1, tb, ub, vb, wb);
+    TVM_MUL_PARTIALS_T(a2, b2, tc, uc, vc, wc);
+    u32 r0a, r1a, s0a, s1a, r0b, r1b, s0b, s1b, r0c, r1c, s0c, s1c;
+    u64 cb, cc, ba, bb, bc;
+    asm(TVM_3WAY(TVM_M1_T) TVM_3WAY(TVM_M2_T) TVM_3WAY(TVM_M3_T) TVM_3WAY(TVM_M4_T) TVM_3WAY(TVM_M5_T) TVM_3WAY(TVM_M6_T)
+        TVM_3WAY(TVM_M7_T) TVM_3WAY(TVM_M8_T) TVM_3WAY(TVM_M9_T) TVM_3WAY(TVM_M10_T)
+        : TVM_MUL_OUT_T(a, r0a, r1a, s0a, s1a, ba), TVM_MUL_OUT_T(b, r0b, r1b, s0b, s1b, bb), TVM_MUL_OUT_T(c, r0c, r1c, s0c, s1c, bc),
+          [cb] "=&s"(cb), [cc] "=&s"(cc)
+        : TVM_MUL_IN_T(a, ta, va, wa), TVM_MUL_IN_T(b, tb, vb, wb), TVM_MUL_IN_T(c, tc, vc, wc)
+        : "vcc", "scc");
+    p0 = ((u64)r1a << 32) | r0a;
+    p1 = ((u64)r1b << 32) | r0b;
+    p2 = ((u64)r1c << 32) | r0c;
+#endif
+#else
     p0 = bfe_mul(a0, b0);
     p1 = bfe_mul(a1, b1);
     p2 = bfe_mul(a2, b2);
@@ -200,6 +263,7 @@ TVM_HD void bfe_mul3(u64 a0, u64 b0, u64 a1, u64 b1, u64 a2, u64 b2, u64& p0, u6
 // two independent products
 TVM_HD void bfe_mul2(u64 a0, u64 b0, u64 a1, u64 b1, u64& p0, u64& p1) {
 #ifdef TVM_FIELD_ASM
+#if TVM_MUL_CARRY_FORM
     TVM_MUL_LOW(a0, b0, ta, ua);
     TVM_MUL_LOW(a1, b1, tb, ub);
     u64 va, vb, cb;
@@ -219,6 +283,19 @@ TVM_HD void bfe_mul2(u64 a0, u64 b0, u64 a1, u64 b1, u64& p0, u64& p1) {
         : "vcc", "scc");
     p0 = ((u64)r1a << 32) | r0a;
     p1 = ((u64)r1b << 32) | r0b;
+#else
+    TVM_MUL_PARTIALS_T(a0, b0, ta, ua, va, wa);
+    TVM_MUL_PARTIALS_T(a1, b1, tb, ub, vb, wb);
+    u32 r0a, r1a, s0a, s1a, r0b, r1b, s0b, s1b;
+    u64 cb, ba, bb;
+    asm(TVM_2WAY(TVM_M1_T) TVM_2WAY(TVM_M2_T) TVM_2WAY(TVM_M3_T) TVM_2WAY(TVM_M4_T) TVM_2WAY(TVM_M5_T) TVM_2WAY(TVM_M6_T)
+        TVM_2WAY(TVM_M7_T) TVM_2WAY(TVM_M8_T) TVM_M9_T(a, TVM_CA) TVM_M9_T(b, TVM_CB) TVM_M10_T(a, TVM_CA) TVM_M10_T(b, TVM_CB)
+        : TVM_MUL_OUT_T(a, r0a, r1a, s0a, s1a, ba), TVM_MUL_OUT_T(b, r0b, r1b, s0b, s1b, bb), [cb] "=&s"(cb)
+        : TVM_MUL_IN_T(a, ta, va, wa), TVM_MUL_IN_T(b, tb, vb, wb)
+        : "vcc", "scc");
+    p0 = ((u64)r1a << 32) | r0a;
+    p1 = ((u64)r1b << 32) | r0b;
+#endif
 #else
     p0 = bfe_mul(a0, b0);
     p1 = bfe_mul(a1, b1);

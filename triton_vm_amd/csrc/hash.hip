@@ -24,7 +24,7 @@ namespace tvm {
 // the matrix cores (tip5_permute_mfma): four lanes per row, sixteen rows per wavefront.  Lane (n, g) absorbs the
 // words g, g + 4 (and g + 8 for g < 2) of each block of ten: with consecutive rows in a wavefront (stride 1) every
 // load instruction touches four full 128-byte lines of the row-block-major table.
-__global__ void __launch_bounds__(TVM_HASH_BLOCK, 8) k_hash_rows_mfma(const u64* __restrict__ table, TabView view, int W,
+__global__ void __launch_bounds__(TVM_HASH_BLOCK, 6) k_hash_rows_mfma(const u64* __restrict__ table, TabView view, int W,
                                                                     u64* __restrict__ digests) {
     __shared__ unsigned char lut[256];
     __shared__ int ctab[TIP5_ROUNDS * TIP5_MFMA_POSITIONS * 16];
@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(TVM_HASH_BLOCK, 8) k_hash_rows_mfma(const u64*
     u64 row, r;
     view.locate(live ? t : view.n_out - 1, row, r);
     const u64* base = table + (row >> TVM_RB_LOG) * (u64)W * TVM_RB + (row & (TVM_RB - 1));
-    const tvm_v4i a = tip5_mfma_matrix_operand(lane);
+    const Tip5MfmaOperands a = tip5_mfma_matrix_operands(lane);
     u64 st[4] = {0, 0, 0, 0};
     const int n_perms = W / TIP5_RATE + 1;
     for (int perm = 0; perm < n_perms; perm++) {
@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(TVM_HASH_BLOCK, 8) k_hash_rows_mfma(const u64*
 
 // nodes[i] = hash_pair(nodes[2i], nodes[2i+1]) for i in [first, first + count): the matrix-core form of the
 // permutation (four lanes per parent, sixteen parents per wavefront; tip5.h), for the levels that fill the chip.
-__global__ void __launch_bounds__(256, 8) k_merkle_level(u64* __restrict__ nodes, u64 first, u64 count) {
+__global__ void __launch_bounds__(256, 6) k_merkle_level(u64* __restrict__ nodes, u64 first, u64 count) {
     __shared__ unsigned char lut[256];
     __shared__ int ctab[TIP5_ROUNDS * TIP5_MFMA_POSITIONS * 16];
     const int tid = threadIdx.x;
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256, 8) k_merkle_level(u64* __restrict__ nodes
     const bool live = j < count;  // every lane of a wavefront takes part in the matrix instructions
     if (!live) j = count - 1;
     const u64 i = first + j;
-    const tvm_v4i a = tip5_mfma_matrix_operand(lane);
+    const Tip5MfmaOperands a = tip5_mfma_matrix_operands(lane);
     u64 st[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {

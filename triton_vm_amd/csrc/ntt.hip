@@ -24,6 +24,9 @@
 //   pass3  forward rows step (DIT) for 16 table columns at once  reads Z,       writes the table
 // Algorithmic HBM bytes per base-field trace cell: 8 (read) + 8*X (write) = 72 at X = 8; the
 // scheme moves 8*(1+1+1+X+X+X) = 216.
+// The LDS-resident transforms run at their VGPR budgets (128 at 4 wavefronts per SIMD): the carry-out form of bfe_mul
+// (field.h) keeps one more register pair live per product and measured 3-7 % slower in the three passes.
+#define TVM_MUL_CARRY_FORM 0
 #include <cstdlib>
 
 #include "context.h"

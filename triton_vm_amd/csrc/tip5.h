@@ -171,23 +171,21 @@ static inline tvm_v4i emu_mfma_i32_16x16x64_i8(tvm_v4i a, tvm_v4i b, tvm_v4i c) 
     return d;
 }
 #define TVM_MFMA_I8(a, b, c) emu_mfma_i32_16x16x64_i8((a), (b), (c))
-static inline u32 tvm_alignbyte(u32 hi, u32 lo, u32 shift) { return (u32)((((u64)hi << 32) | lo) >> (8 * shift)); }
 #else
 typedef int tvm_v4i __attribute__((ext_vector_type(4)));
 #define TVM_MFMA_I8(a, b, c) __builtin_amdgcn_mfma_i32_16x16x64_i8((a), (b), (c), 0, 0, 0)
-static __device__ __forceinline__ u32 tvm_alignbyte(u32 hi, u32 lo, u32 shift) { return __builtin_amdgcn_alignbyte(hi, lo, shift); }
 #endif
 
 #define TIP5_MFMA_POSITIONS 10
 #define TIP5_MFMA_BIAS_LOG 21
 
 // balanced base-256 digits of an MDS entry
-struct Tip5Digits { int d0, d1, d2; };
+struct Tip5Digits { int d[3]; };
 constexpr Tip5Digits tip5_digits(int m) {
     const int d0 = ((m + 128) & 255) - 128;
     const int rem = (m - d0) >> 8;
     const int d1 = ((rem + 128) & 255) - 128;
-    return Tip5Digits{d0, d1, (rem - d1) >> 8};
+    return Tip5Digits{{d0, d1, (rem - d1) >> 8}};
 }
 
 // Accumulator inputs: ctab[((round * 10 + c) * 4 + g) * 4 + v] for row r = 4g + v, i.e. word g + 4v.
@@ -196,10 +194,10 @@ constexpr Tip5MfmaTable tip5_make_mfma_table() {
     Tip5MfmaTable t{};
     const u64 rc[80] = {TVM_TIP5_RC_LIST};
     const int mds[16] = {TVM_TIP5_MDS_LIST};
-    int digit_sum = 0;  // the same for every row of a circulant matrix
+    int digit_sum[3] = {0, 0, 0};  // per digit position; the same for every row of a circulant matrix
     for (int j = 0; j < 16; j++) {
         const Tip5Digits d = tip5_digits(mds[j]);
-        digit_sum += d.d0 + d.d1 + d.d2;
+        for (int k = 0; k < 3; k++) digit_sum[k] += d.d[k];
     }
     // the biases add up to 2^21 * sum_c 2^(8c); the round constants are lowered by that amount (mod p)
     unsigned __int128 bias_total = 0;
@@ -210,46 +208,122 @@ constexpr Tip5MfmaTable tip5_make_mfma_table() {
             for (int v = 0; v < 4; v++) {
                 const u64 word = rc[16 * r + g + 4 * v];
                 const u64 adj = word >= k0 ? word - k0 : word + (TVM_P - k0);
-                for (int c = 0; c < TIP5_MFMA_POSITIONS; c++)
+                for (int c = 0; c < TIP5_MFMA_POSITIONS; c++) {
+                    // position c sums digit k of the matrix against byte c - k of the state (where that byte exists): every
+                    // such product was taken with the byte lowered by 128
+                    int digits_here = 0;
+                    for (int k = 0; k < 3; k++)
+                        if (c - k >= 0 && c - k < 8) digits_here += digit_sum[k];
                     t.v[((r * TIP5_MFMA_POSITIONS + c) * 4 + g) * 4 + v] =
-                        128 * digit_sum + (1 << TIP5_MFMA_BIAS_LOG) + (c < 8 ? (int)((adj >> (8 * c)) & 0xFF) : 0);
+                        128 * digits_here + (1 << TIP5_MFMA_BIAS_LOG) + (c < 8 ? (int)((adj >> (8 * c)) & 0xFF) : 0);
+                }
             }
     return t;
 }
 TVM_CONST_TABLE Tip5MfmaTable d_tip5_mfma_table = tip5_make_mfma_table();
 TVM_CONST_TABLE int d_tip5_mds[16] = {TVM_TIP5_MDS_LIST};
 
-// The constant A operand of lane (r = lane % 16, g = lane / 16): for the four words j = g + 4jj that the lanes
-// (., g) own, the digits of M[r/4 + 4(r%4)][j], laid out against the window bytes (pad, x_{c-2}, x_{c-1}, x_c).
-TVM_D tvm_v4i tip5_mfma_matrix_operand(int lane) {
+// The constant A operands of lane (r = lane % 16, g = lane / 16).  The B operands are the two 32-bit halves of the four
+// words j = g + 4jj that the lanes (., g) own, AS THEY LIE IN THE REGISTERS (bytes 0..3 and 4..7); operand s in 0..5 holds,
+// against byte b of such a half, digit s - b of M[r/4 + 4(r%4)][j] (nothing where s - b is not a digit position): the
+// product with the low halves is the share of the bytes 0..3 in position s, the product with the high halves the share
+// of the bytes 4..7 in position s + 4.
+#define TIP5_MFMA_SHIFTS 6
+struct Tip5MfmaOperands { tvm_v4i a[TIP5_MFMA_SHIFTS]; };
+TVM_D Tip5MfmaOperands tip5_mfma_matrix_operands(int lane) {
     const int r = lane & 15, g = lane >> 4;
     const int i_out = (r >> 2) + 4 * (r & 3);
-    tvm_v4i a;
+    Tip5MfmaOperands o;
 #pragma unroll
     for (int jj = 0; jj < 4; jj++) {
         const Tip5Digits d = tip5_digits(d_tip5_mds[(16 + i_out - (g + 4 * jj)) & 15]);
-        a[jj] = (int)(((u32)(d.d2 & 0xFF) << 8) | ((u32)(d.d1 & 0xFF) << 16) | ((u32)(d.d0 & 0xFF) << 24));
+#pragma unroll
+        for (int s = 0; s < TIP5_MFMA_SHIFTS; s++) {
+            u32 w = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (s - b >= 0 && s - b < 3) w |= (u32)(d.d[s - b] & 0xFF) << (8 * b);
+            o.a[s][jj] = (int)w;
+        }
     }
-    return a;
+    return o;
 }
 
-// ten 22-bit sums D_c -> sum_c 2^(8c) D_c mod p, canonical
-TVM_D u64 tip5_mfma_recombine(const tvm_v4i (&d)[TIP5_MFMA_POSITIONS], int v) {
-    const u32 u0 = (u32)d[0][v] + ((u32)d[1][v] << 8), v0 = (u32)d[2][v] + ((u32)d[3][v] << 8);  // < 2^31
-    const u32 u1 = (u32)d[4][v] + ((u32)d[5][v] << 8), v1 = (u32)d[6][v] + ((u32)d[7][v] << 8);
-    const u64 p0 = (u64)v0 * 65536u + u0;  // bits 0..46
-    const u64 p1 = (u64)v1 * 65536u + u1;  // weight 2^32
-    const u32 p2 = (u32)d[8][v] + ((u32)d[9][v] << 8);  // weight 2^64
-    // 2^64 = EPS (mod p): p0 + 2^32 lo(p1) + (hi(p1) + p2) * EPS
-    const u32 h = (u32)(p1 >> 32) + p2;
-    const u64 t = (u64)h * 0xFFFFFFFFu + p0;  // < 2^63
-    const u64 s = t + ((u64)(u32)p1 << 32);
-    const u64 y = s < t ? s + TVM_EPS : s;  // wrapped once (then s < t < 2^63: adding EPS cannot wrap again)
-    return y >= TVM_P ? y - TVM_P : y;
+// Ten 22-bit sums D_c per word -> sum_c 2^(8c) D_c mod p, canonical, for the four words of a lane.
+//   P0 = D_0 + 2^8 D_1 + 2^16 D_2 + 2^24 D_3 (< 2^47) and P1 likewise from D_4..D_7 (weight 2^32): chains of v_mad_u64_u32,
+//   the first with a zero addend, so that no 32-bit value has to be widened into an aligned register pair;
+//   2^64 = EPS (mod p):  value = P0 + 2^32 lo(P1) + h * EPS,  h = hi(P1) + D_8 + 2^8 D_9 (< 2^31);
+//   t = h * EPS + P0 < 2^63;  s = t + 2^32 lo(P1) (carry c): the value is s + 2^64 c, and it is canonical after ONE
+//   subtraction of p (= addition of EPS modulo 2^64) exactly when c is set (then s < t < 2^63) or s >= p, i.e. when
+//   z = s + EPS carries (c2):  result = (c | c2) ? z : s  -- the shape of bfe_add's tail.
+// The tail of the four words is one instruction stream, chain by chain (carries in VCC and seven SGPR pairs), so that
+// every carry consumer has at least two instructions between it and its producer (field.h: TVM_VCC_WAIT).
+TVM_D void tip5_mfma_recombine(const tvm_v4i (&d)[TIP5_MFMA_POSITIONS], u64 (&st)[4]) {
+    u64 t[4];
+    u32 pl[4];
+    // the shifts as multiplications by values the compiler cannot see through (it would widen every term into a register
+    // pair and use 64-bit shifts and additions instead of one v_mad_u64_u32 per term)
+    u32 w8 = 1u << 8, w16 = 1u << 16, w24 = 1u << 24;
+#ifdef TVM_FIELD_ASM
+    asm("" : "+s"(w8), "+s"(w16), "+s"(w24));
+#endif
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        u64 p0 = (u64)(u32)d[1][v] * w8;
+        p0 += (u64)(u32)d[2][v] * w16;
+        p0 += (u64)(u32)d[3][v] * w24;
+        p0 += (u32)d[0][v];
+        u64 p1 = (u64)(u32)d[5][v] * w8;
+        p1 += (u64)(u32)d[6][v] * w16;
+        p1 += (u64)(u32)d[7][v] * w24;
+        p1 += (u32)d[4][v];
+        const u32 h = (u32)(p1 >> 32) + (u32)d[8][v] + ((u32)d[9][v] << 8);
+        t[v] = (u64)h * 0xFFFFFFFFu + p0;
+        pl[v] = (u32)p1;
+    }
+#ifdef TVM_FIELD_ASM
+    u32 sh0, sh1, sh2, sh3, zl0, zl1, zl2, zl3, zh0, zh1, zh2, zh3;
+    u64 k0, k1, k2, k3, c1, c2, c3;
+#define TIP5_R1(i, K) "v_add_co_u32_e64 %[sh" #i "], " K ", %[th" #i "], %[pl" #i "]\n\t"
+#define TIP5_R2(i, C) "v_add_co_u32_e64 %[zl" #i "], " C ", -1, %[tl" #i "]\n\t"
+#define TIP5_R3(i, C) "v_addc_co_u32_e64 %[zh" #i "], " C ", 0, %[sh" #i "], " C "\n\t"
+#define TIP5_R4(i, C, K) "s_or_b64 " C ", " C ", " K "\n\t"
+#define TIP5_R5(i, C) "v_cndmask_b32_e64 %[zl" #i "], %[tl" #i "], %[zl" #i "], " C "\n\t"
+#define TIP5_R6(i, C) "v_cndmask_b32_e64 %[sh" #i "], %[sh" #i "], %[zh" #i "], " C "\n\t"
+    asm(TIP5_R1(0, "%[k0]") TIP5_R1(1, "%[k1]") TIP5_R1(2, "%[k2]") TIP5_R1(3, "%[k3]")
+        TIP5_R2(0, "vcc") TIP5_R2(1, "%[c1]") TIP5_R2(2, "%[c2]") TIP5_R2(3, "%[c3]")
+        TIP5_R3(0, "vcc") TIP5_R3(1, "%[c1]") TIP5_R3(2, "%[c2]") TIP5_R3(3, "%[c3]")
+        TIP5_R4(0, "vcc", "%[k0]") TIP5_R4(1, "%[c1]", "%[k1]") TIP5_R4(2, "%[c2]", "%[k2]") TIP5_R4(3, "%[c3]", "%[k3]")
+        TIP5_R5(0, "vcc") TIP5_R5(1, "%[c1]") TIP5_R5(2, "%[c2]") TIP5_R5(3, "%[c3]")
+        TIP5_R6(0, "vcc") TIP5_R6(1, "%[c1]") TIP5_R6(2, "%[c2]") TIP5_R6(3, "%[c3]")
+        : [sh0] "=&v"(sh0), [sh1] "=&v"(sh1), [sh2] "=&v"(sh2), [sh3] "=&v"(sh3), [zl0] "=&v"(zl0), [zl1] "=&v"(zl1),
+          [zl2] "=&v"(zl2), [zl3] "=&v"(zl3), [zh0] "=&v"(zh0), [zh1] "=&v"(zh1), [zh2] "=&v"(zh2), [zh3] "=&v"(zh3),
+          [k0] "=&s"(k0), [k1] "=&s"(k1), [k2] "=&s"(k2), [k3] "=&s"(k3), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3)
+        : [tl0] "v"((u32)t[0]), [th0] "v"((u32)(t[0] >> 32)), [pl0] "v"(pl[0]), [tl1] "v"((u32)t[1]), [th1] "v"((u32)(t[1] >> 32)),
+          [pl1] "v"(pl[1]), [tl2] "v"((u32)t[2]), [th2] "v"((u32)(t[2] >> 32)), [pl2] "v"(pl[2]), [tl3] "v"((u32)t[3]),
+          [th3] "v"((u32)(t[3] >> 32)), [pl3] "v"(pl[3])
+        : "vcc", "scc");
+#undef TIP5_R1
+#undef TIP5_R2
+#undef TIP5_R3
+#undef TIP5_R4
+#undef TIP5_R5
+#undef TIP5_R6
+    st[0] = ((u64)sh0 << 32) | zl0;
+    st[1] = ((u64)sh1 << 32) | zl1;
+    st[2] = ((u64)sh2 << 32) | zl2;
+    st[3] = ((u64)sh3 << 32) | zl3;
+#else
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        const u64 s = t[v] + ((u64)pl[v] << 32), z = s + TVM_EPS;
+        st[v] = ((s < t[v]) | (z < s)) ? z : s;
+    }
+#endif
 }
 
 // st[t] = word g + 4t of the state of permutation n; every lane of the wavefront must take part.
-TVM_D void tip5_permute_mfma(u64 (&st)[4], const tvm_v4i a, int g, const unsigned char* lut, const int* ctab) {
+TVM_D void tip5_permute_mfma(u64 (&st)[4], const Tip5MfmaOperands& m, int g, const unsigned char* lut, const int* ctab) {
     for (int r = 0; r < TIP5_ROUNDS; r++) {
         // accumulator inputs first: their LDS latency hides behind the S-box layer
         tvm_v4i d[TIP5_MFMA_POSITIONS];
@@ -262,30 +336,17 @@ TVM_D void tip5_permute_mfma(u64 (&st)[4], const tvm_v4i a, int g, const unsigne
         st[0] = tip5_sbox_lookup(st[0], lut);
 #pragma unroll
         for (int t = 1; t < 4; t++) st[t] = tip5_pow7(st[t]);
-        const u32 pad = 0x80808080u;
-        u32 x0[4], x1[4];
+        const u32 pad = 0x80808080u;  // bytes travel lowered by 128
+        tvm_v4i lo, hi;
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            x0[t] = (u32)st[t] ^ pad;
-            x1[t] = (u32)(st[t] >> 32) ^ pad;
+            lo[t] = (int)((u32)st[t] ^ pad);
+            hi[t] = (int)((u32)(st[t] >> 32) ^ pad);
         }
 #pragma unroll
-        for (int c = 0; c < TIP5_MFMA_POSITIONS; c++) {
-            tvm_v4i b;
+        for (int s = 0; s < TIP5_MFMA_SHIFTS; s++) d[s] = TVM_MFMA_I8(m.a[s], lo, d[s]);
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                // bytes c-3 .. c of (pad pad pad | x | pad pad pad)
-                u32 w;
-                if (c < 3) w = tvm_alignbyte(x0[t], pad, c + 1);
-                else if (c == 3) w = x0[t];
-                else if (c < 7) w = tvm_alignbyte(x1[t], x0[t], c - 3);
-                else if (c == 7) w = x1[t];
-                else w = tvm_alignbyte(pad, x1[t], c - 7);
-                b[t] = (int)w;
-            }
-            d[c] = TVM_MFMA_I8(a, b, d[c]);
-        }
-#pragma unroll
-        for (int t = 0; t < 4; t++) st[t] = tip5_mfma_recombine(d, t);
+        for (int s = 0; s < TIP5_MFMA_SHIFTS; s++) d[s + 4] = TVM_MFMA_I8(m.a[s], hi, d[s + 4]);
+        tip5_mfma_recombine(d, st);
     }
 }

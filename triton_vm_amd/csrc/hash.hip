@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(TVM_HASH_BLOCK, 6) k_hash_rows_mfma(const u64*
     __shared__ int ctab[TIP5_ROUNDS * TIP5_MFMA_POSITIONS * 16];
     const int tid = threadIdx.x;
     for (int i = tid; i < TIP5_ROUNDS * TIP5_MFMA_POSITIONS * 16; i += blockDim.x) ctab[i] = d_tip5_mfma_table.v[i];
-    tip5_stage_lut(lut, tid, blockDim.x);
+    tip5_stage_lut_lowered(lut, tid, blockDim.x);
     const int lane = tid & 63, n = lane & 15, g = lane >> 4;
     // the view's rows in the order that walks storage contiguously (context.h: TabView); digest r goes to the row's index
     // in the domain
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256, 6) k_merkle_level(u64* __restrict__ nodes
     __shared__ int ctab[TIP5_ROUNDS * TIP5_MFMA_POSITIONS * 16];
     const int tid = threadIdx.x;
     for (int i = tid; i < TIP5_ROUNDS * TIP5_MFMA_POSITIONS * 16; i += blockDim.x) ctab[i] = d_tip5_mfma_table.v[i];
-    tip5_stage_lut(lut, tid, blockDim.x);
+    tip5_stage_lut_lowered(lut, tid, blockDim.x);
     const int lane = tid & 63, n = lane & 15, g = lane >> 4;
     u64 j = ((u64)blockIdx.x * 4 + (tid >> 6)) * 16 + n;
     const bool live = j < count;  // every lane of a wavefront takes part in the matrix instructions

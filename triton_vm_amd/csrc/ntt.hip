@@ -850,24 +850,24 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_lde_pass3_rows(LdePass3Args a
 // 16 rows of 1024 points i1 (128-byte runs in memory); wavefront w transforms row w (decimation in frequency, inverse roots),
 // and the store applies the inter-pass twiddle w_N^-(i2 * k1) as a running product over k1 = brev(position) -- the positions
 // of a work-item are visited in bit-reversed order so that k1 advances by one -- instead of two table loads per element.
-template <int LOGN>
-__global__ void __launch_bounds__(1 << LOGN) k_lde_pass1_rows(Ntt2Args a) {
-    constexpr int n1 = 1 << LOGN, ROWW = TVM_ROW_WORDS(n1);
-    static_assert(LOGN == 10, "16 wavefronts for 16 rows");
+template <int LOGN, int ROWS>
+__global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass1_rows(Ntt2Args a) {
+    constexpr int n1 = 1 << LOGN, ROWW = TVM_ROW_WORDS(n1), NT = 64 * ROWS, RLOG = ROWS == 16 ? 4 : 3;
+    static_assert(LOGN == 10 && (ROWS == 16 || ROWS == 8), "one wavefront per row of 1024 points");
     TVM_DYN_SMEM(u64, s);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const u64 n2 = 1ull << a.log_n2;
     const int vl = blockIdx.y, v = a.col0 + vl;
-    const u64 i2_0 = (u64)blockIdx.x * 16;
-    const int b = tid & 15, q0 = tid >> 4;   // this work-item loads / stores row b, positions q0 + 64 * it
+    const u64 i2_0 = (u64)blockIdx.x * ROWS;
+    const int b = tid & (ROWS - 1), q0 = tid >> RLOG;   // this work-item loads / stores row b, positions q0 + 64 * it
     const u64* in = a.in + (u64)(v / a.in_fk) * a.in_col_stride + (v % a.in_fk) + (i2_0 + b) * a.in_fk;
 #pragma unroll
     for (int it = 0; it < 16; it++) {
         const int i1 = q0 + 64 * it;
         s[b * ROWW + TVM_ROW_SKEW(i1)] = TVM_LOAD_STREAM(&in[(u64)i1 * n2 * a.in_fk]);
     }
-    u64* tw_lds = s + 16 * ROWW;
-    tw_lds[tid] = a.tw1[tid];   // all n1 powers of the inverse root (blockDim.x == n1)
+    u64* tw_lds = s + ROWS * ROWW;
+    for (int i = tid; i < n1; i += NT) tw_lds[i] = a.tw1[i];   // all n1 powers of the inverse root
     tvm_lds_barrier();
     row_ntt<false, 4, LOGN, 2>(s + w * ROWW, tw_lds, lane);
     tvm_lds_barrier();
@@ -885,34 +885,47 @@ __global__ void __launch_bounds__(1 << LOGN) k_lde_pass1_rows(Ntt2Args a) {
     }
 }
 
-// Pass 2: as k_lde_pass2_v2 (work-item tid owns position tid of all 16 rows of the tile across the coset loop), but both
-// LDS-resident transforms run one row per wavefront (16 wavefronts, 16 rows): three workgroup barriers per coset -- around
+// Pass 2: as k_lde_pass2_v2 (a work-item owns the same positions of all rows of the tile across the coset loop), but both
+// LDS-resident transforms run one row per wavefront (ROWS wavefronts, ROWS rows): three workgroup barriers per coset -- around
 // the scale phase and before the store phase, where data changes wavefronts -- instead of six.
-template <int LOGN>
-__global__ void __launch_bounds__(1 << LOGN) k_lde_pass2_rows(LdePass2Args a) {
-    constexpr int n2 = 1 << LOGN, ROWW = TVM_ROW_WORDS(n2);
-    static_assert(LOGN == 10, "16 wavefronts for 16 rows");
+//   ROWS = 16: 1024 work-items, one position each, 148 KB of LDS: ONE workgroup per CU -- every barrier drains the CU.
+//   ROWS = 8:  512 work-items, two positions each, 78 KB of LDS: TWO workgroups per CU, one's barriers and tails run under
+//              the other's butterflies; the stores are 64-byte runs (8 adjacent rows) instead of full lines.
+template <int LOGN, int ROWS>
+__global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass2_rows(LdePass2Args a) {
+    constexpr int n2 = 1 << LOGN, ROWW = TVM_ROW_WORDS(n2), NT = 64 * ROWS, PPT = n2 / NT, RLOG = ROWS == 16 ? 4 : 3;
+    static_assert(LOGN == 10 && (ROWS == 16 || ROWS == 8), "one wavefront per row of 1024 points");
     TVM_DYN_SMEM(u64, s);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const u64 n1 = 1ull << a.log_n1;
     const int vl = blockIdx.y, v = a.col0 + vl;
-    const u64 p0 = (u64)blockIdx.x * 16;
+    const u64 p0 = (u64)blockIdx.x * ROWS;
     const u64 n = n1 << LOGN;
     const u64* y = a.y + (u64)vl * n + p0 * n2;
-    const int me = TVM_ROW_SKEW(tid);
+    int me[PPT];
 #pragma unroll
-    for (int e = 0; e < 16; e++) s[e * ROWW + me] = TVM_LOAD_STREAM(&y[(u64)e * n2 + tid]);
-    u64* tw_fwd = s + 16 * ROWW;   // all n2 powers of the forward root, behind the tile
-    tw_fwd[tid] = a.tw_b1[tid];
+    for (int hh = 0; hh < PPT; hh++) me[hh] = TVM_ROW_SKEW(tid + hh * NT);
+#pragma unroll
+    for (int e = 0; e < 16; e++) s[(e & (ROWS - 1)) * ROWW + me[e >> RLOG]] = TVM_LOAD_STREAM(&y[(u64)(e & (ROWS - 1)) * n2 + tid + (e >> RLOG) * NT]);
+    u64* tw_fwd = s + ROWS * ROWW;   // all n2 powers of the forward root, behind the tile
+#pragma unroll
+    for (int hh = 0; hh < PPT; hh++) tw_fwd[tid + hh * NT] = a.tw_b1[tid + hh * NT];
     tvm_lds_barrier();
     // inverse rows step, row w by wavefront w: position q of row e then holds N * t[m1*n1 + m2], m1 = brev(q)
     row_ntt<false, 4, LOGN, 2>(s + w * ROWW, a.tw_a2, lane);
     tvm_lds_barrier();
-    u64 coef[16];
+    u64 coef[16];   // element e: row e % ROWS, position tid + (e / ROWS) * NT
 #pragma unroll
-    for (int e = 0; e < 16; e++) coef[e] = s[e * ROWW + me];
-    const u64 m1 = brev_bits((u32)tid, LOGN);
-    const bool has_rnd = m1 * n1 < a.h;
+    for (int e = 0; e < 16; e++) coef[e] = s[(e & (ROWS - 1)) * ROWW + me[e >> RLOG]];
+    u64 m1[PPT], gh[PPT], gh_step[PPT];
+    bool has_rnd = false;
+#pragma unroll
+    for (int hh = 0; hh < PPT; hh++) {
+        m1[hh] = brev_bits((u32)(tid + hh * NT), LOGN);
+        gh[hh] = a.g_hi[m1[hh]];
+        gh_step[hh] = a.g_hi_step[m1[hh]];
+        has_rnd |= m1[hh] * n1 < a.h;
+    }
     const u64* rnd = a.rnd + (u64)(v / a.fk) * a.h * a.fk + (v % a.fk);
     const bool single = a.h <= n1;   // see k_lde_pass2_v2
     u64* c0 = tw_fwd + n2;
@@ -920,41 +933,38 @@ __global__ void __launch_bounds__(1 << LOGN) k_lde_pass2_rows(LdePass2Args a) {
     if (single) {
         if (tid == 0) {
 #pragma unroll
-            for (int e = 0; e < 16; e++) c0[e] = coef[e];
+            for (int e = 0; e < ROWS; e++) c0[e] = coef[e];
         }
-        if (tid < 16) {
+        if (tid < ROWS) {
             const u64 m = brev_bits((u32)(p0 + tid), a.log_n1);
             r0[tid] = m < a.h ? rnd[m * a.fk] : 0;
         }
     }
-    const int b_out = tid & 15, j1_0 = tid >> 4;
+    const int b_out = tid & (ROWS - 1), j1_0 = tid >> RLOG;
     const u64 m2_out = brev_bits((u32)(p0 + b_out), a.log_n1);
-    constexpr int j1_step = n2 >> 4;
+    constexpr int j1_step = NT >> RLOG;   // 64
     const u64 t_step = pow2_get(a.tw_inter, (m2_out * (u64)j1_step) & (n - 1));
-    u64 gh = a.g_hi[m1];
-    const u64 gh_step = a.g_hi_step[m1];
     u64 t_first = bfe_mul(pow2_get(a.tw_inter, m2_out * (u64)j1_0), a.g_lo[m2_out]);
     const u64 gl_step = a.g_lo_step[m2_out];
     for (int k = 0; k < a.n_cosets; k++) {
         tvm_lds_barrier();   // the store phase of the previous coset has read the tile
         if (single) {
-            if (tid != 0) {
 #pragma unroll
-                for (int e = 0; e < 16; e++) s[e * ROWW + me] = bfe_mul(coef[e], gh);
-            }
-            if (tid < 16) s[tid * ROWW] = bfe_add(c0[tid], bfe_mul(a.zk[k], r0[tid]));
+            for (int e = 0; e < 16; e++)
+                if ((e >> RLOG) || tid) s[(e & (ROWS - 1)) * ROWW + me[e >> RLOG]] = bfe_mul(coef[e], gh[e >> RLOG]);
+            if (tid < ROWS) s[tid * ROWW] = bfe_add(c0[tid], bfe_mul(a.zk[k], r0[tid]));
         } else if (has_rnd) {
             const u64 zk = a.zk[k];
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                const u64 m = m1 * n1 + brev_bits((u32)(p0 + e), a.log_n1);
+                const u64 m = m1[e >> RLOG] * n1 + brev_bits((u32)(p0 + (e & (ROWS - 1))), a.log_n1);
                 u64 c = coef[e];
                 if (m < a.h) c = bfe_add(c, bfe_mul(zk, rnd[m * a.fk]));
-                s[e * ROWW + me] = bfe_mul(c, gh);
+                s[(e & (ROWS - 1)) * ROWW + me[e >> RLOG]] = bfe_mul(c, gh[e >> RLOG]);
             }
         } else {
 #pragma unroll
-            for (int e = 0; e < 16; e++) s[e * ROWW + me] = bfe_mul(coef[e], gh);
+            for (int e = 0; e < 16; e++) s[(e & (ROWS - 1)) * ROWW + me[e >> RLOG]] = bfe_mul(coef[e], gh[e >> RLOG]);
         }
         tvm_lds_barrier();
         row_ntt<true, TVM_P2_MAXK, LOGN, 1>(s + w * ROWW, tw_fwd, lane);   // forward columns step of row w
@@ -967,7 +977,8 @@ __global__ void __launch_bounds__(1 << LOGN) k_lde_pass2_rows(LdePass2Args a) {
             TVM_STORE_STREAM(&z[(u64)j1 * n1], bfe_mul(s[b_out * ROWW + TVM_ROW_SKEW(j1)], t));
             t = bfe_mul(t, t_step);
         }
-        gh = bfe_mul(gh, gh_step);
+#pragma unroll
+        for (int hh = 0; hh < PPT; hh++) gh[hh] = bfe_mul(gh[hh], gh_step[hh]);
         t_first = bfe_mul(t_first, gl_step);
     }
 }
@@ -1106,8 +1117,10 @@ static void set_lds_attributes() {
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<10, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<10, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    (void)hipFuncSetAttribute((const void*)k_lde_pass2_rows<10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    (void)hipFuncSetAttribute((const void*)k_lde_pass1_rows<10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass2_rows<10, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass2_rows<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass1_rows<10, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass1_rows<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_v3<11, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_v3<11, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_v3<12, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -1344,10 +1357,14 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             const int B = 1 << a.batch_log;
             const int tile = (int)n1 << a.batch_log;
             dim3 grid((unsigned)((n2 + B - 1) / B), (unsigned)nc);
-            if (std_roots && lde_rows && sp.log_n1 == 10 && n2 % 16 == 0)   // 1024-point axis: one row per wavefront
-                TVM_LAUNCH((k_lde_pass1_rows<10>), dim3((unsigned)(n2 / 16), (unsigned)nc), dim3(1024),
-                           (size_t)(16 * TVM_ROW_WORDS(n1) + n1) * sizeof(u64), c->stream, a);
-            else
+            if (std_roots && lde_rows && sp.log_n1 == 10 && n2 % 16 == 0) {   // 1024-point axis: one row per wavefront
+                static const int p1_tile = std::getenv("TVM_LDE_PASS1_TILE") ? std::atoi(std::getenv("TVM_LDE_PASS1_TILE")) : 8;  // experiment knob
+                const u64 rows_r = p1_tile == 16 ? 16 : 8;   // 8: two workgroups per CU (see k_lde_pass2_rows)
+                const size_t lds_r = (size_t)(rows_r * TVM_ROW_WORDS(n1) + n1) * sizeof(u64);
+                const dim3 g1r((unsigned)(n2 / rows_r), (unsigned)nc);
+                if (rows_r == 16) TVM_LAUNCH((k_lde_pass1_rows<10, 16>), g1r, dim3(1024), lds_r, c->stream, a);
+                else TVM_LAUNCH((k_lde_pass1_rows<10, 8>), g1r, dim3(512), lds_r, c->stream, a);
+            } else
                 TVM_LAUNCH(k_ntt2_pass1, grid, dim3(threads_for_tile(tile)), (size_t)tile * sizeof(u64), c->stream, a);
         }
         {
@@ -1371,8 +1388,12 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             }
             else if (std_roots && lde_rows && sp.log_n2 == 10 && n1 % 16 == 0) {
                 // 1024-point axis: one row per wavefront inside the LDS-resident transforms (k_lde_pass2_rows)
-                const size_t lds_r = (size_t)(16 * TVM_ROW_WORDS(n2) + n2 + 32) * sizeof(u64);
-                TVM_LAUNCH((k_lde_pass2_rows<10>), dim3((unsigned)(n1 / 16), (unsigned)nc), dim3(1024), lds_r, c->stream, a);
+                static const int p2_tile = std::getenv("TVM_LDE_PASS2_TILE") ? std::atoi(std::getenv("TVM_LDE_PASS2_TILE")) : 8;  // experiment knob
+                const u64 rows_r = p2_tile == 16 ? 16 : 8;
+                const size_t lds_r = (size_t)(rows_r * TVM_ROW_WORDS(n2) + n2 + 32) * sizeof(u64);
+                const dim3 g2r((unsigned)(n1 / rows_r), (unsigned)nc);
+                if (rows_r == 16) TVM_LAUNCH((k_lde_pass2_rows<10, 16>), g2r, dim3(1024), lds_r, c->stream, a);
+                else TVM_LAUNCH((k_lde_pass2_rows<10, 8>), g2r, dim3(512), lds_r, c->stream, a);
             }
             else if (std_roots && a.batch_log == 4 && n2 >= 64 && n1 >= 16)  // production shape: one work-item per column of the tile
                 TVM_LAUNCH(k_lde_pass2_v2, grid, dim3((unsigned)n2), lds + (n2 + 32) * sizeof(u64), c->stream, a);

@@ -32,6 +32,11 @@ TVM_D void tip5_stage_lut(unsigned char* lds_lut, int tid, int nt) {
     for (int i = tid; i < 256; i += nt) lds_lut[i] = d_tip5_lut[i];
     __syncthreads();
 }
+// the table with every entry lowered by 128 (as a signed byte), for tip5_permute_mfma
+TVM_D void tip5_stage_lut_lowered(unsigned char* lds_lut, int tid, int nt) {
+    for (int i = tid; i < 256; i += nt) lds_lut[i] = d_tip5_lut[i] ^ 0x80;
+    __syncthreads();
+}
 
 // x = hi*2^64 + lo with hi < 2^32  ->  x mod p, canonical
 TVM_HD u64 bfe_reduce96(u64 lo, u64 hi) {
@@ -322,7 +327,8 @@ TVM_D void tip5_mfma_recombine(const tvm_v4i (&d)[TIP5_MFMA_POSITIONS], u64 (&st
 #endif
 }
 
-// st[t] = word g + 4t of the state of permutation n; every lane of the wavefront must take part.
+// st[t] = word g + 4t of the state of permutation n; every lane of the wavefront must take part.  `lut` is the S-box table
+// LOWERED by 128 (tip5_stage_lut_lowered): the looked-up word goes to the matrix cores only, where bytes travel that way.
 TVM_D void tip5_permute_mfma(u64 (&st)[4], const Tip5MfmaOperands& m, int g, const unsigned char* lut, const int* ctab) {
     for (int r = 0; r < TIP5_ROUNDS; r++) {
         // accumulator inputs first: their LDS latency hides behind the S-box layer
@@ -338,8 +344,10 @@ TVM_D void tip5_permute_mfma(u64 (&st)[4], const Tip5MfmaOperands& m, int g, con
         for (int t = 1; t < 4; t++) st[t] = tip5_pow7(st[t]);
         const u32 pad = 0x80808080u;  // bytes travel lowered by 128
         tvm_v4i lo, hi;
+        lo[0] = (int)(u32)st[0];
+        hi[0] = (int)(u32)(st[0] >> 32);
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
+        for (int t = 1; t < 4; t++) {
             lo[t] = (int)((u32)st[t] ^ pad);
             hi[t] = (int)((u32)(st[t] >> 32) ^ pad);
         }

@@ -50,7 +50,7 @@ def test_evaluate_at_points(ctx, orc, n):
         assert (got[p] == orc.poly_eval_xfe(co, pts[p])).all()
 
 
-@pytest.mark.parametrize("log_q,log_ldt,n_rand", [(4, 4, 3), (5, 5, 8), (5, 7, 5), (6, 6, 16)])
+@pytest.mark.parametrize("log_q,log_ldt,n_rand", [(4, 4, 3), (5, 5, 8), (5, 7, 5), (6, 6, 16), (9, 11, 7), (8, 9, 100), (7, 5, 32)])
 def test_quotient_segments(ctx, orc, log_q, log_ldt, n_rand):
     rng = np.random.default_rng(log_q * 7 + log_ldt + n_rand)
     g = field.generator()

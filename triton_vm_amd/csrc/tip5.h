@@ -138,20 +138,22 @@ TVM_D u64 tip5_permute_lanes(u64 x, int pos, int lane, const unsigned char* lut)
 // Lane l = (n = l % 16, g = l / 16) of a wavefront holds the words {g, g + 4, g + 8, g + 12} of the state of
 // permutation n (st[t] = word g + 4t), so every lane has one split-and-lookup word (t = 0) and three power-map
 // words: the S-box layer is uniform across lanes.  The MDS layer -- 512 of the ~725 integer multiplications
-// of a round when one lane does everything -- goes to the matrix cores as ten v_mfma_i32_16x16x64_i8:
+// of a round when one lane does everything -- goes to the matrix cores as twelve v_mfma_i32_16x16x64_i8:
 //
 //   y_i = sum_j M_ij x_j over the integers, M_ij = m0 + 2^8 m1 + 2^16 m2 in balanced digits (m0, m1 in
 //   [-128, 127], m2 in {0, 1}), x_j = sum_b 2^(8b) x_jb in bytes.  For c = 0..9:
-//       T_c[i] = sum_j sum_a m_ija x_{j, c-a},           y_i = sum_c 2^(8c) T_c[i].
-//   T_c is a 16 x 48 by 48 x 16 product: A[r][k] holds the digits (a constant operand), B[k][n] the byte windows
-//   (x_{c-2}, x_{c-1}, x_c) of the four words a lane owns -- every B operand is built from the lane's OWN
-//   registers with byte-align instructions, and the 16x16 result puts rows 4g..4g+3 of column n into lane (n, g),
-//   which with the row order r -> word r/4 + 4(r%4) are exactly the words that lane owns: no cross-lane traffic.
+//       T_c[i] = sum_j sum_k m_ijk x_{j, c-k},           y_i = sum_c 2^(8c) T_c[i].
+//   The B operands are the two 32-bit halves of the four words a lane owns, exactly as they lie in its registers; the
+//   byte shifts are in the CONSTANT operands: A_s (s = 0..5) holds digit s - b against byte b of a half, so
+//       T_c = A_c * (low halves)  [c <= 5]  +  A_{c-4} * (high halves)  [c >= 4]
+//   -- no byte-align instruction anywhere.  The 16x16 result puts rows 4g..4g+3 of column n into lane (n, g), which with
+//   the row order r -> word r/4 + 4(r%4) are exactly the words that lane owns: no cross-lane traffic.
 //   The i8 operands are signed, so bytes travel as x - 128 and the accumulator input C carries the correction
-//   128 * sum(digits), a bias 2^21 that keeps every T_c positive, and byte c of the (adjusted) round constant.
+//   128 * sum(digits present at that position), a bias 2^21 that keeps every T_c positive, and byte c of the (adjusted)
+//   round constant.
 //
-// The remaining VALU work per word is the recombination of ten 22-bit sums into one field element (~20
-// instructions), against ~62 for the all-VALU form.
+// The remaining VALU work per word is the recombination of ten 22-bit sums into one field element (17 instructions:
+// tip5_mfma_recombine), against ~62 for the all-VALU form.
 #ifdef TVM_EMU
 struct tvm_v4i {
     int v[4];

@@ -304,6 +304,12 @@ int32_t tvm_host_xfe_interpolate(const uint64_t* points, const uint64_t* values,
  * (Merkle authentication-structure nodes, FRI leaves, single codeword entries) into host memory */
 int32_t tvm_gather_elements(tvm_ctx* ctx, const uint64_t* d_src, uint32_t elem_words, const uint64_t* h_indices,
                             uint64_t n, uint64_t* h_out);
+/* The same for n_jobs gathers at once -- all the FRI responses and authentication structures of a proof (fri.rs:295-319),
+ * or the three trace openings (stark.rs:672-716) -- with ONE transfer of the indices, one of the results and two stream
+ * synchronisations in all instead of two per gather.  Job j reads n[j] elements of elem_words[j] words from d_src[j] at
+ * h_indices[j][0..n[j]) and writes them to h_out[j]. */
+int32_t tvm_gather_elements_batch(tvm_ctx* ctx, uint32_t n_jobs, const uint64_t* const* d_src, const uint32_t* elem_words,
+                                  const uint64_t* const* h_indices, const uint64_t* n, uint64_t* const* h_out);
 /* Host-side (CPU) field helpers for callers that do not link twenty-first (the C++/Python test
  * drivers); a Rust host uses twenty-first instead.  No device work. */
 void tvm_host_tip5_permutation(uint64_t state[16]);

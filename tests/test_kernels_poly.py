@@ -105,3 +105,26 @@ def test_fri_split_and_fold_and_round_tree(ctx, orc, log_n):
     assert (folded.download((len(dom) // 2, 3)) == want).all()
     nodes = stark.merkle_tree_from_codeword(ctx, folded, len(dom) // 2).download((len(dom), 5))
     assert (nodes == orc.merkle_tree(orc.xfe_to_digest(want))).all()
+
+
+def test_gather_elements_batch(ctx):
+    """tvm_gather_elements_batch == one tvm_gather_elements per job (jobs of different element widths, an empty one, repeated
+    indices)"""
+    import ctypes as C
+
+    rng = np.random.default_rng(5)
+    shapes = [(1000, 3), (77, 5), (64, 15), (10, 1)]
+    hosts = [rng.integers(0, 1 << 63, size=s, dtype=np.uint64) for s in shapes]
+    bufs = [ctx.to_device(h) for h in hosts]
+    idxs = [rng.integers(0, s[0], size=k).astype(np.uint64) for s, k in zip(shapes, (173, 9, 0, 4))]
+    outs = [np.zeros((i.size, s[1]), np.uint64) for i, s in zip(idxs, shapes)]
+    n_jobs = len(shapes)
+    src = (C.c_void_p * n_jobs)(*[b.ptr for b in bufs])
+    words = (C.c_uint32 * n_jobs)(*[s[1] for s in shapes])
+    hidx = (C.c_void_p * n_jobs)(*[i.ctypes.data if i.size else None for i in idxs])
+    ns = (C.c_uint64 * n_jobs)(*[i.size for i in idxs])
+    hout = (C.c_void_p * n_jobs)(*[o.ctypes.data if o.size else None for o in outs])
+    ctx._check(ctx.lib.tvm_gather_elements_batch(ctx.handle, n_jobs, src, words, hidx, ns, hout), "gather batch")
+    for h, i, o in zip(hosts, idxs, outs):
+        assert (o == h[i.astype(np.int64)]).all()
+    assert ctx.lib.tvm_gather_elements_batch(ctx.handle, 0, None, None, None, None, None) == 0

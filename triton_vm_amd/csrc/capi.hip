@@ -810,6 +810,49 @@ int32_t tvm_gather_elements(tvm_ctx* c, const uint64_t* d_src, uint32_t elem_wor
     return TVM_OK;
 }
 
+int32_t tvm_gather_elements_batch(tvm_ctx* c, uint32_t n_jobs, const uint64_t* const* d_src, const uint32_t* elem_words,
+                                  const uint64_t* const* h_idx, const uint64_t* n, uint64_t* const* h_out) {
+    if (!c || (n_jobs && (!d_src || !elem_words || !h_idx || !n || !h_out)))
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "gather batch arguments");
+    u64 n_idx = 0, n_words = 0;
+    for (uint32_t j = 0; j < n_jobs; j++) {
+        if (n[j] && (!d_src[j] || !elem_words[j] || !h_idx[j] || !h_out[j]))
+            return set_error(c, TVM_ERR_INVALID_ARGUMENT, "gather batch: null job");
+        n_idx += n[j];
+        n_words += n[j] * elem_words[j];
+    }
+    if (!n_idx) return TVM_OK;
+    std::vector<u64> idx(n_idx), out(n_words);   // (pageable staging: the copies below are complete when the call returns)
+    u64 at = 0;
+    for (uint32_t j = 0; j < n_jobs; j++) {
+        std::memcpy(idx.data() + at, h_idx[j], n[j] * sizeof(u64));
+        at += n[j];
+    }
+    u64* d_idx = (u64*)scratch(c, 4, n_idx * sizeof(u64));
+    u64* d_out = (u64*)scratch(c, 5, n_words * sizeof(u64));
+    if (!d_idx || !d_out) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "gather scratch");
+    TVM_HIP_CHECK(c, hipMemcpyAsync(d_idx, idx.data(), n_idx * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    u64 i0 = 0, w0 = 0;
+    for (uint32_t j = 0; j < n_jobs; j++) {
+        const u64 total = n[j] * elem_words[j];
+        if (!total) continue;
+        TVM_LAUNCH(tvm::k_gather_elements, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_src[j], elem_words[j],
+                   d_idx + i0, n[j], d_out + w0);
+        i0 += n[j];
+        w0 += total;
+    }
+    TVM_HIP_CHECK(c, hipMemcpyAsync(out.data(), d_out, n_words * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    w0 = 0;
+    for (uint32_t j = 0; j < n_jobs; j++) {
+        const u64 total = n[j] * elem_words[j];
+        if (total) std::memcpy(h_out[j], out.data() + w0, total * sizeof(u64));
+        w0 += total;
+    }
+    return TVM_OK;
+}
+
 void tvm_host_tip5_permutation(uint64_t st[16]) {
     static const u64 rc[80] = {TVM_TIP5_RC_LIST};
     static const unsigned char lut[256] = {TVM_TIP5_LUT_LIST};

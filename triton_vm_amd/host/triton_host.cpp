@@ -306,7 +306,7 @@ static std::vector<u64> merkle_root(const Context& c, const DeviceBuffer& nodes)
 
 // [twenty-first MerkleTree::authentication_structure, restated] the nodes a verifier cannot compute from the revealed
 // leaves -- the siblings along the paths that are not themselves on a path -- in descending heap order, gathered to the host
-static std::vector<u64> auth_nodes(const Context& c, const DeviceBuffer& nodes, u64 n_leaves, const std::vector<u64>& indices) {
+static std::vector<u64> auth_node_indices(u64 n_leaves, const std::vector<u64>& indices) {
     auto uniq = [](std::vector<u64> v) {
         std::sort(v.begin(), v.end());
         v.erase(std::unique(v.begin(), v.end()), v.end());
@@ -326,10 +326,44 @@ static std::vector<u64> auth_nodes(const Context& c, const DeviceBuffer& nodes, 
     std::vector<u64> need;
     std::set_difference(needed.begin(), needed.end(), computable.begin(), computable.end(), std::back_inserter(need));
     std::reverse(need.begin(), need.end());
+    return need;
+}
+static std::vector<u64> auth_nodes(const Context& c, const DeviceBuffer& nodes, u64 n_leaves, const std::vector<u64>& indices) {
+    const std::vector<u64> need = auth_node_indices(n_leaves, indices);
     std::vector<u64> out(need.size() * 5);
     if (!need.empty()) c.check(tvm_gather_elements(c.raw(), nodes.ptr(), 5, need.data(), need.size(), out.data()), "tvm_gather_elements");
     return out;
 }
+
+// Many gathers with one round trip (tvm_gather_elements_batch): jobs are queued with their index lists, run() fills `out`.
+struct GatherBatch {
+    struct Job {
+        const u64* src;
+        uint32_t words;
+        std::vector<u64> idx, out;
+    };
+    std::vector<Job> jobs;
+    size_t add(const u64* src, uint32_t words, std::vector<u64> idx) {
+        jobs.push_back(Job{src, words, std::move(idx), {}});
+        return jobs.size() - 1;
+    }
+    void run(const Context& c) {
+        std::vector<const uint64_t*> src, idx;
+        std::vector<uint32_t> words;
+        std::vector<uint64_t> n;
+        std::vector<uint64_t*> out;
+        for (Job& j : jobs) {
+            j.out.assign(j.idx.size() * j.words, 0);
+            src.push_back(j.src);
+            words.push_back(j.words);
+            idx.push_back(j.idx.data());
+            n.push_back(j.idx.size());
+            out.push_back(j.out.data());
+        }
+        c.check(tvm_gather_elements_batch(c.raw(), (uint32_t)jobs.size(), src.data(), words.data(), idx.data(), n.data(), out.data()),
+                "tvm_gather_elements_batch");
+    }
+};
 
 // Challenges::new (challenges.rs:85-121): the 59 sampled challenges, then the terminals of the public input, the public
 // output, the lookup table and the program digest -- EvalArg::compute_terminal(symbols, 1, indeterminate)
@@ -395,6 +429,12 @@ std::vector<u64> Prover::fri(const DeviceBuffer& combination, ProofStream& ps) {
     last_polynomial.resize(dom.length);
     std::memcpy(last_polynomial.data(), last_poly.data(), last_poly.size() * sizeof(u64));
     const std::vector<u64> a_indices = ps.sample_indices(p_.ldt.length, p_.num_collinearity_checks);
+    // the responses of all rounds in one round trip to the device (their order in the proof stream is fixed below)
+    GatherBatch batch;
+    struct Response {
+        size_t round, leaves, auth;
+    };
+    std::vector<Response> responses;
     for (size_t r = 0; r < rounds.size(); r++) {
         const Round& round = rounds[r];
         std::vector<u64> b_idx;
@@ -402,12 +442,16 @@ std::vector<u64> Prover::fri(const DeviceBuffer& combination, ProofStream& ps) {
         for (int which = (r == 0 ? 0 : 1); which < 2; which++) {
             if (which == 1 && r == rounds.size() - 1) continue;
             const std::vector<u64>& ix = which == 0 ? a_indices : b_idx;
-            std::vector<u64> leaves(ix.size() * 3);
-            c_.check(tvm_gather_elements(c_.raw(), round.cw, 3, ix.data(), ix.size(), leaves.data()), "fri leaves");
-            ps.enqueue("fri response " + std::to_string(r), leaves.data(), leaves.size());
-            const std::vector<u64> auth = auth_nodes(c_, round.nodes, round.dom.length, ix);
-            ps.enqueue("fri auth " + std::to_string(r), auth.data(), auth.size());
+            const size_t leaves = batch.add(round.cw, 3, ix);
+            const size_t auth = batch.add(round.nodes.ptr(), 5, auth_node_indices(round.dom.length, ix));
+            responses.push_back(Response{r, leaves, auth});
         }
+    }
+    batch.run(c_);
+    for (const Response& q : responses) {
+        const std::vector<u64>&leaves = batch.jobs[q.leaves].out, &auth = batch.jobs[q.auth].out;
+        ps.enqueue("fri response " + std::to_string(q.round), leaves.data(), leaves.size());
+        ps.enqueue("fri auth " + std::to_string(q.round), auth.data(), auth.size());
     }
     (void)ps.sample_scalars(1);
     return a_indices;

@@ -1358,8 +1358,10 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             const int tile = (int)n1 << a.batch_log;
             dim3 grid((unsigned)((n2 + B - 1) / B), (unsigned)nc);
             if (std_roots && lde_rows && sp.log_n1 == 10 && n2 % 16 == 0) {   // 1024-point axis: one row per wavefront
-                static const int p1_tile = std::getenv("TVM_LDE_PASS1_TILE") ? std::atoi(std::getenv("TVM_LDE_PASS1_TILE")) : 8;  // experiment knob
-                const u64 rows_r = p1_tile == 16 ? 16 : 8;   // 8: two workgroups per CU (see k_lde_pass2_rows)
+                // 16-row tiles: 128-byte runs of the input.  8-row tiles (two workgroups per CU, see k_lde_pass2_rows) measured the
+                // same time and fetch every input line twice (16 instead of 8 B per cell, profiles/r03_q_pmc_lde.txt).
+                static const int p1_tile = std::getenv("TVM_LDE_PASS1_TILE") ? std::atoi(std::getenv("TVM_LDE_PASS1_TILE")) : 16;  // experiment knob
+                const u64 rows_r = p1_tile == 8 ? 8 : 16;
                 const size_t lds_r = (size_t)(rows_r * TVM_ROW_WORDS(n1) + n1) * sizeof(u64);
                 const dim3 g1r((unsigned)(n2 / rows_r), (unsigned)nc);
                 if (rows_r == 16) TVM_LAUNCH((k_lde_pass1_rows<10, 16>), g1r, dim3(1024), lds_r, c->stream, a);

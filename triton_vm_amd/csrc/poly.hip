@@ -10,6 +10,9 @@
 //
 // XFieldElement vectors are arrays of 3-word elements (c0,c1,c2), exactly the reference's layout.
 // All of these are streaming kernels: one pass over their operands, HBM bound.
+#include <cstdlib>
+
+#include "air_eval.h"   // AirAcc: sums of products with one reduction per coefficient at the end
 #include "context.h"
 
 namespace tvm {
@@ -57,59 +60,65 @@ __global__ void k_ood_weights(u64 gen, u64 n, const u64* __restrict__ points, in
 // all-ones column (the barycentric denominator).  A workgroup owns G columns and one chunk of rows: each
 // work-item reads the weights u[.][j] of its row once and the G cells next to them, so the trace is read once
 // per pass and u once per column group (the first version re-read u for every column: 19 GB at 2^20 rows).
-#define TVM_DOT_G 8        // columns per workgroup
+// The products are summed UNREDUCED (AirAcc, air_eval.h: 160-bit sums per coefficient, one Montgomery reduction at the end
+// of the chunk): 13 instructions per product-accumulate instead of 20 for multiply, reduce, add.  An accumulator is 15 VGPRs
+// for a base-field column and 25 for an extension-field one, which sets the columns per workgroup.
 #define TVM_DOT_P 2        // points per pass
 TVM_D u64 wave_sum_u64(u64 v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = bfe_add(v, __shfl_xor(v, m, 64));
     return v;
 }
-__global__ void __launch_bounds__(TVM_RED_BLOCK) k_column_dot(const u64* __restrict__ trace, int fk, u64 n, u64 n_cols,
+template <int FK, int G>   // G columns per workgroup
+__global__ void __launch_bounds__(TVM_RED_BLOCK) k_column_dot(const u64* __restrict__ trace, u64 n, u64 n_cols,
                                                                const u64* __restrict__ u, int p0, int n_points,
                                                                u64 rows_per_chunk, u64 n_chunks, u64* __restrict__ partial) {
-    __shared__ u64 smem[TVM_RED_BLOCK / 64][TVM_DOT_G * TVM_DOT_P * 3];
+    __shared__ u64 smem[TVM_RED_BLOCK / 64][G * TVM_DOT_P * 3];
     const int tid = threadIdx.x, nt = blockDim.x;
-    const u64 c0 = (u64)blockIdx.x * TVM_DOT_G;
+    const u64 c0 = (u64)blockIdx.x * G;
     const u64 chunk = blockIdx.y;
     const u64 r0 = chunk * rows_per_chunk, r1 = (r0 + rows_per_chunk < n) ? r0 + rows_per_chunk : n;
     const int np = (n_points - p0 < TVM_DOT_P) ? n_points - p0 : TVM_DOT_P;
-    xfe acc[TVM_DOT_G][TVM_DOT_P];
+    AirAcc acc[G][TVM_DOT_P];
+    xfe ones[TVM_DOT_P];   // the all-ones column (index n_cols): plain sums of the weights
 #pragma unroll
-    for (int g = 0; g < TVM_DOT_G; g++)
+    for (int q = 0; q < TVM_DOT_P; q++) {
+        ones[q] = xfe_zero();
 #pragma unroll
-        for (int q = 0; q < TVM_DOT_P; q++) acc[g][q] = xfe_zero();
-#pragma unroll 2
+        for (int g = 0; g < G; g++) acc[g][q] = air_acc_zero();
+    }
     for (u64 j = r0 + tid; j < r1; j += nt) {
         xfe w[TVM_DOT_P];
 #pragma unroll
         for (int q = 0; q < TVM_DOT_P; q++) w[q] = (q < np) ? ld_xfe(u + ((u64)(p0 + q) * n + j) * 3) : xfe_zero();
 #pragma unroll
-        for (int g = 0; g < TVM_DOT_G; g++) {
+        for (int g = 0; g < G; g++) {
             const u64 c = c0 + g;
             if (c < n_cols) {
-                const u64* cp = trace + (c * n + j) * fk;
-                if (fk == 1) {
+                const u64* cp = trace + (c * n + j) * FK;
+                if constexpr (FK == 1) {
                     const u64 x = cp[0];
 #pragma unroll
-                    for (int q = 0; q < TVM_DOT_P; q++) acc[g][q] = xfe_add(acc[g][q], xfe_mul_bfe(w[q], x));
+                    for (int q = 0; q < TVM_DOT_P; q++) air_acc_b(acc[g][q], w[q], x);
                 } else {
                     const xfe x = ld_xfe(cp);
 #pragma unroll
-                    for (int q = 0; q < TVM_DOT_P; q++) acc[g][q] = xfe_add(acc[g][q], xfe_mul(x, w[q]));
+                    for (int q = 0; q < TVM_DOT_P; q++) air_acc_x(acc[g][q], w[q], x);
                 }
             } else if (c == n_cols) {
 #pragma unroll
-                for (int q = 0; q < TVM_DOT_P; q++) acc[g][q] = xfe_add(acc[g][q], w[q]);
+                for (int q = 0; q < TVM_DOT_P; q++) ones[q] = xfe_add(ones[q], w[q]);
             }
         }
     }
     // wavefront sums by lane exchange, then the (<= 4) wavefronts of the workgroup through LDS
     const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
-    for (int g = 0; g < TVM_DOT_G; g++)
+    for (int g = 0; g < G; g++)
 #pragma unroll
         for (int q = 0; q < TVM_DOT_P; q++) {
-            const u64 s0 = wave_sum_u64(acc[g][q].c0), s1 = wave_sum_u64(acc[g][q].c1), s2 = wave_sum_u64(acc[g][q].c2);
+            const xfe v = (c0 + g == n_cols) ? ones[q] : air_acc_value(acc[g][q]);
+            const u64 s0 = wave_sum_u64(v.c0), s1 = wave_sum_u64(v.c1), s2 = wave_sum_u64(v.c2);
             if (lane == 0) {
                 smem[wave][(g * TVM_DOT_P + q) * 3 + 0] = s0;
                 smem[wave][(g * TVM_DOT_P + q) * 3 + 1] = s1;
@@ -117,7 +126,7 @@ __global__ void __launch_bounds__(TVM_RED_BLOCK) k_column_dot(const u64* __restr
             }
         }
     __syncthreads();
-    if (tid < TVM_DOT_G * TVM_DOT_P * 3) {
+    if (tid < G * TVM_DOT_P * 3) {
         u64 s = 0;
         for (int wv = 0; wv < nt / 64; wv++) s = bfe_add(s, smem[wv][tid]);
         const int comp = tid % 3, q = (tid / 3) % TVM_DOT_P, g = tid / (3 * TVM_DOT_P);
@@ -151,9 +160,15 @@ __global__ void k_weighted_row_sum(const u64* __restrict__ trace, int fk, u64 n,
                                    int accumulate, u64* __restrict__ out) {
     const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    xfe acc = accumulate ? ld_xfe(out + 3 * j) : xfe_zero();
-    for (u64 c = 0; c < n_cols; c++) acc = xfe_add(acc, cell_times(trace, fk, n, c, j, ld_xfe(w + 3 * c)));
-    st_xfe(out + 3 * j, acc);
+    AirAcc acc = air_acc_zero();   // unreduced sums of the products, see k_column_dot
+    if (fk == 1) {
+        for (u64 c = 0; c < n_cols; c++) air_acc_b(acc, ld_xfe(w + 3 * c), trace[c * n + j]);
+    } else {
+        for (u64 c = 0; c < n_cols; c++) air_acc_x(acc, ld_xfe(w + 3 * c), ld_xfe(trace + (c * n + j) * 3));
+    }
+    xfe r = air_acc_value(acc);
+    if (accumulate) r = xfe_add(r, ld_xfe(out + 3 * j));
+    st_xfe(out + 3 * j, r);
 }
 // R[j] = sum_c w_c r_c[j], j < h; poly[j] -= R[j]; poly[n + j] += R[j]   (mul_zerofier_with, offset 1)
 __global__ void k_randomizer_contribution(const u64* __restrict__ rnd, int fk, u64 n, u64 n_cols, u64 h,
@@ -309,17 +324,25 @@ int out_of_domain_rows(tvm_ctx* c, int fk, const u64* trace, u64 n, u64 n_cols, 
     u64* num = (u64*)scratch(c, 7, (size_t)n_points * (n_cols + 1) * 3 * sizeof(u64));
     if (!u || !num) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "ood scratch");
     TVM_LAUNCH(k_ood_weights, TVM_GRID(n, 256), dim3(256), 0, c->stream, trace_gen, n, d_points, n_points, u);
-    // rows in chunks of 2^15 (128 rows per work-item), columns in groups of TVM_DOT_G, points two at a time
-    // (2^13 for narrow tables so that the grid still fills the chip)
-    const u64 chunk_log = (n_cols + 1 + TVM_DOT_G - 1) / TVM_DOT_G >= 32 ? 15 : 13;
+    // rows in chunks of 2^15 (128 rows per work-item), columns in groups of G (2 columns: the accumulators' registers and the
+    // wavefronts per SIMD they leave), points two at a time (2^13 for narrow tables so that the grid still fills the chip)
+    // (measured at 2^20 rows, both points, main + aux: 4 / 2 columns per workgroup 4.58 ms, 2 / 2 4.07 ms)
+    static const int dot_g = std::getenv("TVM_DOT_G") ? std::atoi(std::getenv("TVM_DOT_G")) : 2;    // experiment knobs
+    static const int dot_gx = std::getenv("TVM_DOT_GX") ? std::atoi(std::getenv("TVM_DOT_GX")) : 2;
+    const u64 G = fk == 1 ? (dot_g == 4 ? 4 : 2) : (dot_gx == 1 ? 1 : 2);
+    const u64 chunk_log = (n_cols + 1 + G - 1) / G >= 64 ? 15 : 13;
     const u64 rows_per_chunk = n < (1ull << chunk_log) ? n : (1ull << chunk_log);
     const u64 n_chunks = (n + rows_per_chunk - 1) / rows_per_chunk;
     const u64 n_sums = (u64)n_points * (n_cols + 1);
     u64* partial = (u64*)scratch(c, 8, (size_t)n_sums * n_chunks * 3 * sizeof(u64));
     if (!partial) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "ood scratch");
-    for (int p0 = 0; p0 < n_points; p0 += TVM_DOT_P)
-        TVM_LAUNCH(k_column_dot, dim3((unsigned)((n_cols + 1 + TVM_DOT_G - 1) / TVM_DOT_G), (unsigned)n_chunks),
-                   dim3(TVM_RED_BLOCK), 0, c->stream, trace, fk, n, n_cols, u, p0, n_points, rows_per_chunk, n_chunks, partial);
+    const dim3 grid((unsigned)((n_cols + 1 + G - 1) / G), (unsigned)n_chunks);
+    for (int p0 = 0; p0 < n_points; p0 += TVM_DOT_P) {
+        if (fk == 1 && G == 2) TVM_LAUNCH((k_column_dot<1, 2>), grid, dim3(TVM_RED_BLOCK), 0, c->stream, trace, n, n_cols, u, p0, n_points, rows_per_chunk, n_chunks, partial);
+        else if (fk == 1) TVM_LAUNCH((k_column_dot<1, 4>), grid, dim3(TVM_RED_BLOCK), 0, c->stream, trace, n, n_cols, u, p0, n_points, rows_per_chunk, n_chunks, partial);
+        else if (G == 1) TVM_LAUNCH((k_column_dot<3, 1>), grid, dim3(TVM_RED_BLOCK), 0, c->stream, trace, n, n_cols, u, p0, n_points, rows_per_chunk, n_chunks, partial);
+        else TVM_LAUNCH((k_column_dot<3, 2>), grid, dim3(TVM_RED_BLOCK), 0, c->stream, trace, n, n_cols, u, p0, n_points, rows_per_chunk, n_chunks, partial);
+    }
     TVM_LAUNCH(k_sum_partials, dim3((unsigned)n_sums), dim3(TVM_RED_BLOCK), 0, c->stream, partial, n_chunks, num);
     TVM_LAUNCH(k_ood_finalize, TVM_GRID(n_cols * n_points, 64), dim3(64), 0, c->stream, num, rnd, fk, n, n_cols, h,
                d_points, n_points, d_rows);

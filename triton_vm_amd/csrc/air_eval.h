@@ -120,10 +120,26 @@ struct Acc160 {
     const u64 v = (u64)(u32)((a) >> 32) * (u32)(b) + (u32)u;                     \
     const u64 w = (u64)(u32)((a) >> 32) * (u32)((b) >> 32) + ((u >> 32) + (v >> 32))
 TVM_D void acc160_mac3(Acc160& A, u64 a0, u64 b0, Acc160& B, u64 a1, u64 b1, Acc160& C, u64 a2, u64 b2) {
+#if TVM_MUL_CARRY_FORM
+    // the partial products of field.h's carry-out form: x = (a1*b1 + (c : v1)) : v0 : t0 with (c : v) = a1*b0 + u
+    TVM_MUL_LOW(a0, b0, ta, ua);
+    TVM_MUL_LOW(a1, b1, tb, ub);
+    TVM_MUL_LOW(a2, b2, tc, uc);
+    u64 va, vb, vc, cb, cc;
+    u32 ka, kb, kc;
+    asm(TVM_3WAY(TVM_MV) TVM_3WAY(TVM_MC)
+        : TVM_MID_OUT(a, va, ka), TVM_MID_OUT(b, vb, kb), TVM_MID_OUT(c, vc, kc), [cb] "=&s"(cb), [cc] "=&s"(cc)
+        : TVM_MID_IN(a, a0, b0, ua), TVM_MID_IN(b, a1, b1, ub), TVM_MID_IN(c, a2, b2, uc)
+        : "vcc");
+    TVM_MUL_HIGH(a0, b0, va, ka, wa);
+    TVM_MUL_HIGH(a1, b1, vb, kb, wb);
+    TVM_MUL_HIGH(a2, b2, vc, kc, wc);
+#else
     AIR_MAC_PARTIALS(a0, b0, ta, ua, va, wa);
     AIR_MAC_PARTIALS(a1, b1, tb, ub, vb, wb);
     AIR_MAC_PARTIALS(a2, b2, tc, uc, vc, wc);
     u64 cb, cc;
+#endif
     asm(TVM_3WAY(AIR_Q1) TVM_3WAY(AIR_Q2) TVM_3WAY(AIR_Q3) TVM_3WAY(AIR_Q4) TVM_3WAY(AIR_Q5)
         : AIR_Q_IO(a, A), AIR_Q_IO(b, B), AIR_Q_IO(c, C), [cb] "=&s"(cb), [cc] "=&s"(cc)
         : AIR_Q_IN(a, ta, va, wa), AIR_Q_IN(b, tb, vb, wb), AIR_Q_IN(c, tc, vc, wc)

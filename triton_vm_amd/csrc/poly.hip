@@ -328,8 +328,8 @@ int out_of_domain_rows(tvm_ctx* c, int fk, const u64* trace, u64 n, u64 n_cols, 
     // wavefronts per SIMD they leave), points two at a time (2^13 for narrow tables so that the grid still fills the chip)
     // (measured at 2^20 rows, both points, main + aux: 4 / 2 columns per workgroup 4.58 ms, 2 / 2 4.07 ms)
     static const int dot_g = std::getenv("TVM_DOT_G") ? std::atoi(std::getenv("TVM_DOT_G")) : 2;    // experiment knobs
-    static const int dot_gx = std::getenv("TVM_DOT_GX") ? std::atoi(std::getenv("TVM_DOT_GX")) : 2;
-    const u64 G = fk == 1 ? (dot_g == 4 ? 4 : 2) : (dot_gx == 1 ? 1 : 2);
+    static const int dot_gx = std::getenv("TVM_DOT_GX") ? std::atoi(std::getenv("TVM_DOT_GX")) : 1;
+    const u64 G = fk == 1 ? (dot_g == 4 ? 4 : 2) : (dot_gx == 2 ? 2 : 1);
     const u64 chunk_log = (n_cols + 1 + G - 1) / G >= 64 ? 15 : 13;
     const u64 rows_per_chunk = n < (1ull << chunk_log) ? n : (1ull << chunk_log);
     const u64 n_chunks = (n + rows_per_chunk - 1) / rows_per_chunk;

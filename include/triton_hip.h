@@ -268,6 +268,20 @@ int32_t tvm_deep_codeword(tvm_ctx* ctx, uint32_t n_components, const uint64_t* c
 int32_t tvm_fri_split_and_fold(tvm_ctx* ctx, const uint64_t* d_codeword, tvm_domain domain,
                                const uint64_t* h_challenge, uint64_t* d_out);
 
+/* ---- F1 + H2 + the transcript in between: the COMMIT PHASE of Fri::prove (fri.rs:212-263) without the host in the loop.
+ * For r = 0 .. n_rounds: the Merkle tree of codeword r (d_nodes[r], 10 * (domain.length >> r) words, as
+ * tvm_codeword_merkle_tree), its root absorbed into the Fiat-Shamir sponge as ProofItem::MerkleRoot (proof_item.rs:96,
+ * proof_stream.rs:54-59: the encoding [0, root] padded with 1, 0, 0, 0 is exactly one absorbed block) and, for r < n_rounds,
+ * one scalar sampled from the sponge (proof_stream.rs:81-84) and codeword r + 1 = split_and_fold(codeword r, that scalar)
+ * written to d_codewords[r] (3 * (domain.length >> (r + 1)) words).  The sponge runs on the device: no stream
+ * synchronisation until the roots and challenges are copied out at the end.
+ * h_sponge_state: the 16 words of the Tip5 sponge before the first root is enqueued (not modified: the caller replays the
+ * n_rounds + 1 enqueues and n_rounds samplings on its own sponge, which must reproduce h_challenges);
+ * h_roots: (n_rounds + 1) * 5 words; h_challenges: n_rounds * 3 words. */
+int32_t tvm_fri_commit_phase(tvm_ctx* ctx, const uint64_t* d_codeword, tvm_domain domain, uint32_t n_rounds,
+                             const uint64_t* h_sponge_state, uint64_t* const* d_codewords, uint64_t* const* d_nodes,
+                             uint64_t* h_roots, uint64_t* h_challenges);
+
 /* ---- coset-wise ("just in time") evaluation: Prover::compute_quotient_segments_with_jit_lde and the JIT branch of
  * hash_all_ldt_domain_rows (stark.rs:805-1006, master_table.rs:470-503) -------------------------------------
  * When the extended tables do not fit, the reference evaluates them coset by coset.  Here a coset group is an

@@ -128,3 +128,46 @@ def test_gather_elements_batch(ctx):
     for h, i, o in zip(hosts, idxs, outs):
         assert (o == h[i.astype(np.int64)]).all()
     assert ctx.lib.tvm_gather_elements_batch(ctx.handle, 0, None, None, None, None, None) == 0
+
+
+@pytest.mark.parametrize("log_n,n_rounds", [(6, 3), (9, 5), (4, 0)])
+def test_fri_commit_phase_equals_the_round_by_round_path(ctx, orc, log_n, n_rounds):
+    """tvm_fri_commit_phase (trees, transcript and folds without the host in the loop: the sponge runs on the device) ==
+    tvm_codeword_merkle_tree + ProofStream.enqueue / sample_scalars on the host + tvm_fri_split_and_fold, round by round"""
+    import ctypes as C
+
+    from triton_vm_amd.arithmetic_domain import ArithmeticDomain
+    from triton_vm_amd.proof_stream import ProofStream
+
+    rng = np.random.default_rng(11)
+    n = 1 << log_n
+    dom = ArithmeticDomain.of_length(n).with_offset(field.to_mont(7))
+    cw = orc.random_elements(rng, (n, 3))
+    d_cw = ctx.to_device(cw)
+    ps = ProofStream(ctx.lib)
+    ps.enqueue("log2 padded height", np.array([field.to_mont(5)], np.uint64))     # some history in the sponge
+    state0 = ps.state.copy()
+    # the device path
+    cws = [ctx.alloc(max(n >> (r + 1), 1) * 3) for r in range(n_rounds)]
+    nodes = [ctx.alloc(10 * (n >> r)) for r in range(n_rounds + 1)]
+    roots = np.zeros((n_rounds + 1, 5), np.uint64)
+    challenges = np.zeros((max(n_rounds, 1), 3), np.uint64)
+    p_cws = (C.c_void_p * max(n_rounds, 1))(*[b.ptr for b in cws])
+    p_nodes = (C.c_void_p * (n_rounds + 1))(*[b.ptr for b in nodes])
+    ctx._check(ctx.lib.tvm_fri_commit_phase(ctx.handle, d_cw.ptr, dom.c(), n_rounds, state0.ctypes.data, p_cws, p_nodes,
+                                            roots.ctypes.data, challenges.ctypes.data), "commit phase")
+    # round by round through the host
+    cur, d = d_cw, dom
+    for r in range(n_rounds + 1):
+        tree = stark.merkle_tree_from_codeword(ctx, cur, d.length)
+        assert (tree.download((2 * d.length, 5)) [1:] == nodes[r].download((2 * d.length, 5))[1:]).all()
+        root = tree.download((2 * d.length, 5))[1]
+        assert (root == roots[r]).all()
+        ps.enqueue(f"fri root {r}", root)
+        if r == n_rounds:
+            break
+        ch = ps.sample_scalars(1)[0]
+        assert (np.asarray(ch, np.uint64) == challenges[r]).all()
+        nxt = stark.split_and_fold(ctx, cur, d, ch)
+        assert (nxt.download((d.length // 2, 3)) == cws[r].download((d.length // 2, 3))).all()
+        cur, d = nxt, d.pow(2)

@@ -572,6 +572,40 @@ int32_t tvm_deep_codeword(tvm_ctx* c, uint32_t n_comp, const uint64_t* const* d_
     return deep_sum(c, (int)n_comp, d_cw, h_points, h_values, h_weights, dom.offset, dom.generator, dom.length, d_out);
 }
 
+int32_t tvm_fri_commit_phase(tvm_ctx* c, const uint64_t* d_cw, tvm_domain dom, uint32_t n_rounds, const uint64_t* h_state,
+                             uint64_t* const* d_codewords, uint64_t* const* d_nodes, uint64_t* h_roots, uint64_t* h_challenges) {
+    if (!c || !d_cw || !valid_domain(dom) || !h_state || !d_nodes || !h_roots || (n_rounds && (!d_codewords || !h_challenges)) ||
+        (dom.length >> n_rounds) < 1)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "fri_commit_phase arguments");
+    for (uint32_t r = 0; r <= n_rounds; r++)
+        if (!d_nodes[r] || (r < n_rounds && !d_codewords[r])) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "fri_commit_phase: null buffer");
+    // device words: the sponge (16), the roots ((n_rounds + 1) * 5), the challenges (n_rounds * 3)
+    const size_t n_words = 16 + (size_t)(n_rounds + 1) * 5 + (size_t)n_rounds * 3;
+    u64* d = (u64*)scratch(c, 24, n_words * sizeof(u64));
+    if (!d) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "fri_commit_phase scratch");
+    u64 *d_state = d, *d_roots = d + 16, *d_ch = d_roots + (size_t)(n_rounds + 1) * 5;
+    TVM_HIP_CHECK(c, hipMemcpyAsync(d_state, h_state, 16 * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));  // h_state may be a caller temporary
+    const u64* cw = d_cw;
+    u64 offset = dom.offset, gen = dom.generator, n = dom.length;
+    for (uint32_t r = 0; r <= n_rounds; r++) {
+        TVM_LAUNCH(tvm::k_xfe_aos_leaves, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, cw, n, d_nodes[r] + 5 * n);
+        TVM_TRY(merkle_tree_from_leaves(c, d_nodes[r], n));
+        TVM_HIP_CHECK(c, hipMemcpyAsync(d_roots + 5 * r, d_nodes[r] + 5, 5 * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        TVM_TRY(sponge_absorb_root_and_sample(c, d_state, d_nodes[r] + 5, r < n_rounds ? d_ch + 3 * r : nullptr));
+        if (r == n_rounds) break;
+        TVM_TRY(fri_fold(c, cw, n, offset, gen, nullptr, d_codewords[r], d_ch + 3 * r));
+        cw = d_codewords[r];
+        offset = bfe_mul(offset, offset);   // ArithmeticDomain::pow(2) (arithmetic_domain.rs:150-160)
+        gen = bfe_mul(gen, gen);
+        n >>= 1;
+    }
+    TVM_HIP_CHECK(c, hipMemcpyAsync(h_roots, d_roots, (size_t)(n_rounds + 1) * 5 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    if (n_rounds) TVM_HIP_CHECK(c, hipMemcpyAsync(h_challenges, d_ch, (size_t)n_rounds * 3 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return TVM_OK;
+}
+
 int32_t tvm_fri_split_and_fold(tvm_ctx* c, const uint64_t* d_cw, tvm_domain dom, const uint64_t* h_ch, uint64_t* d_out) {
     if (!c || !d_cw || !h_ch || !d_out || !valid_domain(dom))
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "fri_split_and_fold arguments");

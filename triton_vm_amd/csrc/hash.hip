@@ -120,6 +120,34 @@ __global__ void __launch_bounds__(1024) k_merkle_top(u64* __restrict__ nodes, u6
     }
 }
 
+// Fiat-Shamir between two FRI rounds, on the device (one wavefront; lanes 0..15 hold the sponge state, the other lanes
+// follow along so that every lane joins the rotations of tip5_permute_lanes):
+//   ProofStream::enqueue(MerkleRoot(root)): the item's encoding [0, root] is 6 words, padded with 1, 0, 0, 0 to one block of the
+//   rate; the sponge absorbs in overwrite mode, then permutes (proof_stream.rs:40-59, twenty-first Sponge::pad_and_absorb_all);
+//   sample_scalars(1): squeeze -- the first 3 words of the state are the scalar -- and permute (proof_stream.rs:81-84).
+__global__ void __launch_bounds__(64) k_sponge_root_and_sample(u64* __restrict__ state, const u64* __restrict__ root,
+                                                                u64* __restrict__ challenge) {
+    __shared__ unsigned char lut[256];
+    tip5_stage_lut(lut, threadIdx.x, blockDim.x);
+    const int lane = (int)threadIdx.x, pos = lane & 15;
+    u64 x = state[pos];
+    if (pos == 0) x = 0;                       // the discriminant of ProofItem::MerkleRoot
+    else if (pos <= 5) x = root[pos - 1];
+    else if (pos == 6) x = TVM_ONE;            // padding: 1, then zeros
+    else if (pos < TIP5_RATE) x = 0;
+    x = tip5_permute_lanes(x, pos, lane, lut);
+    if (challenge) {
+        if (lane < 3) challenge[lane] = x;
+        x = tip5_permute_lanes(x, pos, lane, lut);
+    }
+    if (lane < 16) state[pos] = x;
+}
+int sponge_absorb_root_and_sample(tvm_ctx* c, u64* d_state, const u64* d_root, u64* d_challenge) {
+    TVM_LAUNCH(k_sponge_root_and_sample, dim3(1), dim3(64), 0, c->stream, d_state, d_root, d_challenge);
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+
 // FRI leaves: Digest::from(xfe) = [c0, c1, c2, 0, 0], no hashing (fri.rs:343-347).
 // codeword planar: c0[n], c1[n], c2[n] at stride `plane`.
 __global__ void k_xfe_leaves(const u64* __restrict__ cw, u64 plane, u64 n, u64* __restrict__ leaves) {

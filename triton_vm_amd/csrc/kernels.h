@@ -29,7 +29,11 @@ int table_lincomb(tvm_ctx* c, const u64* table, const TabLayout& layout, int fk,
 int poly_eval(tvm_ctx* c, const u64* d_coeffs, u64 n, const u64* d_points, int n_points, u64* d_out);
 int deep_sum(tvm_ctx* c, int n_comp, const u64* const* d_cw, const u64* h_points, const u64* h_values, const u64* h_weights,
              u64 offset, u64 gen, u64 n, u64* d_out);
-int fri_fold(tvm_ctx* c, const u64* d_cw, u64 n, u64 offset, u64 gen, const u64* h_challenge, u64* d_out);
+int fri_fold(tvm_ctx* c, const u64* d_cw, u64 n, u64 offset, u64 gen, const u64* h_challenge, u64* d_out,
+             const u64* d_challenge = nullptr);   // the challenge from the host, or three words in device memory
+// Fiat-Shamir on the device: absorb ProofItem::MerkleRoot(nodes[1]) into the sponge `state` (16 words, device), then -- if
+// d_challenge -- sample one scalar (3 words) from it
+int sponge_absorb_root_and_sample(tvm_ctx* c, u64* d_state, const u64* d_root, u64* d_challenge);
 // stir.hip
 int stir_hash_stacked(tvm_ctx* c, const u64* cw, u64 n, int stack_height, u64* digests);
 int stir_fold_polynomial(tvm_ctx* c, const u64* poly, u64 n, int ff, const u64* h_r, u64* out);

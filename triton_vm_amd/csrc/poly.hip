@@ -301,11 +301,18 @@ __global__ void k_deep(DeepArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // FRI split-and-fold (fri.rs:349-366): out[i] = ((1 + c/x_i) f[i] + (1 - c/x_i) f[i + n/2]) / 2
+// (challenge: c0, c1, c2 as arguments, or -- d_challenge != nullptr -- three words in device memory written by an earlier
+// kernel of the stream: tvm_fri_commit_phase)
 __global__ void k_fri_fold(const u64* __restrict__ f, u64 n, u64 offset_inv, u64 gen_inv, u64 c0, u64 c1, u64 c2,
-                           u64 two_inv, u64* __restrict__ out) {
+                           const u64* __restrict__ d_challenge, u64 two_inv, u64* __restrict__ out) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 half = n >> 1;
     if (i >= half) return;
+    if (d_challenge) {
+        c0 = d_challenge[0];
+        c1 = d_challenge[1];
+        c2 = d_challenge[2];
+    }
     const u64 xinv = bfe_mul(offset_inv, bfe_pow(gen_inv, i));
     const xfe s = xfe_mul_bfe(xfe_make(c0, c1, c2), xinv);
     const xfe l = xfe_mul(xfe_add_bfe(s, TVM_ONE), ld_xfe(f + 3 * i));
@@ -411,10 +418,12 @@ int deep_sum(tvm_ctx* c, int n_comp, const u64* const* d_cw, const u64* h_points
     TVM_HIP_CHECK(c, hipGetLastError());
     return TVM_OK;
 }
-int fri_fold(tvm_ctx* c, const u64* d_cw, u64 n, u64 offset, u64 gen, const u64* h_challenge, u64* d_out) {
+int fri_fold(tvm_ctx* c, const u64* d_cw, u64 n, u64 offset, u64 gen, const u64* h_challenge, u64* d_out, const u64* d_challenge) {
     if (n < 2) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "fold: codeword of length >= 2");
+    if (!h_challenge && !d_challenge) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "fold: no challenge");
     TVM_LAUNCH(k_fri_fold, TVM_GRID(n / 2, 256), dim3(256), 0, c->stream, d_cw, n, bfe_inv(offset), bfe_inv(gen),
-               h_challenge[0], h_challenge[1], h_challenge[2], bfe_inv(bfe_from_u64(2)), d_out);
+               h_challenge ? h_challenge[0] : 0, h_challenge ? h_challenge[1] : 0, h_challenge ? h_challenge[2] : 0, d_challenge,
+               bfe_inv(bfe_from_u64(2)), d_out);
     TVM_HIP_CHECK(c, hipGetLastError());
     return TVM_OK;
 }

@@ -406,19 +406,33 @@ std::vector<u64> Prover::fri(const DeviceBuffer& combination, ProofStream& ps) {
     std::vector<DeviceBuffer> folded;  // owns the codewords of rounds 1..
     ArithmeticDomain dom = p_.ldt;
     const u64* cw = combination.ptr();
-    for (unsigned r = 0; r <= p_.fri_rounds; r++) {
-        DeviceBuffer nodes(c_, 10 * dom.length);
-        c_.check(tvm_codeword_merkle_tree(c_.raw(), cw, dom.length, nodes.ptr()), "tvm_codeword_merkle_tree");
-        const std::vector<u64> root = merkle_root(c_, nodes);
-        ps.enqueue("fri root " + std::to_string(r), root.data(), 5);
-        rounds.push_back(Round{dom, cw, std::move(nodes)});
-        if (r == p_.fri_rounds) break;
-        const Xfe challenge = ps.sample_scalars(1)[0];
-        DeviceBuffer next(c_, dom.length / 2 * 3);
-        c_.check(tvm_fri_split_and_fold(c_.raw(), cw, dom.c(), challenge.c, next.ptr()), "tvm_fri_split_and_fold");
-        folded.push_back(std::move(next));
-        cw = folded.back().ptr();
-        dom = dom.pow(2);
+    {
+        // The commit phase in one call, the sponge on the device (tvm_fri_commit_phase): trees, roots into the transcript,
+        // folding challenges, folds -- then the same enqueues and samplings are replayed on this host's sponge, which must
+        // arrive at the same challenges.
+        std::vector<u64*> d_cw, d_nodes;
+        ArithmeticDomain d = dom;
+        for (unsigned r = 0; r <= p_.fri_rounds; r++) {
+            rounds.push_back(Round{d, nullptr, DeviceBuffer(c_, 10 * d.length)});
+            d_nodes.push_back(rounds.back().nodes.ptr());
+            if (r == p_.fri_rounds) break;
+            folded.emplace_back(c_, d.length / 2 * 3);
+            d_cw.push_back(folded.back().ptr());
+            d = d.pow(2);
+        }
+        std::vector<u64> roots(5 * (p_.fri_rounds + 1)), challenges(3 * (size_t)p_.fri_rounds + 1);
+        c_.check(tvm_fri_commit_phase(c_.raw(), cw, dom.c(), p_.fri_rounds, ps.sponge_state(), d_cw.data(), d_nodes.data(), roots.data(),
+                                      challenges.data()), "tvm_fri_commit_phase");
+        for (unsigned r = 0; r <= p_.fri_rounds; r++) {
+            rounds[r].cw = r == 0 ? cw : folded[r - 1].ptr();
+            ps.enqueue("fri root " + std::to_string(r), &roots[5 * r], 5);
+            if (r == p_.fri_rounds) break;
+            const Xfe challenge = ps.sample_scalars(1)[0];
+            if (std::memcmp(challenge.c, &challenges[3 * r], 3 * sizeof(u64)) != 0)
+                throw Error(TVM_ERR_DEVICE, "the device's Fiat-Shamir sponge and the host's disagree on a FRI folding challenge");
+        }
+        cw = rounds.back().cw;
+        dom = rounds.back().dom;
     }
     std::vector<u64> last(dom.length * 3);
     c_.check(tvm_memcpy_d2h(c_.raw(), last.data(), cw, last.size() * sizeof(u64)), "last codeword");

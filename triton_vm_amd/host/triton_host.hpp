@@ -105,6 +105,7 @@ public:
     std::vector<Xfe> sample_scalars(u64 n);
     std::vector<u64> sample_indices(u64 upper_bound, u64 n);
     const std::vector<Item>& items() const { return items_; }
+    const u64* sponge_state() const { return state_; }                       // the 16 words of the Fiat-Shamir sponge
     std::vector<u64> proof() const;                                         // proof_stream.rs:115-119: Proof(encode())
 
 private:

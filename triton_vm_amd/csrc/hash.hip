@@ -10,6 +10,8 @@
 // (tip5.h, "matrix-core form"); Merkle levels: one lane per parent while a level fills the chip, sixteen
 // lanes per parent below that.  Hashing is integer-ALU bound (38 + 28 permutations per
 // LDT row; ~60% of a permutation's instructions are the x^7 S-boxes), not HBM bound.
+#include <cstdlib>
+
 #include "context.h"
 #include "tip5.h"
 
@@ -59,28 +61,32 @@ __global__ void __launch_bounds__(TVM_HASH_BLOCK, 6) k_hash_rows_mfma(const u64*
 
 // nodes[i] = hash_pair(nodes[2i], nodes[2i+1]) for i in [first, first + count): the matrix-core form of the
 // permutation (four lanes per parent, sixteen parents per wavefront; tip5.h), for the levels that fill the chip.
-__global__ void __launch_bounds__(256, 6) k_merkle_level(u64* __restrict__ nodes, u64 first, u64 count) {
+__global__ void __launch_bounds__(256, 6) k_merkle_level(u64* __restrict__ nodes, u64 first, u64 count, int reps) {
     __shared__ unsigned char lut[256];
     __shared__ int ctab[TIP5_ROUNDS * TIP5_MFMA_POSITIONS * 16];
     const int tid = threadIdx.x;
     for (int i = tid; i < TIP5_ROUNDS * TIP5_MFMA_POSITIONS * 16; i += blockDim.x) ctab[i] = d_tip5_mfma_table.v[i];
     tip5_stage_lut_lowered(lut, tid, blockDim.x);
     const int lane = tid & 63, n = lane & 15, g = lane >> 4;
-    u64 j = ((u64)blockIdx.x * 4 + (tid >> 6)) * 16 + n;
-    const bool live = j < count;  // every lane of a wavefront takes part in the matrix instructions
-    if (!live) j = count - 1;
-    const u64 i = first + j;
     const Tip5MfmaOperands a = tip5_mfma_matrix_operands(lane);
-    u64 st[4];
+    // `reps` groups of 64 parents per workgroup, one after the other: the tables above and the matrix operands are set up once
+    // (a wide level is ONE permutation per lane quadruple: the set-up was a fifth of the kernel)
+    for (int rep = 0; rep < reps; rep++) {
+        u64 j = (((u64)blockIdx.x * reps + rep) * 4 + (tid >> 6)) * 16 + n;
+        const bool live = j < count;  // every lane of a wavefront takes part in the matrix instructions
+        if (!live) j = count - 1;
+        const u64 i = first + j;
+        u64 st[4];
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-        const int q = g + 4 * t;
-        st[t] = q < 10 ? nodes[10 * i + q] : TVM_ONE;  // fixed-length domain: capacity all ones (tip-0005.md:82)
-    }
-    tip5_permute_mfma(st, a, g, lut, ctab);
-    if (live) {
-        nodes[5 * i + g] = st[0];
-        if (g == 0) nodes[5 * i + 4] = st[1];
+        for (int t = 0; t < 4; t++) {
+            const int q = g + 4 * t;
+            st[t] = q < 10 ? nodes[10 * i + q] : TVM_ONE;  // fixed-length domain: capacity all ones (tip-0005.md:82)
+        }
+        tip5_permute_mfma(st, a, g, lut, ctab);
+        if (live) {
+            nodes[5 * i + g] = st[0];
+            if (g == 0) nodes[5 * i + 4] = st[1];
+        }
     }
 }
 
@@ -215,8 +221,13 @@ int merkle_tree_from_leaves(tvm_ctx* c, u64* nodes, u64 n_leaves) {
     if (!is_pow2(n_leaves)) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "merkle: leaf count must be a power of two");
     TVM_HIP_CHECK(c, hipMemsetAsync(nodes, 0, 5 * sizeof(u64), c->stream));
     u64 lvl = n_leaves >> 1;
-    for (; lvl > 32768; lvl >>= 1)  // wide levels: one lane per parent (throughput form)
-        TVM_LAUNCH(k_merkle_level, dim3((unsigned)((lvl + 63) / 64)), dim3(256), 0, c->stream, nodes, lvl, lvl);
+    for (; lvl > 32768; lvl >>= 1) {  // wide levels: four lanes per parent on the matrix cores (throughput form)
+        const u64 groups = (lvl + 63) / 64;   // of 64 parents; up to 8 per workgroup while >= 4096 workgroups remain
+        const char* env = std::getenv("TVM_MERKLE_MIN_WORKGROUPS");   // (the CPU suite lowers it to reach this path)
+        const u64 min_wgs = env ? (u64)std::atoll(env) : 4096;
+        const int reps = groups >= 8 * min_wgs ? 8 : groups >= 4 * min_wgs ? 4 : groups >= 2 * min_wgs ? 2 : 1;
+        TVM_LAUNCH(k_merkle_level, dim3((unsigned)((groups + reps - 1) / reps)), dim3(256), 0, c->stream, nodes, lvl, lvl, reps);
+    }
     for (; lvl > 64; lvl >>= 1)     // narrow levels: 16 lanes per parent (latency form)
         TVM_LAUNCH(k_merkle_level_lanes, dim3((unsigned)((lvl * 16 + 255) / 256)), dim3(256), 0, c->stream, nodes, lvl, lvl);
     if (lvl >= 1) TVM_LAUNCH(k_merkle_top, dim3(1), dim3(1024), 0, c->stream, nodes, lvl);

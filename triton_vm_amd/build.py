@@ -94,7 +94,7 @@ def build_host(backend_lib=None, out=None):
         fcntl.flock(lock, fcntl.LOCK_EX)
         name = os.path.basename(backend_lib)
         assert name.startswith("lib") and name.endswith(".so")
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"),
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-fPIC", "-shared", "-pthread", "-I", os.path.join(ROOT, "include"),
                                "-o", out + ".tmp", *srcs, "-L", os.path.dirname(backend_lib), "-l" + name[3:-3],
                                "-Wl,-rpath,$ORIGIN"])  # the backend sits next to it
         os.replace(out + ".tmp", out)

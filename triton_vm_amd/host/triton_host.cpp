@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <iterator>
+#include <thread>
 
 namespace triton_vm {
 
@@ -307,25 +308,31 @@ static std::vector<u64> merkle_root(const Context& c, const DeviceBuffer& nodes)
 // [twenty-first MerkleTree::authentication_structure, restated] the nodes a verifier cannot compute from the revealed
 // leaves -- the siblings along the paths that are not themselves on a path -- in descending heap order, gathered to the host
 static std::vector<u64> auth_node_indices(u64 n_leaves, const std::vector<u64>& indices) {
-    auto uniq = [](std::vector<u64> v) {
-        std::sort(v.begin(), v.end());
-        v.erase(std::unique(v.begin(), v.end()), v.end());
-        return v;
-    };
+    // Level by level on the sorted list of path nodes: a sibling is needed unless it is a path node itself (then it sits next
+    // to its sibling in the sorted list); nodes of different levels have disjoint index ranges, so the levels do not interact.
+    // Deeper levels have the larger heap indices: appending each level's siblings in descending order, deepest level first,
+    // IS the descending heap order.  (O(indices x depth), no sets: this runs between two device phases with the GPU idle.)
     std::vector<u64> k;
+    k.reserve(indices.size());
     for (u64 i : indices) k.push_back(i + n_leaves);
-    k = uniq(k);
-    std::vector<u64> needed, computable;
+    std::sort(k.begin(), k.end());
+    k.erase(std::unique(k.begin(), k.end()), k.end());
+    std::vector<u64> need, level;
     while (!k.empty() && k[0] > 1) {
-        for (u64 x : k) computable.push_back(x), needed.push_back(x ^ 1);
-        for (u64& x : k) x >>= 1;
-        k = uniq(k);
+        level.clear();
+        for (size_t i = 0; i < k.size(); i++) {
+            const u64 x = k[i], sibling = x ^ 1;
+            const bool on_a_path = (x & 1) ? (i > 0 && k[i - 1] == sibling) : (i + 1 < k.size() && k[i + 1] == sibling);
+            if (!on_a_path) level.push_back(sibling);
+        }
+        need.insert(need.end(), level.rbegin(), level.rend());
+        size_t m = 0;
+        for (size_t i = 0; i < k.size(); i++) {
+            const u64 parent = k[i] >> 1;
+            if (m == 0 || k[m - 1] != parent) k[m++] = parent;
+        }
+        k.resize(m);
     }
-    needed = uniq(needed);
-    computable = uniq(computable);
-    std::vector<u64> need;
-    std::set_difference(needed.begin(), needed.end(), computable.begin(), computable.end(), std::back_inserter(need));
-    std::reverse(need.begin(), need.end());
     return need;
 }
 static std::vector<u64> auth_nodes(const Context& c, const DeviceBuffer& nodes, u64 n_leaves, const std::vector<u64>& indices) {
@@ -596,23 +603,23 @@ ProofStream Prover::prove() {
         }
     }
 
-    // 19: open the trace leafs  (stark.rs:665-716)
+    // 19: open the trace leafs  (stark.rs:665-716): the three trees have the same shape and the same revealed leaves, hence
+    // the same authentication-structure node indices; their nodes come back in one round trip
     {
-        const std::vector<u64> rows = main_.reveal_rows(a_indices), auth = auth_nodes(c_, main_nodes, L, a_indices);
-        ps.enqueue("main rows", rows.data(), rows.size());
-        ps.enqueue("main auth", auth.data(), auth.size());
-    }
-    {
-        const std::vector<u64> rows = aux_.reveal_rows(a_indices), auth = auth_nodes(c_, aux_nodes, L, a_indices);
-        ps.enqueue("aux rows", rows.data(), rows.size());
-        ps.enqueue("aux auth", auth.data(), auth.size());
-    }
-    {
+        const std::vector<u64> auth_idx = auth_node_indices(L, a_indices);
+        GatherBatch batch;
+        const size_t a_main = batch.add(main_nodes.ptr(), 5, auth_idx), a_aux = batch.add(aux_nodes.ptr(), 5, auth_idx),
+                     a_quot = batch.add(quot_nodes.ptr(), 5, auth_idx);
+        batch.run(c_);
+        const std::vector<u64> main_rows = main_.reveal_rows(a_indices), aux_rows = aux_.reveal_rows(a_indices);
         std::vector<u64> qrows(a_indices.size() * 15);
         c_.check(tvm_table_reveal_rows(c_.raw(), seg_table, L, a_indices.data(), a_indices.size(), qrows.data()), "quotient rows");
-        const std::vector<u64> auth = auth_nodes(c_, quot_nodes, L, a_indices);
+        ps.enqueue("main rows", main_rows.data(), main_rows.size());
+        ps.enqueue("main auth", batch.jobs[a_main].out.data(), batch.jobs[a_main].out.size());
+        ps.enqueue("aux rows", aux_rows.data(), aux_rows.size());
+        ps.enqueue("aux auth", batch.jobs[a_aux].out.data(), batch.jobs[a_aux].out.size());
         ps.enqueue("quot rows", qrows.data(), qrows.size());
-        ps.enqueue("quot auth", auth.data(), auth.size());
+        ps.enqueue("quot auth", batch.jobs[a_quot].out.data(), batch.jobs[a_quot].out.size());
     }
     main_.clear_cache();
     aux_.clear_cache();
@@ -859,13 +866,16 @@ void offset_rng_seed(const uint8_t seed[32], u64 offset, uint8_t out[32]) {
 }
 
 // trace_randomizer_for_column for every column (master_table.rs:423-434) -> device [n_cols][h](x3)
-static DeviceBuffer trace_randomizers(const Context& c, const uint8_t table_seed[32], u64 n_cols, u64 h, int fk) {
+static std::vector<u64> trace_randomizers_host(const uint8_t table_seed[32], u64 n_cols, u64 h, int fk) {
     std::vector<u64> host(n_cols * h * fk);
     for (u64 col = 0; col < n_cols; col++) {
         uint8_t seed[32];
         offset_rng_seed(table_seed, col, seed);
         tvm_host_stdrng_elements(seed, h * fk, host.data() + col * h * fk);
     }
+    return host;
+}
+static DeviceBuffer upload(const Context& c, const std::vector<u64>& host) {
     DeviceBuffer d(c, host.size());
     c.check(tvm_memcpy_h2d(c.raw(), d.ptr(), host.data(), host.size() * sizeof(u64)), "tvm_memcpy_h2d");
     return d;
@@ -875,6 +885,24 @@ std::vector<u64> prove_execution(const Context& c, const StarkParameters& p, con
                                  const uint8_t seed[32]) {
     const u64 n = p.trace.length;
     Stopwatch watch{c};
+    // the seeded randomness: offsets as in the table of master_table.rs:618-628.  The 470 trace-randomizer streams are
+    // sequential ChaCha streams (0.7 ms of host time at 198 randomizers): a helper thread draws them while the device fills
+    // and pads the main table.
+    uint8_t aux_seed[32], batch_seed[32], quotient_seed[32];
+    offset_rng_seed(seed, NUM_MAIN, aux_seed);
+    offset_rng_seed(aux_seed, NUM_AUX, batch_seed);
+    offset_rng_seed(seed, NUM_MAIN + NUM_AUX + 1, quotient_seed);
+    std::vector<u64> main_rnd_host, aux_rnd_host;
+    std::vector<Xfe> quotient_randomizer(p.num_quotient_randomizers);
+    std::thread draws([&] {
+        main_rnd_host = trace_randomizers_host(seed, NUM_MAIN, p.h, 1);
+        aux_rnd_host = trace_randomizers_host(aux_seed, NUM_AUX, p.h, 3);
+        tvm_host_stdrng_elements(quotient_seed, 3 * quotient_randomizer.size(), quotient_randomizer[0].c);
+    });
+    struct Join {
+        std::thread& t;
+        ~Join() { if (t.joinable()) t.join(); }
+    } join{draws};
     // MasterMainTable::new + pad (master_table.rs:881-983)
     DeviceBuffer main_trace(c, NUM_MAIN * n);
     u64 lengths[9];
@@ -885,15 +913,9 @@ std::vector<u64> prove_execution(const Context& c, const StarkParameters& p, con
     c.check(tvm_pad_main_table(c.raw(), main_trace.ptr(), n, lengths), "tvm_pad_main_table");
     c.check(tvm_fill_derived_main_columns(c.raw(), main_trace.ptr(), n), "tvm_fill_derived_main_columns");
     watch.lap("pad + derived main columns");
-    // the seeded randomness: offsets as in the table of master_table.rs:618-628
-    uint8_t aux_seed[32], batch_seed[32], quotient_seed[32];
-    offset_rng_seed(seed, NUM_MAIN, aux_seed);
-    offset_rng_seed(aux_seed, NUM_AUX, batch_seed);
-    offset_rng_seed(seed, NUM_MAIN + NUM_AUX + 1, quotient_seed);
-    const DeviceBuffer main_rnd = trace_randomizers(c, seed, NUM_MAIN, p.h, 1);
-    const DeviceBuffer aux_rnd = trace_randomizers(c, aux_seed, NUM_AUX, p.h, 3);
-    std::vector<Xfe> quotient_randomizer(p.num_quotient_randomizers);
-    tvm_host_stdrng_elements(quotient_seed, 3 * quotient_randomizer.size(), quotient_randomizer[0].c);
+    draws.join();
+    const DeviceBuffer main_rnd = upload(c, main_rnd_host);
+    const DeviceBuffer aux_rnd = upload(c, aux_rnd_host);
     watch.lap("trace randomizers");
     // MasterMainTable::extend (master_table.rs:1006-1075): the batch-randomizer column now, the rest once the challenges exist
     DeviceBuffer aux_trace(c, NUM_AUX * n * 3);

@@ -190,20 +190,67 @@ void ProofStream::enqueue(const std::string& name, const u64* words, u64 n, u64 
     items_.push_back(Item{name, Words(words, words + n), fiat_shamir, stack_words});
     if (fiat_shamir) alter_fiat_shamir_state_with(encode_item(variant, items_.back().words, nullptr));
 }
+namespace {
+// encode_item appended to `out` in place (length prefixes are reserved and filled in afterwards): the proof is 2 MB at 2^20
+// rows and is assembled between two device phases
+struct InPlace {
+    Words& v;
+    size_t open() { v.push_back(0); return v.size() - 1; }
+    void close(size_t at) { v[at] = to_mont(v.size() - at - 1); }
+    void vec(const u64* w, u64 n_words, u64 elem_words) { push_len(v, n_words / elem_words); v.insert(v.end(), w, w + n_words); }
+};
+void encode_item_into(Words& out, int variant, const Words& payload, const Words* auth_structure, u64 stack_words) {
+    const Variant& var = VARIANTS[variant];
+    InPlace e{out};
+    push_len(out, (u64)variant);
+    if (var.kind == STATIC) {
+        append(out, payload);
+    } else if (var.kind > 0) {
+        const size_t a = e.open();
+        e.vec(payload.data(), payload.size(), (u64)var.kind);
+        e.close(a);
+    } else if (var.kind == POLYNOMIAL) {
+        append_dynamic(out, encode_polynomial(payload.data(), payload.size()));
+    } else {  // see encode_item
+        const size_t response = e.open();
+        const size_t auth = e.open();
+        e.vec(auth_structure->data(), auth_structure->size(), 5);
+        e.close(auth);
+        const size_t leaves = e.open();
+        if (stack_words) {
+            push_len(out, payload.size() / stack_words);
+            for (u64 at = 0; at < payload.size(); at += stack_words) {
+                const size_t one = e.open();
+                e.vec(payload.data() + at, stack_words, 3);
+                e.close(one);
+            }
+        } else {
+            e.vec(payload.data(), payload.size(), 3);
+        }
+        e.close(leaves);
+        e.close(response);
+    }
+}
+}  // namespace
 Words ProofStream::proof() const {  // impl From<&ProofStream> for Proof, proof_stream.rs:115-119
-    Words items;
+    size_t words = 16;
+    for (const Item& it : items_) words += it.words.size() + it.words.size() / 8 + 16;
+    Words out;
+    out.reserve(words);
+    InPlace e{out};
+    const size_t vec = e.open();   // struct ProofStream { items: Vec<ProofItem>, .. }
+    out.push_back(0);              // the number of items
     u64 count = 0;
     for (size_t k = 0; k < items_.size(); k++, count++) {
         const int variant = variant_of(items_[k].name);
         const bool response = VARIANTS[variant].kind == RESPONSE;  // its leaves and its authentication structure: one item
-        append_dynamic(items, encode_item(variant, items_[k].words, response ? &items_[k + 1].words : nullptr, items_[k].stack_words));
+        const size_t item = e.open();
+        encode_item_into(out, variant, items_[k].words, response ? &items_[k + 1].words : nullptr, items_[k].stack_words);
+        e.close(item);
         if (response) k++;
     }
-    Words vec;
-    push_len(vec, count);
-    append(vec, items);
-    Words out;
-    append_dynamic(out, vec);  // struct ProofStream { items: Vec<ProofItem>, .. }
+    out[vec + 1] = to_mont(count);
+    e.close(vec);
     return out;
 }
 void ProofStream::squeeze(u64 out[10]) {

@@ -107,8 +107,9 @@ __global__ void __launch_bounds__(256) k_air_scatter(AirArgs a, const u64* __res
 int all_quotients_combined(tvm_ctx* c, const u64* main_table, const TabLayout& layout, u64 main_w, const u64* aux_table,
                            u64 aux_w, u64 trace_len, u64 trace_gen, u64 q_offset, u64 q_gen, u64 q_len,
                            const u64* d_challenges, const u64* d_weights, u64* d_out, int part_select, int accumulate) {
-    // part_select: 0 = every part, 1 = the parts with consistency / transition constraints only ("low degree"),
-    // 2 = the others (initial / terminal constraints); accumulate: the quotient values are added to d_out
+    // part_select: 0 = every part, 1 = the "low degree" parts (air_gen.h: consistency / transition constraints and the initial /
+    // terminal constraints of degree <= 3),
+    // 2 = the others (the initial / terminal constraints of degree 4); accumulate: the quotient values are added to d_out
     const u64 rows = layout.rows();
     if (!is_pow2(q_len) || !is_pow2(trace_len) || q_len < trace_len || rows % q_len)
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "quotients: domain lengths");

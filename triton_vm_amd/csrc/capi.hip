@@ -682,12 +682,13 @@ int32_t tvm_all_quotients_combined(tvm_ctx* c, const tvm_table* mt, const tvm_ta
     // evaluated on all points.  On a VALID trace -- the constraints vanish on the trace domain, so the quotients ARE
     // polynomials -- these are exactly the field elements the row-by-row evaluation yields, at half the cost; on an
     // invalid trace the row-by-row values are those of a rational function and differ (either way the unmodified
-    // verifier rejects: it recomputes the quotient at the out-of-domain point).  The initial / terminal quotients
-    // (zerofier of degree 1, up to 4(m - 1) coefficients) are evaluated on every point.
+    // verifier rejects: it recomputes the quotient at the out-of-domain point).  An initial / terminal quotient (zerofier of
+    // degree 1) has up to d(m - 1) coefficients for a constraint of degree d: the 100 of degree <= 3 fit the half domain too
+    // (3(m - 1) <= half) and are generated as a low-degree part; the FOUR of degree 4 are evaluated on every point.
     const u64 m = mt->interpolant_len > at->interpolant_len ? mt->interpolant_len : at->interpolant_len;
     const u64 half = qd.length / 2;
     const bool split = c->air_valid_trace && mt->interpolant_len && at->interpolant_len && half >= 2 * td.length && half % td.length == 0 &&
-                       4 * (m - 1) + 2 <= half + td.length && mt->rows % half == 0;
+                       4 * (m - 1) + 2 <= half + td.length && 3 * (m - 1) <= half && mt->rows % half == 0;
     if (!split)
         return all_quotients_combined(c, mt->data, mt->layout, (u64)mt->W, at->data, (u64)at->W, td.length, td.generator,
                                       qd.offset, qd.generator, qd.length, d_ch, d_w, d_out);

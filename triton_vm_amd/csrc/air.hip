@@ -107,9 +107,8 @@ __global__ void __launch_bounds__(256) k_air_scatter(AirArgs a, const u64* __res
 int all_quotients_combined(tvm_ctx* c, const u64* main_table, const TabLayout& layout, u64 main_w, const u64* aux_table,
                            u64 aux_w, u64 trace_len, u64 trace_gen, u64 q_offset, u64 q_gen, u64 q_len,
                            const u64* d_challenges, const u64* d_weights, u64* d_out, int part_select, int accumulate) {
-    // part_select: 0 = every part, 1 = the "low degree" parts (air_gen.h: consistency / transition constraints and the initial /
-    // terminal constraints of degree <= 3),
-    // 2 = the others (the initial / terminal constraints of degree 4); accumulate: the quotient values are added to d_out
+    // part_select: 0 = every part, else a mask of part classes (air_gen.h: TVM_AIR_PART_CLASS; bit c = the parts of class c);
+    // accumulate: the quotient values are added to d_out
     const u64 rows = layout.rows();
     if (!is_pow2(q_len) || !is_pow2(trace_len) || q_len < trace_len || rows % q_len)
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "quotients: domain lengths");
@@ -160,8 +159,7 @@ int all_quotients_combined(tvm_ctx* c, const u64* main_table, const TabLayout& l
     a.accumulate = 0;
     bool any = false;
     for (int p = 0; p < TVM_AIR_NUM_PARTS; p++) {
-        if (part_select == 1 && !TVM_AIR_PART_LOW_DEGREE[p]) continue;
-        if (part_select == 2 && TVM_AIR_PART_LOW_DEGREE[p]) continue;
+        if (part_select && !(part_select >> TVM_AIR_PART_CLASS[p] & 1)) continue;
         TVM_LAUNCH(TVM_AIR_PARTS[p], grid, dim3(AIR_BLOCK), 0, c->stream, a);
         a.accumulate = 1;
         any = true;

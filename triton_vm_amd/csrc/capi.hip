@@ -685,25 +685,41 @@ int32_t tvm_all_quotients_combined(tvm_ctx* c, const tvm_table* mt, const tvm_ta
     // verifier rejects: it recomputes the quotient at the out-of-domain point).  An initial / terminal quotient (zerofier of
     // degree 1) has up to d(m - 1) coefficients for a constraint of degree d: the 100 of degree <= 3 fit the half domain too
     // (3(m - 1) <= half) and are generated as a low-degree part; the FOUR of degree 4 are evaluated on every point.
+    // The constraints of lower degree have shorter quotients still (air_gen.h: TVM_AIR_PART_CLASS): those of class 2 -- a quarter
+    // of the multiplications -- have fewer than N + 2h coefficients and are evaluated on a QUARTER of the points, interpolated
+    // there, and their coefficients added to the half-domain interpolant before the one evaluation on all points.
     const u64 m = mt->interpolant_len > at->interpolant_len ? mt->interpolant_len : at->interpolant_len;
-    const u64 half = qd.length / 2;
+    const u64 half = qd.length / 2, quarter = qd.length / 4;
     const bool split = c->air_valid_trace && mt->interpolant_len && at->interpolant_len && half >= 2 * td.length && half % td.length == 0 &&
                        4 * (m - 1) + 2 <= half + td.length && 3 * (m - 1) <= half && mt->rows % half == 0;
     if (!split)
         return all_quotients_combined(c, mt->data, mt->layout, (u64)mt->W, at->data, (u64)at->W, td.length, td.generator,
                                       qd.offset, qd.generator, qd.length, d_ch, d_w, d_out);
-    PoolBlock low_block(c, (size_t)2 * 3 * half * sizeof(u64));  // released on every exit path
+    // (class 2 on the quarter domain: transition quotients of degree-2 constraints have 2(m - 1) + 2 - N coefficients at most)
+    const bool split4 = quarter >= 2 * td.length && quarter % td.length == 0 && 2 * (m - 1) + 2 <= quarter + td.length && m <= quarter;
+    PoolBlock low_block(c, (size_t)(2 * 3 * half + (split4 ? 2 * 3 * quarter : 0)) * sizeof(u64));  // released on every exit path
     u64* low = (u64*)low_block.p;
     if (!low) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "quotient scratch");
     u64* coeffs = low + 3 * half;
     const tvm_domain half_dom = {qd.offset, bfe_mul(qd.generator, qd.generator), half};
+    const int CLASS_FULL = 1 << 0, CLASS_HALF = 1 << 1, CLASS_QUARTER = 1 << 2;
     int rc = all_quotients_combined(c, mt->data, mt->layout, (u64)mt->W, at->data, (u64)at->W, td.length, td.generator,
-                                    half_dom.offset, half_dom.generator, half, d_ch, d_w, low, 1, 0);
+                                    half_dom.offset, half_dom.generator, half, d_ch, d_w, low, split4 ? CLASS_HALF : CLASS_HALF | CLASS_QUARTER, 0);
     if (rc == TVM_OK) rc = tvm_interpolate(c, 3, low, half_dom, coeffs);
+    if (rc == TVM_OK && split4) {
+        u64* low4 = coeffs + 3 * half;
+        u64* coeffs4 = low4 + 3 * quarter;
+        const u64 g2 = bfe_mul(qd.generator, qd.generator);
+        const tvm_domain quarter_dom = {qd.offset, bfe_mul(g2, g2), quarter};
+        rc = all_quotients_combined(c, mt->data, mt->layout, (u64)mt->W, at->data, (u64)at->W, td.length, td.generator,
+                                    quarter_dom.offset, quarter_dom.generator, quarter, d_ch, d_w, low4, CLASS_QUARTER, 0);
+        if (rc == TVM_OK) rc = tvm_interpolate(c, 3, low4, quarter_dom, coeffs4);
+        if (rc == TVM_OK) rc = tvm_xfe_add_assign(c, coeffs, coeffs4, quarter);
+    }
     if (rc == TVM_OK) rc = tvm_evaluate(c, 3, coeffs, half, qd, d_out);
     if (rc == TVM_OK)
         rc = all_quotients_combined(c, mt->data, mt->layout, (u64)mt->W, at->data, (u64)at->W, td.length, td.generator,
-                                    qd.offset, qd.generator, qd.length, d_ch, d_w, d_out, 2, 1);
+                                    qd.offset, qd.generator, qd.length, d_ch, d_w, d_out, CLASS_FULL, 1);
     return rc;
 }
 

@@ -430,6 +430,26 @@ static const u64* stage_small(tvm_ctx* c, int slot, const u64* h, size_t words) 
     if (hipStreamSynchronize(c->stream) != hipSuccess) return nullptr;  // h may be a caller temporary
     return d;
 }
+// coeffs[i + N * r] += sum_k w[3 * r + k] * q[k][i]  (r, k < 3; i < N; XFE vectors q, base-field weights w): the polynomial
+// A + X^N B + X^2N C from its restrictions Q_k = A + c_k B + c_k^2 C to three cosets (w = the inverse Vandermonde matrix)
+struct ThreeCosetWeights {
+    u64 w[9];
+};
+__global__ void k_three_coset_combine(const u64* __restrict__ q0, const u64* __restrict__ q1, const u64* __restrict__ q2, u64 n,
+                                      ThreeCosetWeights m, u64* __restrict__ coeffs) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const xfe a = xfe_make(q0[3 * i], q0[3 * i + 1], q0[3 * i + 2]), b = xfe_make(q1[3 * i], q1[3 * i + 1], q1[3 * i + 2]),
+              c = xfe_make(q2[3 * i], q2[3 * i + 1], q2[3 * i + 2]);
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const xfe v = xfe_add(xfe_add(xfe_mul_bfe(a, m.w[3 * r]), xfe_mul_bfe(b, m.w[3 * r + 1])), xfe_mul_bfe(c, m.w[3 * r + 2]));
+        u64* p = coeffs + 3 * (i + n * r);
+        p[0] = bfe_add(p[0], v.c0);
+        p[1] = bfe_add(p[1], v.c1);
+        p[2] = bfe_add(p[2], v.c2);
+    }
+}
 __global__ void k_xfe_add_assign(u64* __restrict__ a, const u64* __restrict__ b, u64 n_words) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_words) a[i] = bfe_add(a[i], b[i]);
@@ -695,26 +715,79 @@ int32_t tvm_all_quotients_combined(tvm_ctx* c, const tvm_table* mt, const tvm_ta
     if (!split)
         return all_quotients_combined(c, mt->data, mt->layout, (u64)mt->W, at->data, (u64)at->W, td.length, td.generator,
                                       qd.offset, qd.generator, qd.length, d_ch, d_w, d_out);
-    // (class 2 on the quarter domain: transition quotients of degree-2 constraints have 2(m - 1) + 2 - N coefficients at most)
-    const bool split4 = quarter >= 2 * td.length && quarter % td.length == 0 && 2 * (m - 1) + 2 <= quarter + td.length && m <= quarter;
-    PoolBlock low_block(c, (size_t)(2 * 3 * half + (split4 ? 2 * 3 * quarter : 0)) * sizeof(u64));  // released on every exit path
+    // (class 2 on the quarter domain: transition quotients of degree-2 constraints have 2(m - 1) + 2 - N coefficients at most;
+    // class 3 on THREE cosets of the trace domain: those of degree-3 constraints have 3(m - 1) + 2 - N <= 3N)
+    const u64 N = td.length;
+    const bool split4 = quarter >= 2 * N && quarter % N == 0 && 2 * (m - 1) + 2 <= quarter + N && m <= quarter;
+    const bool split3 = split4 && half == 4 * N && 3 * (m - 1) + 2 <= 4 * N && 2 * (m - 1) <= 3 * N && mt->layout.X == at->layout.X &&
+                        mt->layout.pitch == at->layout.pitch && mt->layout.X == 2 * (half / N) && mt->layout.pitch % TVM_RB == 0;
+    PoolBlock low_block(c, (size_t)(2 * 3 * half + (split4 ? 2 * 3 * quarter : 0) + (split3 ? 6 * 3 * N : 0)) * sizeof(u64));  // released on every exit path
     u64* low = (u64*)low_block.p;
     if (!low) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "quotient scratch");
     u64* coeffs = low + 3 * half;
     const tvm_domain half_dom = {qd.offset, bfe_mul(qd.generator, qd.generator), half};
-    const int CLASS_FULL = 1 << 0, CLASS_HALF = 1 << 1, CLASS_QUARTER = 1 << 2;
+    const int CLASS_FULL = 1 << 0, CLASS_HALF = 1 << 1, CLASS_QUARTER = 1 << 2, CLASS_THREE = 1 << 3;
     int rc = all_quotients_combined(c, mt->data, mt->layout, (u64)mt->W, at->data, (u64)at->W, td.length, td.generator,
-                                    half_dom.offset, half_dom.generator, half, d_ch, d_w, low, split4 ? CLASS_HALF : CLASS_HALF | CLASS_QUARTER, 0);
+                                    half_dom.offset, half_dom.generator, half, d_ch, d_w, low,
+                                    CLASS_HALF | (split4 ? 0 : CLASS_QUARTER) | (split3 ? 0 : CLASS_THREE), 0);
     if (rc == TVM_OK) rc = tvm_interpolate(c, 3, low, half_dom, coeffs);
+    u64* extra = coeffs + 3 * half;
     if (rc == TVM_OK && split4) {
-        u64* low4 = coeffs + 3 * half;
+        u64* low4 = extra;
         u64* coeffs4 = low4 + 3 * quarter;
+        extra = coeffs4 + 3 * quarter;
         const u64 g2 = bfe_mul(qd.generator, qd.generator);
         const tvm_domain quarter_dom = {qd.offset, bfe_mul(g2, g2), quarter};
         rc = all_quotients_combined(c, mt->data, mt->layout, (u64)mt->W, at->data, (u64)at->W, td.length, td.generator,
                                     quarter_dom.offset, quarter_dom.generator, quarter, d_ch, d_w, low4, CLASS_QUARTER, 0);
         if (rc == TVM_OK) rc = tvm_interpolate(c, 3, low4, quarter_dom, coeffs4);
         if (rc == TVM_OK) rc = tvm_xfe_add_assign(c, coeffs, coeffs4, quarter);
+    }
+    if (rc == TVM_OK && split3) {
+        // P = A + X^N B + X^2N C with A, B, C of degree < N.  On the coset gamma_k <w_N> (gamma_k = offset * generator^k) X^N is the
+        // constant c_k = gamma_k^N, so P restricted to it is the polynomial Q_k = A + c_k B + c_k^2 C of degree < N: three cosets
+        // (k = 0, 2, 4: among the rows the tables hold for the half domain), three N-point interpolations, and the inverse of the
+        // 3 x 3 Vandermonde matrix of (c_0, c_2, c_4) coefficient by coefficient.
+        const u64 gN = bfe_mul(bfe_mul(bfe_mul(qd.generator, qd.generator), bfe_mul(qd.generator, qd.generator)),
+                               bfe_mul(bfe_mul(qd.generator, qd.generator), bfe_mul(qd.generator, qd.generator)));  // generator^8: order N
+        const u64 rows_per_table_coset = mt->layout.X / (qd.length / N);   // table cosets per quotient-domain coset (1 when the LDT domain is the quotient domain)
+        u64 cs[3];
+        u64* vals = extra;          // [3][N] XFE values, then [3][N] XFE coefficients
+        u64* qk = vals + 9 * N;
+        for (int j = 0; j < 3 && rc == TVM_OK; j++) {
+            const u64 k = 2 * (u64)j;
+            const u64 gamma = bfe_mul(qd.offset, bfe_pow(qd.generator, k));
+            cs[j] = bfe_pow(gamma, N);
+            const tvm_domain dom = {gamma, gN, N};
+            TabLayout lm = mt->layout;   // the one coset of the tables this domain is: a table of its own
+            lm.X = 1;
+            lm.log_x = 0;
+            const u64 first_row = k * rows_per_table_coset * mt->layout.pitch;
+            const u64* sub_main = mt->data + tvm_tab_idx(first_row, 0, (u64)mt->W);
+            const u64* sub_aux = at->data + tvm_tab_idx(first_row, 0, (u64)at->W);
+            rc = all_quotients_combined(c, sub_main, lm, (u64)mt->W, sub_aux, (u64)at->W, td.length, td.generator, dom.offset,
+                                        dom.generator, N, d_ch, d_w, vals + 3 * N * j, CLASS_THREE, 0);
+            if (rc == TVM_OK) rc = tvm_interpolate(c, 3, vals + 3 * N * j, dom, qk + 3 * N * j);
+        }
+        if (rc == TVM_OK) {
+            // inverse Vandermonde: row r of V^-1 holds the coefficients of the Lagrange basis polynomial data, i.e.
+            // [A B C]^T = V^-1 [Q_0 Q_2 Q_4]^T with V = [[1, c, c^2]]
+            tvm::ThreeCosetWeights w;
+            const u64 c0 = cs[0], c1 = cs[1], c2 = cs[2];
+            const u64 d0 = bfe_inv(bfe_mul(bfe_sub(c0, c1), bfe_sub(c0, c2)));
+            const u64 d1 = bfe_inv(bfe_mul(bfe_sub(c1, c0), bfe_sub(c1, c2)));
+            const u64 d2 = bfe_inv(bfe_mul(bfe_sub(c2, c0), bfe_sub(c2, c1)));
+            // Lagrange polynomial L_k(t) = prod_{j != k} (t - c_j) / prod (c_k - c_j) = (t^2 - (sum of the other two) t + product) * d_k
+            const u64 dk[3] = {d0, d1, d2};
+            const u64 oth[3][2] = {{c1, c2}, {c0, c2}, {c0, c1}};
+            for (int k3 = 0; k3 < 3; k3++) {
+                w.w[0 * 3 + k3] = bfe_mul(bfe_mul(oth[k3][0], oth[k3][1]), dk[k3]);             // t^0 -> A
+                w.w[1 * 3 + k3] = bfe_mul(bfe_neg(bfe_add(oth[k3][0], oth[k3][1])), dk[k3]);    // t^1 -> B
+                w.w[2 * 3 + k3] = dk[k3];                                                       // t^2 -> C
+            }
+            TVM_LAUNCH(tvm::k_three_coset_combine, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, qk, qk + 3 * N, qk + 6 * N, N, w, coeffs);
+            TVM_HIP_CHECK(c, hipGetLastError());
+        }
     }
     if (rc == TVM_OK) rc = tvm_evaluate(c, 3, coeffs, half, qd, d_out);
     if (rc == TVM_OK)

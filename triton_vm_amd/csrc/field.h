@@ -84,6 +84,13 @@ TVM_HD u64 bfe_montyred(u64 lo, u64 hi) {
     return (hi < b) ? r - TVM_EPS : r;
 }
 TVM_HD void mul64wide(u64 a, u64 b, u64& lo, u64& hi) {
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__SIZEOF_INT128__)
+    // host code (the Fiat-Shamir sponge of the hosts, the fiber emulation of the CPU suite): the CPU's 64 x 64 -> 128 multiply
+    const unsigned __int128 p = (unsigned __int128)a * b;
+    lo = (u64)p;
+    hi = (u64)(p >> 64);
+    return;
+#endif
     u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     u64 p00 = (u64)a0 * b0;
     u64 m1 = (u64)a0 * b1 + (p00 >> 32);        // <= (2^32-1)^2 + 2^32 - 1 < 2^64

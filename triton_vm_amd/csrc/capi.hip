@@ -977,6 +977,10 @@ int32_t tvm_gather_elements_batch(tvm_ctx* c, uint32_t n_jobs, const uint64_t* c
     return TVM_OK;
 }
 
+// (host code: an AVX2 clone beside the baseline one, picked at load time -- the MDS layer is 512 multiply-adds of 32-bit values)
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+__attribute__((target_clones("avx2", "default")))
+#endif
 void tvm_host_tip5_permutation(uint64_t st[16]) {
     static const u64 rc[80] = {TVM_TIP5_RC_LIST};
     static const unsigned char lut[256] = {TVM_TIP5_LUT_LIST};

@@ -54,6 +54,9 @@ def stir_prove(ctx, host_lib, stir, d_codeword):
     return [int(i) for i in first], out[:n.value].copy()
 
 
+_PROOF_BUFFER = None
+
+
 def prove_execution(ctx, host_lib, aet, padded_height, claim, randomness_seed, security_level=160, log2_expansion=2, ldt=None):
     """The C++ host's Prover::prove(claim, aet) (triton_vm::prove_execution): fill, pad, extend and the hot path on the
     device, the seeded randomness and the transcript in C++.  aet: the arrays master_table.fill takes (host arrays, or
@@ -64,7 +67,8 @@ def prove_execution(ctx, host_lib, aet, padded_height, claim, randomness_seed, s
     s, keep = aet_struct(aet)
     log2 = padded_height.bit_length() - 1
     err, n = C.create_string_buffer(512), C.c_uint64(0)
-    out = np.empty(1 << 20, np.uint64)   # a 2^20-row proof is ~0.3 M words
+    global _PROOF_BUFFER
+    out = _PROOF_BUFFER if _PROOF_BUFFER is not None else np.empty(1 << 20, np.uint64)   # a 2^20-row proof is ~0.3 M words
     while True:
         rc = host_lib.tvmh_prove_execution(ctx.handle, C.addressof(s), log2, security_level, log2_expansion, {"fri": 0, "stir": 1, None: 2}[ldt],
                                            bytes(randomness_seed),
@@ -73,6 +77,7 @@ def prove_execution(ctx, host_lib, aet, padded_height, claim, randomness_seed, s
         if rc != 0:
             raise RuntimeError(f"tvmh_prove_execution failed ({rc}): {err.value.decode()}")
         if n.value <= out.size:
+            _PROOF_BUFFER = out                       # (kept: its pages are mapped by now)
             return out[:n.value].copy()
         out = np.empty(int(n.value), np.uint64)   # the proof did not fit: grow and run again
 

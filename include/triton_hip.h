@@ -76,6 +76,11 @@ int32_t tvm_ctx_set_memory_limit(tvm_ctx* ctx, size_t bytes);
 int32_t tvm_ctx_memory_held(const tvm_ctx* ctx, size_t* bytes);
 int32_t tvm_memcpy_h2d(tvm_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int32_t tvm_memcpy_d2h(tvm_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+/* device to device, ordered on the context's stream, NOT synchronised (same device, or a peer-accessible one). */
+int32_t tvm_memcpy_d2d(tvm_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
+/* the hipStream_t every call of this context is ordered on (so that a collective library -- RCCL -- can be enqueued
+ * behind the kernels that produce its operands and ahead of those that consume its results; triton_vm_amd/host/rccl_comm.cpp) */
+void* tvm_ctx_stream(const tvm_ctx* ctx);
 
 /* HIP-event stopwatch on the context's stream (bench.py's live kernel timing) */
 int32_t tvm_timer_start(tvm_ctx* ctx);
@@ -149,6 +154,11 @@ int32_t tvm_weighted_sum_of_columns(tvm_ctx* ctx, int32_t field_kind, const uint
                                     tvm_domain trace_domain, const uint64_t* h_weights, uint64_t* d_poly);
 /* d_a[i] += d_b[i] for n XFE (main + aux combination polynomial, stark.rs:516) */
 int32_t tvm_xfe_add_assign(tvm_ctx* ctx, uint64_t* d_a, const uint64_t* d_b, uint64_t n);
+/* d_out[i] = sum_k h_weights[k] * d_vectors[k * stride + i], i < n: a weighted sum of XFE vectors (polynomials) that lie
+ * `stride` elements apart -- the P and R combinations of the segment POLYNOMIALS (stark.rs:520-536), which the sharded
+ * host evaluates on its own rows of the short domain when the quotient domain is shorter than the LDT domain. */
+int32_t tvm_xfe_linear_combination(tvm_ctx* ctx, const uint64_t* d_vectors, uint32_t n_vectors, uint64_t stride, uint64_t n,
+                                   const uint64_t* h_weights, uint64_t* d_out);
 /* Polynomial::evaluate at XFE points (stark.rs:480,491,568,579,590,600): d_coeffs n XFE -> h_out n_points XFE */
 int32_t tvm_evaluate_at_points(tvm_ctx* ctx, const uint64_t* d_coeffs, uint64_t n, const uint64_t* h_points,
                                uint32_t n_points, uint64_t* h_out);

@@ -1,0 +1,242 @@
+"""The C++ host's sharded / coset-wise prover (triton_vm_amd/host/sharded_host.cpp) against the single-GPU C++ prover: the same
+proof, word for word -- over 2, 4 and 8 ranks (the communicators between the contexts of one process, one proving thread per
+rank; and two real processes over torch.distributed's gloo backend), with the Merkle trees split over the ranks and built
+whole, FRI and STIR, LDT expansion 16 (quotient domain shorter than the LDT domain), from an execution trace (the
+reference's snapshot digest, proof.rs:200-226), coset by coset on one rank, and under the reference's memory policy
+(master_table.rs:268-271: a cached extension that does not fit is not an error)."""
+import os
+import socket
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from triton_vm_amd import native_host
+from triton_vm_amd.prover import Prover, StarkParameters
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SEED = 9
+
+
+def host_library(ctx):
+    backend = ctx.lib._name
+    if getattr(ctx, "kind", "gpu") == "emu":
+        return native_host.load_host_library(backend, os.path.join(os.path.dirname(backend), "libtriton_host_emu.so"))
+    return native_host.load_host_library(backend)
+
+
+def _params(kind, log2_rows=3):
+    if kind == "fri":
+        return StarkParameters(log2_rows, num_trace_randomizers=3, num_collinearity_checks=2)
+    if kind == "fri16":
+        return StarkParameters(log2_rows, num_trace_randomizers=3, num_collinearity_checks=2, log2_expansion=4)
+    from triton_vm_amd import low_degree_test as ldt_module   # STIR at a security level that still has a quotienting round at this size
+
+    stir = ldt_module.stark_stir(1 << log2_rows, security_level=8)
+    p = StarkParameters(log2_rows, num_trace_randomizers=stir.num_trace_randomizers(), num_collinearity_checks=2)
+    p.stir = stir
+    return p
+
+
+def _inputs(orc, p):
+    rng = np.random.default_rng(77)
+    n = p.trace.length
+    return orc.random_elements(rng, (379, n)), orc.random_elements(rng, (91, n, 3))
+
+
+def _new_context(ctx):
+    from triton_vm_amd.capi import Context
+
+    return Context(device=0, lib=ctx.lib)
+
+
+def _single_proof(ctx, host, p, main_trace, aux_trace):
+    py = Prover(ctx, p, main_trace, aux_trace, seed=SEED)
+    if p.stir is not None:   # (tvmh_prove derives its STIR instance at security level 160; the Python host proves this small one --
+        return py, py.prove().proof().words   # tests/test_native_host.py holds the two hosts' STIR proofs equal)
+    native = native_host.NativeProver(ctx, host, p, py.main.d_trace, py.main.d_randomizers, py.aux.d_trace, py.aux.d_randomizers,
+                                      py.quotient_randomizer)
+    return py, native.prove()
+
+
+def _run_ranks(world, body):
+    """one thread per rank; `body(rank)` -> result; exceptions are re-raised here"""
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            results[rank] = body(rank)
+        except BaseException as e:   # noqa: BLE001
+            errors.append((rank, e))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=1200)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in threads), "a rank hung"
+    return results
+
+
+@pytest.mark.parametrize("world,split_trees,kind,lockstep", [(2, True, "fri", False), (4, False, "fri", False), (8, True, "fri", True),
+                                                             (2, True, "stir", False), (2, True, "fri16", False), (8, False, "fri16", False)])
+def test_sharded_cpp_proof_equals_single_gpu_proof(ctx, orc, world, split_trees, kind, lockstep):
+    host = host_library(ctx)
+    p = _params(kind)
+    main_trace, aux_trace = _inputs(orc, p)
+    py, want = _single_proof(ctx, host, p, main_trace, aux_trace)
+    comms = native_host.LocalComms(host, world, lockstep=lockstep)
+    try:
+        def rank_body(rank):
+            c = _new_context(ctx)   # one context per proving thread (lib.rs:522-532)
+            try:
+                mine = Prover(c, p, main_trace, aux_trace, seed=SEED)   # the same traces and randomizers on every rank
+                return native_host.prove_sharded(c, host, comms.ptrs[rank], p, mine.main.d_trace, mine.main.d_randomizers, mine.aux.d_trace,
+                                                 mine.aux.d_randomizers, mine.quotient_randomizer, split_tree_min_leaves=0 if split_trees else 1 << 62,
+                                                 stir_security_level=8)
+            finally:
+                c.close()
+
+        proofs = _run_ranks(world, rank_body)
+        for rank, got in enumerate(proofs):
+            assert got.size == want.size and (got == want).all(), rank
+        if lockstep:
+            report = comms.report()
+            assert "main LDE" in report and len(report["main LDE"]) == world and all(ms > 0 for ms in report["AIR quotients"])
+    finally:
+        comms.close()
+
+
+@pytest.mark.parametrize("passes", [2, 8])
+def test_coset_wise_cpp_proof_equals_cached_proof(ctx, orc, passes):
+    """the just-in-time path (stark.rs:805-1006, master_table.rs:470-503, 556-609) in the C++ host, one rank"""
+    host = host_library(ctx)
+    p = _params("fri")
+    main_trace, aux_trace = _inputs(orc, p)
+    py, want = _single_proof(ctx, host, p, main_trace, aux_trace)
+    got = native_host.prove_sharded(ctx, host, None, p, py.main.d_trace, py.main.d_randomizers, py.aux.d_trace, py.aux.d_randomizers,
+                                    py.quotient_randomizer, jit_passes=passes)
+    assert got.size == want.size and (got == want).all()
+
+
+def _snapshot_inputs(orc):
+    from tests import test_proof_snapshot as snap
+    from tests import vm_fixture as vf
+    from tests.test_fill import aet_arrays
+
+    program, aet, public_input, output = vf.run("tiny")
+    return aet_arrays(orc, aet), aet.padded_height(), snap.claim_of(orc, program, public_input, output), snap.prover_seed(snap.SEED_U64)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_prove_execution_reproduces_the_reference_snapshot(ctx, orc, world):
+    """Prover::prove(claim, aet) over the ranks: fill, pad, extend replicated, everything else split -- the proof hashes to the
+    digest the reference holds (proof.rs:218-225), on every rank; the leaf digests went through the all-to-all"""
+    from tests import test_proof_snapshot as snap
+    from triton_vm_amd.proof_stream import Proof
+
+    host = host_library(ctx)
+    aet, padded_height, claim, seed = _snapshot_inputs(orc)
+    comms = native_host.LocalComms(host, world)
+    try:
+        def rank_body(rank):
+            c = _new_context(ctx)
+            try:
+                return native_host.prove_execution_sharded(c, host, comms.ptrs[rank], aet, padded_height, claim, seed, jit_passes=1,
+                                                           split_tree_min_leaves=0, profile=True)
+            finally:
+                c.close()
+
+        for words, stats in _run_ranks(world, rank_body):
+            assert Proof(words).digest(ctx.lib) == snap.SNAPSHOT
+            assert stats["world"] == world and stats["split_trees_built"] >= 3
+            assert stats["exchanges"]["main leaf digests"]["calls"] == 1 and "AIR quotients" in stats["stage_ms"]
+    finally:
+        comms.close()
+
+
+def test_memory_policy_of_the_cpp_host(ctx, orc):
+    """master_table.rs:268-271, stark.rs:730-768: when the cached extension does not fit (the context's memory limit stands in
+    for a full device) tvmh_prove_execution_sharded with jit_passes = 0 starts over coset by coset; the proof does not change"""
+    from tests import test_proof_snapshot as snap
+    from triton_vm_amd.proof_stream import Proof
+
+    host = host_library(ctx)
+    aet, padded_height, claim, seed = _snapshot_inputs(orc)
+    words, stats = native_host.prove_execution_sharded(ctx, host, None, aet, padded_height, claim, seed, jit_passes=0)
+    assert stats["passes"] == 1 and Proof(words).digest(ctx.lib) == snap.SNAPSHOT
+    ctx.trim()
+    p = StarkParameters(padded_height.bit_length() - 1)
+    n, L = p.trace.length, p.ldt.length
+    traces_bytes = 8 * n * (379 + 273)
+    full_tables = 8 * L * (379 + 273)
+    ctx.set_memory_limit(ctx.memory_held() + 2 * traces_bytes + full_tables // 2)
+    try:
+        words, stats = native_host.prove_execution_sharded(ctx, host, None, aet, padded_height, claim, seed, jit_passes=0)
+    finally:
+        ctx.set_memory_limit(0)
+    assert stats["passes"] >= 2 and Proof(words).digest(ctx.lib) == snap.SNAPSHOT
+
+
+# ---- two real processes over gloo -------------------------------------------------------------------------------------
+def _gloo_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from oracle import oracle as orc
+    from tests.emu_fixture import emu_context
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    ctx = emu_context()
+    ctx.kind = "emu"
+    host = host_library(ctx)
+    comm = native_host.gloo_comm(dist)
+    aet, padded_height, claim, seed = _snapshot_inputs(orc)
+    words, stats = native_host.prove_execution_sharded(ctx, host, comm.ptr, aet, padded_height, claim, seed, jit_passes=1, split_tree_min_leaves=0)
+    out.put((rank, words, stats))
+    dist.barrier()
+    dist.destroy_process_group()
+    ctx.close()
+
+
+def test_two_gloo_processes_reproduce_the_reference_snapshot(orc):
+    import queue
+    import time
+
+    import torch.multiprocessing as mp
+
+    from tests import test_proof_snapshot as snap
+    from tests.emu_fixture import emu_context
+    from triton_vm_amd.proof_stream import Proof
+
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mpctx = mp.get_context("spawn")
+    out = mpctx.Queue()
+    procs = [mpctx.Process(target=_gloo_worker, args=(r, world, port, out)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results, deadline = {}, time.time() + 900
+    while len(results) < world:
+        try:
+            rank, words, stats = out.get(timeout=5)
+            results[rank] = (words, stats)
+        except queue.Empty:
+            assert all(pr.exitcode in (None, 0) for pr in procs), "a rank died"
+            assert time.time() < deadline, "timed out"
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    ctx = emu_context()
+    try:
+        for rank in range(world):
+            words, stats = results[rank]
+            assert Proof(words).digest(ctx.lib) == snap.SNAPSHOT, rank
+            assert stats["rank"] == rank and stats["split_trees_built"] >= 3
+    finally:
+        ctx.close()

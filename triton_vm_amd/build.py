@@ -84,8 +84,9 @@ def build_host(backend_lib=None, out=None):
     backend_lib = backend_lib or build()
     out = out or HOST_LIB
     assert os.path.dirname(os.path.abspath(out)) == os.path.dirname(os.path.abspath(backend_lib)), "host library next to its backend"
-    srcs = [os.path.join(HERE, "host", "triton_host.cpp")]
-    deps = srcs + [os.path.join(HERE, "host", "triton_host.hpp"), os.path.join(ROOT, "include", "triton_hip.h"), backend_lib]
+    srcs = [os.path.join(HERE, "host", "triton_host.cpp"), os.path.join(HERE, "host", "sharded_host.cpp")]
+    deps = srcs + [os.path.join(HERE, "host", "triton_host.hpp"), os.path.join(HERE, "host", "host_internal.hpp"),
+                   os.path.join(ROOT, "include", "triton_hip.h"), backend_lib]
     if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
         return out
     import fcntl

@@ -62,6 +62,8 @@ _SIGNATURES = {
     "tvm_ctx_memory_held": (C.c_int32, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "tvm_memcpy_h2d": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "tvm_memcpy_d2h": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "tvm_memcpy_d2d": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "tvm_ctx_stream": (C.c_void_p, [C.c_void_p]),
     "tvm_timer_start": (C.c_int32, [C.c_void_p]),
     "tvm_timer_stop": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float)]),
     "tvm_synthetic_fill": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
@@ -87,6 +89,7 @@ _SIGNATURES = {
     "tvm_weighted_sum_of_columns": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
                                                 C.c_uint64, Domain, C.c_void_p, C.c_void_p]),
     "tvm_xfe_add_assign": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "tvm_xfe_linear_combination": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "tvm_evaluate_at_points": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
     "tvm_fill_derived_main_columns": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "tvm_fill_derived_aux_columns": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),

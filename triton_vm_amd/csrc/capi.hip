@@ -118,6 +118,12 @@ int32_t tvm_memcpy_d2h(tvm_ctx* c, void* h, const void* d, size_t bytes) {
     TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     return TVM_OK;
 }
+int32_t tvm_memcpy_d2d(tvm_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c || (bytes && (!dst || !src))) return TVM_ERR_INVALID_ARGUMENT;
+    if (bytes) TVM_HIP_CHECK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return TVM_OK;
+}
+void* tvm_ctx_stream(const tvm_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 int32_t tvm_timer_start(tvm_ctx* c) {
     if (!c) return TVM_ERR_INVALID_ARGUMENT;
@@ -450,6 +456,18 @@ __global__ void k_three_coset_combine(const u64* __restrict__ q0, const u64* __r
         p[2] = bfe_add(p[2], v.c2);
     }
 }
+// out[i] = sum_k w[k] * v[k * stride + i]  (XFE vectors, XFE weights; k < 8)
+__global__ void k_xfe_linear_combination(const u64* __restrict__ v, int n_vectors, u64 stride, u64 n, const u64* __restrict__ w,
+                                         u64* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    xfe acc = xfe_zero();
+    for (int k = 0; k < n_vectors; k++) {
+        const u64* e = v + 3 * ((u64)k * stride + i);
+        acc = xfe_add(acc, xfe_mul(xfe_make(e[0], e[1], e[2]), xfe_make(w[3 * k], w[3 * k + 1], w[3 * k + 2])));
+    }
+    out[3 * i] = acc.c0, out[3 * i + 1] = acc.c1, out[3 * i + 2] = acc.c2;
+}
 __global__ void k_xfe_add_assign(u64* __restrict__ a, const u64* __restrict__ b, u64 n_words) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_words) a[i] = bfe_add(a[i], b[i]);
@@ -499,6 +517,19 @@ int32_t tvm_xfe_add_assign(tvm_ctx* c, uint64_t* d_a, const uint64_t* d_b, uint6
     return TVM_OK;
 }
 
+int32_t tvm_xfe_linear_combination(tvm_ctx* c, const uint64_t* d_vectors, uint32_t n_vectors, uint64_t stride, uint64_t n,
+                                   const uint64_t* h_weights, uint64_t* d_out) {
+    if (!c || !d_vectors || !h_weights || !d_out || !n_vectors || n_vectors > 64 || stride < n)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "xfe_linear_combination arguments");
+    if (!n) return TVM_OK;
+    const u64* d_w = stage_small(c, 9, h_weights, 3 * (size_t)n_vectors);
+    if (!d_w) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "weights staging");
+    TVM_LAUNCH(tvm::k_xfe_linear_combination, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_vectors, (int)n_vectors, stride, n,
+               d_w, d_out);
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+
 int32_t tvm_evaluate_at_points(tvm_ctx* c, const uint64_t* d_coeffs, uint64_t n, const uint64_t* h_points, uint32_t n_points,
                                uint64_t* h_out) {
     if (!c || (n && !d_coeffs) || !h_points || !h_out || !n_points)
@@ -517,7 +548,7 @@ int32_t tvm_quotient_segments(tvm_ctx* c, const uint64_t* d_cw, tvm_domain qd, t
     if (!c || !out_table) return TVM_ERR_INVALID_ARGUMENT;
     *out_table = nullptr;
     if (!d_cw || !d_polys || (n_rand && !h_rnd) || !valid_domain(qd) || !valid_domain(ldt) || qd.length < 4 ||
-        poly_len < qd.length / 4 || poly_len < n_rand || poly_len > ldt.length)
+        poly_len < qd.length / 4 || poly_len < n_rand || ldt.length < 2)
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "quotient_segments arguments");
     const u64 Q = qd.length, L = ldt.length;
     u64* coeffs = (u64*)scratch(c, 11, Q * 3 * sizeof(u64));
@@ -527,6 +558,20 @@ int32_t tvm_quotient_segments(tvm_ctx* c, const uint64_t* d_cw, tvm_domain qd, t
     TVM_TRY(randomized_segments(c, coeffs, Q, d_rnd, n_rand, zeta, poly_len, d_polys));
     u64 M = 2;
     while (M < poly_len) M <<= 1;
+    const u64* polys_in = d_polys;       // what is evaluated: the segment polynomials, or their reductions below
+    u64 in_len = poly_len;
+    if (M > L) {
+        // More coefficients than points: `ldt` is one rank's share of the LDT domain in a many-GPU split (8 ranks: one coset
+        // of the trace domain, half as long as a segment polynomial).  Reduce modulo X^L - offset^L first, which leaves the
+        // values on the coset unchanged (arithmetic_domain.rs:153-167); d_polys keeps the polynomials themselves.
+        u64* folded = (u64*)scratch(c, 25, (size_t)15 * L * sizeof(u64));
+        if (!folded) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "segment folding scratch");
+        for (int k = 0; k < 5; k++)
+            TVM_LAUNCH(k_fold_chunks, dim3((unsigned)((3 * L + 255) / 256)), dim3(256), 0, c->stream, d_polys + (u64)k * poly_len * 3,
+                       poly_len, 3, L, bfe_pow(ldt.offset, L), folded + (u64)k * L * 3);
+        polys_in = folded;
+        in_len = M = L;
+    }
     const u64 X = L / M;
     const bool via_lde = M >= 16 && X >= 2;   // the table kernels' shapes (ntt.hip: lde_table)
     tvm_table* t = new (std::nothrow) tvm_table();
@@ -551,7 +596,7 @@ int32_t tvm_quotient_segments(tvm_ctx* c, const uint64_t* d_cw, tvm_domain qd, t
         u64* values = (u64*)scratch(c, 12, (size_t)15 * M * sizeof(u64));
         if (!values) rc = set_error(c, TVM_ERR_OUT_OF_MEMORY, "segment values scratch");
         const u64 w_m = bfe_pow(ldt.generator, X);
-        if (rc == TVM_OK) rc = ntt_columns(c, d_polys, poly_len, 3, 3 * poly_len, values, 3, 3 * M, 1, 0, 15, M, w_m, TVM_ONE, TVM_ONE, TVM_ONE);
+        if (rc == TVM_OK) rc = ntt_columns(c, polys_in, in_len, 3, 3 * in_len, values, 3, 3 * M, 1, 0, 15, M, w_m, TVM_ONE, TVM_ONE, TVM_ONE);
         if (rc == TVM_OK && t->layout.storage_rows() % TVM_RB) {
             const u64 full = t->layout.storage_rows() / TVM_RB * TVM_RB * (u64)t->W;
             (void)hipMemsetAsync(t->data + full, 0, t->bytes() - full * sizeof(u64), c->stream);
@@ -563,7 +608,7 @@ int32_t tvm_quotient_segments(tvm_ctx* c, const uint64_t* d_cw, tvm_domain qd, t
         if (!planar) rc = set_error(c, TVM_ERR_OUT_OF_MEMORY, "segment codewords scratch");
         for (u64 k = 0; k < X && rc == TVM_OK; k++) {
             const u64 off = bfe_mul(ldt.offset, bfe_pow(ldt.generator, k));
-            rc = ntt_columns(c, d_polys, poly_len, 3, 3 * poly_len, planar, 1, L, X, k, 15, M, bfe_pow(ldt.generator, X), off,
+            rc = ntt_columns(c, polys_in, in_len, 3, 3 * in_len, planar, 1, L, X, k, 15, M, bfe_pow(ldt.generator, X), off,
                              TVM_ONE, TVM_ONE);
         }
         if (rc == TVM_OK) rc = columns_to_table(c, planar, L, L, 15, t->data);
@@ -595,7 +640,7 @@ int32_t tvm_deep_codeword(tvm_ctx* c, uint32_t n_comp, const uint64_t* const* d_
 int32_t tvm_fri_commit_phase(tvm_ctx* c, const uint64_t* d_cw, tvm_domain dom, uint32_t n_rounds, const uint64_t* h_state,
                              uint64_t* const* d_codewords, uint64_t* const* d_nodes, uint64_t* h_roots, uint64_t* h_challenges) {
     if (!c || !d_cw || !valid_domain(dom) || !h_state || !d_nodes || !h_roots || (n_rounds && (!d_codewords || !h_challenges)) ||
-        (dom.length >> n_rounds) < 1)
+        n_rounds >= 64 || (dom.length >> n_rounds) < 1)   // every folded codeword has at least two elements
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "fri_commit_phase arguments");
     for (uint32_t r = 0; r <= n_rounds; r++)
         if (!d_nodes[r] || (r < n_rounds && !d_codewords[r])) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "fri_commit_phase: null buffer");

@@ -1,5 +1,6 @@
 // triton_host.cpp -- see triton_host.hpp.  Step order, names and comments follow stark.rs:331-719.
 #include "triton_host.hpp"
+#include "host_internal.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -7,6 +8,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <iterator>
 #include <thread>
 
@@ -36,15 +38,15 @@ u64 primitive_root_of_unity(u64 order) {
     if (!order || (order & (order - 1)) || order > (1ull << 32)) throw Error(TVM_ERR_INVALID_ARGUMENT, "PrimitiveRootNotSupported");
     return mont_pow(to_mont(7), (P - 1) / order);
 }
-static u64 bfe_add(u64 a, u64 b) { return (u64)(((u128)a + b) % P); }
-static Xfe xfe_add(const Xfe& a, const Xfe& b) { return Xfe{{bfe_add(a.c[0], b.c[0]), bfe_add(a.c[1], b.c[1]), bfe_add(a.c[2], b.c[2])}}; }
-static Xfe xfe_mul(const Xfe& a, const Xfe& b) {
+u64 bfe_add(u64 a, u64 b) { return (u64)(((u128)a + b) % P); }
+Xfe xfe_add(const Xfe& a, const Xfe& b) { return Xfe{{bfe_add(a.c[0], b.c[0]), bfe_add(a.c[1], b.c[1]), bfe_add(a.c[2], b.c[2])}}; }
+Xfe xfe_mul(const Xfe& a, const Xfe& b) {
     Xfe o;
     tvm_host_xfe_mul(a.c, b.c, o.c);
     return o;
 }
-static Xfe xfe_scale(const Xfe& a, u64 s) { return Xfe{{mont_mul(a.c[0], s), mont_mul(a.c[1], s), mont_mul(a.c[2], s)}}; }
-static std::vector<Xfe> xfe_powers(const Xfe& x, u64 first, u64 n) {
+Xfe xfe_scale(const Xfe& a, u64 s) { return Xfe{{mont_mul(a.c[0], s), mont_mul(a.c[1], s), mont_mul(a.c[2], s)}}; }
+std::vector<Xfe> xfe_powers(const Xfe& x, u64 first, u64 n) {
     std::vector<Xfe> out(n);
     if (n) tvm_host_xfe_powers(x.c, first, n, out[0].c);
     return out;
@@ -317,6 +319,24 @@ std::vector<u64> MasterTable::out_of_domain_rows(const std::vector<Xfe>& points)
                                     (uint32_t)points.size(), out.data()), "tvm_out_of_domain_rows");
     return out;
 }
+std::vector<u64> MasterTable::out_of_domain_rows(const std::vector<Xfe>& points, u64 first_col, u64 n) const {
+    std::vector<u64> out(points.size() * n * 3);
+    if (n == 0) return out;
+    if (first_col + n > n_cols_) throw Error(TVM_ERR_INVALID_ARGUMENT, "out_of_domain_rows: column range");
+    c_.check(tvm_out_of_domain_rows(c_.raw(), fk_, d_trace_ + first_col * n_rows_ * fk_, n_rows_, n, d_rnd_ + first_col * h_ * fk_, h_,
+                                    trace_.c(), points[0].c, (uint32_t)points.size(), out.data()), "tvm_out_of_domain_rows");
+    return out;
+}
+std::vector<u64> MasterTable::reveal_rows_of(const std::vector<u64>& idx, u64 view_rows) const {
+    std::vector<u64> out(idx.size() * n_cols_ * fk_);
+    if (!idx.empty()) c_.check(tvm_table_reveal_rows(c_.raw(), table(), view_rows, idx.data(), idx.size(), out.data()), "tvm_table_reveal_rows");
+    return out;
+}
+void MasterTable::set_domains(ArithmeticDomain quotient, ArithmeticDomain ldt) {
+    clear_cache();
+    quotient_ = quotient;
+    ldt_ = ldt;
+}
 DeviceBuffer MasterTable::weighted_sum_of_columns(const Xfe* weights) const {
     DeviceBuffer poly(c_, 2 * n_rows_ * 3);
     c_.check(tvm_weighted_sum_of_columns(c_.raw(), fk_, d_trace_, n_rows_, n_cols_, d_rnd_, h_, trace_.c(), weights[0].c, poly.ptr()),
@@ -325,7 +345,7 @@ DeviceBuffer MasterTable::weighted_sum_of_columns(const Xfe* weights) const {
 }
 
 // ------------------------------------------------------------------------------------------------ parameters
-static unsigned bit_length(u64 v) {
+unsigned bit_length(u64 v) {
     unsigned n = 0;
     for (; v; v >>= 1) n++;
     return n;
@@ -348,13 +368,12 @@ StarkParameters::StarkParameters(unsigned log2_padded_height, u64 num_trace_rand
 }
 
 // ------------------------------------------------------------------------------------------------ helpers of prove
-static const u64 NUM_MAIN = TVM_NUM_MAIN_COLUMNS, NUM_AUX = TVM_NUM_AUX_COLUMNS, NUM_SAMPLED_CHALLENGES = TVM_NUM_CHALLENGES - 4;
 
-static std::vector<u64> merkle_root(const Context& c, const DeviceBuffer& nodes) { return nodes.download(5, 5); }  // node 1; drains the stream
+std::vector<u64> merkle_root(const Context& c, const DeviceBuffer& nodes) { return nodes.download(5, 5); }  // node 1; drains the stream
 
 // [twenty-first MerkleTree::authentication_structure, restated] the nodes a verifier cannot compute from the revealed
 // leaves -- the siblings along the paths that are not themselves on a path -- in descending heap order, gathered to the host
-static std::vector<u64> auth_node_indices(u64 n_leaves, const std::vector<u64>& indices) {
+std::vector<u64> auth_node_indices(u64 n_leaves, const std::vector<u64>& indices) {
     // Level by level on the sorted list of path nodes: a sibling is needed unless it is a path node itself (then it sits next
     // to its sibling in the sorted list); nodes of different levels have disjoint index ranges, so the levels do not interact.
     // Deeper levels have the larger heap indices: appending each level's siblings in descending order, deepest level first,
@@ -389,39 +408,9 @@ static std::vector<u64> auth_nodes(const Context& c, const DeviceBuffer& nodes, 
     return out;
 }
 
-// Many gathers with one round trip (tvm_gather_elements_batch): jobs are queued with their index lists, run() fills `out`.
-struct GatherBatch {
-    struct Job {
-        const u64* src;
-        uint32_t words;
-        std::vector<u64> idx, out;
-    };
-    std::vector<Job> jobs;
-    size_t add(const u64* src, uint32_t words, std::vector<u64> idx) {
-        jobs.push_back(Job{src, words, std::move(idx), {}});
-        return jobs.size() - 1;
-    }
-    void run(const Context& c) {
-        std::vector<const uint64_t*> src, idx;
-        std::vector<uint32_t> words;
-        std::vector<uint64_t> n;
-        std::vector<uint64_t*> out;
-        for (Job& j : jobs) {
-            j.out.assign(j.idx.size() * j.words, 0);
-            src.push_back(j.src);
-            words.push_back(j.words);
-            idx.push_back(j.idx.data());
-            n.push_back(j.idx.size());
-            out.push_back(j.out.data());
-        }
-        c.check(tvm_gather_elements_batch(c.raw(), (uint32_t)jobs.size(), src.data(), words.data(), idx.data(), n.data(), out.data()),
-                "tvm_gather_elements_batch");
-    }
-};
-
 // Challenges::new (challenges.rs:85-121): the 59 sampled challenges, then the terminals of the public input, the public
 // output, the lookup table and the program digest -- EvalArg::compute_terminal(symbols, 1, indeterminate)
-static std::vector<Xfe> derive_challenges(std::vector<Xfe> ch, const Claim& claim) {
+std::vector<Xfe> derive_challenges(std::vector<Xfe> ch, const Claim& claim) {
     auto terminal = [](const u64* symbols, u64 n, const Xfe& x) {
         Xfe acc{{to_mont(1), 0, 0}};
         for (u64 i = 0; i < n; i++) {
@@ -560,7 +549,7 @@ ProofStream Prover::prove() {
     const u64 poly_len = std::max<u64>(p_.quotient.length / 4, quotient_randomizer_.size());
     DeviceBuffer polys(c_, 5 * poly_len * 3);
     tvm_table* seg_table = nullptr;
-    c_.check(tvm_quotient_segments(c_.raw(), quot.ptr(), p_.quotient.c(), p_.ldt.c(), quotient_randomizer_[0].c,
+    c_.check(tvm_quotient_segments(c_.raw(), quot.ptr(), p_.quotient.c(), p_.ldt.c(), quotient_randomizer_.data()->c,
                                    quotient_randomizer_.size(), zeta, &seg_table, polys.ptr(), poly_len), "tvm_quotient_segments");
     struct TableGuard {
         const Context& c;
@@ -913,7 +902,7 @@ void offset_rng_seed(const uint8_t seed[32], u64 offset, uint8_t out[32]) {
 }
 
 // trace_randomizer_for_column for every column (master_table.rs:423-434) -> device [n_cols][h](x3)
-static std::vector<u64> trace_randomizers_host(const uint8_t table_seed[32], u64 n_cols, u64 h, int fk) {
+std::vector<u64> trace_randomizers_host(const uint8_t table_seed[32], u64 n_cols, u64 h, int fk) {
     std::vector<u64> host(n_cols * h * fk);
     for (u64 col = 0; col < n_cols; col++) {
         uint8_t seed[32];
@@ -922,16 +911,15 @@ static std::vector<u64> trace_randomizers_host(const uint8_t table_seed[32], u64
     }
     return host;
 }
-static DeviceBuffer upload(const Context& c, const std::vector<u64>& host) {
+DeviceBuffer upload(const Context& c, const std::vector<u64>& host) {
     DeviceBuffer d(c, host.size());
     c.check(tvm_memcpy_h2d(c.raw(), d.ptr(), host.data(), host.size() * sizeof(u64)), "tvm_memcpy_h2d");
     return d;
 }
 
-std::vector<u64> prove_execution(const Context& c, const StarkParameters& p, const tvm_aet& aet, const Claim& claim,
-                                 const uint8_t seed[32]) {
+ExecutionTables::ExecutionTables(const Context& c, const StarkParameters& p, const tvm_aet& aet, const uint8_t seed[32],
+                                 const std::function<void(const char*)>& lap) {
     const u64 n = p.trace.length;
-    Stopwatch watch{c};
     // the seeded randomness: offsets as in the table of master_table.rs:618-628.  The 470 trace-randomizer streams are
     // sequential ChaCha streams (0.7 ms of host time at 198 randomizers): a helper thread draws them while the device fills
     // and pads the main table.
@@ -940,40 +928,56 @@ std::vector<u64> prove_execution(const Context& c, const StarkParameters& p, con
     offset_rng_seed(aux_seed, NUM_AUX, batch_seed);
     offset_rng_seed(seed, NUM_MAIN + NUM_AUX + 1, quotient_seed);
     std::vector<u64> main_rnd_host, aux_rnd_host;
-    std::vector<Xfe> quotient_randomizer(p.num_quotient_randomizers);
+    quotient_randomizer.resize(p.num_quotient_randomizers);
+    std::exception_ptr draw_error;  // an exception on the helper thread (bad_alloc) is rethrown on this one
     std::thread draws([&] {
-        main_rnd_host = trace_randomizers_host(seed, NUM_MAIN, p.h, 1);
-        aux_rnd_host = trace_randomizers_host(aux_seed, NUM_AUX, p.h, 3);
-        tvm_host_stdrng_elements(quotient_seed, 3 * quotient_randomizer.size(), quotient_randomizer[0].c);
+        try {
+            main_rnd_host = trace_randomizers_host(seed, NUM_MAIN, p.h, 1);
+            aux_rnd_host = trace_randomizers_host(aux_seed, NUM_AUX, p.h, 3);
+            if (!quotient_randomizer.empty())
+                tvm_host_stdrng_elements(quotient_seed, 3 * quotient_randomizer.size(), quotient_randomizer.data()->c);
+        } catch (...) {
+            draw_error = std::current_exception();
+        }
     });
     struct Join {
         std::thread& t;
         ~Join() { if (t.joinable()) t.join(); }
     } join{draws};
     // MasterMainTable::new + pad (master_table.rs:881-983)
-    DeviceBuffer main_trace(c, NUM_MAIN * n);
+    main_trace = DeviceBuffer(c, NUM_MAIN * n);
     u64 lengths[9];
     c.check(tvm_fill_main_table(c.raw(), &aet, main_trace.ptr(), n, lengths), "tvm_fill_main_table");
     for (u64 len : lengths)
         if (len > p.padded_height) throw Error(TVM_ERR_INVALID_ARGUMENT, "a table is longer than the padded height");
-    watch.lap("fill from the AET");
+    lap("fill from the AET");
     c.check(tvm_pad_main_table(c.raw(), main_trace.ptr(), n, lengths), "tvm_pad_main_table");
     c.check(tvm_fill_derived_main_columns(c.raw(), main_trace.ptr(), n), "tvm_fill_derived_main_columns");
-    watch.lap("pad + derived main columns");
+    lap("pad + derived main columns");
     draws.join();
-    const DeviceBuffer main_rnd = upload(c, main_rnd_host);
-    const DeviceBuffer aux_rnd = upload(c, aux_rnd_host);
-    watch.lap("trace randomizers");
+    if (draw_error) std::rethrow_exception(draw_error);
+    main_rnd = upload(c, main_rnd_host);
+    aux_rnd = upload(c, aux_rnd_host);
+    lap("trace randomizers");
     // MasterMainTable::extend (master_table.rs:1006-1075): the batch-randomizer column now, the rest once the challenges exist
-    DeviceBuffer aux_trace(c, NUM_AUX * n * 3);
+    aux_trace = DeviceBuffer(c, NUM_AUX * n * 3);
     c.check(tvm_stdrng_elements(c.raw(), batch_seed, 3 * n, aux_trace.ptr() + (NUM_AUX - 1) * n * 3), "tvm_stdrng_elements");
-    watch.lap("batch randomizer column");
-    Prover prover(c, p, main_trace.ptr(), main_rnd.ptr(), aux_trace.ptr(), aux_rnd.ptr(), quotient_randomizer, claim);
+    lap("batch randomizer column");
+}
+
+void ExecutionTables::extend(const Context& c, u64 n, const std::vector<Xfe>& challenges) const {
+    c.check(tvm_extend_aux_table(c.raw(), main_trace.ptr(), aux_trace.ptr(), n, challenges[0].c), "tvm_extend_aux_table");
+    c.check(tvm_fill_derived_aux_columns(c.raw(), main_trace.ptr(), aux_trace.ptr(), n, challenges[0].c), "tvm_fill_derived_aux_columns");
+}
+
+std::vector<u64> prove_execution(const Context& c, const StarkParameters& p, const tvm_aet& aet, const Claim& claim,
+                                 const uint8_t seed[32]) {
+    const u64 n = p.trace.length;
+    Stopwatch watch{c};
+    const ExecutionTables t(c, p, aet, seed, [&](const char* what) { watch.lap(what); });
+    Prover prover(c, p, t.main_trace.ptr(), t.main_rnd.ptr(), t.aux_trace.ptr(), t.aux_rnd.ptr(), t.quotient_randomizer, claim);
     prover.assume_valid_trace = true;
-    prover.extend = [&](const std::vector<Xfe>& challenges) {
-        c.check(tvm_extend_aux_table(c.raw(), main_trace.ptr(), aux_trace.ptr(), n, challenges[0].c), "tvm_extend_aux_table");
-        c.check(tvm_fill_derived_aux_columns(c.raw(), main_trace.ptr(), aux_trace.ptr(), n, challenges[0].c), "tvm_fill_derived_aux_columns");
-    };
+    prover.extend = [&](const std::vector<Xfe>& challenges) { t.extend(c, n, challenges); };
     const ProofStream stream = prover.prove();
     watch.lap("prove (extend + hot path)");
     std::vector<u64> proof = stream.proof();

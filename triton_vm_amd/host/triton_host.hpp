@@ -131,6 +131,15 @@ public:
     DeviceBuffer weighted_sum_of_columns(const Xfe* weights) const;       // :512-542 -> 2 * n_rows XFE coefficients
     int field_kind() const { return fk_; }
     u64 n_cols() const { return n_cols_; }
+    // the quotient / LDT domain this table is extended onto: a coset group of the real domains when the extended rows are
+    // split over ranks or evaluated pass by pass (sharded_host.cpp); drops the cached extension
+    void set_domains(ArithmeticDomain quotient, ArithmeticDomain ldt);
+    // a second table object over the same trace and randomizer arrays, with no cached extension of its own
+    MasterTable sibling() const { return MasterTable(c_, fk_, d_trace_, n_rows_, n_cols_, d_rnd_, h_, trace_, quotient_, ldt_); }
+    // reveal_rows over the view of `view_rows` rows of the cached extension (its own LDT domain by default)
+    std::vector<u64> reveal_rows_of(const std::vector<u64>& row_indices, u64 view_rows) const;
+    // out_of_domain_rows for the n columns from first_col on (a rank's share when the columns are split): [n_points][n][3]
+    std::vector<u64> out_of_domain_rows(const std::vector<Xfe>& points, u64 first_col, u64 n) const;
 
 private:
     const Context& c_;
@@ -197,6 +206,18 @@ StarkParameters stark_parameters(unsigned log2_padded_height, unsigned security_
 // offset_rng_seed (master_table.rs:630-662)
 void offset_rng_seed(const uint8_t seed[32], u64 offset, uint8_t out[32]);
 
+// What Prover::prove(claim, aet) builds before the hot path (stark.rs:331-400): MasterMainTable::new + pad on the device
+// (master_table.rs:881-983), every randomizer drawn from `seed` the way the reference draws it (master_table.rs:423-434,
+// 1006-1024, stark.rs:1315-1322), the auxiliary trace buffer with its batch-randomizer column; `extend` runs
+// MasterMainTable::extend once the challenges exist (master_table.rs:1006-1075).  lap(name) is called after each step.
+struct ExecutionTables {
+    DeviceBuffer main_trace, main_rnd, aux_trace, aux_rnd;
+    std::vector<Xfe> quotient_randomizer;
+    ExecutionTables(const Context& c, const StarkParameters& p, const tvm_aet& aet, const uint8_t seed[32],
+                    const std::function<void(const char*)>& lap);
+    void extend(const Context& c, u64 n_rows, const std::vector<Xfe>& challenges) const;
+};
+
 // Prover::prove(claim, aet) from its first line (stark.rs:331-719): the master main table is filled from the algebraic
 // execution trace and padded on the device, every randomizer is drawn from `seed` the way the reference draws it
 // (master_table.rs:423-434, 1006-1024, stark.rs:1315-1322), the auxiliary table is extended on the device once the
@@ -205,6 +226,109 @@ std::vector<u64> prove_execution(const Context& c, const StarkParameters& p, con
                                  const uint8_t seed[32]);
 
 }  // namespace triton_vm
+
+// ---- one proof over the GPUs of a node, and/or coset by coset (sharded_host.cpp) ----------------------------------------
+// The collectives the sharded prover needs, as a table of functions so that this library stays free of device code and of
+// any communication library: rccl_comm.cpp (libtriton_rccl.so) fills it with RCCL calls on the context's stream, the local
+// implementation below with copies between the contexts of one process (tests, the single-GPU lockstep measurement of
+// bench.py --simulate-gpus), the CPU tests with callbacks that go through torch.distributed's gloo backend.  Buffers are
+// DEVICE buffers of 64-bit words; a call is ordered after the work already queued on the context's stream and its result
+// is visible to work queued afterwards (it need not have completed when the call returns).
+extern "C" {
+typedef struct tvmh_comm {
+    void* self;
+    uint32_t rank, world;
+    /* d_recv[r * words_per_rank ...] = rank r's d_send[0 .. words_per_rank) */
+    int32_t (*all_gather)(void* self, tvm_ctx* ctx, const uint64_t* d_send, uint64_t* d_recv, uint64_t words_per_rank);
+    /* d_recv[r * words_per_pair ...] = rank r's d_send[me * words_per_pair ...] */
+    int32_t (*all_to_all)(void* self, tvm_ctx* ctx, const uint64_t* d_send, uint64_t* d_recv, uint64_t words_per_pair);
+    /* optional hooks (may be null): prove begins / a named stage begins / prove ends on this rank */
+    void (*begin)(void* self, tvm_ctx* ctx);
+    void (*mark)(void* self, tvm_ctx* ctx, const char* stage);
+    void (*end)(void* self, tvm_ctx* ctx);
+} tvmh_comm;
+}
+
+namespace triton_vm {
+
+// rows i = g (mod G) of `domain`, as a domain (offset * generator^g, generator^G, length / G)
+ArithmeticDomain coset_group(const ArithmeticDomain& domain, u64 g, u64 G);
+
+// Prover::prove with the extended master tables split by cosets of the trace domain: over the ranks of `comm` (rank r of R
+// owns the extended rows i = r (mod R): SURVEY 8(e), stark.rs:805-1006 and master_table.rs:1305-1306 are the reference's
+// formulation of the same decomposition) and/or over `passes` passes per rank that never hold more than 1/passes of a
+// rank's share (the reference's just-in-time path, master_table.rs:268-271, 470-503, 556-609).  Same constructor data as
+// Prover; every rank passes the same traces, randomizers and claim and obtains the same transcript.  What is split: the
+// table extensions, row hashing, the Merkle trees (by leaf ranges, digests by all-to-all), the AIR, the quotient-segment
+// table, the out-of-domain rows (by columns), the linear combinations and DEEP (row-local), the first FRI rounds (i and
+// i + n/2 share a residue mod R: the fold is rank-local; codewords by all-to-all for the split trees).  What is replicated:
+// the trace-side work, the inverse transforms inside the table extension, the interpolation of the quotient codeword,
+// the weighted column sums, the small FRI rounds.
+class ShardedProver {
+public:
+    ShardedProver(const Context& c, const StarkParameters& p, const tvmh_comm* comm, unsigned passes, const u64* d_main_trace,
+                  const u64* d_main_randomizers, const u64* d_aux_trace, const u64* d_aux_randomizers,
+                  const std::vector<Xfe>& quotient_randomizer, const Claim& claim = Claim());
+    ProofStream prove();
+    std::function<void(const std::vector<Xfe>&)> extend;  // as Prover::extend
+    bool assume_valid_trace = false;
+    u64 split_tree_min_leaves = 1ull << 21;  // trees with fewer leaves are built whole on every rank
+    bool profile = false;                    // drain the stream at every stage boundary and record stage times
+    // what the last prove() did: stage -> ms (profile only), collective -> {calls, bytes sent by this rank}
+    std::vector<std::pair<std::string, double>> stage_ms;
+    std::vector<std::pair<std::string, std::pair<u64, u64>>> exchanges;
+    u64 split_trees_built = 0;
+    std::string stats_json() const;
+
+private:
+    friend struct ShardedRun;  // one prove(): sharded_host.cpp
+    const Context& c_;
+    StarkParameters p_;
+    const tvmh_comm* comm_;
+    unsigned passes_;
+    Claim claim_;
+    MasterTable main_, aux_;
+    std::vector<Xfe> quotient_randomizer_;
+};
+
+// Prover::prove(claim, aet) over the ranks of `comm` (null: this process alone) with `passes` passes per rank; passes == 0
+// is the reference's memory policy (master_table.rs:268-271, stark.rs:730-768): the cached path, and if the device (or the
+// context's memory limit) cannot hold it, the coset-wise path with as few passes as fit.  stats: optional, see ShardedProver.
+std::vector<u64> prove_execution_sharded(const Context& c, const StarkParameters& p, const tvmh_comm* comm, unsigned passes,
+                                         const tvm_aet& aet, const Claim& claim, const uint8_t seed[32], bool profile = false,
+                                         std::string* stats = nullptr, u64 split_tree_min_leaves = 1ull << 21);
+
+}  // namespace triton_vm
+
+// tvmh_prove_execution over a communicator and / or coset by coset (see triton_vm::prove_execution_sharded): comm may be null,
+// jit_passes == 0 selects the memory policy.  stats_json (optional): a JSON object with this rank's stage times (when
+// profile != 0) and its exchanges.
+extern "C" int32_t tvmh_prove_execution_sharded(tvm_ctx* ctx, const tvmh_comm* comm, uint32_t jit_passes, uint64_t split_tree_min_leaves,
+                                                const tvm_aet* aet, uint32_t log2_padded_height, uint32_t security_level,
+                                                uint32_t log2_expansion, uint32_t use_stir, const uint8_t randomness_seed[32],
+                                                const uint64_t* h_program_digest, const uint64_t* h_public_input,
+                                                uint64_t n_public_input, const uint64_t* h_public_output, uint64_t n_public_output,
+                                                uint64_t* h_proof, uint64_t proof_capacity_words, uint64_t* proof_words,
+                                                uint32_t profile, char* stats_json, uint64_t stats_capacity, char* error,
+                                                uint64_t error_capacity);
+// the hot path alone on device-resident traces (as tvmh_prove), sharded / coset-wise
+extern "C" int32_t tvmh_prove_sharded(tvm_ctx* ctx, const tvmh_comm* comm, uint32_t jit_passes, uint64_t split_tree_min_leaves,
+                                      uint32_t log2_padded_height, uint64_t num_trace_randomizers, uint64_t num_collinearity_checks,
+                                      uint32_t log2_expansion, const uint64_t* d_main_trace, const uint64_t* d_main_randomizers,
+                                      const uint64_t* d_aux_trace, const uint64_t* d_aux_randomizers,
+                                      const uint64_t* h_quotient_randomizer, uint32_t use_stir, uint32_t stir_security_level,
+                                      uint64_t* h_proof, uint64_t proof_capacity_words, uint64_t* proof_words, char* error,
+                                      uint64_t error_capacity);
+
+// Communicators between the contexts of ONE process (one thread per rank): collectives are a rendezvous plus device-to-device
+// copies on each rank's own stream.  lockstep != 0: between two collectives only one rank computes at a time, in rank
+// order, and the time each rank spends per stage (its stream drained at every stage mark) is recorded -- on a single GPU
+// that measures, rank by rank and without contention, the work the ranks of a real N-GPU run would do concurrently
+// (bench.py --simulate-gpus).  out: `world` pointers; all of them are freed by destroying comms[0].
+extern "C" int32_t tvmh_local_comms_create(uint32_t world, uint32_t lockstep, tvmh_comm** out);
+extern "C" void tvmh_local_comms_destroy(tvmh_comm* first);
+// lockstep accounting of a local communicator: JSON {"stage": [ms of rank 0, rank 1, ...], ...}, stages in first-seen order
+extern "C" uint64_t tvmh_local_comms_report(const tvmh_comm* any, char* json, uint64_t capacity);
 
 // C entry for hosts without a C++ ABI (the Python tests and bench.py): runs Prover::prove on device-resident traces
 // and returns the proof (the words of the reference's `Proof`).  h_program_digest (5 words) may be null (all zero), the

@@ -25,7 +25,153 @@ def load_host_library(backend_path=None, out=None):
                                     C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64]
     lib.tvmh_stir_parameters.restype = C.c_uint64
     lib.tvmh_stir_parameters.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64]
+    lib.tvmh_prove_execution_sharded.restype = C.c_int32
+    lib.tvmh_prove_execution_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                 C.c_uint32, C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
+                                                 C.c_uint64, C.POINTER(C.c_uint64), C.c_uint32, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]
+    lib.tvmh_prove_sharded.restype = C.c_int32
+    lib.tvmh_prove_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64,
+                                       C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64]
+    lib.tvmh_local_comms_create.restype = C.c_int32
+    lib.tvmh_local_comms_create.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+    lib.tvmh_local_comms_destroy.restype = None
+    lib.tvmh_local_comms_destroy.argtypes = [C.c_void_p]
+    lib.tvmh_local_comms_report.restype = C.c_uint64
+    lib.tvmh_local_comms_report.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
     return lib
+
+
+# ---- communicators for the sharded C++ host (triton_host.hpp: tvmh_comm) -----------------------------------------------
+_COLLECTIVE = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
+_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+_MARK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_char_p)
+
+
+class CommStruct(C.Structure):
+    """struct tvmh_comm"""
+    _fields_ = [("self", C.c_void_p), ("rank", C.c_uint32), ("world", C.c_uint32), ("all_gather", _COLLECTIVE), ("all_to_all", _COLLECTIVE),
+                ("begin", _HOOK), ("mark", _MARK), ("end", _HOOK)]
+
+
+class LocalComms:
+    """`world` communicators between the contexts of THIS process, one proving thread per rank (tvmh_local_comms_create):
+    collectives are a rendezvous plus device-to-device copies.  lockstep: one rank computes at a time and the per-rank,
+    per-stage compute time is recorded (`report()`), which on one GPU measures what the ranks of a real run do concurrently."""
+
+    def __init__(self, host_lib, world, lockstep=False):
+        self.lib, self.world = host_lib, world
+        arr = (C.c_void_p * world)()
+        if host_lib.tvmh_local_comms_create(world, 1 if lockstep else 0, arr) != 0:
+            raise RuntimeError("tvmh_local_comms_create failed")
+        self.ptrs = [arr[r] for r in range(world)]
+
+    def report(self):
+        import json
+
+        buf = C.create_string_buffer(1 << 16)
+        self.lib.tvmh_local_comms_report(self.ptrs[0], buf, len(buf))
+        return json.loads(buf.value.decode() or "{}")
+
+    def close(self):
+        if self.ptrs:
+            self.lib.tvmh_local_comms_destroy(self.ptrs[0])
+            self.ptrs = []
+
+
+class CallbackComm:
+    """A tvmh_comm whose collectives are Python callables over (send pointer, receive pointer, words) -- the CPU tests put
+    torch.distributed's gloo backend behind it (the "device" buffers of the emulation are host memory)."""
+
+    def __init__(self, rank, world, all_gather, all_to_all):
+        def wrap(fn):
+            def call(_self, _ctx, send, recv, words):
+                try:
+                    fn(send, recv, int(words))
+                    return 0
+                except Exception:   # noqa: BLE001 -- reported to the C++ host as a device error, with the traceback on stderr
+                    import traceback
+
+                    traceback.print_exc()
+                    return 3
+            return _COLLECTIVE(call)
+
+        self._keep = (wrap(all_gather), wrap(all_to_all))
+        self.struct = CommStruct(None, rank, world, self._keep[0], self._keep[1], _HOOK(), _MARK(), _HOOK())
+        self.ptr = C.addressof(self.struct)
+
+
+def gloo_comm(dist):
+    """CallbackComm over an initialised torch.distributed gloo group, for buffers in host memory (the CPU emulation)"""
+    import torch
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+
+    def view(ptr, words):
+        return torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int64)), shape=(words,)))
+
+    def all_gather(send, recv, words):
+        dist.all_gather_into_tensor(view(recv, words * world), view(send, words).clone())
+
+    def all_to_all(send, recv, words):   # gloo has no all-to-all on CPU tensors: one all-gather of everything, then this rank's blocks
+        everything = torch.empty(world * world * words, dtype=torch.int64)
+        dist.all_gather_into_tensor(everything, view(send, words * world).clone())
+        out = view(recv, words * world)
+        for r in range(world):
+            out[r * words:(r + 1) * words] = everything[(r * world + rank) * words:(r * world + rank + 1) * words]
+
+    return CallbackComm(rank, world, all_gather, all_to_all)
+
+
+def prove_execution_sharded(ctx, host_lib, comm_ptr, aet, padded_height, claim, randomness_seed, security_level=160, log2_expansion=2,
+                            ldt=None, jit_passes=0, split_tree_min_leaves=1 << 21, profile=False):
+    """The C++ host's Prover::prove(claim, aet) over the ranks of a communicator (comm_ptr: a tvmh_comm*, or None for this
+    process alone) and / or coset by coset (jit_passes; 0 = the reference's memory policy: cached, else as few passes as fit).
+    -> (proof words, stats dict)"""
+    import json
+
+    from .master_table import aet_struct
+
+    s, keep = aet_struct(aet)
+    log2 = padded_height.bit_length() - 1
+    err, stats, n = C.create_string_buffer(512), C.create_string_buffer(1 << 14), C.c_uint64(0)
+    out = np.empty(1 << 20, np.uint64)
+    while True:
+        rc = host_lib.tvmh_prove_execution_sharded(ctx.handle, comm_ptr, jit_passes, split_tree_min_leaves, C.addressof(s), log2, security_level,
+                                                   log2_expansion, {"fri": 0, "stir": 1, None: 2}[ldt], bytes(randomness_seed),
+                                                   claim.program_digest.ctypes.data, claim.input.ctypes.data, claim.input.size,
+                                                   claim.output.ctypes.data, claim.output.size, out.ctypes.data, out.size, C.byref(n),
+                                                   1 if profile else 0, stats, len(stats), err, len(err))
+        if rc != 0:
+            raise NativeHostError(rc, f"tvmh_prove_execution_sharded failed ({rc}): {err.value.decode()}")
+        if n.value <= out.size:
+            return out[:n.value].copy(), json.loads(stats.value.decode() or "{}")
+        out = np.empty(int(n.value), np.uint64)
+
+
+def prove_sharded(ctx, host_lib, comm_ptr, params, d_main_trace, d_main_randomizers, d_aux_trace, d_aux_randomizers, quotient_randomizer,
+                  jit_passes=1, split_tree_min_leaves=1 << 21, stir_security_level=160):
+    """The hot path alone (as NativeProver.prove) through the sharded / coset-wise C++ prover -> proof words"""
+    qr = np.ascontiguousarray(quotient_randomizer, dtype=np.uint64).reshape(-1, 3)
+    err, n = C.create_string_buffer(512), C.c_uint64(0)
+    out = np.empty(1 << 20, np.uint64)
+    log2 = params.padded_height.bit_length() - 1
+    while True:
+        rc = host_lib.tvmh_prove_sharded(ctx.handle, comm_ptr, jit_passes, split_tree_min_leaves, log2, params.h, params.num_collinearity_checks,
+                                         params.log2_expansion, d_main_trace.ptr, d_main_randomizers.ptr, d_aux_trace.ptr, d_aux_randomizers.ptr,
+                                         qr.ctypes.data, 1 if params.stir is not None else 0, stir_security_level, out.ctypes.data, out.size,
+                                         C.byref(n), err, len(err))
+        if rc != 0:
+            raise NativeHostError(rc, f"tvmh_prove_sharded failed ({rc}): {err.value.decode()}")
+        if n.value <= out.size:
+            return out[:n.value].copy()
+        out = np.empty(int(n.value), np.uint64)
+
+
+class NativeHostError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
 
 
 def stir_parameters(host_lib, padded_height, security_level=160, log2_expansion=2):
@@ -54,7 +200,8 @@ def stir_prove(ctx, host_lib, stir, d_codeword):
     return [int(i) for i in first], out[:n.value].copy()
 
 
-_PROOF_BUFFER = None
+_PROOF_BUFFERS = __import__("threading").local()   # one buffer per proving thread: ctypes releases the GIL inside the C++ host,
+#                                                     and the backend's contract is one context per proving thread
 
 
 def prove_execution(ctx, host_lib, aet, padded_height, claim, randomness_seed, security_level=160, log2_expansion=2, ldt=None):
@@ -67,8 +214,9 @@ def prove_execution(ctx, host_lib, aet, padded_height, claim, randomness_seed, s
     s, keep = aet_struct(aet)
     log2 = padded_height.bit_length() - 1
     err, n = C.create_string_buffer(512), C.c_uint64(0)
-    global _PROOF_BUFFER
-    out = _PROOF_BUFFER if _PROOF_BUFFER is not None else np.empty(1 << 20, np.uint64)   # a 2^20-row proof is ~0.3 M words
+    out = getattr(_PROOF_BUFFERS, "buffer", None)
+    if out is None:
+        out = np.empty(1 << 20, np.uint64)   # a 2^20-row proof is ~0.3 M words
     while True:
         rc = host_lib.tvmh_prove_execution(ctx.handle, C.addressof(s), log2, security_level, log2_expansion, {"fri": 0, "stir": 1, None: 2}[ldt],
                                            bytes(randomness_seed),
@@ -77,7 +225,7 @@ def prove_execution(ctx, host_lib, aet, padded_height, claim, randomness_seed, s
         if rc != 0:
             raise RuntimeError(f"tvmh_prove_execution failed ({rc}): {err.value.decode()}")
         if n.value <= out.size:
-            _PROOF_BUFFER = out                       # (kept: its pages are mapped by now)
+            _PROOF_BUFFERS.buffer = out               # (kept: its pages are mapped by now)
             return out[:n.value].copy()
         out = np.empty(int(n.value), np.uint64)   # the proof did not fit: grow and run again
 

@@ -302,7 +302,8 @@ class ProofStream:
                         raise ProofDecodingError("StirResponse: the stacks do not span the field")
                     if len({len(st) for st in stacks}) > 1:   # (the verifier rejects ragged stacks; never a numpy error)
                         raise ProofDecodingError("StirResponse: stacks of different heights")
-                    leaves = np.array(stacks, np.uint64).reshape(len(stacks), -1, 3)
+                    height = len(stacks[0]) if stacks else 0   # (explicit shape: no stacks at all is an empty response, not a numpy error)
+                    leaves = np.array(stacks, np.uint64).reshape(len(stacks), height, 3)
                 self.log.append((DECODED_LABELS[name][0], leaves.copy(), fs))
                 self.log.append((DECODED_LABELS[name][1], auth.copy(), fs))
         if take(0) != len(w):

@@ -71,27 +71,97 @@ def init_distributed(local_rank):
 USE_CPP_HOST = True
 
 
+def load_host_library():
+    """the C++ host above the C ABI (triton_vm_amd/host/), linked against the product library"""
+    from triton_vm_amd import native_host
+
+    return native_host.load_host_library()
+
+
+def make_comm(dist, device, rank, world, local_rank):
+    """this rank's communicator for the sharded C++ host: RCCL on the context's stream (triton_vm_amd/host/rccl_comm.cpp).
+    Rank 0 draws the ncclUniqueId; torch.distributed (already initialised for the barrier / max-over-ranks timing contract)
+    carries its 128 bytes to the other ranks."""
+    import numpy as np
+    import torch
+
+    from triton_vm_amd import native_host
+
+    uid = torch.from_numpy(native_host.RcclComm.unique_id() if rank == 0 else np.zeros(128, np.uint8)).to(device)
+    dist.broadcast(uid, 0)
+    return native_host.RcclComm(uid.cpu().numpy(), rank, world, local_rank)
+
+
 # ---- the CPU baseline ----------------------------------------------------------------------------------------------
+def available_cores():
+    """CPUs this process may actually run on: the affinity mask, capped by the cgroup's CPU quota (a container on a 256-thread
+    host is often allowed a few cores' worth of time: os.cpu_count() says 256 there and is not the number to parallelise by)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, round(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, round(quota / period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(log2_rows, log2_expansion=2):
-    """The oracle ("port" of the reference's algorithms: oracle/tvm_oracle.c, OpenMP) on a bounded sample of the same
-    workload, stage by stage, each stage scaled to the full prove():
-      LDE            C main-table columns at the full height (2^log2_rows -> x expansion*2 rows)      x 652 / C
-      row hashing    Tip5 hash_varlen over the first 2^20 rows of that C-column table                   x permutations(full) / permutations(C) x L / 2^20
-      Merkle         one tree over those 2^20 leaf digests                                              x (3 table trees + the FRI round trees ~ 1) = 4, x L / 2^20
-      AIR            all 604 constraints + zerofiers on 2^15 full-width quotient-domain rows            x |quotient domain| / 2^15
-      DEEP, FRI      4 DEEP components and one fold on 2^18-point codewords                             x |LDT domain| / 2^18 (folds: x 2, the geometric series)
-    -> a prove()-shaped estimate in trace-cells/s.  It is a textbook restatement on all host cores, NOT the Rust prover."""
+    """The CPU port (`kind: "port"`; the reference is Rust and cannot be built here): oracle/tvm_oracle_fast.c -- the hot
+    stages restated in the forms a CPU implementation uses (Tip5 with the integer-halves MDS, table-driven transforms, a typed
+    walk of the AIR circuit, batched inversions; held bit-equal to the textbook oracle by tests/test_oracle_fast.py), OpenMP over
+    rows / (column, coset) pairs -- on a bounded sample of the same workload, stage by stage, each stage scaled to prove():
+      LDE            C main-table columns at the full height onto the expansion-times-2 cosets                  x 652 / C
+      row hashing    Tip5 hash_varlen over 2^18 rows of that C-column table                                     x permutations(full) / permutations(sample)
+      Merkle         one tree over those leaf digests                                                           x (3 table trees + the FRI round trees ~ 1) x L / 2^18
+      AIR            all 604 constraints + zerofiers on 2^13 full-width quotient-domain rows                    x |quotient domain| / 2^13
+      DEEP, FRI      4 DEEP components and one fold on 2^18-point codewords                                     x |LDT domain| / 2^18 (folds: x 2)
+    `cores` = the OpenMP threads used = the CPUs this process may run on (affinity and cgroup quota, not os.cpu_count());
+    `parallel_speedup` = the measured ratio of the all-thread and the one-thread hashing rate."""
+    import ctypes
+
     import numpy as np
 
     from oracle import oracle as orc
 
-    cores = os.cpu_count() or 1
-    cols, h = max(8, min(cores, 64)), 198
+    fast = orc.fast
+    orc.lib()
+    cores = available_cores()
+    try:
+        gomp = ctypes.CDLL("libgomp.so.1")
+        set_threads = gomp.omp_set_num_threads
+    except OSError:
+        set_threads = lambda n: None   # noqa: E731
     n = 1 << log2_rows
     X = 2 << log2_expansion
     L = X * n
     rng = np.random.default_rng(1)
     g = orc.lib().orc_bfe_generator()
+    perms = lambda w: w // 10 + 1   # noqa: E731
+    # calibration: one thread against all of them on the same hashing job
+    cal = orc.random_elements(rng, (1 << 14, 64))
+    set_threads(1)
+    t0 = time.perf_counter()
+    fast.hash_rows(cal)
+    us_per_perm_1 = (time.perf_counter() - t0) / (cal.shape[0] * perms(64)) * 1e6
+    t0 = time.perf_counter()
+    fast.ntt(orc.random_elements(rng, 1 << 18), orc.lib().orc_bfe_primitive_root(1 << 18))
+    ns_per_butterfly_1 = (time.perf_counter() - t0) / ((1 << 18) * 9) * 1e9
+    set_threads(cores)
+    big = np.tile(cal, (max(1, min(cores, 16)), 1))
+    fast.hash_rows(big[:1 << 12])   # (the thread team starts here, not inside the timed call)
+    t0 = time.perf_counter()
+    fast.hash_rows(big)
+    us_per_perm_all = (time.perf_counter() - t0) / (big.shape[0] * perms(64)) * 1e6
+    speedup = us_per_perm_1 / us_per_perm_all
+    del cal, big
+    cols, h = 16, 198
     t, scaled = {}, {}
 
     def timed(name, scale, fn):
@@ -104,62 +174,165 @@ def cpu_baseline(log2_rows, log2_expansion=2):
     trace = orc.random_elements(rng, (cols, n))
     rnd = orc.random_elements(rng, (cols, h))
     ev = orc.domain_of_length(L, offset=g)
-    table = timed("lde", MASTER_WORDS / cols, lambda: orc.lde_table(trace, rnd, ev, 1))
-    perms = lambda w: w // 10 + 1
-    hs = min(L, 1 << 20)                          # rows hashed / leaves of the sampled tree
-    digests = timed("hash_rows", (perms(379) + perms(273) + perms(15)) / perms(cols) * L / hs, lambda: orc.hash_rows(table[:hs]))
-    timed("merkle", 4.0 * L / hs, lambda: orc.merkle_tree(digests))
+    table = timed("lde", MASTER_WORDS / cols, lambda: fast.lde_table(trace, rnd, ev))
+    hs = min(L, 1 << 18)                          # rows hashed / leaves of the sampled tree
+    digests = timed("hash_rows", (perms(379) + perms(273) + perms(15)) / perms(cols) * L / hs, lambda: fast.hash_rows(table[:hs]))
+    timed("merkle", 4.0 * L / hs, lambda: fast.merkle_tree(digests))
     del table, digests, trace
-    q_s, n_s = 1 << 15, 1 << 12
+    q_s = 1 << 13
     main_rows = orc.random_elements(rng, (q_s, 379))
     aux_rows = orc.random_elements(rng, (q_s, 91, 3))
     ch, w = orc.random_elements(rng, (63, 3)), orc.random_elements(rng, (604, 3))
-    timed("air", L / q_s, lambda: orc.quotients_combined(main_rows, aux_rows, orc.domain_of_length(n_s), orc.domain_of_length(q_s, offset=g), ch, w))
+    timed("air", L / q_s, lambda: fast.quotients_combined(main_rows, aux_rows, orc.domain_of_length(q_s // 8), orc.domain_of_length(q_s, offset=g), ch, w))
     d_s = orc.domain_of_length(1 << 18, offset=g)
     cw = orc.random_elements(rng, (d_s.length, 3))
     pt, val = orc.random_elements(rng, 3), orc.random_elements(rng, 3)
-    timed("deep", 4 * L / d_s.length, lambda: orc.deep_codeword(cw, d_s, pt, val))
+    timed("deep", 4 * L / d_s.length, lambda: fast.deep_codeword(cw, d_s, pt, val))
     timed("fri_fold", 2 * L / d_s.length, lambda: orc.fri_split_and_fold(cw, d_s, pt))
     est = sum(scaled.values())
+    butterflies = cols * (X + 1) * n * log2_rows / 2
     return {"value": round(n * MASTER_WORDS / est, 1), "unit": "trace-cells/s", "cores": cores, "kind": "port",
-            "estimated_prove_seconds": round(est, 1), "sample_seconds": {k: round(v, 2) for k, v in t.items()},
+            "host_threads_reported_by_os": os.cpu_count(), "parallel_speedup": round(speedup, 1),
+            "estimated_prove_seconds": round(est, 1), "sample_seconds": {k: round(v, 3) for k, v in t.items()},
             "scaled_seconds": {k: round(v, 1) for k, v in scaled.items()},
-            "sample": f"oracle (C, OpenMP, {cores} host threads; the LDE parallelises over its {cols} sampled columns only): LDE of {cols} "
-                      f"main columns at 2^{log2_rows} rows onto the {X}x domain, Tip5 hashing of 2^20 of that table's rows, one Merkle tree over them, the "
-                      "AIR on 2^15 full-width quotient rows, DEEP (4 components) and one FRI fold on 2^18-point codewords; every stage "
-                      f"scaled to the full prove() ({sum(t.values()):.1f} s measured -> {est:.0f} s estimated).  A textbook restatement, "
-                      "NOT the Rust prover (no cargo in this image): do not read value/cpu as a speed-up over the reference"}
+            "rates": {"tip5_us_per_permutation_one_thread": round(us_per_perm_1, 2),
+                      "tip5_us_per_permutation_all_threads": round(us_per_perm_all, 3),
+                      "row_hashing_us_per_permutation": round(t["hash_rows"] / (hs * perms(cols)) * 1e6, 3),
+                      "ntt_ns_per_butterfly_one_thread": round(ns_per_butterfly_1, 1),
+                      "lde_ns_per_butterfly": round(t["lde"] / butterflies * 1e9, 2),
+                      "air_us_per_row": round(t["air"] / q_s * 1e6, 1)},
+            "sample": f"oracle/tvm_oracle_fast.c (C, OpenMP, {cores} threads = the CPUs this process may use; os.cpu_count() = {os.cpu_count()}): LDE of {cols} "
+                      f"main columns at 2^{log2_rows} rows onto the {X}x domain, Tip5 hashing of 2^18 of that table's rows, one Merkle tree over them, the "
+                      "AIR on 2^13 full-width quotient rows, DEEP (4 components) and one FRI fold on 2^18-point codewords; every stage "
+                      f"scaled to the full prove() ({sum(t.values()):.1f} s measured -> {est:.0f} s estimated).  An optimised restatement, "
+                      "NOT the Rust prover (no cargo in this image): a reported baseline, not a speed-up claim"}
 
 
-def valu_roofline(launch_ms, rows, n_words):
-    """VALU roofline of the row-hashing kernel (k_hash_rows_mfma), the kernel furthest from the HBM roofline by time.
-    achieved = the kernel's VALU lane-operations per second: its static wave-level VALU instruction count per row and
-    permutation (profiles/valu_counts.json <- tools/valu_static_count.py over the shipped code object) x 64 lanes x rows x
-    permutations / the launch time measured live; peak = the hardware's plain VALU rate, 128 lane-ops/clk/CU x 256 CUs x
-    2.4 GHz (MI355X_MICROARCH.md).  `issue_model` is the explanatory extra: the same instructions priced with the
-    per-class issue costs of profiles/r02_valu_rates_microbench.txt (carry-out / VOP3 forms and v_mad_u64_u32 issue at
-    about half the plain rate) -- the share of SIMD cycles the kernel's instruction mix occupies."""
-    perms = n_words // 10 + 1            # absorb blocks of 10 words incl. the padding block (master_table.rs:667-716)
+def kernel_counters():
+    """profiles/kernel_counters.json: per-dispatch hardware counters of the SHIPPED hot kernels (rocprofv3 --pmc in separate passes,
+    tools/pmc.sh -> tools/kernel_counters.py; the file names its source profile and command)"""
     try:
-        with open(os.path.join(ROOT, "profiles", "valu_counts.json")) as f:
-            k = json.load(f)["k_hash_rows_mfma"]
-    except (OSError, KeyError, ValueError):
+        with open(os.path.join(ROOT, "profiles", "kernel_counters.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
         return None
-    instr = k["wave_valu_instructions_per_row_permutation"] * rows * perms
-    cycles = k["modelled_valu_issue_cycles_per_row_permutation"] * rows * perms
-    secs = launch_ms * 1e-3
-    achieved = instr * 64 / secs / 1e12                                   # T lane-ops/s
-    peak = VALU_PEAK_LANE_OPS_PER_CLK_PER_CU * N_CUS * CLOCK_GHZ * 1e9 / 1e12
-    return {"bound": "valu", "kernel": "k_hash_rows_mfma (main-table row hashing)", "achieved": round(achieved, 2),
-            "peak": round(peak, 2), "unit": "T VALU lane-ops/s", "frac": round(achieved / peak, 4),
-            "launch_ms": round(launch_ms, 3), "permutations_per_row": perms,
-            "wave_valu_instructions_per_row": round(k["wave_valu_instructions_per_row_permutation"] * perms, 1),
-            "lane_ops_per_clk_per_cu": round(instr * 64 / secs / (N_CUS * CLOCK_GHZ * 1e9), 1),
-            "instruction_counts_from": "profiles/valu_counts.json (tools/valu_static_count.py)",
-            "issue_model": {"simd_cycle_share": round(cycles / secs / 1e9 / (N_CUS * 4 * CLOCK_GHZ), 4),
-                            "note": "modelled issue cycles (per-class rates from asm microbenchmarks) / SIMD cycles available; "
-                                    "a model, not a measurement"},
-            "hbm_frac": round(rows * n_words * 8 / secs / 1e9 / HBM_PEAK_GBPS, 4)}
+
+
+VALU_PEAK_T = VALU_PEAK_LANE_OPS_PER_CLK_PER_CU * N_CUS * CLOCK_GHZ * 1e9 / 1e12   # T lane-ops/s, plain VALU (MI355X_MICROARCH.md)
+
+
+def lde_roofline(lde_ms, n_rows, n_cols, expansion, share, counters, shape_matches):
+    """`roofline` of the dominant kernel FAMILY by bytes, the main-table LDE.  The contract's figure -- algorithmic bytes (SURVEY
+    8(d): 8 B read + 8 B x expansion written per trace cell) / launch time against the 8 TB/s HBM peak -- is `achieved` / `frac`.
+    What bounds the kernels is stated next to it from MEASURED counters: `traffic` (fabric bytes, PMC) and the VALU rate from
+    SQ_INSTS_VALU (wave instructions x 64 lanes / time against the plain-VALU peak); `bound` is the larger of the two fractions'
+    resource.  `work` is the figure that cannot be raised by executing more instructions: butterflies per second."""
+    cells = n_rows * n_cols
+    bytes_per_cell = 8 + 8 * expansion / share
+    secs = lde_ms * 1e-3
+    achieved = cells * bytes_per_cell / secs / 1e9
+    out = {"kernel": "main-table LDE: tvm_lde_table of 379 columns (k_lde_pass1_rows + k_lde_pass2_rows + k_lde_pass3_rows, column chunks of 96)",
+           "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+           "launch_ms": round(lde_ms, 3), "algorithmic_bytes_per_launch": int(cells * bytes_per_cell), "traffic": None, "bound": "valu"}
+    log_n = n_rows.bit_length() - 1
+    butterflies = cells * (1 + expansion / share) * log_n / 2          # one inverse + expansion/share forward transforms per column
+    out["work"] = {"butterflies_per_s": round(butterflies / secs, 1), "unit": "radix-2 butterflies/s (log2(n)/2 per point and transform)"}
+    fam = (counters or {}).get("lde") if shape_matches else None
+    if fam:
+        traffic = fam["hbm_bytes_per_trace_cell"] * cells
+        insts = fam["wave_valu_instructions_per_trace_cell"] * cells
+        hbm_counter_frac = traffic / secs / 1e9 / HBM_PEAK_GBPS
+        valu_frac = insts * 64 / secs / 1e12 / VALU_PEAK_T
+        out.update(traffic=int(traffic), traffic_source=fam.get("source"),
+                   hbm={"algorithmic_gbps": round(achieved, 1), "algorithmic_frac": round(achieved / HBM_PEAK_GBPS, 4),
+                        "counter_gbps": round(traffic / secs / 1e9, 1), "counter_frac": round(hbm_counter_frac, 4),
+                        "traffic_over_algorithmic": round(traffic / (cells * bytes_per_cell), 2)},
+                   valu={"wave_instructions_per_launch": int(insts), "lane_ops_per_s_T": round(insts * 64 / secs / 1e12, 2), "peak_T": round(VALU_PEAK_T, 2),
+                         "frac": round(valu_frac, 4), "wave_instructions_per_butterfly": round(insts * 64 / butterflies / 64, 3),
+                         "lane_ops_per_layer_point": round(insts * 64 / (cells * (1 + expansion / share) * log_n), 2),
+                         "source": "SQ_INSTS_VALU, " + str(fam.get("source"))},
+                   bound="valu" if valu_frac >= hbm_counter_frac else "hbm",
+                   bound_note="both fractions are of hardware peaks; the kernels issue carry-chain and v_mad_u64_u32 instructions at about half "
+                              "the plain-VALU rate (DESIGN.md section 3), so the VALU fraction understates how close they are to their issue limit")
+    return out
+
+
+def hash_roofline(hash_ms, rows, n_words, counters):
+    """second roofline object: main-table row hashing (k_hash_rows_mfma), the largest stage of a proof.  VALU-bound: the fraction is
+    MEASURED wave VALU instructions (SQ_INSTS_VALU per row and permutation, profiles/kernel_counters.json) x 64 lanes / launch time
+    against the plain-VALU peak; `work` = Tip5 permutations per second."""
+    perms = n_words // 10 + 1            # absorb blocks of 10 words incl. the padding block (master_table.rs:667-716)
+    secs = hash_ms * 1e-3
+    out = {"kernel": "k_hash_rows_mfma (main-table row hashing)", "bound": "valu", "launch_ms": round(hash_ms, 3), "permutations_per_row": perms,
+           "work": {"tip5_permutations_per_s": round(rows * perms / secs, 1)},
+           "hbm": {"algorithmic_gbps": round(rows * n_words * 8 / secs / 1e9, 1), "algorithmic_frac": round(rows * n_words * 8 / secs / 1e9 / HBM_PEAK_GBPS, 4)}}
+    k = (counters or {}).get("hash_rows")
+    if k:
+        insts = k["wave_valu_instructions_per_row_permutation"] * rows * perms
+        out.update(achieved=round(insts * 64 / secs / 1e12, 2), peak=round(VALU_PEAK_T, 2), unit="T VALU lane-ops/s",
+                   frac=round(insts * 64 / secs / 1e12 / VALU_PEAK_T, 4),
+                   wave_valu_instructions_per_row_permutation=k["wave_valu_instructions_per_row_permutation"],
+                   lds_bank_conflict_share=k.get("lds_bank_conflict_share"), source="SQ_INSTS_VALU, " + str(k.get("source")))
+    return out
+
+
+XGMI_EGRESS_GBPS, COLLECTIVE_LATENCY_US = 300.0, 25.0   # assumptions of the projection below: 7 xGMI links x ~153 GB/s per GPU on
+#                                                          paper; 300 GB/s is what an all-to-all / all-gather is assumed to sustain
+
+
+def simulate_ranks(ctx, host_lib, n_ranks, aet, padded_height, claim, kw):
+    """One proof as `n_ranks` ranks of the sharded C++ prover on ONE GPU, in lockstep: every rank has its own context and
+    stream, the communicators are the in-process ones (collectives = rendezvous + device-to-device copies), and between two
+    collectives only one rank computes at a time -- so each rank's stage times are measured without contention, which is what
+    that rank would spend on its own GPU.  Returns per-stage per-rank compute ms, the exchanged bytes, and the projection
+    critical path = sum over stages of the slowest rank + bytes / assumed xGMI bandwidth.  A single-GPU measurement of the
+    multi-GPU code path, NOT a multi-GPU measurement."""
+    import threading
+
+    from triton_vm_amd import native_host
+
+    comms = native_host.LocalComms(host_lib, n_ranks, lockstep=True)
+    ctxs = [type(ctx)(device=0, lib=ctx.lib) for _ in range(n_ranks)]
+    out, errors = {}, []
+
+    def run(r, phase):
+        try:
+            out[(r, phase)] = native_host.prove_execution_sharded(ctxs[r], host_lib, comms.ptrs[r], aet, padded_height, claim, PROVER_SEED,
+                                                                  jit_passes=1, **kw)
+        except BaseException as e:   # noqa: BLE001
+            errors.append((r, e))
+
+    reports = []
+    try:
+        for phase in (0, 1):   # phase 0 warms the pools of the contexts up, phase 1 is the measurement
+            threads = [threading.Thread(target=run, args=(r, phase)) for r in range(n_ranks)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            if errors:
+                raise RuntimeError(f"simulated rank failed: {errors[0]}")
+            reports.append(comms.report())
+    finally:
+        comms.close()
+        for c in ctxs:
+            c.close()
+    stages = {k: [round(b - a, 3) for a, b in zip(reports[0].get(k, [0.0] * n_ranks), v)] for k, v in reports[1].items()}
+    proofs = [out[(r, 1)][0] for r in range(n_ranks)]
+    exchanges = out[(0, 1)][1]["exchanges"]
+    sent = sum(e["bytes_sent"] for e in exchanges.values())
+    calls = sum(e["calls"] for e in exchanges.values())
+    compute = sum(max(v) for v in stages.values())
+    replicated = sum(max(v) for k, v in stages.items() if k in ("trace tables (fill, pad, randomizers)", "extend"))
+    exchange_ms = sent / (XGMI_EGRESS_GBPS * 1e6) + calls * COLLECTIVE_LATENCY_US * 1e-3
+    return {"ranks": n_ranks, "stage_ms_per_rank": stages, "slowest_rank_sum_ms": round(compute, 3),
+            "replicated_stages_ms": round(replicated, 3), "exchanges_of_rank_0": exchanges, "bytes_sent_per_rank": sent, "collective_calls": calls,
+            "projected_exchange_ms": round(exchange_ms, 3), "projected_ms_per_proof": round(compute + exchange_ms, 3),
+            "assumptions": f"{XGMI_EGRESS_GBPS:.0f} GB/s sustained per-rank egress over xGMI, {COLLECTIVE_LATENCY_US:.0f} us per collective call",
+            "all_ranks_same_proof": all((p.size == proofs[0].size and (p == proofs[0]).all()) for p in proofs),
+            "proof": proofs[0],
+            "note": "single-GPU LOCKSTEP run of the N-rank code path (one rank computes at a time, own context and stream per rank): per-rank "
+                    "compute is measured, the exchanges are projected; not a multi-GPU measurement"}
 
 
 def spawn_ranks(n):
@@ -273,6 +446,9 @@ def main():
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent proofs per GPU instead of one sharded proof")
     ap.add_argument("--sharded", action="store_true", help="run the sharded prover (process group, collectives) even with ONE rank: the "
                     "code path of the N > 1 runs on a single-GPU box (plumbing check; the collectives are identities)")
+    ap.add_argument("--simulate-gpus", type=int, default=0, help="single GPU: run one proof as this many ranks of the sharded C++ prover in "
+                    "LOCKSTEP (one rank computes at a time, communicators between the contexts of this process) and report, per stage, what "
+                    "each rank computes -- the measured critical path of an N-GPU run, without N GPUs (DESIGN.md section 6)")
     ap.add_argument("--host", choices=["cpp", "python"], default="cpp",
                     help="host side that sequences the C-ABI calls of the timed step: the C++ mirror of Prover::prove "
                          "(triton_vm_amd/host/, the default where it applies: cached tables, one proof per GPU) or the "
@@ -307,14 +483,17 @@ def main():
     sharded = (world > 1 or args.sharded) and not args.replicas
     ldt = None if args.ldt == "auto" else args.ldt
     effective_ldt = ldt or ("fri" if args.log2_rows < 16 else "stir")
-    host_lib = None
-    if args.host == "cpp" and USE_CPP_HOST and not sharded and not args.jit_passes:
+    host_lib, comm = None, None
+    if args.host == "cpp" and USE_CPP_HOST:
         from triton_vm_amd import native_host
 
         try:
-            host_lib = native_host.load_host_library()
+            host_lib = load_host_library()
         except Exception as e:  # no g++ on this machine: the Python mirror sequences the same C-ABI calls
             print(f"bench.py: C++ host library unavailable ({e}); timing the Python host", file=sys.stderr)
+    if sharded and host_lib is not None:
+        comm = make_comm(dist, device, rank, world, local_rank)
+    split_min = 0 if args.sharded and world == 1 else 1 << 21   # one rank: still build the trees split (all-to-all, subtree roots)
     out_extra, last = {}, {}
 
     if args.data == "real":
@@ -332,8 +511,12 @@ def main():
         resident = aet_to_device(ctx, e["aet"])
         kw = dict(log2_expansion=args.log2_expansion, ldt=ldt)
 
-        def prove_from(aet):
-            if sharded:
+        def prove_from(aet, profile=False):
+            if host_lib is not None and (sharded or args.jit_passes):
+                last["proof"], last["stats"] = native_host.prove_execution_sharded(
+                    ctx, host_lib, comm.ptr if comm is not None else None, aet, padded_height, claim, PROVER_SEED,
+                    jit_passes=args.jit_passes or (1 if sharded else 0), split_tree_min_leaves=split_min, profile=profile, **kw)
+            elif sharded:
                 from triton_vm_amd.sharded import ShardedProver
 
                 prover = ShardedProver.from_execution(ctx, dist, device, aet, padded_height, claim, PROVER_SEED, **kw)
@@ -351,16 +534,18 @@ def main():
         step = lambda: prove_from(resident)
         params = stark_parameters(args.log2_rows, 160, args.log2_expansion, ldt)
         cells_per_step = padded_height * MASTER_WORDS * (1 if sharded or world == 1 else world)
-        host = "python (sharded)" if sharded else ("cpp" if host_lib is not None else "python")
+        host = ("cpp (sharded)" if host_lib is not None else "python (sharded)") if sharded else ("cpp" if host_lib is not None else "python")
     else:
         ldt_s = effective_ldt
         params = StarkParameters(args.log2_rows, num_trace_randomizers=args.trace_randomizers,
                                  num_collinearity_checks=args.queries, ldt=ldt_s, log2_expansion=args.log2_expansion)
-        if sharded:
+        if sharded and host_lib is not None:
+            prover = Prover(ctx, params, seed=1000)          # the same tables on every rank; the C++ sharded host proves them
+        elif sharded:
             from triton_vm_amd.sharded import ShardedProver
 
             prover = ShardedProver(ctx, params, dist, device, seed=1000)
-        elif args.jit_passes:
+        elif args.jit_passes and host_lib is None:
             from triton_vm_amd.jit import JitProver
 
             prover = JitProver(ctx, params, args.jit_passes, seed=1000 + rank)
@@ -368,7 +553,12 @@ def main():
             prover = Prover(ctx, params, seed=1000 + rank)
         cells_per_step = params.padded_height * MASTER_WORDS * (1 if sharded else world)
         step, host = prover.prove, "python"
-        if host_lib is not None:
+        if host_lib is not None and (sharded or args.jit_passes):
+            step = lambda: native_host.prove_sharded(ctx, host_lib, comm.ptr if comm is not None else None, params, prover.main.d_trace,   # noqa: E731
+                                                     prover.main.d_randomizers, prover.aux.d_trace, prover.aux.d_randomizers,
+                                                     prover.quotient_randomizer, jit_passes=args.jit_passes or 1, split_tree_min_leaves=split_min)
+            host = "cpp (sharded)" if sharded else "cpp"
+        elif host_lib is not None:
             native = native_host.NativeProver(ctx, host_lib, params, prover.main.d_trace, prover.main.d_randomizers,
                                               prover.aux.d_trace, prover.aux.d_randomizers, prover.quotient_randomizer)
             step, host = (lambda: native.prove(parse=False)), "cpp"
@@ -390,8 +580,18 @@ def main():
         verified = {"verifier": "triton_vm_amd.verifier.Verifier (Verifier::verify, stark.rs:1388-1763)", "accepted": True,
                     "revealed_rows": len(accepted_at), "proof_words": int(last["proof"].size), "seconds": round(time.perf_counter() - t0, 2)}
     barrier()
-    stage_ms, stage_wall, t_prof = {}, {}, 0.0
-    if rank == 0 or sharded:  # a sharded prove() contains collectives: every rank has to take part
+    stage_ms, stage_wall, t_prof, rank_stats = {}, {}, 0.0, None
+    cpp_stats = host_lib is not None and (sharded or args.jit_passes) and args.data == "real"
+    if cpp_stats:   # the sharded / coset-wise C++ host times its own stages (stream drained at every stage boundary)
+        t_prof = time.perf_counter()
+        prove_from(resident, profile=True)
+        t_prof = 1e3 * (time.perf_counter() - t_prof)
+        rank_stats = [last["stats"]]
+        if dist is not None and world > 1:
+            rank_stats = [None] * world
+            dist.all_gather_object(rank_stats, last["stats"])
+        stage_ms = dict(rank_stats[0]["stage_ms"])
+    elif (rank == 0 or sharded) and not (host_lib is not None and (sharded or args.jit_passes)):  # a sharded prove() contains collectives: every rank has to take part
         if args.data == "real":
             if sharded:
                 from triton_vm_amd.sharded import ShardedProver
@@ -424,20 +624,10 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        lde_cells = params.trace.length * 379
         share = world if sharded else (args.jit_passes or 1)
-        lde_bytes_per_cell = 8 + 8 * (params.ldt.length // params.trace.length) / share  # read the trace once, write L/N values per cell
-        achieved = lde_cells * lde_bytes_per_cell / (lde_avg_ms * 1e-3) / 1e9
-        traffic, traffic_from = None, None  # fabric-side bytes per launch family: PMC passes over the SHIPPED kernels (tools/pmc.sh)
-        try:
-            with open(os.path.join(ROOT, "profiles", "lde_traffic.json")) as f:
-                tj = json.load(f)
-            if share == 1 and args.log2_expansion == 2 and args.log2_rows == 20:   # (measured for this shape only)
-                traffic = int(tj["hbm_bytes_per_trace_cell"] * lde_cells)
-                traffic_from = {"file": "profiles/lde_traffic.json", "kernels": tj.get("kernels"), "method": tj.get("method"),
-                                "measured_on": tj.get("measured_on")}
-        except (OSError, KeyError, ValueError):
-            pass
+        counters = kernel_counters()
+        roofline = lde_roofline(lde_avg_ms, params.trace.length, 379, params.ldt.length // params.trace.length, share, counters,
+                                share == 1 and args.log2_expansion == 2 and args.log2_rows == 20)   # (the counters were taken on this shape)
         if args.data == "real":
             workload_text = (f"Prover::prove(claim, aet) for real: {args.program} program run for {e['cycles']} cycles (public input "
                              f"{e['index']}), padded height 2^{args.log2_rows}, 379 main + 91 aux columns (652 words/row); Stark::default() parameters with "
@@ -463,24 +653,24 @@ def main():
             "config": {"workload": workload_text,
                        "host": {"cpp": "C++ mirror of Prover::prove over the C ABI (triton_vm_amd/host/triton_host.cpp)",
                                 "python": "Python mirror of Prover::prove over the C ABI (triton_vm_amd/prover.py)",
-                                "python (sharded)": "Python mirror, one proof over the ranks (triton_vm_amd/sharded.py)"}[host],
+                                "python (sharded)": "Python mirror, one proof over the ranks (triton_vm_amd/sharded.py)",
+                                "cpp (sharded)": "C++ host, one proof over the ranks: ShardedProver (triton_vm_amd/host/sharded_host.cpp), collectives by "
+                                                 "RCCL on the context's stream (triton_vm_amd/host/rccl_comm.cpp)"}[host],
                        "padded_rows": params.padded_height, "master_words": MASTER_WORDS, "ldt": effective_ldt,
                        "ldt_domain": params.ldt.length, "parallelism": (f"one proof over {world} GPUs: coset sharding of the extended tables, all-to-all of leaf "
                                        "digests, all-gather of the quotient codeword" if sharded else f"{world} independent proofs, one per GPU" if world > 1
                                        else f"single GPU, tables evaluated coset-wise in {args.jit_passes} passes (nothing cached)"
                                        if args.jit_passes else "single GPU")},
-            "roofline": {"bound": "hbm", "kernel": "main-table LDE: tvm_lde_table of 379 columns (k_lde_pass1_rows + k_lde_pass2_rows + k_lde_pass3_rows at 2^20 rows, column chunks of 96)",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_from,
-                         "launch_ms": round(lde_avg_ms, 3),
-                         "algorithmic_bytes_per_launch": int(lde_cells * lde_bytes_per_cell)},
-            "roofline_valu": valu_roofline(hash_avg_ms, hash_rows, 379),
+            "roofline": roofline,
+            "roofline_valu": hash_roofline(hash_avg_ms, hash_rows, 379, counters),
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "stage_wall_ms": {k: round(v, 3) for k, v in stage_wall.items()},
             "profiled_prove_wall_ms": round(t_prof, 3),
         }
         if verified is not None:
             out["verified"] = verified
+        if rank_stats is not None:   # per rank: stage times of one profiled proof and the bytes each collective sent
+            out["ranks"] = rank_stats
         if args.data == "real":
             out["workload_generation"] = {"vm_seconds": round(vm_s, 2), "cycles": e["cycles"], "table_heights": e["table_heights"],
                                           "note": "oracle-side VM (oracle/vm), outside the timed region; the product path starts at Prover::prove(claim, aet)"}
@@ -502,6 +692,29 @@ def main():
                 t = timed_steps(ostep, 2, 1, ctx.sync)
                 out["reference_default_ldt" if other == "stir" else "with_ldt_choice_fri"] = {
                     "ldt": other, "ms_per_step": round(1e3 * t / 2, 3), "value": round(cells_per_step * 2 / t, 1), "unit": "trace-cells/s", "host": host}
+            # (2b) the reference's own formulation of the AIR on the REAL trace: every constraint on every point of the quotient domain
+            if host_lib is not None:
+                host_lib.tvmh_set_option(native_host.OPTION_EXACT_AIR, 1)
+                try:
+                    t = timed_steps(lambda: prove_from(resident), 3, 1, ctx.sync)
+                    exact_proof = last["proof"]
+                finally:
+                    host_lib.tvmh_set_option(native_host.OPTION_EXACT_AIR, 0)
+                prove_from(resident)
+                out["exact_air_real"] = {"ms_per_step": round(1e3 * t / 3, 3), "value": round(cells_per_step * 3 / t, 1), "unit": "trace-cells/s",
+                                         "same_proof_as_valid_trace_mode": bool(exact_proof.size == last["proof"].size and (exact_proof == last["proof"]).all()),
+                                         "note": "the same step with the AIR evaluated row by row on every point of the quotient domain "
+                                                 "(master_table.rs:1264-1363), not in valid-trace mode"}
+            # (2c) the multi-GPU code path, rank by rank in lockstep on this one GPU
+            n_sim = args.simulate_gpus or (8 if args.log2_rows <= 20 and args.log2_expansion == 2 and effective_ldt == "fri" else 0)
+            if host_lib is not None and n_sim > 1:
+                try:
+                    sim = simulate_ranks(ctx, host_lib, n_sim, resident, padded_height, claim, kw)
+                    sim["same_proof_as_single_gpu"] = bool(sim["proof"].size == last["proof"].size and (sim.pop("proof") == last["proof"]).all())
+                    sim.pop("proof", None)
+                    out["simulated_multi_gpu"] = sim
+                except Exception as err:   # noqa: BLE001 (an extra: never lose the headline to it)
+                    out["simulated_multi_gpu"] = {"error": str(err)[:400]}
             # (3) rounds 1-2's headline: the hot path alone on synthetic tables resident in HBM, exact AIR
             sp = stark_parameters(args.log2_rows, 160, args.log2_expansion, "fri")
             syn = Prover(ctx, sp, seed=1000)

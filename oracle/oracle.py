@@ -18,7 +18,7 @@ P = 2**64 - 2**32 + 1
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("tvm_oracle.c", "tvm_oracle.h", "tip5_constants.h", "air_circuit.h")]
+    src = [os.path.join(_HERE, f) for f in ("tvm_oracle.c", "tvm_oracle_fast.c", "tvm_oracle.h", "tip5_constants.h", "air_circuit.h", "Makefile")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
@@ -337,3 +337,61 @@ def fri_split_and_fold(codeword, d, challenge):
     out = np.zeros((d.length // 2, 3), np.uint64)
     lib().orc_fri_split_and_fold(_p(codeword), d, _p(challenge), _p(out))
     return out
+
+
+# ---- the optimised restatement (oracle/tvm_oracle_fast.c): what bench.py's cpu_baseline leg times ------------------------
+class fast:
+    """Same results as the functions above, bit for bit (tests/test_oracle_fast.py); CPU-efficient forms."""
+
+    @staticmethod
+    def tip5_permutation(state):
+        s = _arr(state).copy()
+        lib().orcf_tip5_permutation(_p(s))
+        return s
+
+    @staticmethod
+    def hash_rows(rows):
+        rows = _arr(rows)
+        n = rows.shape[0]
+        out = np.zeros((n, 5), np.uint64)
+        lib().orcf_hash_rows(_p(rows), C.c_uint64(n), C.c_uint64(rows.size // n), _p(out))
+        return out
+
+    @staticmethod
+    def merkle_tree(leaves):
+        leaves = _arr(leaves)
+        n = leaves.shape[0]
+        nodes = np.zeros((2 * n, 5), np.uint64)
+        lib().orcf_merkle_tree(_p(leaves), C.c_uint64(n), _p(nodes))
+        return nodes
+
+    @staticmethod
+    def ntt(values, generator):
+        a = _arr(values).copy()
+        lib().orcf_ntt(_p(a), C.c_uint64(a.size), C.c_uint64(int(generator)))
+        return a
+
+    @staticmethod
+    def lde_table(trace, randomizers, eval_domain):
+        """base-field columns: trace [n_cols, n_rows], randomizers [n_cols, h] -> [L, n_cols]"""
+        trace, randomizers = _arr(trace), _arr(randomizers)
+        n_cols, n_rows = trace.shape
+        out = np.zeros((eval_domain.length, n_cols), np.uint64)
+        lib().orcf_lde_table(_p(trace), C.c_uint64(n_rows), C.c_uint64(n_cols), _p(randomizers), C.c_uint64(randomizers.shape[1]),
+                             eval_domain, _p(out))
+        return out
+
+    @staticmethod
+    def quotients_combined(main_rows, aux_rows, trace_domain, quotient_domain, challenges, weights):
+        main_rows, aux_rows, challenges, weights = _arr(main_rows), _arr(aux_rows), _arr(challenges), _arr(weights)
+        out = np.zeros((quotient_domain.length, 3), np.uint64)
+        lib().orcf_quotients_combined(_p(main_rows), C.c_uint64(main_rows.shape[1]), _p(aux_rows), C.c_uint64(aux_rows.shape[1]),
+                                      trace_domain, quotient_domain, _p(challenges), _p(weights), _p(out))
+        return out
+
+    @staticmethod
+    def deep_codeword(codeword, d, point, value_):
+        codeword, point, value_ = _arr(codeword), _arr(point), _arr(value_)
+        out = np.zeros((d.length, 3), np.uint64)
+        lib().orcf_deep_codeword(_p(codeword), d, _p(point), _p(value_), _p(out))
+        return out

@@ -125,6 +125,16 @@ void orc_deep_codeword(const uint64_t* codeword, orc_domain d, const uint64_t po
                        const uint64_t value[3], uint64_t* out);
 void orc_fri_split_and_fold(const uint64_t* codeword, orc_domain d, const uint64_t challenge[3], uint64_t* out);
 
+/* ---- tvm_oracle_fast.c: the optimised restatement timed by bench.py's cpu_baseline leg (same results, bit for bit) ---- */
+void orcf_tip5_permutation(uint64_t st[16]);
+void orcf_hash_rows(const uint64_t* rows, uint64_t n_rows, uint64_t w, uint64_t* digests);
+void orcf_merkle_tree(const uint64_t* leaves, uint64_t n, uint64_t* nodes);
+void orcf_ntt(uint64_t* a, uint64_t n, uint64_t generator);
+void orcf_lde_table(const uint64_t* trace, uint64_t n, uint64_t n_cols, const uint64_t* rnd, uint64_t h, orc_domain eval, uint64_t* out);
+void orcf_quotients_combined(const uint64_t* main_rows, uint64_t n_main, const uint64_t* aux_rows, uint64_t n_aux, orc_domain trace,
+                             orc_domain q, const uint64_t* challenges, const uint64_t* weights, uint64_t* out);
+void orcf_deep_codeword(const uint64_t* cw, orc_domain d, const uint64_t pt[3], const uint64_t val[3], uint64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

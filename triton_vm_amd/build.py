@@ -57,9 +57,15 @@ def _build(force, verbose, extra_flags, variant):
              "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-Wno-unused-variable",
              *extra_flags]
     procs, objs = [], []
+    headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    newest_header = max(os.path.getmtime(h) for h in headers)
+    stamp = os.path.join(objdir, ".flags")   # objects are reused only if they were compiled with the same flags
+    same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(flags)
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
         objs.append(obj)
+        if not force and same_flags and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
+            continue   # this translation unit is up to date
         cmd = [_hipcc(), *flags, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
@@ -70,6 +76,8 @@ def _build(force, verbose, extra_flags, variant):
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out, file=sys.stderr)
+    with open(stamp, "w") as f:
+        f.write(" ".join(flags))
     subprocess.check_call([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib + ".tmp", *objs])
     os.replace(lib + ".tmp", lib)  # never a half-written library under the final name
     return lib
@@ -102,6 +110,32 @@ def build_host(backend_lib=None, out=None):
     return out
 
 
+RCCL_LIB = os.path.join(HERE, "libtriton_rccl.so")
+
+
+def build_rccl(backend_lib=None):
+    """The RCCL communicator of the multi-GPU prover (triton_vm_amd/host/rccl_comm.cpp): host code that enqueues RCCL
+    collectives on the context's stream.  g++ against the ROCm headers; linked with the product library, librccl and
+    libamdhip64 (in a process that has imported torch, torch's bundled copies of those two are the ones already loaded)."""
+    backend_lib = backend_lib or build()
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    src = os.path.join(HERE, "host", "rccl_comm.cpp")
+    deps = [src, os.path.join(HERE, "host", "triton_host.hpp"), os.path.join(ROOT, "include", "triton_hip.h"), backend_lib]
+    if os.path.exists(RCCL_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(RCCL_LIB) for d in deps):
+        return RCCL_LIB
+    import fcntl
+
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+                               "-I", os.path.join(HERE, "host"), "-I", os.path.join(rocm, "include"), "-o", RCCL_LIB + ".tmp", src,
+                               "-L", os.path.dirname(backend_lib), "-ltriton_hip", "-L", os.path.join(rocm, "lib"), "-lrccl", "-lamdhip64",
+                               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(rocm, "lib")])
+        os.replace(RCCL_LIB + ".tmp", RCCL_LIB)
+    return RCCL_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_host())
+    print(build_rccl())

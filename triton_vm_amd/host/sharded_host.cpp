@@ -708,7 +708,7 @@ std::vector<u64> prove_execution_sharded(const Context& c, const StarkParameters
         const ExecutionTables t(c, p, aet, seed, [](const char*) {});
         ShardedProver prover(c, p, comm, pass_count, t.main_trace.ptr(), t.main_rnd.ptr(), t.aux_trace.ptr(), t.aux_rnd.ptr(),
                              t.quotient_randomizer, claim);
-        prover.assume_valid_trace = true;
+        prover.assume_valid_trace = !tvmh_get_option(TVMH_OPTION_EXACT_AIR);
         prover.profile = profile;
         prover.split_tree_min_leaves = split_tree_min_leaves;
         prover.extend = [&](const std::vector<Xfe>& challenges) { t.extend(c, n, challenges); };

@@ -3,6 +3,7 @@
 #include "host_internal.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -976,7 +977,7 @@ std::vector<u64> prove_execution(const Context& c, const StarkParameters& p, con
     Stopwatch watch{c};
     const ExecutionTables t(c, p, aet, seed, [&](const char* what) { watch.lap(what); });
     Prover prover(c, p, t.main_trace.ptr(), t.main_rnd.ptr(), t.aux_trace.ptr(), t.aux_rnd.ptr(), t.quotient_randomizer, claim);
-    prover.assume_valid_trace = true;
+    prover.assume_valid_trace = !tvmh_get_option(TVMH_OPTION_EXACT_AIR);
     prover.extend = [&](const std::vector<Xfe>& challenges) { t.extend(c, n, challenges); };
     const ProofStream stream = prover.prove();
     watch.lap("prove (extend + hot path)");
@@ -986,6 +987,12 @@ std::vector<u64> prove_execution(const Context& c, const StarkParameters& p, con
 }
 
 }  // namespace triton_vm
+
+static std::atomic<uint64_t> g_exact_air{0};
+extern "C" void tvmh_set_option(uint32_t option, uint64_t value) {
+    if (option == TVMH_OPTION_EXACT_AIR) g_exact_air.store(value);
+}
+extern "C" uint64_t tvmh_get_option(uint32_t option) { return option == TVMH_OPTION_EXACT_AIR ? g_exact_air.load() : 0; }
 
 extern "C" int32_t tvmh_prove(tvm_ctx* ctx, uint32_t log2_padded_height, uint64_t num_trace_randomizers,
                               uint64_t num_collinearity_checks, uint32_t log2_expansion, const uint64_t* d_main_trace,

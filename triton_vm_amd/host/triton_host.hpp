@@ -352,6 +352,13 @@ extern "C" int32_t tvmh_prove_execution(tvm_ctx* ctx, const tvm_aet* aet, uint32
                                         uint64_t* h_proof, uint64_t proof_capacity_words, uint64_t* proof_words, char* error,
                                         uint64_t error_capacity);
 
+// Process-wide switches of this host library.  TVMH_OPTION_EXACT_AIR != 0: prove_execution (plain and sharded) evaluates the AIR row
+// by row on every point of the quotient domain, as the reference does (master_table.rs:1264-1363), instead of in valid-trace mode
+//  -- the same proof on a valid trace; bench.py times both.
+#define TVMH_OPTION_EXACT_AIR 1
+extern "C" void tvmh_set_option(uint32_t option, uint64_t value);
+extern "C" uint64_t tvmh_get_option(uint32_t option);
+
 // Stir::prove alone for an explicitly given instance (round_queries: [in-domain, out-of-domain] pairs); the proof of a
 // stream holding only the STIR items; h_first_round_indices: room for the first round's in-domain query count.
 extern "C" int32_t tvmh_stir_prove(tvm_ctx* ctx, tvm_domain initial_domain, uint32_t folding_factor, const uint64_t* round_queries,

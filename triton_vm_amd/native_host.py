@@ -33,6 +33,10 @@ def load_host_library(backend_path=None, out=None):
     lib.tvmh_prove_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64,
                                        C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64]
+    lib.tvmh_set_option.restype = None
+    lib.tvmh_set_option.argtypes = [C.c_uint32, C.c_uint64]
+    lib.tvmh_get_option.restype = C.c_uint64
+    lib.tvmh_get_option.argtypes = [C.c_uint32]
     lib.tvmh_local_comms_create.restype = C.c_int32
     lib.tvmh_local_comms_create.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
     lib.tvmh_local_comms_destroy.restype = None
@@ -40,6 +44,9 @@ def load_host_library(backend_path=None, out=None):
     lib.tvmh_local_comms_report.restype = C.c_uint64
     lib.tvmh_local_comms_report.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
     return lib
+
+
+OPTION_EXACT_AIR = 1   # tvmh_set_option: prove_execution evaluates the AIR row by row instead of in valid-trace mode
 
 
 # ---- communicators for the sharded C++ host (triton_host.hpp: tvmh_comm) -----------------------------------------------
@@ -77,6 +84,50 @@ class LocalComms:
         if self.ptrs:
             self.lib.tvmh_local_comms_destroy(self.ptrs[0])
             self.ptrs = []
+
+
+class RcclComm:
+    """The production communicator: RCCL collectives on the context's stream (triton_vm_amd/host/rccl_comm.cpp).  One per
+    rank; `unique_id` is drawn on rank 0 (RcclComm.unique_id) and handed to the other ranks by the launcher's channel."""
+
+    _lib = None
+
+    @classmethod
+    def library(cls):
+        if cls._lib is None:
+            from .build import build_rccl
+
+            lib = C.CDLL(build_rccl())
+            lib.tvmh_rccl_unique_id.restype = C.c_int32
+            lib.tvmh_rccl_unique_id.argtypes = [C.c_void_p]
+            lib.tvmh_rccl_comm_create.restype = C.c_int32
+            lib.tvmh_rccl_comm_create.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.POINTER(C.c_void_p)]
+            lib.tvmh_rccl_comm_destroy.restype = None
+            lib.tvmh_rccl_comm_destroy.argtypes = [C.c_void_p]
+            lib.tvmh_rccl_last_error.restype = C.c_char_p
+            cls._lib = lib
+        return cls._lib
+
+    @classmethod
+    def unique_id(cls):
+        out = np.zeros(128, np.uint8)
+        if cls.library().tvmh_rccl_unique_id(out.ctypes.data) != 0:
+            raise RuntimeError("ncclGetUniqueId: " + cls.library().tvmh_rccl_last_error().decode())
+        return out
+
+    def __init__(self, unique_id, rank, world, device):
+        lib = self.library()
+        uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
+        assert uid.size == 128
+        ptr = C.c_void_p()
+        if lib.tvmh_rccl_comm_create(uid.ctypes.data, rank, world, device, C.byref(ptr)) != 0:
+            raise RuntimeError("tvmh_rccl_comm_create: " + lib.tvmh_rccl_last_error().decode())
+        self.ptr, self.rank, self.world = ptr.value, rank, world
+
+    def close(self):
+        if self.ptr:
+            self.library().tvmh_rccl_comm_destroy(self.ptr)
+            self.ptr = None
 
 
 class CallbackComm:

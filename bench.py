@@ -446,6 +446,8 @@ def main():
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent proofs per GPU instead of one sharded proof")
     ap.add_argument("--sharded", action="store_true", help="run the sharded prover (process group, collectives) even with ONE rank: the "
                     "code path of the N > 1 runs on a single-GPU box (plumbing check; the collectives are identities)")
+    ap.add_argument("--split-all-trees", action="store_true", help="sharded proof: build EVERY Merkle tree split over the ranks, not only those of "
+                    "at least 2^21 leaves")
     ap.add_argument("--simulate-gpus", type=int, default=0, help="single GPU: run one proof as this many ranks of the sharded C++ prover in "
                     "LOCKSTEP (one rank computes at a time, communicators between the contexts of this process) and report, per stage, what "
                     "each rank computes -- the measured critical path of an N-GPU run, without N GPUs (DESIGN.md section 6)")
@@ -493,7 +495,9 @@ def main():
             print(f"bench.py: C++ host library unavailable ({e}); timing the Python host", file=sys.stderr)
     if sharded and host_lib is not None:
         comm = make_comm(dist, device, rank, world, local_rank)
-    split_min = 0 if args.sharded and world == 1 else 1 << 21   # one rank: still build the trees split (all-to-all, subtree roots)
+    # trees of at least 2^21 leaves are built split over the ranks (the three table trees and the first FRI rounds at 2^20 rows);
+    # --split-all-trees forces every tree through the split path (plumbing check: ~14 ms of extra copies and host round trips)
+    split_min = 0 if args.split_all_trees else 1 << 21
     out_extra, last = {}, {}
 
     if args.data == "real":
@@ -521,7 +525,7 @@ def main():
 
                 prover = ShardedProver.from_execution(ctx, dist, device, aet, padded_height, claim, PROVER_SEED, **kw)
                 if args.sharded:
-                    prover.split_tree_min_leaves = 0   # one rank: still build the trees split (all-to-all, subtree roots, remote nodes)
+                    prover.split_tree_min_leaves = split_min
                 last["proof"] = prover.prove().proof().words
                 prover.release()
             elif host_lib is not None:

@@ -1,0 +1,71 @@
+"""Pins beyond the reference's two FRI-sized proof snapshots (tests/test_proof_snapshot.py), at no cargo cost:
+
+  * whole-proof equality, word for word, between the device path (`Prover.from_execution` over the C ABI, and the C++ host) and
+    the oracle prover (oracle/real_prover.py -- which reproduces BOTH of the reference's proof digests, so on these executions
+    it IS the reference's prover as far as the repository can know) at padded heights 2^12 and 2^14: larger domains, more FRI
+    rounds, 1024- and 4096-point transform axes, multi-chunk tables;
+  * STIR regression digests: `Tip5::hash(proof)` of the two snapshot programs with `LdtChoice::Stir` forced.  The reference holds
+    no STIR vector (its snapshots are FRI-sized), so these are NOT parity pins -- they freeze today's STIR proofs, which both
+    restated verifiers accept (tests/test_stir.py, tests/test_ldt_verifiers.py), against drift.
+"""
+import numpy as np
+import pytest
+
+from tests import test_proof_snapshot as snap
+from tests import vm_fixture as vf
+
+
+def _golden():
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "stir_regression_digests.json")) as f:
+        return json.load(f)
+
+
+def test_stir_proof_of_the_first_snapshot_program_has_not_drifted(ctx, orc):
+    from triton_vm_amd.verifier import Verifier
+
+    program, aet, public_input, output = vf.run("tiny")
+    claim = snap.claim_of(orc, program, public_input, output)
+    proof = snap.device_proof(ctx, orc, "tiny", snap.SEED_U64, 160, ldt="stir")
+    assert [int(w) for w in proof.digest(ctx.lib)] == _golden()["tiny"]["digest"]
+    Verifier(ctx, security_level=160, ldt="stir").verify(claim, proof.words)   # raises on rejection
+
+
+@pytest.mark.gpu
+def test_stir_proof_of_the_second_snapshot_program_has_not_drifted(orc):
+    """every instruction, every table, security level 32, STIR forced (GPU only: ten minutes on the emulation)"""
+    from triton_vm_amd import Context
+
+    ctx = Context(device=0)
+    try:
+        proof = snap.device_proof(ctx, orc, "every", snap.SEED_U64_EVERY, 32, ldt="stir")
+        assert [int(w) for w in proof.digest(ctx.lib)] == _golden()["every"]["digest"]
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log2_rows", [12, 14])
+def test_device_proof_equals_the_oracle_provers_at_larger_heights(orc, log2_rows):
+    """prove_fib padded to 2^12 and 2^14 rows: every word of the device proof (Python host and C++ host) equals the oracle
+    prover's -- the prover that reproduces the reference's two proof digests"""
+    from oracle import real_prover
+    from oracle.vm import workload
+    from triton_vm_amd import Context, native_host
+    from triton_vm_amd.prover import Claim, Prover
+
+    e = workload.execution("fib", log2_rows)
+    want = real_prover.prove(e["program"], [e["index"]], seed_u64=snap.SEED_U64)
+    seed = snap.prover_seed(snap.SEED_U64)
+    claim = Claim(e["program_digest"], e["public_input"], e["public_output"])
+    ctx = Context(device=0)
+    try:
+        prover = Prover.from_execution(ctx, e["aet"], e["padded_height"], claim, seed, ldt="fri")
+        words = prover.prove().proof().words
+        assert [int(v) for v in orc.from_mont(words)] == want["proof"]
+        native = native_host.prove_execution(ctx, native_host.load_host_library(), e["aet"], e["padded_height"], claim, seed, ldt="fri")
+        assert native.size == words.size and (native == words).all()
+    finally:
+        ctx.close()

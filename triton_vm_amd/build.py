@@ -35,20 +35,23 @@ def _stale():
     return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
 
 
-def build(force=False, verbose=False, extra_flags=(), variant=None):
-    """Compile every .hip translation unit for gfx950 and link the shared library.
+def build(force=False, verbose=False, extra_flags=(), variant=None, recompile=()):
+    """Compile the .hip translation units for gfx950 (those whose object is older than its source or any header; all of them
+    with force) and link the shared library.  `recompile`: translation units (file names) that are compiled again even when
+    up to date, followed by a relink -- __graft_entry__.build() names the row-hashing unit, so that the library a machine
+    loads always contains a hot kernel compiled and linked BY THAT MACHINE's toolchain, not only prebuilt objects.
     `variant` (a name) builds an experiment library libtriton_hip_<variant>.so with extra flags.
     Serialised by a file lock: the ranks of a multi-process launch may all find the library stale at once."""
     import fcntl
 
     with open(os.path.join(HERE, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
-        return _build(force, verbose, extra_flags, variant)
+        return _build(force, verbose, extra_flags, variant, tuple(recompile))
 
 
-def _build(force, verbose, extra_flags, variant):
+def _build(force, verbose, extra_flags, variant, recompile=()):
     lib = LIB if variant is None else os.path.join(HERE, f"libtriton_hip_{variant}.so")
-    if variant is None and not force and not _stale():
+    if variant is None and not force and not recompile and not _stale():
         return LIB
     objdir = os.path.join(HERE, "build" if variant is None else f"build_{variant}")
     os.makedirs(objdir, exist_ok=True)
@@ -64,7 +67,8 @@ def _build(force, verbose, extra_flags, variant):
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
         objs.append(obj)
-        if not force and same_flags and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
+        if not force and os.path.basename(src) not in recompile and same_flags and os.path.exists(obj) and \
+                os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
             continue   # this translation unit is up to date
         cmd = [_hipcc(), *flags, "-c", src, "-o", obj]
         if verbose:

@@ -154,14 +154,15 @@ def cpu_baseline(log2_rows, log2_expansion=2):
     fast.ntt(orc.random_elements(rng, 1 << 18), orc.lib().orc_bfe_primitive_root(1 << 18))
     ns_per_butterfly_1 = (time.perf_counter() - t0) / ((1 << 18) * 9) * 1e9
     set_threads(cores)
-    big = np.tile(cal, (max(1, min(cores, 16)), 1))
-    fast.hash_rows(big[:1 << 12])   # (the thread team starts here, not inside the timed call)
+    tiled = np.tile(cal, (max(1, min(cores, 16)), 1))
+    fast.hash_rows(tiled[:1 << 12])   # (the thread team starts here, not inside the timed call)
     t0 = time.perf_counter()
-    fast.hash_rows(big)
-    us_per_perm_all = (time.perf_counter() - t0) / (big.shape[0] * perms(64)) * 1e6
+    fast.hash_rows(tiled)
+    us_per_perm_all = (time.perf_counter() - t0) / (tiled.shape[0] * perms(64)) * 1e6
     speedup = us_per_perm_1 / us_per_perm_all
-    del cal, big
-    cols, h = 16, 198
+    del cal, tiled
+    big = cores >= 8                      # sample sizes: about 10-30 s of CPU work either way
+    cols, h = (64 if big else 16), 198
     t, scaled = {}, {}
 
     def timed(name, scale, fn):
@@ -175,11 +176,11 @@ def cpu_baseline(log2_rows, log2_expansion=2):
     rnd = orc.random_elements(rng, (cols, h))
     ev = orc.domain_of_length(L, offset=g)
     table = timed("lde", MASTER_WORDS / cols, lambda: fast.lde_table(trace, rnd, ev))
-    hs = min(L, 1 << 18)                          # rows hashed / leaves of the sampled tree
+    hs = min(L, 1 << (20 if big else 18))         # rows hashed / leaves of the sampled tree
     digests = timed("hash_rows", (perms(379) + perms(273) + perms(15)) / perms(cols) * L / hs, lambda: fast.hash_rows(table[:hs]))
     timed("merkle", 4.0 * L / hs, lambda: fast.merkle_tree(digests))
     del table, digests, trace
-    q_s = 1 << 13
+    q_s = 1 << (15 if big else 13)
     main_rows = orc.random_elements(rng, (q_s, 379))
     aux_rows = orc.random_elements(rng, (q_s, 91, 3))
     ch, w = orc.random_elements(rng, (63, 3)), orc.random_elements(rng, (604, 3))
@@ -202,8 +203,8 @@ def cpu_baseline(log2_rows, log2_expansion=2):
                       "lde_ns_per_butterfly": round(t["lde"] / butterflies * 1e9, 2),
                       "air_us_per_row": round(t["air"] / q_s * 1e6, 1)},
             "sample": f"oracle/tvm_oracle_fast.c (C, OpenMP, {cores} threads = the CPUs this process may use; os.cpu_count() = {os.cpu_count()}): LDE of {cols} "
-                      f"main columns at 2^{log2_rows} rows onto the {X}x domain, Tip5 hashing of 2^18 of that table's rows, one Merkle tree over them, the "
-                      "AIR on 2^13 full-width quotient rows, DEEP (4 components) and one FRI fold on 2^18-point codewords; every stage "
+                      f"main columns at 2^{log2_rows} rows onto the {X}x domain, Tip5 hashing of {hs} of that table's rows, one Merkle tree over them, the "
+                      f"AIR on {q_s} full-width quotient rows, DEEP (4 components) and one FRI fold on 2^18-point codewords; every stage "
                       f"scaled to the full prove() ({sum(t.values()):.1f} s measured -> {est:.0f} s estimated).  An optimised restatement, "
                       "NOT the Rust prover (no cargo in this image): a reported baseline, not a speed-up claim"}
 
@@ -709,16 +710,6 @@ def main():
                                          "same_proof_as_valid_trace_mode": bool(exact_proof.size == last["proof"].size and (exact_proof == last["proof"]).all()),
                                          "note": "the same step with the AIR evaluated row by row on every point of the quotient domain "
                                                  "(master_table.rs:1264-1363), not in valid-trace mode"}
-            # (2c) the multi-GPU code path, rank by rank in lockstep on this one GPU
-            n_sim = args.simulate_gpus or (8 if args.log2_rows <= 20 and args.log2_expansion == 2 and effective_ldt == "fri" else 0)
-            if host_lib is not None and n_sim > 1:
-                try:
-                    sim = simulate_ranks(ctx, host_lib, n_sim, resident, padded_height, claim, kw)
-                    sim["same_proof_as_single_gpu"] = bool(sim["proof"].size == last["proof"].size and (sim.pop("proof") == last["proof"]).all())
-                    sim.pop("proof", None)
-                    out["simulated_multi_gpu"] = sim
-                except Exception as err:   # noqa: BLE001 (an extra: never lose the headline to it)
-                    out["simulated_multi_gpu"] = {"error": str(err)[:400]}
             # (3) rounds 1-2's headline: the hot path alone on synthetic tables resident in HBM, exact AIR
             sp = stark_parameters(args.log2_rows, 160, args.log2_expansion, "fri")
             syn = Prover(ctx, sp, seed=1000)
@@ -731,6 +722,17 @@ def main():
             out["synthetic_hot_path"] = {"ms_per_step": round(1e3 * t / 3, 3), "value": round(cells_per_step * 3 / t, 1), "unit": "trace-cells/s",
                                          "note": "random tables resident in HBM, FRI, exact row-by-row AIR, no fill/pad/extend: the timed step of rounds 1-2"}
             syn.release()
+        # (2c) the multi-GPU code path, rank by rank in lockstep on this one GPU
+        n_sim = args.simulate_gpus or (8 if extras and args.log2_rows <= 20 and args.log2_expansion == 2 and effective_ldt == "fri" else 0)
+        if host_lib is not None and n_sim > 1 and args.data == "real" and world == 1 and not sharded:
+            ctx.trim()   # (the simulated ranks need the pool's cached blocks)
+            try:
+                sim = simulate_ranks(ctx, host_lib, n_sim, resident, padded_height, claim, kw)
+                sim["same_proof_as_single_gpu"] = bool(sim["proof"].size == last["proof"].size and (sim.pop("proof") == last["proof"]).all())
+                sim.pop("proof", None)
+                out["simulated_multi_gpu"] = sim
+            except Exception as err:   # noqa: BLE001 (an extra: never lose the headline to it)
+                out["simulated_multi_gpu"] = {"error": str(err)[:400]}
         if extras and args.data == "synthetic":
             # TVM_OPTION_AIR_VALID_TRACE on the same synthetic tables (the work does not depend on the contents)
             ctx.assume_valid_trace(True)

@@ -117,10 +117,13 @@ def test_bench_sharded_code_path_over_rccl_with_one_rank():
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--sharded", "--steps", "1", "--warmup", "0", "--log2-rows", "16",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--sharded", "--split-all-trees", "--steps", "1", "--warmup", "0", "--log2-rows", "16",
            "--no-cpu-baseline", "--no-extras"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert rec["data"] == "real" and rec["verified"]["accepted"] and rec["n_gpus"] == 1
     assert "one proof over" in rec["config"]["parallelism"]
+    # the C++ sharded host over the RCCL communicator: its own stage times and exchanges are in the line, every tree was built split
+    assert "sharded_host.cpp" in rec["config"]["host"] and rec["ranks"][0]["split_trees_built"] >= 4
+    assert rec["ranks"][0]["exchanges"]["main leaf digests"]["calls"] == 1

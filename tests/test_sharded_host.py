@@ -240,3 +240,95 @@ def test_two_gloo_processes_reproduce_the_reference_snapshot(orc):
             assert stats["rank"] == rank and stats["split_trees_built"] >= 3
     finally:
         ctx.close()
+
+
+# ---- two real GPUs over RCCL (runs as soon as two are visible; the boxes of the builder's rounds had one) -----------------
+def _rccl_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from oracle import oracle as orc
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(rank)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # carries the ncclUniqueId; the proof's collectives are RCCL
+    from triton_vm_amd import Context
+
+    ctx = Context(device=rank)
+    host = native_host.load_host_library()
+    uid = torch.from_numpy(native_host.RcclComm.unique_id() if rank == 0 else np.zeros(128, np.uint8))
+    dist.broadcast(uid, 0)
+    comm = native_host.RcclComm(uid.numpy(), rank, world, rank)
+    aet, padded_height, claim, seed = _snapshot_inputs(orc)
+    words, stats = native_host.prove_execution_sharded(ctx, host, comm.ptr, aet, padded_height, claim, seed, jit_passes=1, split_tree_min_leaves=0)
+    out.put((rank, words, stats))
+    dist.barrier()
+    comm.close()
+    dist.destroy_process_group()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_two_gpus_over_rccl_reproduce_the_reference_snapshot(orc):
+    import queue
+    import time
+
+    import torch
+    import torch.multiprocessing as mp
+
+    from tests import test_proof_snapshot as snap
+    from triton_vm_amd import Context
+    from triton_vm_amd.proof_stream import Proof
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mpctx = mp.get_context("spawn")
+    out = mpctx.Queue()
+    procs = [mpctx.Process(target=_rccl_worker, args=(r, world, port, out)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results, deadline = {}, time.time() + 600
+    while len(results) < world:
+        try:
+            rank, words, stats = out.get(timeout=5)
+            results[rank] = (words, stats)
+        except queue.Empty:
+            assert all(pr.exitcode in (None, 0) for pr in procs), "a rank died"
+            assert time.time() < deadline, "timed out"
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    ctx = Context(device=0)
+    try:
+        for rank in range(world):
+            assert Proof(results[rank][0]).digest(ctx.lib) == snap.SNAPSHOT, rank
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_one_rank_over_rccl_reproduces_the_reference_snapshot(orc):
+    """the RCCL communicator (triton_vm_amd/host/rccl_comm.cpp) with a single rank, in this process: every collective of the
+    sharded proof runs through RCCL on the context's stream"""
+    from tests import test_proof_snapshot as snap
+    from triton_vm_amd import Context
+    from triton_vm_amd.proof_stream import Proof
+
+    ctx = Context(device=0)
+    comm = None
+    try:
+        host = native_host.load_host_library()
+        comm = native_host.RcclComm(native_host.RcclComm.unique_id(), 0, 1, 0)
+        aet, padded_height, claim, seed = _snapshot_inputs(orc)
+        words, stats = native_host.prove_execution_sharded(ctx, host, comm.ptr, aet, padded_height, claim, seed, jit_passes=1, split_tree_min_leaves=0)
+        assert Proof(words).digest(ctx.lib) == snap.SNAPSHOT
+        assert stats["split_trees_built"] >= 3 and stats["exchanges"]["quotient codeword"]["calls"] == 1
+    finally:
+        if comm is not None:
+            comm.close()
+        ctx.close()

@@ -24,6 +24,27 @@ for STAGE in 2 1; do
     TRITON_HIP_STAGE=$STAGE cargo test --release -p triton-vm --features hip -- "$T"
   done
 done
-# the headline benchmark, CPU vs device, same box
+# STIR, the reference's automatic low-degree test from 2^16 padded rows on (stark.rs:1944-1951) -- the one part of the proof no
+# reference-held value pins (both proof-hash snapshots are FRI-sized): prove_fib at 2^16 rows through the device backend, the
+# UNMODIFIED verifier must accept.  FIBONACCI_INDEX 6500 -> ~65 000 cycles -> padded height 2^16; the bench's own
+# `program.prove()` verifies nothing, so the example-style check runs as a doc-less integration test generated here.
+mkdir -p triton-vm/tests
+cat > triton-vm/tests/hip_stir_acceptance.rs <<'RS'
+use triton_vm::prelude::*;
+#[test]
+fn prove_fib_at_2_pow_16_rows_with_the_automatic_stir_is_accepted_by_the_unmodified_verifier() {
+    let program = dev_util::example_programs::fibonacci_sequence();
+    let (stark, claim, proof) = triton_vm::prove_program(program, PublicInput::new(bfe_vec![6500_u32]), NonDeterminism::default()).unwrap();
+    assert_eq!(1 << 16, proof.padded_height().unwrap());
+    assert!(triton_vm::verify(stark, &claim, &proof));
+}
+RS
+for STAGE in 2 1; do
+  TRITON_HIP_STAGE=$STAGE cargo test --release -p triton-vm --features hip --test hip_stir_acceptance
+done
+# the headline benchmark, CPU vs device, same box; then the same at 2^16 rows, where Stark::default() is STIR
+cargo bench -p triton-vm --bench prove_fib --no-default-features
+cargo bench -p triton-vm --bench prove_fib --no-default-features --features hip
+sed -i 's/const FIBONACCI_INDEX: u32 = 100;/const FIBONACCI_INDEX: u32 = 6500;/' triton-vm/benches/prove_fib.rs
 cargo bench -p triton-vm --bench prove_fib --no-default-features
 cargo bench -p triton-vm --bench prove_fib --no-default-features --features hip

@@ -1162,6 +1162,8 @@ static Split split_for(u64 n) {
     Split s;
     s.log_n = ilog2(n);
     s.log_n1 = s.log_n / 2;
+    static const int forced_n1 = std::getenv("TVM_LDE_SPLIT_N1") ? std::atoi(std::getenv("TVM_LDE_SPLIT_N1")) : 0;   // experiment knob
+    if (forced_n1 > 0 && forced_n1 < s.log_n) s.log_n1 = forced_n1;
     s.log_n2 = s.log_n - s.log_n1;
     s.shift = (s.log_n + 1) / 2;
     return s;
@@ -1276,9 +1278,10 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     const Split sp = split_for(N);
     const u64 n1 = 1ull << sp.log_n1, n2 = 1ull << sp.log_n2;
     const int W = (int)(n_cols * fk);
-    // columns per chunk: 96 while the chunk's intermediate (96 * L words) stays below 8 GiB, else 32.  Measured at 2^20 rows
-    // (main table, with 8 row tiles per pass-3 workgroup): 16 -> 48.0 ms, 32 -> 47.0, 96 -> 45.6, 192 -> 45.5, 379 -> 45.1
-    if (chunk_cols <= 0) chunk_cols = ((size_t)96 * X * n_rows * sizeof(u64) <= ((size_t)8 << 30)) ? 96 : 32;
+    // columns per chunk: 96 while the chunk's intermediate (96 * L words) stays below 32 GiB, else 32.  Measured at 2^20 rows
+    // (main table, with 8 row tiles per pass-3 workgroup): 16 -> 48.0 ms, 32 -> 47.0, 96 -> 45.6, 192 -> 45.5, 379 -> 45.1; at 2^22
+    // rows (intermediate 25.8 GB; round 4, whole proof): 32 -> 836.9 ms, 64 -> 821.8, 96 -> 820.6; at 2^21 rows 398.1 -> 392.0
+    if (chunk_cols <= 0) chunk_cols = ((size_t)96 * X * n_rows * sizeof(u64) <= ((size_t)32 << 30)) ? 96 : 32;
     if (std::getenv("TVM_LDE_CHUNK") && std::atoi(std::getenv("TVM_LDE_CHUNK")) > 0) chunk_cols = std::atoi(std::getenv("TVM_LDE_CHUNK"));  // experiment knob
 
     const u64 w = trace_gen, wi = bfe_inv(trace_gen);

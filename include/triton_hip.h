@@ -253,6 +253,28 @@ int32_t tvm_all_quotients_combined(tvm_ctx* ctx, const tvm_table* main_table, co
                                    const uint64_t* h_challenges, const uint64_t* h_weights,
                                    uint64_t* d_quotient_codeword);
 
+/* ---- A3 in valid-trace mode, piecewise (for a host that distributes the evaluation over several GPUs).  The
+ * constraints are generated in four classes by the length of their quotients: bit 0 = the initial / terminal quotients of degree-4
+ * constraints (needed on every point of the quotient domain), bit 1 = "half" (fewer than 4N coefficients), bit 2 = "quarter"
+ * (fewer than 2N), bit 3 = "three cosets" (fewer than 3N).  tvm_air_class_cosets: how many cosets of the trace domain determine
+ * each class's quotient polynomial for these tables' interpolant lengths (out[class bit]; 0 = the degree bound does not hold: use
+ * tvm_all_quotients_combined on every point).  tvm_air_class_values: sum over the constraints of the classes in class_mask of
+ * weight * constraint * zerofier inverse on coset `coset` of table_domain (the domain the tables were extended onto; X = its
+ * length / N cosets, coset k = the points k + X j) -> trace_domain.length XFE in the coset's natural order.
+ * tvm_coset_values_to_coefficients: the values of a polynomial of fewer than n_cosets * N coefficients on n_cosets <= 4 cosets
+ * h_offsets[j] * <w_N> -> its coefficients, ADDED to d_coeffs (n_cosets * N XFE).  On a valid trace the sum over the classes,
+ * evaluated on the quotient domain, plus the class-0 values is exactly the output of tvm_all_quotients_combined. */
+#define TVM_AIR_CLASS_FULL 1
+#define TVM_AIR_CLASS_HALF 2
+#define TVM_AIR_CLASS_QUARTER 4
+#define TVM_AIR_CLASS_THREE 8
+int32_t tvm_air_class_cosets(const tvm_table* main_table, const tvm_table* aux_table, tvm_domain trace_domain, uint32_t out[4]);
+int32_t tvm_air_class_values(tvm_ctx* ctx, const tvm_table* main_table, const tvm_table* aux_table, tvm_domain trace_domain,
+                             tvm_domain table_domain, uint32_t coset, uint32_t class_mask, const uint64_t* h_challenges,
+                             const uint64_t* h_weights, uint64_t* d_out);
+int32_t tvm_coset_values_to_coefficients(tvm_ctx* ctx, tvm_domain trace_domain, uint32_t n_cosets, const uint64_t* h_offsets,
+                                         const uint64_t* const* d_values, uint64_t* d_coeffs);
+
 /* ---- Q3-Q5: interpolate_quotient_segments, ldt_domain_segment_polynomials and
  * randomize_quotient_segments (stark.rs:1224-1283, 1302-1356) in one call ---------------------
  * d_quotient_codeword: quotient_domain.length XFE (the output of all_quotients_combined).

@@ -80,9 +80,14 @@ def _run_ranks(world, body):
     return results
 
 
+ON_THE_EMULATION_TOO = {(2, True, "fri", False), (8, True, "fri", True), (2, True, "fri16", False)}   # (CPU suite time; all of them on the GPU)
+
+
 @pytest.mark.parametrize("world,split_trees,kind,lockstep", [(2, True, "fri", False), (4, False, "fri", False), (8, True, "fri", True),
                                                              (2, True, "stir", False), (2, True, "fri16", False), (8, False, "fri16", False)])
 def test_sharded_cpp_proof_equals_single_gpu_proof(ctx, orc, world, split_trees, kind, lockstep):
+    if ctx.kind == "emu" and (world, split_trees, kind, lockstep) not in ON_THE_EMULATION_TOO:
+        pytest.skip("on the GPU only (CPU suite time); tests/test_sharded_prover.py runs these shapes through the Python mirror on the emulation")
     host = host_library(ctx)
     p = _params(kind)
     main_trace, aux_trace = _inputs(orc, p)
@@ -137,6 +142,8 @@ def test_sharded_prove_execution_reproduces_the_reference_snapshot(ctx, orc, wor
     from tests import test_proof_snapshot as snap
     from triton_vm_amd.proof_stream import Proof
 
+    if ctx.kind == "emu" and world == 8:
+        pytest.skip("eight ranks on the GPU only (CPU suite time)")
     host = host_library(ctx)
     aet, padded_height, claim, seed = _snapshot_inputs(orc)
     comms = native_host.LocalComms(host, world)
@@ -332,3 +339,37 @@ def test_one_rank_over_rccl_reproduces_the_reference_snapshot(orc):
         if comm is not None:
             comm.close()
         ctx.close()
+
+
+# ---- the valid-trace AIR dealt over the ranks (sharded_host.cpp: quotient_codeword_by_classes) ---------------------------------
+@pytest.mark.parametrize("world", [4, pytest.param(2, marks=pytest.mark.gpu), pytest.param(8, marks=pytest.mark.gpu)])
+def test_valid_trace_air_over_the_ranks_yields_the_single_gpu_proof(ctx, orc, world):
+    """prove_fib at 2^9 padded rows, security level 32 (60 trace randomizers: the degree bounds of the valid-trace classes hold):
+    the ranks evaluate the constraint classes on the cosets dealt to them, exchange the values once and rebuild the quotient
+    codeword -- the proof must be the single-GPU prover's, word for word (whose valid-trace AIR is held equal to the row-by-row
+    one by tests/test_kernels_air.py and tests/test_gpu_baseline_configs.py)"""
+    if world != 4 and ctx.kind == "emu":
+        pytest.skip("one world size on the emulation (CPU suite time); all on the GPU")
+    from oracle.vm import workload
+    from triton_vm_amd.prover import Claim
+
+    host = host_library(ctx)
+    e = workload.execution("fib", 9)
+    claim = Claim(e["program_digest"], e["public_input"], e["public_output"])
+    seed = bytes(range(32))
+    want = native_host.prove_execution(ctx, host, e["aet"], e["padded_height"], claim, seed, security_level=32, ldt="fri")
+    comms = native_host.LocalComms(host, world)
+    try:
+        def rank_body(rank):
+            c = _new_context(ctx)
+            try:
+                return native_host.prove_execution_sharded(c, host, comms.ptrs[rank], e["aet"], e["padded_height"], claim, seed, security_level=32,
+                                                           ldt="fri", jit_passes=1, split_tree_min_leaves=0)
+            finally:
+                c.close()
+
+        for words, stats in _run_ranks(world, rank_body):
+            assert words.size == want.size and (words == want).all()
+            assert stats["exchanges"]["quotient class values"]["calls"] == 1 and "quotient codeword" not in stats["exchanges"]
+    finally:
+        comms.close()

@@ -98,6 +98,9 @@ _SIGNATURES = {
     "tvm_extend_aux_table": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "tvm_all_quotients_combined": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, Domain, Domain, C.c_void_p,
                                                C.c_void_p, C.c_void_p]),
+    "tvm_air_class_cosets": (C.c_int32, [C.c_void_p, C.c_void_p, Domain, C.c_void_p]),
+    "tvm_air_class_values": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, Domain, Domain, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tvm_coset_values_to_coefficients": (C.c_int32, [C.c_void_p, Domain, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tvm_quotient_segments": (C.c_int32, [C.c_void_p, C.c_void_p, Domain, Domain, C.c_void_p, C.c_uint64, C.c_uint64,
                                           C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64]),
     "tvm_table_linear_combination": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),

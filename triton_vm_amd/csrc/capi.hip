@@ -441,6 +441,26 @@ static const u64* stage_small(tvm_ctx* c, int slot, const u64* h, size_t words) 
 struct ThreeCosetWeights {
     u64 w[9];
 };
+// coeffs[i * N + t] += sum_j w[4 i + j] * q_j[t]  (i, j < n <= 4; t < N; XFE vectors q_j, base-field weights): the polynomial
+// sum_i X^(iN) A_i from its restrictions Q_j = sum_i c_j^i A_i to n cosets (w = the inverse Vandermonde matrix)
+struct CosetCombineWeights {
+    u64 w[16];
+};
+struct CosetCombinePointers {
+    const u64* q[4];
+};
+__global__ void k_coset_combine(CosetCombinePointers p, int n, u64 N, CosetCombineWeights m, u64* __restrict__ coeffs) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    xfe v[4];
+    for (int j = 0; j < n; j++) v[j] = xfe_make(p.q[j][3 * t], p.q[j][3 * t + 1], p.q[j][3 * t + 2]);
+    for (int i = 0; i < n; i++) {
+        u64* o = coeffs + 3 * ((u64)i * N + t);
+        xfe acc = xfe_make(o[0], o[1], o[2]);
+        for (int j = 0; j < n; j++) acc = xfe_add(acc, xfe_mul_bfe(v[j], m.w[4 * i + j]));
+        o[0] = acc.c0, o[1] = acc.c1, o[2] = acc.c2;
+    }
+}
 __global__ void k_three_coset_combine(const u64* __restrict__ q0, const u64* __restrict__ q1, const u64* __restrict__ q2, u64 n,
                                       ThreeCosetWeights m, u64* __restrict__ coeffs) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -840,6 +860,96 @@ int32_t tvm_all_quotients_combined(tvm_ctx* c, const tvm_table* mt, const tvm_ta
                                     qd.offset, qd.generator, qd.length, d_ch, d_w, d_out, CLASS_FULL, 1);
     return rc;
 }
+
+// ---- the valid-trace AIR piecewise: what tvm_all_quotients_combined does in one call on one device, as the pieces a multi-GPU
+// host distributes over its ranks (triton_vm_amd/host/sharded_host.cpp).  A class's quotient polynomial has fewer than n * N
+// coefficients (n = tvm_air_class_cosets), so its values on ANY n cosets of the trace domain determine it.
+extern "C" {
+int32_t tvm_air_class_cosets(const tvm_table* mt, const tvm_table* at, tvm_domain td, uint32_t out[4]) {
+    if (!mt || !at || !out || !valid_domain(td)) return TVM_ERR_INVALID_ARGUMENT;
+    const u64 m = mt->interpolant_len > at->interpolant_len ? mt->interpolant_len : at->interpolant_len;
+    const u64 N = td.length;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (!mt->interpolant_len || !at->interpolant_len) return TVM_OK;
+    // the bounds of tvm_all_quotients_combined (above): consistency / transition quotients of degree-d constraints have at most
+    // d (m - 1) + 2 - N coefficients, initial / terminal ones d' (m - 1) + 1 with d' one class lower
+    if (4 * (m - 1) + 2 <= 5 * N && 3 * (m - 1) <= 4 * N) out[1] = 4;   // class "half"
+    if (2 * (m - 1) + 2 <= 3 * N && m <= 2 * N) out[2] = 2;             // class "quarter"
+    if (3 * (m - 1) + 2 <= 4 * N && 2 * (m - 1) <= 3 * N) out[3] = 3;   // class "three cosets"
+    return TVM_OK;
+}
+
+int32_t tvm_air_class_values(tvm_ctx* c, const tvm_table* mt, const tvm_table* at, tvm_domain td, tvm_domain table_dom, uint32_t coset,
+                             uint32_t class_mask, const uint64_t* h_challenges, const uint64_t* h_weights, uint64_t* d_out) {
+    if (!c || !mt || !at || !h_challenges || !h_weights || !d_out || !valid_domain(td) || !valid_domain(table_dom) || !class_mask || class_mask > 15)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "air_class_values arguments");
+    const u64 N = td.length;
+    if (mt->fk != 1 || mt->n_cols != TVM_NUM_MAIN_COLUMNS || at->fk != 3 || at->n_cols != TVM_NUM_AUX_COLUMNS || mt->rows != at->rows ||
+        mt->rows != table_dom.length || table_dom.length % N || coset >= table_dom.length / N || !mt->has_successor_blocks ||
+        !at->has_successor_blocks || mt->layout.X != table_dom.length / N || at->layout.X != mt->layout.X || mt->layout.pitch != at->layout.pitch ||
+        mt->layout.pitch % TVM_RB)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "air_class_values: tables made by tvm_lde_table over table_domain, one coset of them");
+    u64* staged = (u64*)scratch(c, 13, (size_t)3 * (TVM_NUM_CHALLENGES + TVM_NUM_QUOTIENT_WEIGHTS) * sizeof(u64));
+    if (!staged) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "challenge staging");
+    TVM_HIP_CHECK(c, hipMemcpyAsync(staged, h_challenges, 3 * TVM_NUM_CHALLENGES * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    TVM_HIP_CHECK(c, hipMemcpyAsync(staged + 3 * TVM_NUM_CHALLENGES, h_weights, 3 * TVM_NUM_QUOTIENT_WEIGHTS * sizeof(u64),
+                                    hipMemcpyHostToDevice, c->stream));
+    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    const u64 X = table_dom.length / N;
+    const u64 gamma = bfe_mul(table_dom.offset, bfe_pow(table_dom.generator, coset));
+    TabLayout lm = mt->layout;   // the one coset of the tables: a table of its own (the layout is coset-major, context.h)
+    lm.X = 1;
+    lm.log_x = 0;
+    const u64 first_row = (u64)coset * mt->layout.pitch;
+    return all_quotients_combined(c, mt->data + tvm_tab_idx(first_row, 0, (u64)mt->W), lm, (u64)mt->W, at->data + tvm_tab_idx(first_row, 0, (u64)at->W),
+                                  (u64)at->W, N, td.generator, gamma, bfe_pow(table_dom.generator, X), N, staged, staged + 3 * TVM_NUM_CHALLENGES,
+                                  d_out, (int)class_mask, 0);
+}
+
+int32_t tvm_coset_values_to_coefficients(tvm_ctx* c, tvm_domain td, uint32_t n_cosets, const uint64_t* h_offsets,
+                                         const uint64_t* const* d_values, uint64_t* d_coeffs) {
+    if (!c || !valid_domain(td) || !n_cosets || n_cosets > 4 || !h_offsets || !d_values || !d_coeffs)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "coset_values_to_coefficients arguments");
+    const u64 N = td.length;
+    // P = sum_i X^(iN) A_i with A_i of degree < N.  On the coset gamma_j <w_N>, X^N is the constant c_j = gamma_j^N, so the
+    // interpolant of P's values there is Q_j = sum_i c_j^i A_i: n interpolations, then the inverse of the n x n Vandermonde
+    // matrix of (c_0 .. c_{n-1}) coefficient by coefficient.  Row i of the inverse holds the coefficients of x^i in the
+    // Lagrange basis polynomials L_j(x) = prod_{l != j} (x - c_l) / (c_j - c_l).
+    u64 cs[4];
+    for (uint32_t j = 0; j < n_cosets; j++) cs[j] = bfe_pow(h_offsets[j], N);
+    tvm::CosetCombineWeights w;
+    for (int i = 0; i < 16; i++) w.w[i] = 0;
+    for (uint32_t j = 0; j < n_cosets; j++) {
+        u64 poly[4] = {TVM_ONE, 0, 0, 0};   // running product prod (x - c_l), low coefficient first
+        u64 denom = TVM_ONE;
+        int deg = 0;
+        for (uint32_t l = 0; l < n_cosets; l++) {
+            if (l == j) continue;
+            if (cs[l] == cs[j]) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "coset_values_to_coefficients: two cosets with the same X^N");
+            for (int e = deg + 1; e >= 1; e--) poly[e] = bfe_sub(poly[e - 1], bfe_mul(poly[e], cs[l]));
+            poly[0] = bfe_neg(bfe_mul(poly[0], cs[l]));
+            deg++;
+            denom = bfe_mul(denom, bfe_sub(cs[j], cs[l]));
+        }
+        const u64 dinv = bfe_inv(denom);
+        for (uint32_t i = 0; i < n_cosets; i++) w.w[4 * i + j] = bfe_mul(poly[i], dinv);
+    }
+    PoolBlock block(c, (size_t)n_cosets * 3 * N * sizeof(u64));
+    u64* q = (u64*)block.p;
+    if (!q) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "coset interpolants");
+    tvm::CosetCombinePointers ptrs;
+    for (uint32_t j = 0; j < 4; j++) ptrs.q[j] = nullptr;
+    for (uint32_t j = 0; j < n_cosets; j++) {
+        if (!d_values[j]) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "coset_values_to_coefficients: null values");
+        const tvm_domain dom = {h_offsets[j], td.generator, N};
+        TVM_TRY(tvm_interpolate(c, 3, d_values[j], dom, q + (u64)j * 3 * N));
+        ptrs.q[j] = q + (u64)j * 3 * N;
+    }
+    TVM_LAUNCH(tvm::k_coset_combine, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, ptrs, (int)n_cosets, N, w, d_coeffs);
+    TVM_HIP_CHECK(c, hipGetLastError());
+    return TVM_OK;
+}
+}  // extern "C"
 
 // ---------------------------------------------------------------------------------- STIR
 extern "C" {

@@ -1162,8 +1162,6 @@ static Split split_for(u64 n) {
     Split s;
     s.log_n = ilog2(n);
     s.log_n1 = s.log_n / 2;
-    static const int forced_n1 = std::getenv("TVM_LDE_SPLIT_N1") ? std::atoi(std::getenv("TVM_LDE_SPLIT_N1")) : 0;   // experiment knob
-    if (forced_n1 > 0 && forced_n1 < s.log_n) s.log_n1 = forced_n1;
     s.log_n2 = s.log_n - s.log_n1;
     s.shift = (s.log_n + 1) / 2;
     return s;

@@ -11,6 +11,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -271,8 +272,81 @@ struct ShardedRun {
         return tree_from_local(std::move(digests), L, false, what);
     }
 
+    // The valid-trace AIR over the ranks.  On a valid trace the constraint quotients are polynomials of known
+    // length: class H ("half") has fewer than 4N coefficients, class QT (the "quarter" and "three cosets" classes together) fewer
+    // than 3N, so the values of H on ANY four cosets of the trace domain and of QT on any three determine them -- the single-GPU
+    // path takes the even cosets for both, which in a coset sharding all sit on the even ranks.  Here the seven (class, coset)
+    // evaluations are dealt to the ranks by load (a rank can only evaluate on cosets it holds), every rank also evaluates the
+    // four full-domain constraints on its own cosets, ONE all-gather moves all values, and every rank rebuilds the quotient
+    // codeword: interpolate per coset, invert the Vandermonde matrix of the cosets' X^N per coefficient, evaluate the sum on the
+    // whole domain, add the full-domain class.  The same field elements as tvm_all_quotients_combined yields (valid trace), at
+    // about 1/R of its work per rank instead of 1/R of the EXACT evaluation.  Returns an empty buffer when it does not apply.
+    DeviceBuffer quotient_codeword_by_classes(const std::vector<Xfe>& challenges, const std::vector<Xfe>& weights) {
+        const u64 Q = p.quotient.length, N = p.trace.length, X = Q / N;
+        if (!comm || R < 2 || P != 1 || Q != p.ldt.length || X < 4 || X % R) return DeviceBuffer();
+        uint32_t need[4] = {0, 0, 0, 0};
+        c.check(tvm_air_class_cosets(sp.main_.table(), sp.aux_.table(), p.trace.c(), need), "tvm_air_class_cosets");
+        if (need[1] != 4 || need[2] != 2 || need[3] != 3) return DeviceBuffer();   // the degree bounds do not hold (h large against N)
+        struct Task {
+            uint32_t mask;
+            u64 coset;   // of the quotient domain: the points coset + X j
+        };
+        const struct { uint32_t mask; unsigned cosets, weight; } classes[2] = {{TVM_AIR_CLASS_HALF, 4, 5}, {TVM_AIR_CLASS_QUARTER | TVM_AIR_CLASS_THREE, 3, 2}};
+        std::vector<Task> tasks;
+        std::vector<u64> load(R, 0);
+        for (const auto& cl : classes) {
+            std::vector<bool> used(X, false);
+            for (unsigned i = 0; i < cl.cosets; i++) {   // the unused coset whose owner has the least work so far
+                u64 best = X;
+                for (u64 k = 0; k < X; k++)
+                    if (!used[k] && (best == X || load[k % R] < load[best % R])) best = k;
+                used[best] = true;
+                load[best % R] += cl.weight;
+                tasks.push_back(Task{cl.mask, best});
+            }
+        }
+        std::vector<u64> n_tasks(R, 0), slot_of(tasks.size());
+        for (size_t t = 0; t < tasks.size(); t++) slot_of[t] = n_tasks[tasks[t].coset % R]++;
+        const u64 task_slots = *std::max_element(n_tasks.begin(), n_tasks.end()), own = X / R, slots = task_slots + own, slot_words = 3 * N;
+        const ArithmeticDomain ldt_rank = coset_group(p.ldt, me, R);
+        DeviceBuffer send(c, slots * slot_words), recv(c, R * slots * slot_words);
+        for (u64 sl = n_tasks[me]; sl < task_slots; sl++)   // (unused slots travel as zeros: an evaluation of the zero polynomial)
+            c.check(tvm_evaluate(c.raw(), 3, nullptr, 0, tvm_domain{to_mont(1), to_mont(1), N}, send.ptr() + sl * slot_words), "zero fill");
+        for (size_t t = 0; t < tasks.size(); t++)
+            if (tasks[t].coset % R == me)
+                c.check(tvm_air_class_values(c.raw(), sp.main_.table(), sp.aux_.table(), p.trace.c(), ldt_rank.c(), (uint32_t)(tasks[t].coset / R),
+                                             tasks[t].mask, challenges[0].c, weights[0].c, send.ptr() + slot_of[t] * slot_words), "tvm_air_class_values");
+        for (u64 j = 0; j < own; j++)
+            c.check(tvm_air_class_values(c.raw(), sp.main_.table(), sp.aux_.table(), p.trace.c(), ldt_rank.c(), (uint32_t)j, TVM_AIR_CLASS_FULL,
+                                         challenges[0].c, weights[0].c, send.ptr() + (task_slots + j) * slot_words), "tvm_air_class_values");
+        comm_check(comm->all_gather(comm->self, c.raw(), send.ptr(), recv.ptr(), slots * slot_words), "quotient class values");
+        count("quotient class values", slots * slot_words * 8 * (R - 1));
+        auto slot = [&](u64 rank, u64 s) { return recv.ptr() + (rank * slots + s) * slot_words; };
+        DeviceBuffer coeffs(c, 4 * N * 3);
+        c.check(tvm_evaluate(c.raw(), 3, nullptr, 0, tvm_domain{to_mont(1), to_mont(1), 4 * N}, coeffs.ptr()), "zero fill");
+        size_t at = 0;
+        for (const auto& cl : classes) {
+            u64 offsets[4];
+            const u64* values[4];
+            for (unsigned i = 0; i < cl.cosets; i++, at++) {
+                offsets[i] = p.quotient.value(tasks[at].coset);
+                values[i] = slot(tasks[at].coset % R, slot_of[at]);
+            }
+            c.check(tvm_coset_values_to_coefficients(c.raw(), p.trace.c(), cl.cosets, offsets, values, coeffs.ptr()), "tvm_coset_values_to_coefficients");
+        }
+        DeviceBuffer out = p.quotient.evaluate(c, coeffs.ptr(), 4 * N, 3);
+        DeviceBuffer full(c, 3 * Q);
+        for (u64 k = 0; k < X; k++) scatter(slot(k % R, task_slots + k / R), 3, N, X, k, full.ptr());
+        c.check(tvm_xfe_add_assign(c.raw(), out.ptr(), full.ptr(), Q), "tvm_xfe_add_assign");
+        return out;
+    }
+
     // all_quotients_combined over the quotient domain (master_table.rs:1264-1363): every group on its own rows -> all rows
     DeviceBuffer quotient_codeword(const std::vector<Xfe>& challenges, const std::vector<Xfe>& weights) {
+        if (sp.assume_valid_trace) {
+            DeviceBuffer by_classes = quotient_codeword_by_classes(challenges, weights);
+            if (by_classes.ptr()) return by_classes;
+        }
         const u64 Q = p.quotient.length, local_rows = Q / R, pass_rows = local_rows / P;
         const bool cached = P == 1 && Q == p.ldt.length;  // the quotient rows are the rows of the cached tables
         DeviceBuffer local(c, 3 * local_rows), part;
@@ -703,19 +777,36 @@ std::vector<u64> prove_execution_sharded(const Context& c, const StarkParameters
                                          u64 split_tree_min_leaves) {
     const u64 n = p.trace.length;
     const CommSession session(comm, c);
+    // TVMH_TRACE=1: host wall time of the phases of one proof on stderr (no stream synchronisation is added)
+    static const bool trace = std::getenv("TVMH_TRACE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[tvmh sharded] %-32s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     auto attempt = [&](unsigned pass_count) {
         if (comm && comm->mark) comm->mark(comm->self, c.raw(), "trace tables (fill, pad, randomizers)");
-        const ExecutionTables t(c, p, aet, seed, [](const char*) {});
+        lap("entry");
+        const ExecutionTables t(c, p, aet, seed, [&](const char* what) { lap(what); });
         ShardedProver prover(c, p, comm, pass_count, t.main_trace.ptr(), t.main_rnd.ptr(), t.aux_trace.ptr(), t.aux_rnd.ptr(),
                              t.quotient_randomizer, claim);
         prover.assume_valid_trace = !tvmh_get_option(TVMH_OPTION_EXACT_AIR);
         prover.profile = profile;
         prover.split_tree_min_leaves = split_tree_min_leaves;
         prover.extend = [&](const std::vector<Xfe>& challenges) { t.extend(c, n, challenges); };
-        std::vector<u64> proof = prover.prove().proof();
+        ProofStream stream = prover.prove();
+        lap("prove (device drained)");
+        std::vector<u64> proof = stream.proof();
         if (stats) *stats = prover.stats_json();
+        lap("proof encoding");
         return proof;
     };
+    struct Done {
+        decltype(lap)& l;
+        ~Done() { l("tables released, return"); }
+    } done{lap};
     if (passes) return attempt(passes);
     // The reference's memory policy (master_table.rs:268-271, stark.rs:730-768): try the cached extension; if the device (or
     // the context's memory limit) cannot hold it, start over coset by coset with as few passes as fit.  The transcript is

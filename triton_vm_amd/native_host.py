@@ -186,7 +186,9 @@ def prove_execution_sharded(ctx, host_lib, comm_ptr, aet, padded_height, claim, 
     s, keep = aet_struct(aet)
     log2 = padded_height.bit_length() - 1
     err, stats, n = C.create_string_buffer(512), C.create_string_buffer(1 << 14), C.c_uint64(0)
-    out = np.empty(1 << 20, np.uint64)
+    out = getattr(_PROOF_BUFFERS, "buffer", None)   # one buffer per proving thread, kept between calls (its pages are mapped)
+    if out is None:
+        out = np.empty(1 << 20, np.uint64)
     while True:
         rc = host_lib.tvmh_prove_execution_sharded(ctx.handle, comm_ptr, jit_passes, split_tree_min_leaves, C.addressof(s), log2, security_level,
                                                    log2_expansion, {"fri": 0, "stir": 1, None: 2}[ldt], bytes(randomness_seed),
@@ -196,6 +198,7 @@ def prove_execution_sharded(ctx, host_lib, comm_ptr, aet, padded_height, claim, 
         if rc != 0:
             raise NativeHostError(rc, f"tvmh_prove_execution_sharded failed ({rc}): {err.value.decode()}")
         if n.value <= out.size:
+            _PROOF_BUFFERS.buffer = out
             return out[:n.value].copy(), json.loads(stats.value.decode() or "{}")
         out = np.empty(int(n.value), np.uint64)
 

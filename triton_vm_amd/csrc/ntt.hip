@@ -802,10 +802,12 @@ __global__ void __launch_bounds__(1 << TLOG) k_lde_pass3_v3(LdePass3Args a) {
 // them in its own LDS words and stores the 1024 results into 1024 consecutive storage rows of the table (context.h): NO
 // workgroup barrier after the twiddle table is staged.  Work-item = lane of wavefront w of WAVES; the workgroup walks a.tiles
 // tiles of WAVES rows, every wavefront with the loads of its next row in flight under the butterflies of the current one.
+// (2048-point rows, round 4: 32 elements per lane, 17 KB of LDS per wavefront -- eight wavefronts fill a CU's LDS, two per SIMD, so
+// the kernel may use 256 VGPRs and keeps the next row's 32 loads in flight)
 template <int LOGN, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES, 4) k_lde_pass3_rows(LdePass3Args a) {   // room for 4 wavefronts per SIMD: 128 VGPRs
+__global__ void __launch_bounds__(64 * WAVES, LOGN == 10 ? 4 : 2) k_lde_pass3_rows(LdePass3Args a) {   // 1024 points: room for 4 wavefronts per SIMD (128 VGPRs)
     constexpr int n1 = 1 << LOGN, ROWW = TVM_ROW_WORDS(n1), E = n1 / 64;
-    static_assert(E == 16, "16 elements per lane");
+    static_assert(E == 16 || E == 32, "16 or 32 elements per lane");
     TVM_DYN_SMEM(u64, s);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const u64 n2 = 1ull << a.log_n2;
@@ -891,10 +893,12 @@ __global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass1_rows(Ntt2Args a) {
 //   ROWS = 16: 1024 work-items, one position each, 148 KB of LDS: ONE workgroup per CU -- every barrier drains the CU.
 //   ROWS = 8:  512 work-items, two positions each, 78 KB of LDS: TWO workgroups per CU, one's barriers and tails run under
 //              the other's butterflies; the stores are 64-byte runs (8 adjacent rows) instead of full lines.
+//   LOGN = 11 (round 4): rows of 2048 points, 8 rows = 156 KB of LDS, ONE workgroup of 8 wavefronts per CU (two per SIMD: 256 VGPRs),
+//              32 elements per work-item across the coset loop.
 template <int LOGN, int ROWS>
-__global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass2_rows(LdePass2Args a) {
-    constexpr int n2 = 1 << LOGN, ROWW = TVM_ROW_WORDS(n2), NT = 64 * ROWS, PPT = n2 / NT, RLOG = ROWS == 16 ? 4 : 3;
-    static_assert(LOGN == 10 && (ROWS == 16 || ROWS == 8), "one wavefront per row of 1024 points");
+__global__ void __launch_bounds__(64 * ROWS, LOGN == 10 ? 4 : 2) k_lde_pass2_rows(LdePass2Args a) {
+    constexpr int n2 = 1 << LOGN, ROWW = TVM_ROW_WORDS(n2), NT = 64 * ROWS, PPT = n2 / NT, RLOG = ROWS == 16 ? 4 : 3, EPT = n2 / 64;
+    static_assert((LOGN == 10 || LOGN == 11) && (ROWS == 16 || ROWS == 8), "one wavefront per row of 1024 or 2048 points");
     TVM_DYN_SMEM(u64, s);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const u64 n1 = 1ull << a.log_n1;
@@ -906,7 +910,7 @@ __global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass2_rows(LdePass2Args a)
 #pragma unroll
     for (int hh = 0; hh < PPT; hh++) me[hh] = TVM_ROW_SKEW(tid + hh * NT);
 #pragma unroll
-    for (int e = 0; e < 16; e++) s[(e & (ROWS - 1)) * ROWW + me[e >> RLOG]] = TVM_LOAD_STREAM(&y[(u64)(e & (ROWS - 1)) * n2 + tid + (e >> RLOG) * NT]);
+    for (int e = 0; e < EPT; e++) s[(e & (ROWS - 1)) * ROWW + me[e >> RLOG]] = TVM_LOAD_STREAM(&y[(u64)(e & (ROWS - 1)) * n2 + tid + (e >> RLOG) * NT]);
     u64* tw_fwd = s + ROWS * ROWW;   // all n2 powers of the forward root, behind the tile
 #pragma unroll
     for (int hh = 0; hh < PPT; hh++) tw_fwd[tid + hh * NT] = a.tw_b1[tid + hh * NT];
@@ -914,9 +918,9 @@ __global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass2_rows(LdePass2Args a)
     // inverse rows step, row w by wavefront w: position q of row e then holds N * t[m1*n1 + m2], m1 = brev(q)
     row_ntt<false, 4, LOGN, 2>(s + w * ROWW, a.tw_a2, lane);
     tvm_lds_barrier();
-    u64 coef[16];   // element e: row e % ROWS, position tid + (e / ROWS) * NT
+    u64 coef[EPT];   // element e: row e % ROWS, position tid + (e / ROWS) * NT
 #pragma unroll
-    for (int e = 0; e < 16; e++) coef[e] = s[(e & (ROWS - 1)) * ROWW + me[e >> RLOG]];
+    for (int e = 0; e < EPT; e++) coef[e] = s[(e & (ROWS - 1)) * ROWW + me[e >> RLOG]];
     u64 m1[PPT], gh[PPT], gh_step[PPT];
     bool has_rnd = false;
 #pragma unroll
@@ -950,13 +954,13 @@ __global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass2_rows(LdePass2Args a)
         tvm_lds_barrier();   // the store phase of the previous coset has read the tile
         if (single) {
 #pragma unroll
-            for (int e = 0; e < 16; e++)
+            for (int e = 0; e < EPT; e++)
                 if ((e >> RLOG) || tid) s[(e & (ROWS - 1)) * ROWW + me[e >> RLOG]] = bfe_mul(coef[e], gh[e >> RLOG]);
             if (tid < ROWS) s[tid * ROWW] = bfe_add(c0[tid], bfe_mul(a.zk[k], r0[tid]));
         } else if (has_rnd) {
             const u64 zk = a.zk[k];
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
+            for (int e = 0; e < EPT; e++) {
                 const u64 m = m1[e >> RLOG] * n1 + brev_bits((u32)(p0 + (e & (ROWS - 1))), a.log_n1);
                 u64 c = coef[e];
                 if (m < a.h) c = bfe_add(c, bfe_mul(zk, rnd[m * a.fk]));
@@ -964,7 +968,7 @@ __global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass2_rows(LdePass2Args a)
             }
         } else {
 #pragma unroll
-            for (int e = 0; e < 16; e++) s[(e & (ROWS - 1)) * ROWW + me[e >> RLOG]] = bfe_mul(coef[e], gh[e >> RLOG]);
+            for (int e = 0; e < EPT; e++) s[(e & (ROWS - 1)) * ROWW + me[e >> RLOG]] = bfe_mul(coef[e], gh[e >> RLOG]);
         }
         tvm_lds_barrier();
         row_ntt<true, TVM_P2_MAXK, LOGN, 1>(s + w * ROWW, tw_fwd, lane);   // forward columns step of row w
@@ -972,7 +976,7 @@ __global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass2_rows(LdePass2Args a)
         u64* z = a.z + ((u64)vl * a.n_cosets + k) * n + p0 + b_out;
         u64 t = t_first;
 #pragma unroll 4
-        for (int i = 0; i < 16; i++) {
+        for (int i = 0; i < EPT; i++) {
             const int j1 = j1_0 + i * j1_step;
             TVM_STORE_STREAM(&z[(u64)j1 * n1], bfe_mul(s[b_out * ROWW + TVM_ROW_SKEW(j1)], t));
             t = bfe_mul(t, t_step);
@@ -1119,6 +1123,8 @@ static void set_lds_attributes() {
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<10, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_rows<10, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_rows<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass2_rows<11, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<11, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass1_rows<10, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass1_rows<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_v3<11, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -1383,6 +1389,16 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             const u64 rows3 = 16 >> ppt_log;
             const size_t lds_v3 = (size_t)(rows3 * (n2 + TVM_ROW_PAD) + (sp.log_n2 < 12 ? n2 : 0) + 32) * sizeof(u64);
             const dim3 g2((unsigned)(n1 / rows3), (unsigned)nc);
+            // 2048-point rows, one per wavefront (k_lde_pass2_rows<11, 8>): OFF by default.  Measured in round 4 (profiles/r04_f_*): 8 rows
+            // fill a CU's LDS, so two wavefronts per SIMD instead of the tile kernel's four, and the carry chains of a field
+            // multiplication issue at 60-78 % of the rate with two: 24.5 ms per 96-column chunk at 2^22 rows against
+            // 21.6 ms for k_lde_pass2_v3<11, 10>; whole proof 2^21 rows 409.5 vs 397.9 ms, 2^22 rows 855.8 vs 840.2 (passes 2 and 3).
+            static const bool rows11 = std::getenv("TVM_LDE_ROWS11_PASS2") && std::atoi(std::getenv("TVM_LDE_ROWS11_PASS2")) != 0;  // experiment knob
+            if (std_roots && lde_rows && rows11 && sp.log_n2 == 11 && n1 % 8 == 0) {
+                // 2048-point axis (2^21 and 2^22 rows): one row per wavefront, 8 rows per workgroup (k_lde_pass2_rows<11, 8>)
+                const size_t lds_r = (size_t)(8 * TVM_ROW_WORDS(n2) + n2 + 32) * sizeof(u64);
+                TVM_LAUNCH((k_lde_pass2_rows<11, 8>), dim3((unsigned)(n1 / 8), (unsigned)nc), dim3(512), lds_r, c->stream, a);
+            } else
             if (std_roots && ppt_log && n1 % rows3 == 0) {
                 if (sp.log_n2 == 11) TVM_LAUNCH((k_lde_pass2_v3<11, 10>), g2, dim3(1024), lds_v3, c->stream, a);
                 else if (sp.log_n2 == 12) TVM_LAUNCH((k_lde_pass2_v3<12, 10>), g2, dim3(1024), lds_v3, c->stream, a);
@@ -1414,6 +1430,17 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             const int ppt_log = (sp.log_n1 == 11 || sp.log_n1 == 7) ? 1 : (sp.log_n1 == 12 || sp.log_n1 == 8) ? 2 : 0;
             const u64 rows3 = 16 >> ppt_log, tiles3 = X * n2 / rows3;  // see pass 2
             static const int p3_rows = std::getenv("TVM_LDE_PASS3_ROWS") ? std::atoi(std::getenv("TVM_LDE_PASS3_ROWS")) : 8;  // experiment knob
+            // (pass 3 has no coset loop and no workgroup barrier: here the 2048-point row form is 8 % faster than k_lde_pass3_v3<11, 10>,
+            // 15.5 against 16.8 ms per 96 columns at 2^22 rows, even at two wavefronts per SIMD)
+            static const bool rows11_p3 = !(std::getenv("TVM_LDE_ROWS11") && std::atoi(std::getenv("TVM_LDE_ROWS11")) == 0);  // experiment knob
+            if (std_roots && lde_rows && rows11_p3 && sp.log_n1 == 11 && (X * n2) % 8 == 0) {
+                // 2048-point axis (2^22 rows): one (k, j1) row per wavefront, 8 wavefronts = one workgroup per CU (k_lde_pass3_rows<11, 8>)
+                const u64 tiles_w = X * n2 / 8;
+                a.tiles = tiles_w % 16 == 0 ? 16 : tiles_w % 8 == 0 ? 8 : tiles_w % 4 == 0 ? 4 : 1;
+                if (tiles_w / a.tiles >= 65536) return set_error(c, TVM_ERR_UNSUPPORTED, "lde: too many row tiles");
+                const size_t lds_w = (size_t)(8 * TVM_ROW_WORDS(n1) + n1) * sizeof(u64);
+                TVM_LAUNCH((k_lde_pass3_rows<11, 8>), dim3((unsigned)nc, (unsigned)(tiles_w / a.tiles)), dim3(512), lds_w, c->stream, a);
+            } else
             if (std_roots && lde_rows && sp.log_n1 == 10 && (X * n2) % 8 == 0) {
                 // 1024-point axis: one (k, j1) row per wavefront, no workgroup barrier (k_lde_pass3_rows): 8 wavefronts per
                 // workgroup, 78 KB of LDS -- two workgroups per CU

@@ -499,7 +499,20 @@ def main():
         except Exception as e:  # no g++ on this machine: the Python mirror sequences the same C-ABI calls
             print(f"bench.py: C++ host library unavailable ({e}); timing the Python host", file=sys.stderr)
     if sharded and host_lib is not None:
-        comm = make_comm(dist, device, rank, world, local_rank)
+        try:
+            comm = make_comm(dist, device, rank, world, local_rank)
+            ok = 1
+        except Exception as e:   # noqa: BLE001 -- e.g. no RCCL headers to build libtriton_rccl.so against
+            print(f"bench.py: RCCL communicator unavailable on rank {rank} ({e}); the Python sharded host (torch.distributed collectives) takes over", file=sys.stderr)
+            ok = 0
+        if world > 1:   # every rank must take the same path
+            import torch
+
+            flag = torch.tensor([ok], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if not ok:
+            comm, host_lib = None, None
     # trees of at least 2^21 leaves are built split over the ranks (the three table trees and the first FRI rounds at 2^20 rows);
     # --split-all-trees forces every tree through the split path (plumbing check: ~14 ms of extra copies and host round trips)
     split_min = 0 if args.split_all_trees else 1 << 21

@@ -356,6 +356,8 @@ struct LdePass2Args {
     const u64* g_hi_step;  // [N2]: (gamma_{k+1} / gamma_k)^(N1*m1)    products: no table load inside its coset loop)
     u64 zk[TVM_LDE_MAX_COSETS];  // N * (gamma_k^N - 1)
     int std_roots;       // the trace domain's generator is the domains' own root of unity (shift twiddles, lds_ntt_group)
+    const u64* store_tw; // optional (k_lde_pass2_rows<10, 8>): the store phase's factors w_N^(m2 j1) gamma_k^m2 / N as a table in the
+                         // order the kernel reads them, [X][n1 / 8][16][512] (k_lde_store_table); null: running products
 };
 
 __global__ void __launch_bounds__(1024) k_lde_pass2(LdePass2Args a) {
@@ -895,7 +897,8 @@ __global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass1_rows(Ntt2Args a) {
 //              the other's butterflies; the stores are 64-byte runs (8 adjacent rows) instead of full lines.
 //   LOGN = 11 (round 4): rows of 2048 points, 8 rows = 156 KB of LDS, ONE workgroup of 8 wavefronts per CU (two per SIMD: 256 VGPRs),
 //              32 elements per work-item across the coset loop.
-template <int LOGN, int ROWS>
+//   TABLE (round 4): the store phase's factor w_N^(m2 j1) gamma_k^m2 / N comes from a table (a.store_tw) instead of a running product.
+template <int LOGN, int ROWS, bool TABLE = false>
 __global__ void __launch_bounds__(64 * ROWS, LOGN == 10 ? 4 : 2) k_lde_pass2_rows(LdePass2Args a) {
     constexpr int n2 = 1 << LOGN, ROWW = TVM_ROW_WORDS(n2), NT = 64 * ROWS, PPT = n2 / NT, RLOG = ROWS == 16 ? 4 : 3, EPT = n2 / 64;
     static_assert((LOGN == 10 || LOGN == 11) && (ROWS == 16 || ROWS == 8), "one wavefront per row of 1024 or 2048 points");
@@ -947,9 +950,12 @@ __global__ void __launch_bounds__(64 * ROWS, LOGN == 10 ? 4 : 2) k_lde_pass2_row
     const int b_out = tid & (ROWS - 1), j1_0 = tid >> RLOG;
     const u64 m2_out = brev_bits((u32)(p0 + b_out), a.log_n1);
     constexpr int j1_step = NT >> RLOG;   // 64
-    const u64 t_step = pow2_get(a.tw_inter, (m2_out * (u64)j1_step) & (n - 1));
-    u64 t_first = bfe_mul(pow2_get(a.tw_inter, m2_out * (u64)j1_0), a.g_lo[m2_out]);
-    const u64 gl_step = a.g_lo_step[m2_out];
+    u64 t_step = 0, t_first = 0, gl_step = 0;
+    if constexpr (!TABLE) {
+        t_step = pow2_get(a.tw_inter, (m2_out * (u64)j1_step) & (n - 1));
+        t_first = bfe_mul(pow2_get(a.tw_inter, m2_out * (u64)j1_0), a.g_lo[m2_out]);
+        gl_step = a.g_lo_step[m2_out];
+    }
     for (int k = 0; k < a.n_cosets; k++) {
         tvm_lds_barrier();   // the store phase of the previous coset has read the tile
         if (single) {
@@ -974,6 +980,20 @@ __global__ void __launch_bounds__(64 * ROWS, LOGN == 10 ? 4 : 2) k_lde_pass2_row
         row_ntt<true, TVM_P2_MAXK, LOGN, 1>(s + w * ROWW, tw_fwd, lane);   // forward columns step of row w
         tvm_lds_barrier();
         u64* z = a.z + ((u64)vl * a.n_cosets + k) * n + p0 + b_out;
+        if constexpr (TABLE) {
+            // the factors from the table (shared by every column of the chunk: L2 / Infinity Cache hits after the first column),
+            // one coalesced load instead of the running product's multiplication
+            const u64* tq = a.store_tw + (((u64)k * gridDim.x + blockIdx.x) * EPT) * NT + tid;
+            // Measured in round 4 (profiles/r04_g_*, r04_h_*): 4.51 ms per 96-column chunk against 4.56-4.63 with the running product --
+            // the multiplication it removes (8 % of the kernel's VALU instructions) buys nothing, so pass 2 is not bound by its
+            // instruction count alone; with the loads batched ahead of the multiplications (4, 8 or 16 in flight) it is 15 % SLOWER
+            // (main table 36.4 against 31.5 ms).  Off by default (TVM_LDE_STORE_TABLE=1 selects it).
+#pragma unroll 4
+            for (int i = 0; i < EPT; i++) {
+                const int j1 = j1_0 + i * j1_step;
+                TVM_STORE_STREAM(&z[(u64)j1 * n1], bfe_mul(s[b_out * ROWW + TVM_ROW_SKEW(j1)], tq[(u64)i * NT]));
+            }
+        } else {
         u64 t = t_first;
 #pragma unroll 4
         for (int i = 0; i < EPT; i++) {
@@ -981,9 +1001,10 @@ __global__ void __launch_bounds__(64 * ROWS, LOGN == 10 ? 4 : 2) k_lde_pass2_row
             TVM_STORE_STREAM(&z[(u64)j1 * n1], bfe_mul(s[b_out * ROWW + TVM_ROW_SKEW(j1)], t));
             t = bfe_mul(t, t_step);
         }
+        }
 #pragma unroll
         for (int hh = 0; hh < PPT; hh++) gh[hh] = bfe_mul(gh[hh], gh_step[hh]);
-        t_first = bfe_mul(t_first, gl_step);
+        if constexpr (!TABLE) t_first = bfe_mul(t_first, gl_step);
     }
 }
 
@@ -1124,6 +1145,7 @@ static void set_lds_attributes() {
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_rows<10, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_rows<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_rows<11, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass2_rows<10, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<11, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass1_rows<10, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass1_rows<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -1133,6 +1155,17 @@ static void set_lds_attributes() {
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_v3<12, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
 }
 
+// st[((k * tiles + tile) * 16 + i) * 512 + tid] = w_N^(m2 j1) * g_lo[k][m2] with m2 = brev(8 tile + tid % 8), j1 = tid / 8 + 64 i:
+// the factor the store phase of k_lde_pass2_rows<10, 8> applies to element (row tid % 8, position j1) of tile `tile` on coset k,
+// in the order its work-items read it (one 4 KB run per (k, tile, i))
+__global__ void k_lde_store_table(Pow2 tw_inter, const u64* __restrict__ g_lo, int log_n1, int log_n, u64 X, u64* __restrict__ out) {
+    const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 n1 = 1ull << log_n1, tiles = n1 >> 3;
+    if (e >= X * tiles * 16 * 512) return;
+    const u64 tid = e & 511, i = (e >> 9) & 15, tile = (e >> 13) % tiles, k = (e >> 13) / tiles;
+    const u64 m2 = brev_bits((u32)(tile * 8 + (tid & 7)), log_n1), j1 = (tid >> 3) + 64 * i;
+    out[e] = bfe_mul(pow2_get(tw_inter, (m2 * j1) & ((1ull << log_n) - 1)), g_lo[k * n1 + m2]);
+}
 // lo[k][i] = scale * gamma_k^i (i < n1), hi[k][i] = gamma_k^(n1*i) (i < n2), gamma_k = offset * gen^k
 __global__ void k_coset_tables(u64 offset, u64 gen, u64 X, u64 n1, u64 n2, u64 scale, u64* lo, u64* hi) {
     const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1328,6 +1361,21 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     TVM_TRY(coset_tables(c, eval_offset, eval_gen, X, n1, n2, n_inv, &p2.g_lo, &p2.g_hi));
     p2.g_lo_step = pow_table(c, eval_gen, n1);
     p2.g_hi_step = pow_table(c, bfe_pow(eval_gen, n1), n2);
+    p2.store_tw = nullptr;
+    static const bool store_table = std::getenv("TVM_LDE_STORE_TABLE") && std::atoi(std::getenv("TVM_LDE_STORE_TABLE")) != 0;  // experiment knob
+    if (store_table && sp.log_n2 == 10 && n1 % 8 == 0 && X * N * sizeof(u64) <= ((size_t)256 << 20)) {
+        // X * N words (64 MB at 2^20 rows, expansion 8), cached per context like the other tables of a domain
+        auto key = std::make_tuple(eval_offset ^ 0x57AB1E57AB1Eull, eval_gen, (X << 56) | (n1 << 28) | n2);
+        auto it = c->tables.find(key);
+        u64* d = nullptr;
+        if (it != c->tables.end()) {
+            d = it->second;
+        } else if (hipMalloc((void**)&d, X * N * sizeof(u64)) == hipSuccess) {
+            TVM_LAUNCH(k_lde_store_table, dim3((unsigned)((X * N + 255) / 256)), dim3(256), 0, c->stream, p2.tw_inter, p2.g_lo, sp.log_n1, sp.log_n, X, d);
+            c->tables[key] = d;
+        }
+        p2.store_tw = d;
+    }
     const u64 n_mont = bfe_from_u64(N);
     for (u64 k = 0; k < X; k++) {
         const u64 gamma = bfe_mul(eval_offset, bfe_pow(eval_gen, k));
@@ -1412,6 +1460,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
                 const size_t lds_r = (size_t)(rows_r * TVM_ROW_WORDS(n2) + n2 + 32) * sizeof(u64);
                 const dim3 g2r((unsigned)(n1 / rows_r), (unsigned)nc);
                 if (rows_r == 16) TVM_LAUNCH((k_lde_pass2_rows<10, 16>), g2r, dim3(1024), lds_r, c->stream, a);
+                else if (a.store_tw) TVM_LAUNCH((k_lde_pass2_rows<10, 8, true>), g2r, dim3(512), lds_r, c->stream, a);
                 else TVM_LAUNCH((k_lde_pass2_rows<10, 8>), g2r, dim3(512), lds_r, c->stream, a);
             }
             else if (std_roots && a.batch_log == 4 && n2 >= 64 && n1 >= 16)  // production shape: one work-item per column of the tile

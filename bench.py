@@ -302,6 +302,7 @@ def simulate_ranks(ctx, host_lib, n_ranks, aet, padded_height, claim, kw):
                                                                   jit_passes=1, **kw)
         except BaseException as e:   # noqa: BLE001
             errors.append((r, e))
+            comms.abort()            # the other ranks leave their collectives instead of waiting for this one
 
     reports = []
     repeats = 3

@@ -60,7 +60,7 @@ def _single_proof(ctx, host, p, main_trace, aux_trace):
     return py, native.prove()
 
 
-def _run_ranks(world, body):
+def _run_ranks(world, body, comms=None):
     """one thread per rank; `body(rank)` -> result; exceptions are re-raised here"""
     results, errors = [None] * world, []
 
@@ -69,6 +69,8 @@ def _run_ranks(world, body):
             results[rank] = body(rank)
         except BaseException as e:   # noqa: BLE001
             errors.append((rank, e))
+            if comms is not None:
+                comms.abort()   # the other ranks leave their collectives with an error instead of waiting for this one
 
     threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
     for t in threads:
@@ -104,7 +106,7 @@ def test_sharded_cpp_proof_equals_single_gpu_proof(ctx, orc, world, split_trees,
             finally:
                 c.close()
 
-        proofs = _run_ranks(world, rank_body)
+        proofs = _run_ranks(world, rank_body, comms)
         for rank, got in enumerate(proofs):
             assert got.size == want.size and (got == want).all(), rank
         if lockstep:
@@ -156,7 +158,7 @@ def test_sharded_prove_execution_reproduces_the_reference_snapshot(ctx, orc, wor
             finally:
                 c.close()
 
-        for words, stats in _run_ranks(world, rank_body):
+        for words, stats in _run_ranks(world, rank_body, comms):
             assert Proof(words).digest(ctx.lib) == snap.SNAPSHOT
             assert stats["world"] == world and stats["split_trees_built"] >= 3
             assert stats["exchanges"]["main leaf digests"]["calls"] == 1 and "AIR quotients" in stats["stage_ms"]
@@ -368,8 +370,33 @@ def test_valid_trace_air_over_the_ranks_yields_the_single_gpu_proof(ctx, orc, wo
             finally:
                 c.close()
 
-        for words, stats in _run_ranks(world, rank_body):
+        for words, stats in _run_ranks(world, rank_body, comms):
             assert words.size == want.size and (words == want).all()
             assert stats["exchanges"]["quotient class values"]["calls"] == 1 and "quotient codeword" not in stats["exchanges"]
+    finally:
+        comms.close()
+
+
+def test_a_failing_rank_does_not_hang_the_others(ctx, orc):
+    """one rank of two hands the prover a null trace: it fails before its first collective, aborts the group, and the other rank
+    leaves its collective with an error instead of waiting forever"""
+    host = host_library(ctx)
+    p = _params("fri")
+    main_trace, aux_trace = _inputs(orc, p)
+    comms = native_host.LocalComms(host, 2)
+    try:
+        def rank_body(rank):
+            c = _new_context(ctx)
+            try:
+                mine = Prover(c, p, main_trace, aux_trace, seed=SEED)
+                bad = type("Null", (), {"ptr": None})()
+                return native_host.prove_sharded(c, host, comms.ptrs[rank], p, bad if rank == 1 else mine.main.d_trace, mine.main.d_randomizers,
+                                                 mine.aux.d_trace, mine.aux.d_randomizers, mine.quotient_randomizer, split_tree_min_leaves=0)
+            finally:
+                c.close()
+
+        with pytest.raises(AssertionError) as info:
+            _run_ranks(2, rank_body, comms)
+        assert "tvmh_prove_sharded failed" in str(info.value)
     finally:
         comms.close()

@@ -845,15 +845,17 @@ struct LocalGroup {
     };
     std::vector<Member> members;
 
-    void barrier(std::unique_lock<std::mutex>& lock) {
+    bool broken = false;   // a rank failed: every waiting rank leaves its collective with an error instead of hanging
+    bool barrier(std::unique_lock<std::mutex>& lock) {
         const uint64_t gen = generation;
         if (++arrived == world) {
             arrived = 0;
             generation++;
             cv.notify_all();
         } else {
-            cv.wait(lock, [&] { return generation != gen; });
+            cv.wait(lock, [&] { return generation != gen || broken; });
         }
+        return !broken;
     }
     void account(uint32_t r) {  // (lock held) close rank r's current compute segment
         const auto now = std::chrono::steady_clock::now();
@@ -868,7 +870,7 @@ struct LocalGroup {
         since[r] = now;
     }
     void acquire(uint32_t r, std::unique_lock<std::mutex>& lock) {
-        cv.wait(lock, [&] { return turn == r; });
+        cv.wait(lock, [&] { return turn == r || broken; });
         since[r] = std::chrono::steady_clock::now();
     }
     void release(uint32_t r) {  // (lock held)
@@ -886,14 +888,14 @@ int32_t local_collective(void* self, tvm_ctx* ctx, const uint64_t* d_send, uint6
     std::unique_lock<std::mutex> lock(g.m);
     if (g.lockstep) g.release(r);
     g.send[r] = d_send;
-    g.barrier(lock);
+    if (!g.barrier(lock)) return TVM_ERR_DEVICE;
     std::vector<const uint64_t*> from = g.send;
     lock.unlock();
     for (uint32_t peer = 0; peer < g.world && status == TVM_OK; peer++)
         status = tvm_memcpy_d2d(ctx, d_recv + (uint64_t)peer * words, from[peer] + (all_to_all ? (uint64_t)r * words : 0), words * 8);
     if (status == TVM_OK) status = tvm_sync(ctx);
     lock.lock();
-    g.barrier(lock);  // nobody reuses its send buffer before everybody has read it
+    if (!g.barrier(lock)) return TVM_ERR_DEVICE;  // nobody reuses its send buffer before everybody has read it
     if (g.lockstep) {
         if (r == 0) g.turn = 0, g.cv.notify_all();
         g.acquire(r, lock);
@@ -951,6 +953,13 @@ extern "C" int32_t tvmh_local_comms_create(uint32_t world, uint32_t lockstep, tv
         out[r] = &g->comms[r];
     }
     return TVM_OK;
+}
+extern "C" void tvmh_local_comms_abort(tvmh_comm* any) {
+    if (!any) return;
+    triton_vm::LocalGroup& g = *((triton_vm::LocalGroup::Member*)any->self)->group;
+    std::unique_lock<std::mutex> lock(g.m);
+    g.broken = true;
+    g.cv.notify_all();
 }
 extern "C" void tvmh_local_comms_destroy(tvmh_comm* first) {
     if (first) delete ((triton_vm::LocalGroup::Member*)first->self)->group;

@@ -327,6 +327,8 @@ extern "C" int32_t tvmh_prove_sharded(tvm_ctx* ctx, const tvmh_comm* comm, uint3
 // (bench.py --simulate-gpus).  out: `world` pointers; all of them are freed by destroying comms[0].
 extern "C" int32_t tvmh_local_comms_create(uint32_t world, uint32_t lockstep, tvmh_comm** out);
 extern "C" void tvmh_local_comms_destroy(tvmh_comm* first);
+// a rank failed outside a collective (its caller reports the error): every rank waiting in one leaves it with TVM_ERR_DEVICE
+extern "C" void tvmh_local_comms_abort(tvmh_comm* any);
 // lockstep accounting of a local communicator: JSON {"stage": [ms of rank 0, rank 1, ...], ...}, stages in first-seen order
 extern "C" uint64_t tvmh_local_comms_report(const tvmh_comm* any, char* json, uint64_t capacity);
 

@@ -41,6 +41,8 @@ def load_host_library(backend_path=None, out=None):
     lib.tvmh_local_comms_create.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
     lib.tvmh_local_comms_destroy.restype = None
     lib.tvmh_local_comms_destroy.argtypes = [C.c_void_p]
+    lib.tvmh_local_comms_abort.restype = None
+    lib.tvmh_local_comms_abort.argtypes = [C.c_void_p]
     lib.tvmh_local_comms_report.restype = C.c_uint64
     lib.tvmh_local_comms_report.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
     return lib
@@ -79,6 +81,11 @@ class LocalComms:
         buf = C.create_string_buffer(1 << 16)
         self.lib.tvmh_local_comms_report(self.ptrs[0], buf, len(buf))
         return json.loads(buf.value.decode() or "{}")
+
+    def abort(self):
+        """a rank failed: release the ranks that wait for it in a collective (they report a device error)"""
+        if self.ptrs:
+            self.lib.tvmh_local_comms_abort(self.ptrs[0])
 
     def close(self):
         if self.ptrs:

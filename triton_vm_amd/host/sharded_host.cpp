@@ -125,27 +125,56 @@ struct ShardedRun {
         for (u64 r = 0; r < R; r++) out[r].assign(all.begin() + r * cap, all.begin() + (r + 1) * cap);
         return out;
     }
+    // Several small gathers in ONE exchange (the openings of a proof: rows of three tables, leaves of the FRI rounds, the
+    // authentication nodes of every tree).  A job names, per element, the rank that holds it (R = "known to every rank already")
+    // and brings this rank's elements in order; run() moves every rank's blocks with one all-gather and fills `out` (w words per
+    // element, in the order of `owner`; the elements with owner R are left for the caller).
+    struct Exchange {
+        struct Job {
+            std::vector<u64> owner;
+            uint32_t w;
+            Words mine, out;
+        };
+        std::vector<Job> jobs;
+        size_t add(std::vector<u64> owner, uint32_t w, Words mine) {
+            jobs.push_back(Job{std::move(owner), w, std::move(mine), {}});
+            return jobs.size() - 1;
+        }
+    };
+    void run(Exchange& ex, const char* what) {
+        std::vector<u64> offset(ex.jobs.size()), cap(ex.jobs.size());
+        u64 block_words = 0;
+        for (size_t j = 0; j < ex.jobs.size(); j++) {
+            std::vector<u64> per_rank(R + 1, 0);
+            for (u64 r : ex.jobs[j].owner) per_rank[r]++;
+            cap[j] = *std::max_element(per_rank.begin(), per_rank.begin() + R);
+            if (ex.jobs[j].mine.size() != per_rank[me] * ex.jobs[j].w) throw Error(TVM_ERR_INVALID_ARGUMENT, "exchange: a job's own elements");
+            offset[j] = block_words;
+            block_words += cap[j] * ex.jobs[j].w;
+        }
+        Words block(block_words, 0);
+        for (size_t j = 0; j < ex.jobs.size(); j++) std::copy(ex.jobs[j].mine.begin(), ex.jobs[j].mine.end(), block.begin() + offset[j]);
+        const std::vector<Words> all = all_gather_host(block, block_words, what);
+        for (size_t j = 0; j < ex.jobs.size(); j++) {
+            Exchange::Job& job = ex.jobs[j];
+            job.out.assign(job.owner.size() * job.w, 0);
+            std::vector<u64> taken(R, 0);
+            for (size_t k = 0; k < job.owner.size(); k++) {
+                const u64 r = job.owner[k];
+                if (r < R) std::copy_n(all[r].begin() + offset[j] + taken[r]++ * job.w, job.w, job.out.begin() + k * job.w);
+            }
+        }
+    }
     // elements (w words) at global indices of an array that is distributed by residue class: element i is local element
-    // i / R of rank i % R; `fetch` reads this rank's elements at local indices.  Returns them in the order of `idx`.
+    // i / R of rank i % R; `fetch` reads this rank's elements at local indices.  -> the job (its `out` is in the order of `idx`)
     template <class Fetch>
-    Words gather_distributed(const std::vector<u64>& idx, uint32_t w, Fetch fetch, const char* what) {
-        std::vector<u64> local;
-        std::vector<u64> per_rank(R, 0);
+    size_t add_distributed(Exchange& ex, const std::vector<u64>& idx, uint32_t w, Fetch fetch) {
+        std::vector<u64> local, owner;
         for (u64 i : idx) {
-            per_rank[i % R]++;
+            owner.push_back(i % R);
             if (i % R == me) local.push_back(i / R);
         }
-        Words mine = local.empty() ? Words() : fetch(local);
-        if (!comm) return mine;
-        const u64 cap = *std::max_element(per_rank.begin(), per_rank.end());
-        const std::vector<Words> all = all_gather_host(mine, cap * w, what);
-        Words out(idx.size() * w);
-        std::vector<u64> taken(R, 0);
-        for (size_t k = 0; k < idx.size(); k++) {
-            const u64 r = idx[k] % R;
-            std::copy_n(all[r].begin() + taken[r]++ * w, w, out.begin() + k * w);
-        }
-        return out;
+        return ex.add(std::move(owner), w, local.empty() ? Words() : fetch(local));
     }
 
     // ---------------------------------------------------------------------------------------------- Merkle trees
@@ -197,55 +226,67 @@ struct ShardedRun {
         sp.split_trees_built++;
         return t;
     }
-    // MerkleTree::authentication_structure for trees of the same shape opened at the same leaves (their node lists
-    // coincide): one round trip to the device, and for split trees one exchange, for all of them
-    std::vector<Words> auth_nodes(const std::vector<const Tree*>& trees, const std::vector<u64>& indices, const char* what) {
-        const u64 n = trees[0]->n_leaves;
-        const std::vector<u64> need = auth_node_indices(n, indices);
-        std::vector<Words> out(trees.size(), Words(need.size() * 5));
-        if (need.empty()) return out;
+    // MerkleTree::authentication_structure for trees of the same shape opened at the same leaves (their node lists coincide): one
+    // round trip to the device for all of them, and for split trees one job of the exchange (an element = the node of every tree).
+    struct AuthJob {
+        std::vector<const Tree*> trees;
+        std::vector<u64> need;
+        size_t job = 0;
+        bool exchanged = false;
+        std::vector<Words> local;   // whole trees: the nodes, read locally
+    };
+    AuthJob add_auth(Exchange& ex, const std::vector<const Tree*>& trees, const std::vector<u64>& indices) {
+        AuthJob a;
+        a.trees = trees;
+        a.need = auth_node_indices(trees[0]->n_leaves, indices);
+        if (a.need.empty()) return a;
         if (!trees[0]->split) {
             GatherBatch batch;
-            for (const Tree* t : trees) batch.add(t->nodes.ptr(), 5, need);
+            for (const Tree* t : trees) batch.add(t->nodes.ptr(), 5, a.need);
             batch.run(c);
-            for (size_t t = 0; t < trees.size(); t++) out[t] = batch.jobs[t].out;
-            return out;
+            for (size_t t = 0; t < trees.size(); t++) a.local.push_back(batch.jobs[t].out);
+            return a;
         }
         // node k of the whole tree sits at depth d = floor(log2 k); below the subtree roots (depth >= log2 R) its position
         // pos = k - 2^d within the level selects subtree pos >> (d - log2 R), where it is node 2^(d - log2 R) + the low bits
         unsigned log_r = 0;
         while ((1ull << log_r) < R) log_r++;
-        std::vector<u64> owner(need.size()), local(need.size()), per_rank(R, 0), my_local;
-        for (size_t k = 0; k < need.size(); k++) {
-            const u64 node = need[k];
+        std::vector<u64> owner(a.need.size()), my_local;
+        for (size_t k = 0; k < a.need.size(); k++) {
+            const u64 node = a.need[k];
             if (node < 2 * R) {
-                owner[k] = R;  // the top tree
+                owner[k] = R;  // the top tree, on every rank
                 continue;
             }
             const unsigned d = bit_length(node) - 1, dd = d - log_r;
             const u64 pos = node - (1ull << d);
             owner[k] = pos >> dd;
-            local[k] = (1ull << dd) + (pos & ((1ull << dd) - 1));
-            per_rank[owner[k]]++;
-            if (owner[k] == me) my_local.push_back(local[k]);
+            if (owner[k] == me) my_local.push_back((1ull << dd) + (pos & ((1ull << dd) - 1)));
         }
-        const u64 cap = std::max<u64>(*std::max_element(per_rank.begin(), per_rank.end()), 1);
-        Words mine(trees.size() * cap * 5, 0);
+        const size_t T = trees.size();
+        Words mine(my_local.size() * T * 5);
         if (!my_local.empty()) {
             GatherBatch batch;
             for (const Tree* t : trees) batch.add(t->nodes.ptr(), 5, my_local);
             batch.run(c);
-            for (size_t t = 0; t < trees.size(); t++) std::copy(batch.jobs[t].out.begin(), batch.jobs[t].out.end(), mine.begin() + t * cap * 5);
+            for (size_t k = 0; k < my_local.size(); k++)
+                for (size_t t = 0; t < T; t++) std::copy_n(batch.jobs[t].out.begin() + 5 * k, 5, mine.begin() + (k * T + t) * 5);
         }
-        const std::vector<Words> all = all_gather_host(mine, mine.size(), what);
-        std::vector<u64> taken(R, 0);
-        for (size_t k = 0; k < need.size(); k++) {
-            for (size_t t = 0; t < trees.size(); t++) {
-                const u64* src = owner[k] == R ? &trees[t]->top[5 * need[k]] : &all[owner[k]][(t * cap + taken[owner[k]]) * 5];
+        a.job = ex.add(std::move(owner), (uint32_t)(5 * T), std::move(mine));
+        a.exchanged = true;
+        return a;
+    }
+    std::vector<Words> take_auth(const Exchange& ex, const AuthJob& a) {   // after run(ex): per tree, the nodes in the order of `need`
+        const size_t T = a.trees.size();
+        std::vector<Words> out(T, Words(a.need.size() * 5));
+        if (a.need.empty()) return out;
+        if (!a.exchanged) return a.local;
+        const Exchange::Job& job = ex.jobs[a.job];
+        for (size_t k = 0; k < a.need.size(); k++)
+            for (size_t t = 0; t < T; t++) {
+                const u64* src = job.owner[k] == R ? &a.trees[t]->top[5 * a.need[k]] : &job.out[(k * T + t) * 5];
                 std::copy_n(src, 5, out[t].begin() + 5 * k);
             }
-            if (owner[k] != R) taken[owner[k]]++;
-        }
         return out;
     }
 
@@ -405,7 +446,7 @@ struct ShardedRun {
 
     // reveal_rows (master_table.rs:548-609): row i of the extended table lives on rank i % R as local row a = i / R, and
     // in pass a % P of that rank as row a / P
-    Words reveal_master_rows(MasterTable& mt, const std::vector<u64>& indices, const char* what) {
+    size_t add_master_rows(Exchange& ex, MasterTable& mt, const std::vector<u64>& indices) {
         const u64 width = mt.n_cols() * mt.field_kind(), local_rows = p.ldt.length / R;
         auto fetch = [&](const std::vector<u64>& local) {
             if (P == 1) return mt.reveal_rows_of(local, local_rows);
@@ -424,7 +465,7 @@ struct ShardedRun {
             mt.clear_cache();
             return rows;
         };
-        return gather_distributed(indices, (uint32_t)width, fetch, what);
+        return add_distributed(ex, indices, (uint32_t)width, fetch);
     }
 
     // ---------------------------------------------------------------------------------------------- FRI
@@ -527,6 +568,16 @@ struct ShardedRun {
         const Words last_poly = last_poly_d.download(0, dom.length * 3);
         ps.enqueue("fri last polynomial", last_poly.data(), last_poly.size());
         const std::vector<u64> a_indices = ps.sample_indices(p.ldt.length, p.num_collinearity_checks);
+        // the responses of all rounds in ONE exchange (their order in the proof stream is fixed below)
+        Exchange ex;
+        struct Response {
+            size_t round;
+            bool distributed;
+            size_t leaves_job;
+            Words leaves;
+            AuthJob auth;
+        };
+        std::vector<Response> responses;
         for (size_t k = 0; k < rounds.size(); k++) {
             const Round& round = rounds[k];
             std::vector<u64> b_idx;
@@ -539,11 +590,19 @@ struct ShardedRun {
                     c.check(tvm_gather_elements(c.raw(), round.cw, 3, at.data(), at.size(), out.data()), "tvm_gather_elements");
                     return out;
                 };
-                const Words leaves = round.distributed ? gather_distributed(ix, 3, fetch, "FRI responses") : fetch(ix);
-                const Words auth = auth_nodes({&round.tree}, ix, "FRI authentication nodes")[0];
-                ps.enqueue("fri response " + std::to_string(k), leaves.data(), leaves.size());
-                ps.enqueue("fri auth " + std::to_string(k), auth.data(), auth.size());
+                Response q{k, round.distributed, 0, {}, {}};
+                if (round.distributed) q.leaves_job = add_distributed(ex, ix, 3, fetch);
+                else q.leaves = fetch(ix);
+                q.auth = add_auth(ex, {&round.tree}, ix);
+                responses.push_back(std::move(q));
             }
+        }
+        run(ex, "FRI responses and authentication nodes");
+        for (const Response& q : responses) {
+            const Words& leaves = q.distributed ? ex.jobs[q.leaves_job].out : q.leaves;
+            const Words auth = take_auth(ex, q.auth)[0];
+            ps.enqueue("fri response " + std::to_string(q.round), leaves.data(), leaves.size());
+            ps.enqueue("fri auth " + std::to_string(q.round), auth.data(), auth.size());
         }
         (void)ps.sample_scalars(1);
         return a_indices;
@@ -714,15 +773,18 @@ struct ShardedRun {
         // 19: open the trace leafs  (stark.rs:665-716)
         mark("open trace leafs");
         {
-            const std::vector<Words> auth = auth_nodes({&main_tree, &aux_tree, &quot_tree}, a_indices, "authentication nodes");
-            const Words main_rows = reveal_master_rows(main, a_indices, "opened main rows");
-            const Words aux_rows = reveal_master_rows(aux, a_indices, "opened aux rows");
+            Exchange ex;   // the rows of the three tables and the authentication nodes of the three trees: one exchange
+            const AuthJob auth_job = add_auth(ex, {&main_tree, &aux_tree, &quot_tree}, a_indices);
+            const size_t main_job = add_master_rows(ex, main, a_indices), aux_job = add_master_rows(ex, aux, a_indices);
             auto fetch = [&](const std::vector<u64>& local) {
                 Words rows(local.size() * 15);
                 c.check(tvm_table_reveal_rows(c.raw(), seg.t, ldt_rank.length, local.data(), local.size(), rows.data()), "quotient rows");
                 return rows;
             };
-            const Words qrows = gather_distributed(a_indices, 15, fetch, "opened quotient rows");
+            const size_t quot_job = add_distributed(ex, a_indices, 15, fetch);
+            run(ex, "opened rows and authentication nodes");
+            const std::vector<Words> auth = take_auth(ex, auth_job);
+            const Words &main_rows = ex.jobs[main_job].out, &aux_rows = ex.jobs[aux_job].out, &qrows = ex.jobs[quot_job].out;
             ps.enqueue("main rows", main_rows.data(), main_rows.size());
             ps.enqueue("main auth", auth[0].data(), auth[0].size());
             ps.enqueue("aux rows", aux_rows.data(), aux_rows.size());

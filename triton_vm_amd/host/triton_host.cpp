@@ -1044,7 +1044,29 @@ extern "C" int32_t tvmh_prove_execution(tvm_ctx* ctx, const tvm_aet* aet, uint32
         if (h_program_digest) std::memcpy(claim.program_digest, h_program_digest, sizeof(claim.program_digest));
         if (n_public_input) claim.input.assign(h_public_input, h_public_input + n_public_input);
         if (n_public_output) claim.output.assign(h_public_output, h_public_output + n_public_output);
-        const std::vector<u64> proof = prove_execution(c, p, *aet, claim, randomness_seed);
+        // The reference's memory policy (master_table.rs:268-271, stark.rs:730-768): the cached extension first; when the device (or
+        // the context's memory limit) cannot hold it, the same proof coset by coset with as few passes as fit (sharded_host.cpp).
+        std::vector<u64> proof;
+        bool out_of_memory = false;
+        try {
+            proof = prove_execution(c, p, *aet, claim, randomness_seed);
+        } catch (const Error& e) {
+            if (e.status != TVM_ERR_OUT_OF_MEMORY || p.quotient.length != p.ldt.length) throw;
+            out_of_memory = true;   // (outside the handler: the failed attempt's buffers are back in the pool by now)
+        }
+        if (out_of_memory) {
+            (void)tvm_ctx_trim(c.raw());
+            const unsigned expansion = (unsigned)(p.ldt.length / p.trace.length);
+            for (unsigned passes = 2;; passes *= 2) {
+                try {
+                    proof = prove_execution_sharded(c, p, nullptr, passes, *aet, claim, randomness_seed);
+                    break;
+                } catch (const Error& e) {
+                    if (e.status != TVM_ERR_OUT_OF_MEMORY || passes * 2 > expansion) throw;
+                }
+                (void)tvm_ctx_trim(c.raw());
+            }
+        }
         if (proof_words) *proof_words = proof.size();
         if (h_proof && capacity >= proof.size()) std::memcpy(h_proof, proof.data(), proof.size() * sizeof(u64));
         return TVM_OK;

@@ -127,3 +127,24 @@ def test_bench_sharded_code_path_over_rccl_with_one_rank():
     # the C++ sharded host over the RCCL communicator: its own stage times and exchanges are in the line, every tree was built split
     assert "sharded_host.cpp" in rec["config"]["host"] and rec["ranks"][0]["split_trees_built"] >= 4
     assert rec["ranks"][0]["exchanges"]["main leaf digests"]["calls"] == 1
+
+
+@pytest.mark.gpu
+def test_bench_lockstep_measurement_of_the_multi_gpu_code_path():
+    """`bench.py --simulate-gpus 4`: four ranks of the sharded C++ prover in one process on one GPU, in lockstep --
+    every rank proves the single-GPU proof, and the line carries per-rank stage times and the bytes of the exchanges"""
+    import json
+    import subprocess
+
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--simulate-gpus", "4", "--steps", "1", "--warmup", "0", "--log2-rows", "16",
+           "--no-cpu-baseline", "--no-extras"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    sim = rec["simulated_multi_gpu"]
+    assert sim["ranks"] == 4 and sim["all_ranks_same_proof"] and sim["same_proof_as_single_gpu"], sim.get("error")
+    assert len(sim["stage_ms_per_rank"]["AIR quotients"]) == 4 and sim["bytes_sent_per_rank"] > 0
+    assert sim["projected_ms_per_proof"] > 0 and sim["slowest_rank_sum_ms"] > 0

@@ -12,5 +12,6 @@ fn main() {
     println!("cargo:rustc-link-search=native={}", dir.display());
     println!("cargo:rustc-link-lib=dylib=triton_hip");
     println!("cargo:rustc-link-lib=dylib=triton_host");
+    println!("cargo:rustc-link-lib=dylib=triton_rccl");   // the RCCL communicator of the multi-GPU prover (host/rccl_comm.cpp)
     println!("cargo:rustc-link-arg=-Wl,-rpath,{}", dir.display());
 }

@@ -11,7 +11,7 @@ set -euo pipefail
 CHECKOUT=${1:?path to a TritonVM/triton-vm checkout}
 HERE=$(cd "$(dirname "$0")" && pwd)
 REPO=$(dirname "$HERE")
-python3 -c "import sys; sys.path.insert(0, '$REPO'); from triton_vm_amd.build import build, build_host; build(); build_host()"
+python3 -c "import sys; sys.path.insert(0, '$REPO'); from triton_vm_amd.build import build, build_host, build_rccl; build(); build_host(); build_rccl()"
 cd "$CHECKOUT"
 git apply --check -p1 "$HERE/patches/triton-vm-hip.patch" && git apply -p1 "$HERE/patches/triton-vm-hip.patch"
 # point the dependency at this crate

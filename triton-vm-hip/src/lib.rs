@@ -389,25 +389,8 @@ unsafe extern "C" {
     ) -> i32;
 }
 
-/// `Prover::prove(claim, aet)` (stark.rs:331-719) on the device: fill, pad, randomizers, extend, LDE, Merkle trees, AIR,
-/// quotient segments, DEEP, the low-degree test and the openings with the master tables resident in HBM throughout;
-/// the RAM table's Bezout coefficient polynomials are computed on the device.  Returns the `raw_u64` words of the
-/// reference's `Proof` -- for the same seed, the words the CPU prover emits.
-#[allow(clippy::too_many_arguments)]
-pub fn prove_execution(
-    ctx: &Context,
-    aet: &ExecutionTrace,
-    padded_height: usize,
-    security_level: usize,
-    log2_expansion: usize,
-    ldt: Ldt,
-    randomness_seed: &[u8; 32],
-    program_digest: &[u64],
-    public_input: &[u64],
-    public_output: &[u64],
-) -> Result<Vec<u64>> {
-    assert!(padded_height.is_power_of_two());
-    assert_eq!(5, program_digest.len());
+/// the `tvm_aet` view of an `ExecutionTrace` (lengths checked; the Bezout coefficient polynomials are left to the device)
+fn raw_aet(aet: &ExecutionTrace) -> TvmAet {
     assert_eq!(aet.program_words.len(), aet.instruction_multiplicities.len());
     assert_eq!(256, aet.lookup_multiplicities.len());
     for (words, width) in [
@@ -422,7 +405,7 @@ pub fn prove_execution(
     ] {
         assert_eq!(0, words.len() % width);
     }
-    let raw = TvmAet {
+    TvmAet {
         program_words: aet.program_words.as_ptr(),
         instruction_multiplicities: aet.instruction_multiplicities.as_ptr(),
         program_len: aet.program_words.len() as u64,
@@ -446,7 +429,29 @@ pub fn prove_execution(
         cascade_entries: aet.cascade_entries.as_ptr(),
         cascade_len: (aet.cascade_entries.len() / 2) as u64,
         lookup_multiplicities: aet.lookup_multiplicities.as_ptr(),
-    };
+    }
+}
+
+/// `Prover::prove(claim, aet)` (stark.rs:331-719) on the device: fill, pad, randomizers, extend, LDE, Merkle trees, AIR,
+/// quotient segments, DEEP, the low-degree test and the openings with the master tables resident in HBM throughout;
+/// the RAM table's Bezout coefficient polynomials are computed on the device.  Returns the `raw_u64` words of the
+/// reference's `Proof` -- for the same seed, the words the CPU prover emits.
+#[allow(clippy::too_many_arguments)]
+pub fn prove_execution(
+    ctx: &Context,
+    aet: &ExecutionTrace,
+    padded_height: usize,
+    security_level: usize,
+    log2_expansion: usize,
+    ldt: Ldt,
+    randomness_seed: &[u8; 32],
+    program_digest: &[u64],
+    public_input: &[u64],
+    public_output: &[u64],
+) -> Result<Vec<u64>> {
+    assert!(padded_height.is_power_of_two());
+    assert_eq!(5, program_digest.len());
+    let raw = raw_aet(aet);
     let mut proof = vec![0_u64; 1 << 20];
     let mut error = [0 as std::ffi::c_char; 512];
     loop {
@@ -478,6 +483,146 @@ pub fn prove_execution(
                 return Ok(proof);
             }
             TVM_OK => proof = vec![0_u64; n as usize],   // the proof did not fit: grow and run again
+            TVM_ERR_OUT_OF_MEMORY => return Err(HipError::OutOfMemory),
+            TVM_ERR_INVALID_ARGUMENT => {
+                return Err(HipError::InvalidArgument(unsafe { CStr::from_ptr(error.as_ptr()) }.to_string_lossy().into_owned()))
+            }
+            _ => return Err(HipError::Device(unsafe { CStr::from_ptr(error.as_ptr()) }.to_string_lossy().into_owned())),
+        }
+    }
+}
+
+// ---- one proof over the GPUs of a node (triton_vm_amd/host/sharded_host.cpp, rccl_comm.cpp) ----------------
+/// `tvmh_comm` of triton_host.hpp: the collectives of the sharded prover as a table of functions.  `libtriton_rccl.so` fills it
+/// with RCCL calls on the context's stream; a Rust deployment only passes the pointer along.
+#[repr(C)]
+pub struct TvmhComm {
+    _private: [u8; 0],
+}
+
+#[link(name = "triton_rccl")]
+unsafe extern "C" {
+    /// rank 0 draws the 128-byte `ncclUniqueId`; the launcher carries it to the other ranks
+    fn tvmh_rccl_unique_id(out: *mut u8) -> i32;
+    fn tvmh_rccl_comm_create(unique_id: *const u8, rank: u32, world: u32, device: i32, out: *mut *mut TvmhComm) -> i32;
+    fn tvmh_rccl_comm_destroy(comm: *mut TvmhComm);
+}
+
+#[link(name = "triton_host")]
+unsafe extern "C" {
+    fn tvmh_prove_execution_sharded(
+        ctx: *mut TvmCtx,
+        comm: *const TvmhComm,
+        jit_passes: u32,
+        split_tree_min_leaves: u64,
+        aet: *const TvmAet,
+        log2_padded_height: u32,
+        security_level: u32,
+        log2_expansion: u32,
+        use_stir: u32,
+        randomness_seed: *const u8,
+        h_program_digest: *const u64,
+        h_public_input: *const u64,
+        n_public_input: u64,
+        h_public_output: *const u64,
+        n_public_output: u64,
+        h_proof: *mut u64,
+        capacity: u64,
+        proof_words: *mut u64,
+        profile: u32,
+        stats_json: *mut std::ffi::c_char,
+        stats_capacity: u64,
+        error: *mut std::ffi::c_char,
+        error_capacity: u64,
+    ) -> i32;
+}
+
+/// One rank's RCCL communicator (one process per GPU).
+pub struct RcclComm {
+    raw: *mut TvmhComm,
+}
+
+impl RcclComm {
+    pub fn unique_id() -> Result<[u8; 128]> {
+        let mut id = [0_u8; 128];
+        match unsafe { tvmh_rccl_unique_id(id.as_mut_ptr()) } {
+            TVM_OK => Ok(id),
+            _ => Err(HipError::Device("ncclGetUniqueId failed".into())),
+        }
+    }
+
+    pub fn new(unique_id: &[u8; 128], rank: u32, world: u32, device: i32) -> Result<Self> {
+        let mut raw = ptr::null_mut();
+        match unsafe { tvmh_rccl_comm_create(unique_id.as_ptr(), rank, world, device, &mut raw) } {
+            TVM_OK => Ok(Self { raw }),
+            _ => Err(HipError::Device("ncclCommInitRank failed".into())),
+        }
+    }
+}
+
+impl Drop for RcclComm {
+    fn drop(&mut self) {
+        unsafe { tvmh_rccl_comm_destroy(self.raw) }
+    }
+}
+
+/// `prove_execution` over the ranks of `comm` (every rank passes the same trace, claim and seed and obtains the same proof),
+/// and / or coset by coset: `jit_passes` = 0 is the reference's memory policy (cached first, master_table.rs:268-271).
+#[allow(clippy::too_many_arguments)]
+pub fn prove_execution_sharded(
+    ctx: &Context,
+    comm: Option<&RcclComm>,
+    jit_passes: u32,
+    aet: &ExecutionTrace,
+    padded_height: usize,
+    security_level: usize,
+    log2_expansion: usize,
+    ldt: Ldt,
+    randomness_seed: &[u8; 32],
+    program_digest: &[u64],
+    public_input: &[u64],
+    public_output: &[u64],
+) -> Result<Vec<u64>> {
+    assert!(padded_height.is_power_of_two());
+    assert_eq!(5, program_digest.len());
+    let raw = raw_aet(aet);
+    let mut proof = vec![0_u64; 1 << 20];
+    let mut error = [0 as std::ffi::c_char; 512];
+    loop {
+        let mut n = 0_u64;
+        let status = unsafe {
+            tvmh_prove_execution_sharded(
+                ctx.raw,
+                comm.map_or(ptr::null(), |c| c.raw as *const TvmhComm),
+                jit_passes,
+                1 << 21,
+                &raw,
+                padded_height.trailing_zeros(),
+                security_level as u32,
+                log2_expansion as u32,
+                ldt as u32,
+                randomness_seed.as_ptr(),
+                program_digest.as_ptr(),
+                public_input.as_ptr(),
+                public_input.len() as u64,
+                public_output.as_ptr(),
+                public_output.len() as u64,
+                proof.as_mut_ptr(),
+                proof.len() as u64,
+                &mut n,
+                0,
+                ptr::null_mut(),
+                0,
+                error.as_mut_ptr(),
+                error.len() as u64,
+            )
+        };
+        match status {
+            TVM_OK if n as usize <= proof.len() => {
+                proof.truncate(n as usize);
+                return Ok(proof);
+            }
+            TVM_OK => proof = vec![0_u64; n as usize],
             TVM_ERR_OUT_OF_MEMORY => return Err(HipError::OutOfMemory),
             TVM_ERR_INVALID_ARGUMENT => {
                 return Err(HipError::InvalidArgument(unsafe { CStr::from_ptr(error.as_ptr()) }.to_string_lossy().into_owned()))

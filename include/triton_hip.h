@@ -344,6 +344,9 @@ int32_t tvm_stir_next_polynomial(tvm_ctx* ctx, const uint64_t* d_folded_poly, ui
                                  uint64_t* d_out_poly);
 /* host: coefficients of the polynomial of degree < k through k XFE points (pairwise distinct) */
 int32_t tvm_host_xfe_interpolate(const uint64_t* points, const uint64_t* values, uint32_t k, uint64_t* out_coeffs);
+/* the same on the device (one workgroup; k <= 256, beyond that it calls the host function): the prover's round loop does not
+ * leave the GPU idle for the 0.9 ms the host form takes at k = 204 */
+int32_t tvm_xfe_interpolate(tvm_ctx* ctx, const uint64_t* h_points, const uint64_t* h_values, uint32_t k, uint64_t* h_out_coeffs);
 
 /* ---- small transfers and host-side helpers ----------------------------------------------------
  * gather n elements of elem_words words each from a device array at the given element indices

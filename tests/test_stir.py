@@ -146,3 +146,19 @@ def test_prove_with_stir_as_the_low_degree_test(ctx, orc):
     assert set(prover.opened) == {"main", "aux"} and prover.opened["main"].shape[0] == stir.num_first_round_queries()
     # the default-security instance exists and is consistent at this size too
     assert p.stir.initial_domain.length == p.ldt.length and p.h == p.stir.num_trace_randomizers()
+
+
+@pytest.mark.parametrize("k", [1, 2, 7, 64, 204, 256, 300])
+def test_device_interpolation_equals_host_interpolation(ctx, orc, k):
+    """tvm_xfe_interpolate (one workgroup on the device; k > 256 falls through to the host form) against tvm_host_xfe_interpolate
+    (Newton, itself checked against the oracle above): the same coefficients, and a repeated point is refused"""
+    rng = np.random.default_rng(k)
+    pts, vals = orc.random_elements(rng, (k, 3)), orc.random_elements(rng, (k, 3))
+    pts[: k // 2, 1:] = 0      # as in STIR: the in-domain points are base-field elements, the out-of-domain ones are not
+    want, got = np.empty((k, 3), np.uint64), np.empty((k, 3), np.uint64)
+    assert ctx.lib.tvm_host_xfe_interpolate(pts.ctypes.data, vals.ctypes.data, k, want.ctypes.data) == 0
+    assert ctx.lib.tvm_xfe_interpolate(ctx.handle, pts.ctypes.data, vals.ctypes.data, k, got.ctypes.data) == 0
+    assert (got == want).all()
+    if k >= 2:
+        pts[k - 1] = pts[0]
+        assert ctx.lib.tvm_xfe_interpolate(ctx.handle, pts.ctypes.data, vals.ctypes.data, k, got.ctypes.data) != 0

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "tvm_stir_next_polynomial": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
                                              Domain, C.c_void_p]),
     "tvm_host_xfe_interpolate": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "tvm_xfe_interpolate": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "tvm_scatter_strided": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
     "tvm_gather_elements": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]),
     "tvm_fri_commit_phase": (C.c_int32, [C.c_void_p, C.c_void_p, Domain, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -306,6 +306,11 @@ int32_t tvm_evaluate(tvm_ctx* c, int32_t fk, const uint64_t* d_coeffs, uint64_t 
     u64 M = 2;
     while (M < n_coeffs) M <<= 1;
     const u64 X = L / M;
+    if (X >= 4 && L <= (1ull << 22))
+        // Many short cosets (the later rounds of STIR evaluate a polynomial of 2^15 ... 2^9 coefficients on domains 8 ... 256
+        // times as long): one zero-padded transform of length L -- (log L / log M) times the butterflies, but two launches
+        // instead of 2 X, each of which costs 20-40 us whatever its size (round 4: 217 transform pairs per STIR proof, 11.8 ms).
+        return ntt_columns(c, co, n_coeffs, fk, 0, d_values, fk, 0, 1, 0, fk, L, dom.generator, dom.offset, TVM_ONE, TVM_ONE);
     const u64 gen_m = bfe_pow(dom.generator, X);
     for (u64 k = 0; k < X; k++) {
         const u64 off = bfe_mul(dom.offset, bfe_pow(dom.generator, k));
@@ -989,6 +994,25 @@ int32_t tvm_stir_next_polynomial(tvm_ctx* c, const uint64_t* d_folded_poly, uint
     TVM_TRY(stir_quotient(c, vals, M, work_domain.offset, work_domain.generator, staged, staged + 3 * (size_t)k, k, kb,
                           h_degree_correction_randomness));
     return tvm_interpolate(c, 3, vals, work_domain, d_out_poly);
+}
+
+// the same interpolation on the device (one workgroup, k <= 256; stir.hip: k_xfe_interpolate); larger k: the host function below
+int32_t tvm_xfe_interpolate(tvm_ctx* c, const uint64_t* h_points, const uint64_t* h_values, uint32_t k, uint64_t* h_out) {
+    if (!c || (k && (!h_points || !h_values || !h_out))) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "xfe_interpolate arguments");
+    if (!k) return TVM_OK;
+    if (k > 256) return tvm_host_xfe_interpolate(h_points, h_values, k, h_out);
+    u64* d = (u64*)scratch(c, 27, (size_t)(9 * k + 2) * sizeof(u64));
+    if (!d) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "interpolation staging");
+    int* d_status = (int*)(d + 9 * k);
+    TVM_HIP_CHECK(c, hipMemcpyAsync(d, h_points, 3 * (size_t)k * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    TVM_HIP_CHECK(c, hipMemcpyAsync(d + 3 * k, h_values, 3 * (size_t)k * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    TVM_HIP_CHECK(c, hipMemsetAsync(d_status, 0, sizeof(int), c->stream));
+    TVM_TRY(xfe_interpolate(c, d, d + 3 * k, (int)k, d + 6 * k, d_status));
+    int status = 0;
+    TVM_HIP_CHECK(c, hipMemcpyAsync(h_out, d + 6 * k, 3 * (size_t)k * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    TVM_HIP_CHECK(c, hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return status ? set_error(c, TVM_ERR_INVALID_ARGUMENT, "xfe_interpolate: repeated point") : TVM_OK;
 }
 
 // Polynomial::interpolate for a handful of XFE points (the STIR "Ans" polynomial, stir.rs:954): Newton's divided

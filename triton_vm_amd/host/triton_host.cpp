@@ -750,7 +750,7 @@ Stir Stir::for_stark(u64 padded_height, unsigned security_level, unsigned log2_e
 }
 
 // Stir::prove (stir.rs:885-993).  Device work through the C ABI: stacked Merkle trees, polynomial folding, the witness
-// polynomial of the next round; host: sampling, the answer polynomial (tvm_host_xfe_interpolate), inclusion proofs.
+// polynomial of the next round, the answer polynomial (tvm_xfe_interpolate); host: sampling, inclusion proofs.
 std::vector<u64> Stir::prove(const Context& c, const u64* d_codeword, ProofStream& ps) const {
     const u64 ff = folding_factor;
     struct Commitment {
@@ -831,7 +831,7 @@ std::vector<u64> Stir::prove(const Context& c, const u64* d_codeword, ProofStrea
             }
         }
         for (u64 i = 0; i < q.second; i++) quotient_set[folded_queried.size() + i] = ood_queries[i], quotient_answers[folded_queried.size() + i] = ood_values[i];
-        if (tvm_host_xfe_interpolate(quotient_set[0].c, quotient_answers[0].c, (uint32_t)k, answer_poly[0].c))
+        if (tvm_xfe_interpolate(c.raw(), quotient_set[0].c, quotient_answers[0].c, (uint32_t)k, answer_poly[0].c))   // on the device (one workgroup)
             throw Error(TVM_ERR_INVALID_ARGUMENT, "STIR quotient set has repeated points");
         const Xfe degree_correction_randomness = ps.sample_scalars(1)[0];
         // any coset of >= n_folded points that avoids the quotient set: 7 generates F_p^*, so 7 * offset * <w> is disjoint from

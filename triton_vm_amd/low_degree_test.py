@@ -234,9 +234,9 @@ class Stir:
             quotient_set = np.ascontiguousarray(np.concatenate([queried_domain_values, ood_queries]))
             k = quotient_set.shape[0]
             answer_poly = np.empty((k, 3), np.uint64)
-            if lib.tvm_host_xfe_interpolate(quotient_set.ctypes.data, quotient_answers.ctypes.data, k,
-                                            answer_poly.ctypes.data):
-                raise ValueError("STIR quotient set has repeated points")
+            quotient_answers = np.ascontiguousarray(quotient_answers)
+            if lib.tvm_xfe_interpolate(ctx.handle, quotient_set.ctypes.data, quotient_answers.ctypes.data, k, answer_poly.ctypes.data):
+                raise ValueError("STIR quotient set has repeated points")   # (on the device: the host form leaves it idle ~1 ms)
             degree_correction_randomness = proof_stream.sample_scalars(1)[0]
             # any coset of >= n_folded points that avoids the quotient set: 7 generates F_p^*, so 7 * offset * <w>
             # is disjoint from offset * <w'> for every 2-power subgroup; the out-of-domain points are not in F_p

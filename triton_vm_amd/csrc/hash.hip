@@ -22,28 +22,6 @@ namespace tvm {
 #define TVM_HASH_BLOCK 256
 #endif
 
-// which matrix instruction carries the MDS layer (tip5.h): the f64 one (two exact double-precision products per round) or the
-// i8 one (twelve byte products and a ten-position recombination); same lane layout, same results
-#ifndef TVM_TIP5_F64
-#define TVM_TIP5_F64 1
-#endif
-#if TVM_TIP5_F64
-typedef Tip5F64Operands Tip5MatrixOperands;
-#define tip5_matrix_operands tip5_f64_matrix_operands
-#define tip5_permute_matrix tip5_permute_f64
-#define TIP5_MATRIX_TABLES(lut, ctab, tid, nt) \
-    __shared__ double ctab[TIP5_F64_TABLE_WORDS]; \
-    tip5_stage_f64_tables(lut, ctab, tid, nt)
-#else
-typedef Tip5MfmaOperands Tip5MatrixOperands;
-#define tip5_matrix_operands tip5_mfma_matrix_operands
-#define tip5_permute_matrix tip5_permute_mfma
-#define TIP5_MATRIX_TABLES(lut, ctab, tid, nt)                                                                    \
-    __shared__ int ctab[TIP5_ROUNDS * TIP5_MFMA_POSITIONS * 16];                                                  \
-    for (int i_ = tid; i_ < TIP5_ROUNDS * TIP5_MFMA_POSITIONS * 16; i_ += nt) ctab[i_] = d_tip5_mfma_table.v[i_]; \
-    tip5_stage_lut_lowered(lut, tid, nt)
-#endif
-
 // digests[r] = Tip5::hash_varlen(domain row r*stride of the table), W words per row, with the permutation's MDS layer on
 // the matrix cores (tip5_permute_mfma): four lanes per row, sixteen rows per wavefront.  Lane (n, g) absorbs the
 // words g, g + 4 (and g + 8 for g < 2) of each block of ten: with consecutive rows in a wavefront (stride 1) every
@@ -51,8 +29,10 @@ typedef Tip5MfmaOperands Tip5MatrixOperands;
 __global__ void __launch_bounds__(TVM_HASH_BLOCK, 6) k_hash_rows_mfma(const u64* __restrict__ table, TabView view, int W,
                                                                     u64* __restrict__ digests) {
     __shared__ unsigned char lut[256];
+    __shared__ int ctab[TIP5_ROUNDS * TIP5_MFMA_POSITIONS * 16];
     const int tid = threadIdx.x;
-    TIP5_MATRIX_TABLES(lut, ctab, tid, blockDim.x);
+    for (int i = tid; i < TIP5_ROUNDS * TIP5_MFMA_POSITIONS * 16; i += blockDim.x) ctab[i] = d_tip5_mfma_table.v[i];
+    tip5_stage_lut_lowered(lut, tid, blockDim.x);
     const int lane = tid & 63, n = lane & 15, g = lane >> 4;
     // the view's rows in the order that walks storage contiguously (context.h: TabView); digest r goes to the row's index
     // in the domain
@@ -61,7 +41,7 @@ __global__ void __launch_bounds__(TVM_HASH_BLOCK, 6) k_hash_rows_mfma(const u64*
     u64 row, r;
     view.locate(live ? t : view.n_out - 1, row, r);
     const u64* base = table + (row >> TVM_RB_LOG) * (u64)W * TVM_RB + (row & (TVM_RB - 1));
-    const Tip5MatrixOperands a = tip5_matrix_operands(lane);
+    const Tip5MfmaOperands a = tip5_mfma_matrix_operands(lane);
     u64 st[4] = {0, 0, 0, 0};
     const int n_perms = W / TIP5_RATE + 1;
     for (int perm = 0; perm < n_perms; perm++) {
@@ -71,7 +51,7 @@ __global__ void __launch_bounds__(TVM_HASH_BLOCK, 6) k_hash_rows_mfma(const u64*
             const int wi = perm * TIP5_RATE + q;
             if (q < TIP5_RATE) st[t3] = wi < W ? TVM_LOAD_STREAM(&base[(u64)wi * TVM_RB]) : (wi == W ? TVM_ONE : 0);  // padding: 1 then 0s
         }
-        tip5_permute_matrix(st, a, g, lut, ctab);
+        tip5_permute_mfma(st, a, g, lut, ctab);
     }
     if (live) {
         digests[r * 5 + g] = st[0];
@@ -83,10 +63,12 @@ __global__ void __launch_bounds__(TVM_HASH_BLOCK, 6) k_hash_rows_mfma(const u64*
 // permutation (four lanes per parent, sixteen parents per wavefront; tip5.h), for the levels that fill the chip.
 __global__ void __launch_bounds__(256, 6) k_merkle_level(u64* __restrict__ nodes, u64 first, u64 count, int reps) {
     __shared__ unsigned char lut[256];
+    __shared__ int ctab[TIP5_ROUNDS * TIP5_MFMA_POSITIONS * 16];
     const int tid = threadIdx.x;
-    TIP5_MATRIX_TABLES(lut, ctab, tid, blockDim.x);
+    for (int i = tid; i < TIP5_ROUNDS * TIP5_MFMA_POSITIONS * 16; i += blockDim.x) ctab[i] = d_tip5_mfma_table.v[i];
+    tip5_stage_lut_lowered(lut, tid, blockDim.x);
     const int lane = tid & 63, n = lane & 15, g = lane >> 4;
-    const Tip5MatrixOperands a = tip5_matrix_operands(lane);
+    const Tip5MfmaOperands a = tip5_mfma_matrix_operands(lane);
     // `reps` groups of 64 parents per workgroup, one after the other: the tables above and the matrix operands are set up once
     // (a wide level is ONE permutation per lane quadruple: the set-up was a fifth of the kernel)
     for (int rep = 0; rep < reps; rep++) {
@@ -100,7 +82,7 @@ __global__ void __launch_bounds__(256, 6) k_merkle_level(u64* __restrict__ nodes
             const int q = g + 4 * t;
             st[t] = q < 10 ? nodes[10 * i + q] : TVM_ONE;  // fixed-length domain: capacity all ones (tip-0005.md:82)
         }
-        tip5_permute_matrix(st, a, g, lut, ctab);
+        tip5_permute_mfma(st, a, g, lut, ctab);
         if (live) {
             nodes[5 * i + g] = st[0];
             if (g == 0) nodes[5 * i + 4] = st[1];

@@ -353,162 +353,6 @@ TVM_D void tip5_mfma_recombine(const tvm_v4i (&d)[TIP5_MFMA_POSITIONS], u64 (&st
 #endif
 }
 
-// ------------------------------------------------------------------------------------------------
-// Matrix-core form on the f64 matrix instruction (v_mfma_f64_16x16x4_f64): the same four-lanes-per-permutation layout, the
-// MDS layer as TWO exact double-precision products per round instead of twelve i8 ones:
-//
-//   y_i = sum_j M_ij x_j + rc_i with M_ij < 2^16: over the 32-bit halves of the words, sum_j M_ij half_j <= 524757 (2^32 - 1)
-//   < 2^51.01 -- an integer a double holds exactly, as is every partial sum of the instruction's fused multiply-add chain.
-//   The accumulator input is 2^52 + (a 32-bit half of the adjusted round constant): every intermediate value then lies in
-//   [2^52, 2^53), where doubles are the integers, and the RAW BITS of a result are E + S with E = 0x4330000000000000 (the
-//   exponent field of 2^52) and S the integer sum: no float-to-integer conversion.  With X_lo, X_hi the raw bits of the two
-//   results,  X_lo + 2^32 X_hi = y_i + E (1 + 2^32)  once the round constant is lowered by E (1 + 2^32) mod p.
-//
-//   Operands: lane l supplies A[i = l % 16][k = l / 16] and B[k = l / 16][n = l % 16]; instruction t of four covers the state
-//   words j = k + 4t, so B is (the half of) st[t] as the lane holds it and A is M[i][k + 4t], a constant of the lane.  The result
-//   register v of lane (n, g) is row g + 4v of column n (the f64 form's own map: row = lane / 16 + 4 reg) -- the word st[v].
-//
-// What is left on the VALU per word: two u32 -> f64 conversions and the reduction of X_lo + 2^32 X_hi (one v_mad_u64_u32 and
-// the six-instruction tail of tip5_reduce_tail), against six v_mad_u64_u32 and eleven more for the recombination of the ten
-// byte positions of the i8 form.
-#ifdef TVM_EMU
-struct tvm_v4d {
-    double v[4];
-    double& operator[](int i) { return v[i]; }
-    const double& operator[](int i) const { return v[i]; }
-};
-// v_mfma_f64_16x16x4_f64 as this file relies on it: lane (i = l % 16, q = l / 16) supplies A[i][q] and B[q][i] and receives
-// D[q + 4v][i] = C + sum_k A[q + 4v][k] B[k][i] in element v.  The GPU parity tests of tvm_hash_rows run the same kernel on the
-// hardware: they fail if it differs from this model.
-static inline tvm_v4d emu_mfma_f64_16x16x4(double a, double b, tvm_v4d c) {
-    struct { double a, b; } mine = {a, b}, all[64];
-    emu_wave_gather(&mine, sizeof(mine), all);
-    const int lane = emu::lane_id(), col = lane & 15, q = lane >> 4;
-    tvm_v4d d = c;
-    for (int v = 0; v < 4; v++)
-        for (int k = 0; k < 4; k++) d[v] = __builtin_fma(all[16 * k + q + 4 * v].a, all[16 * k + col].b, d[v]);
-    return d;
-}
-#define TVM_MFMA_F64(a, b, c) emu_mfma_f64_16x16x4((a), (b), (c))
-static inline u64 tvm_double_bits(double d) { u64 x; __builtin_memcpy(&x, &d, 8); return x; }
-#else
-typedef double tvm_v4d __attribute__((ext_vector_type(4)));
-#define TVM_MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
-TVM_D u64 tvm_double_bits(double d) { return (u64)__double_as_longlong(d); }
-#endif
-
-#define TIP5_F64_EXPONENT 0x4330000000000000ull   // the bits of 2^52
-// Accumulator inputs: ctab[((round * 4 + g) * 2 + half) * 4 + v] = 2^52 + half of the lowered round constant of word g + 4v
-struct Tip5F64Table { double v[TIP5_ROUNDS * 32]; };
-constexpr Tip5F64Table tip5_make_f64_table() {
-    Tip5F64Table t{};
-    const u64 rc[80] = {TVM_TIP5_RC_LIST};
-    const u64 k0 = (u64)(((unsigned __int128)TIP5_F64_EXPONENT * (((unsigned __int128)1 << 32) + 1)) % TVM_P);
-    for (int r = 0; r < TIP5_ROUNDS; r++)
-        for (int g = 0; g < 4; g++)
-            for (int v = 0; v < 4; v++) {
-                const u64 word = rc[16 * r + g + 4 * v];
-                const u64 adj = word >= k0 ? word - k0 : word + (TVM_P - k0);
-                t.v[((r * 4 + g) * 2 + 0) * 4 + v] = 4503599627370496.0 + (double)(u32)adj;
-                t.v[((r * 4 + g) * 2 + 1) * 4 + v] = 4503599627370496.0 + (double)(u32)(adj >> 32);
-            }
-    return t;
-}
-TVM_CONST_TABLE Tip5F64Table d_tip5_f64_table = tip5_make_f64_table();
-
-struct Tip5F64Operands { double a[4]; };
-TVM_D Tip5F64Operands tip5_f64_matrix_operands(int lane) {
-    const int i = lane & 15, k = lane >> 4;
-    Tip5F64Operands o;
-#pragma unroll
-    for (int t = 0; t < 4; t++) o.a[t] = (double)d_tip5_mds[(16 + i - (k + 4 * t)) & 15];
-    return o;
-}
-
-// the plain S-box table and the accumulator inputs into shared memory
-#define TIP5_F64_TABLE_WORDS (TIP5_ROUNDS * 32)
-TVM_D void tip5_stage_f64_tables(unsigned char* lds_lut, double* lds_ctab, int tid, int nt) {
-    for (int i = tid; i < TIP5_F64_TABLE_WORDS; i += nt) lds_ctab[i] = d_tip5_f64_table.v[i];
-    tip5_stage_lut(lds_lut, tid, nt);
-}
-
-// value_v = t_v + 2^32 pl_v + (carry) 2^64 for t_v < 2^63.1, reduced to the canonical word: s = t + 2^32 pl (carry c); the value
-// is s + 2^64 c and it is canonical after ONE subtraction of p (= addition of EPS modulo 2^64) exactly when c is set (then
-// s < 2^63.1) or s >= p, i.e. when z = s + EPS carries (c2):  result = (c | c2) ? z : s  -- the shape of bfe_add's tail.  The
-// four words are one instruction stream, chain by chain (carries in VCC and seven SGPR pairs), so that every carry consumer
-// has at least two instructions between it and its producer (field.h: TVM_VCC_WAIT).
-TVM_D void tip5_reduce_tail(const u64 (&t)[4], const u32 (&pl)[4], u64 (&st)[4]) {
-#ifdef TVM_FIELD_ASM
-    u32 sh0, sh1, sh2, sh3, zl0, zl1, zl2, zl3, zh0, zh1, zh2, zh3;
-    u64 k0, k1, k2, k3, c1, c2, c3;
-#define TIP5_R1(i, K) "v_add_co_u32_e64 %[sh" #i "], " K ", %[th" #i "], %[pl" #i "]\n\t"
-#define TIP5_R2(i, C) "v_add_co_u32_e64 %[zl" #i "], " C ", -1, %[tl" #i "]\n\t"
-#define TIP5_R3(i, C) "v_addc_co_u32_e64 %[zh" #i "], " C ", 0, %[sh" #i "], " C "\n\t"
-#define TIP5_R4(i, C, K) "s_or_b64 " C ", " C ", " K "\n\t"
-#define TIP5_R5(i, C) "v_cndmask_b32_e64 %[zl" #i "], %[tl" #i "], %[zl" #i "], " C "\n\t"
-#define TIP5_R6(i, C) "v_cndmask_b32_e64 %[sh" #i "], %[sh" #i "], %[zh" #i "], " C "\n\t"
-    asm(TIP5_R1(0, "%[k0]") TIP5_R1(1, "%[k1]") TIP5_R1(2, "%[k2]") TIP5_R1(3, "%[k3]")
-        TIP5_R2(0, "vcc") TIP5_R2(1, "%[c1]") TIP5_R2(2, "%[c2]") TIP5_R2(3, "%[c3]")
-        TIP5_R3(0, "vcc") TIP5_R3(1, "%[c1]") TIP5_R3(2, "%[c2]") TIP5_R3(3, "%[c3]")
-        TIP5_R4(0, "vcc", "%[k0]") TIP5_R4(1, "%[c1]", "%[k1]") TIP5_R4(2, "%[c2]", "%[k2]") TIP5_R4(3, "%[c3]", "%[k3]")
-        TIP5_R5(0, "vcc") TIP5_R5(1, "%[c1]") TIP5_R5(2, "%[c2]") TIP5_R5(3, "%[c3]")
-        TIP5_R6(0, "vcc") TIP5_R6(1, "%[c1]") TIP5_R6(2, "%[c2]") TIP5_R6(3, "%[c3]")
-        : [sh0] "=&v"(sh0), [sh1] "=&v"(sh1), [sh2] "=&v"(sh2), [sh3] "=&v"(sh3), [zl0] "=&v"(zl0), [zl1] "=&v"(zl1),
-          [zl2] "=&v"(zl2), [zl3] "=&v"(zl3), [zh0] "=&v"(zh0), [zh1] "=&v"(zh1), [zh2] "=&v"(zh2), [zh3] "=&v"(zh3),
-          [k0] "=&s"(k0), [k1] "=&s"(k1), [k2] "=&s"(k2), [k3] "=&s"(k3), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3)
-        : [tl0] "v"((u32)t[0]), [th0] "v"((u32)(t[0] >> 32)), [pl0] "v"(pl[0]), [tl1] "v"((u32)t[1]), [th1] "v"((u32)(t[1] >> 32)),
-          [pl1] "v"(pl[1]), [tl2] "v"((u32)t[2]), [th2] "v"((u32)(t[2] >> 32)), [pl2] "v"(pl[2]), [tl3] "v"((u32)t[3]),
-          [th3] "v"((u32)(t[3] >> 32)), [pl3] "v"(pl[3])
-        : "vcc", "scc");
-#undef TIP5_R1
-#undef TIP5_R2
-#undef TIP5_R3
-#undef TIP5_R4
-#undef TIP5_R5
-#undef TIP5_R6
-    st[0] = ((u64)sh0 << 32) | zl0;
-    st[1] = ((u64)sh1 << 32) | zl1;
-    st[2] = ((u64)sh2 << 32) | zl2;
-    st[3] = ((u64)sh3 << 32) | zl3;
-#else
-#pragma unroll
-    for (int v = 0; v < 4; v++) {
-        const u64 s = t[v] + ((u64)pl[v] << 32), z = s + TVM_EPS;
-        st[v] = ((s < t[v]) | (z < s)) ? z : s;
-    }
-#endif
-}
-
-// st[t] = word g + 4t of the state of permutation n; every lane of the wavefront must take part.  `lut` is the plain S-box
-// table, `ctab` the accumulator inputs (tip5_stage_f64_tables).
-TVM_D void tip5_permute_f64(u64 (&st)[4], const Tip5F64Operands& m, int g, const unsigned char* lut, const double* ctab) {
-    for (int r = 0; r < TIP5_ROUNDS; r++) {
-        // accumulator inputs first: their LDS latency hides behind the S-box layer
-        const double* cp = ctab + (r * 4 + g) * 8;
-        tvm_v4d dlo, dhi;
-#pragma unroll
-        for (int v = 0; v < 4; v++) dlo[v] = cp[v], dhi[v] = cp[4 + v];
-        st[0] = tip5_sbox_lookup(st[0], lut);
-#pragma unroll
-        for (int t = 1; t < 4; t++) st[t] = tip5_pow7(st[t]);
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            dlo = TVM_MFMA_F64(m.a[t], (double)(u32)st[t], dlo);
-            dhi = TVM_MFMA_F64(m.a[t], (double)(u32)(st[t] >> 32), dhi);
-        }
-        // X_lo + 2^32 X_hi = X_lo + 2^32 lo(X_hi) + 2^64 hi(X_hi), 2^64 = EPS (mod p): t = hi(X_hi) EPS + X_lo < 2^63.1
-        u64 tt[4];
-        u32 pl[4];
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-            const u64 xlo = tvm_double_bits(dlo[v]), xhi = tvm_double_bits(dhi[v]);
-            tt[v] = (u64)(u32)(xhi >> 32) * 0xFFFFFFFFu + xlo;
-            pl[v] = (u32)xhi;
-        }
-        tip5_reduce_tail(tt, pl, st);
-    }
-}
-
 // st[t] = word g + 4t of the state of permutation n; every lane of the wavefront must take part.  `lut` is the S-box table
 // LOWERED by 128 (tip5_stage_lut_lowered): the looked-up word goes to the matrix cores only, where bytes travel that way.
 TVM_D void tip5_permute_mfma(u64 (&st)[4], const Tip5MfmaOperands& m, int g, const unsigned char* lut, const int* ctab) {

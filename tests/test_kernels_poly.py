@@ -77,7 +77,7 @@ def test_quotient_segments(ctx, orc, log_q, log_ldt, n_rand):
     assert (got == want).all()
 
 
-@pytest.mark.parametrize("log_n,k", [(3, 1), (6, 4), (8, 2)])
+@pytest.mark.parametrize("log_n,k", [(1, 2), (3, 1), (6, 4), (8, 2)])
 def test_deep_codeword(ctx, orc, log_n, k):
     rng = np.random.default_rng(log_n + k)
     dom = ArithmeticDomain.of_length(1 << log_n).with_offset(field.generator())

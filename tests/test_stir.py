@@ -96,14 +96,15 @@ def test_prover_rounds_match_the_coefficient_form_restatement(ctx, orc, log2_bou
     assert len(got_final) <= stir.final_degree + 1
 
 
-def test_next_polynomial_kernel_matches_long_division(ctx, orc):
+@pytest.mark.parametrize("n,k,n_base", [(32, 5, 2), (128, 40, 38), (256, 33, 33)])
+def test_next_polynomial_kernel_matches_long_division(ctx, orc, n, k, n_base):
     """tvm_stir_next_polynomial (pointwise on a coset + one interpolation) against interpolate / zerofier / long
-    division / schoolbook product"""
-    rng = np.random.default_rng(9)
-    n, k = 32, 5
+    division / schoolbook product; from 32 points on the answer polynomial is evaluated on the coset by a transform instead of
+    Horner's rule at every point"""
+    rng = np.random.default_rng(9 + k)
     folded = orc.random_elements(rng, (n, 3))
     pts = orc.random_elements(rng, (k, 3))
-    pts[:2, 1:] = 0  # two base-field points, like queried domain values
+    pts[:n_base, 1:] = 0  # leading base-field points, like queried domain values
     answers = np.array([orc.poly_eval_xfe(folded, p) for p in pts], np.uint64)
     r = orc.random_elements(rng, 3)
     ans_poly = np.empty((k, 3), np.uint64)
@@ -162,3 +163,19 @@ def test_device_interpolation_equals_host_interpolation(ctx, orc, k):
     if k >= 2:
         pts[k - 1] = pts[0]
         assert ctx.lib.tvm_xfe_interpolate(ctx.handle, pts.ctypes.data, vals.ctypes.data, k, got.ctypes.data) != 0
+
+
+@pytest.mark.parametrize("pattern", ["all in the base field", "none", "interleaved", "extension points first", "one extension point last"])
+@pytest.mark.parametrize("k", [33, 204])
+def test_device_interpolation_takes_base_field_points_first_wherever_they_are(ctx, orc, k, pattern):
+    """the device kernel multiplies the base-field points in first (cheaper steps) whatever their place in the input: the
+    interpolant does not depend on the order, so every pattern gives the host form's coefficients"""
+    rng = np.random.default_rng(1000 + k)
+    pts, vals = orc.random_elements(rng, (k, 3)), orc.random_elements(rng, (k, 3))
+    base = {"all in the base field": np.ones(k, bool), "none": np.zeros(k, bool), "interleaved": rng.integers(0, 2, k).astype(bool),
+            "extension points first": np.arange(k) >= 2, "one extension point last": np.arange(k) < k - 1}[pattern]
+    pts[base, 1:] = 0
+    want, got = np.empty((k, 3), np.uint64), np.empty((k, 3), np.uint64)
+    assert ctx.lib.tvm_host_xfe_interpolate(pts.ctypes.data, vals.ctypes.data, k, want.ctypes.data) == 0
+    assert ctx.lib.tvm_xfe_interpolate(ctx.handle, pts.ctypes.data, vals.ctypes.data, k, got.ctypes.data) == 0
+    assert (got == want).all()

@@ -638,6 +638,9 @@ TVM_D xfe ext_apply(int kind, ExtMap m) {
     return xfe_add(m.a, m.b);
 }
 #define EXT_SCAN_THREADS 256
+// rows per work-item.  (Round 4: 16 rows with the terms re-read in the second pass -- 4.06 compositions per row instead of
+// 7.25 -- measured SLOWER, extend 4.95 -> 5.83 ms at 2^20 rows: a work-item's rows are 24 x K contiguous bytes, and at K = 16 a
+// wavefront's load touches 64 lines 384 bytes apart.)
 #define EXT_SCAN_K 4
 #define EXT_SCAN_TILE (EXT_SCAN_THREADS * EXT_SCAN_K)
 TVM_D void ext_lds_put(u64* lds, int i, ExtMap m) {

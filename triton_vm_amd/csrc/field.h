@@ -413,7 +413,24 @@ TVM_HD u64 bfe_pow(u64 a, u64 e) {
     }
     return r;
 }
-TVM_HD u64 bfe_inv(u64 a) { return bfe_pow(a, TVM_P - 2); }
+// a^(p - 2), p - 2 = 2^64 - 2^32 - 1 (thirty-one ones, a zero, thirty-two ones): 63 squarings and 9 multiplications along the
+// chain 2^2-1, 2^3-1, 2^6-1, 2^12-1, 2^24-1, 2^30-1, 2^31-1, (2^31-1) 2^32 + 2^31-1, then one more squaring and a -- where
+// square-and-multiply over the bits of the exponent takes 64 + 62.  0 -> 0.
+TVM_HD u64 bfe_sqr_n(u64 a, int n) {
+    for (int i = 0; i < n; i++) a = bfe_sqr(a);
+    return a;
+}
+TVM_HD u64 bfe_inv(u64 a) {
+    const u64 t2 = bfe_mul(bfe_sqr(a), a);
+    const u64 t3 = bfe_mul(bfe_sqr(t2), a);
+    const u64 t6 = bfe_mul(bfe_sqr_n(t3, 3), t3);
+    const u64 t12 = bfe_mul(bfe_sqr_n(t6, 6), t6);
+    const u64 t24 = bfe_mul(bfe_sqr_n(t12, 12), t12);
+    const u64 t30 = bfe_mul(bfe_sqr_n(t24, 6), t6);
+    const u64 t31 = bfe_mul(bfe_sqr(t30), a);
+    const u64 t63 = bfe_mul(bfe_sqr_n(t31, 32), t31);
+    return bfe_mul(bfe_sqr(t63), a);
+}
 
 // ---------------------------------------------------------------- F_p[X]/(X^3 - X + 1)
 struct xfe {

@@ -38,8 +38,8 @@ int sponge_absorb_root_and_sample(tvm_ctx* c, u64* d_state, const u64* d_root, u
 int stir_hash_stacked(tvm_ctx* c, const u64* cw, u64 n, int stack_height, u64* digests);
 int xfe_interpolate(tvm_ctx* c, const u64* d_points, const u64* d_values, int k, u64* d_out, int* d_status);   // k <= 256
 int stir_fold_polynomial(tvm_ctx* c, const u64* poly, u64 n, int ff, const u64* h_r, u64* out);
-int stir_quotient(tvm_ctx* c, u64* vals, u64 n, u64 offset, u64 gen, const u64* d_points, const u64* d_answer, u32 k,
-                  u32 kb, const u64* h_r);
+int stir_quotient(tvm_ctx* c, u64* vals, u64 n, u64 offset, u64 gen, const u64* d_points, const u64* d_answer,
+                  const u64* d_answer_values, u32 k, u32 kb, const u64* h_r);
 // fill.hip
 int fill_degree_lowering(tvm_ctx* c, int table, u64* d_main, u64* d_aux, const u64* d_challenges, u64 n);
 // bezout.hip

@@ -269,32 +269,60 @@ struct DeepArgs {
     u64 offset, gen, n;
     u64* out;
 };
-__global__ void k_deep(DeepArgs a) {
+// Four points per work-item, a quarter of the domain apart: x_{i + j n/4} = x_i w^j with w = gen^(n/4) a fourth root of unity, so
+// one power of the generator serves four points, and ONE inversion the 4 n_comp denominators of all of them (Montgomery's
+// trick; the denominators are recomputed on the way back instead of kept: sixteen prefix products are what the registers hold).
+#define TVM_DEEP_POINTS 4
+__global__ void __launch_bounds__(256) k_deep(DeepArgs a) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
-    const u64 x = bfe_mul(a.offset, bfe_pow(a.gen, i));
-    xfe den[TVM_DEEP_MAX], pre[TVM_DEEP_MAX];
+    const u64 quarter = a.n / TVM_DEEP_POINTS;
+    if (i >= quarter) return;
+    const u64 w = bfe_pow(a.gen, quarter);
+    u64 x[TVM_DEEP_POINTS];
+    x[0] = bfe_mul(a.offset, bfe_pow(a.gen, i));
+#pragma unroll
+    for (int j = 1; j < TVM_DEEP_POINTS; j++) x[j] = bfe_mul(x[j - 1], w);
+    xfe pre[TVM_DEEP_POINTS][TVM_DEEP_MAX];
     xfe run = xfe_one();
 #pragma unroll
-    for (int k = 0; k < TVM_DEEP_MAX; k++) {
-        if (k < a.n_comp) {
-            xfe pt = xfe_make(a.point[k][0], a.point[k][1], a.point[k][2]);
-            den[k] = xfe_sub(xfe_lift(x), pt);
-            pre[k] = run;
-            run = xfe_mul(run, den[k]);
+    for (int j = 0; j < TVM_DEEP_POINTS; j++) {
+#pragma unroll
+        for (int k = 0; k < TVM_DEEP_MAX; k++) {
+            if (k < a.n_comp) {
+                pre[j][k] = run;
+                run = xfe_mul(run, xfe_bfe_minus(x[j], xfe_make(a.point[k][0], a.point[k][1], a.point[k][2])));
+            }
         }
     }
     xfe inv = xfe_inv(run);
-    xfe acc = xfe_zero();
 #pragma unroll
-    for (int k = TVM_DEEP_MAX - 1; k >= 0; k--) {
-        if (k < a.n_comp) {
-            xfe dinv = xfe_mul(inv, pre[k]);
-            inv = xfe_mul(inv, den[k]);
-            xfe num = xfe_sub(ld_xfe(a.cw[k] + 3 * i), xfe_make(a.value[k][0], a.value[k][1], a.value[k][2]));
-            xfe w = xfe_make(a.weight[k][0], a.weight[k][1], a.weight[k][2]);
-            acc = xfe_add(acc, xfe_mul(xfe_mul(num, dinv), w));
+    for (int j = TVM_DEEP_POINTS - 1; j >= 0; j--) {
+        xfe acc = xfe_zero();
+        const u64 row = i + (u64)j * quarter;
+#pragma unroll
+        for (int k = TVM_DEEP_MAX - 1; k >= 0; k--) {
+            if (k < a.n_comp) {
+                const xfe den = xfe_bfe_minus(x[j], xfe_make(a.point[k][0], a.point[k][1], a.point[k][2]));
+                const xfe dinv = xfe_mul(inv, pre[j][k]);
+                inv = xfe_mul(inv, den);
+                const xfe num = xfe_sub(ld_xfe(a.cw[k] + 3 * row), xfe_make(a.value[k][0], a.value[k][1], a.value[k][2]));
+                const xfe wk = xfe_make(a.weight[k][0], a.weight[k][1], a.weight[k][2]);
+                acc = xfe_add(acc, xfe_mul(xfe_mul(num, dinv), wk));
+            }
         }
+        st_xfe(a.out + 3 * row, acc);
+    }
+}
+// a domain shorter than four points: one point per work-item
+__global__ void k_deep_short(DeepArgs a) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const u64 x = bfe_mul(a.offset, bfe_pow(a.gen, i));
+    xfe acc = xfe_zero();
+    for (int k = 0; k < a.n_comp; k++) {
+        const xfe den = xfe_bfe_minus(x, xfe_make(a.point[k][0], a.point[k][1], a.point[k][2]));
+        const xfe num = xfe_sub(ld_xfe(a.cw[k] + 3 * i), xfe_make(a.value[k][0], a.value[k][1], a.value[k][2]));
+        acc = xfe_add(acc, xfe_mul(xfe_mul(num, xfe_inv(den)), xfe_make(a.weight[k][0], a.weight[k][1], a.weight[k][2])));
     }
     st_xfe(a.out + 3 * i, acc);
 }
@@ -414,7 +442,8 @@ int deep_sum(tvm_ctx* c, int n_comp, const u64* const* d_cw, const u64* h_points
     a.gen = gen;
     a.n = n;
     a.out = d_out;
-    TVM_LAUNCH(k_deep, TVM_GRID(n, 256), dim3(256), 0, c->stream, a);
+    if (n % TVM_DEEP_POINTS) TVM_LAUNCH(k_deep_short, TVM_GRID(n, 256), dim3(256), 0, c->stream, a);
+    else TVM_LAUNCH(k_deep, TVM_GRID(n / TVM_DEEP_POINTS, 256), dim3(256), 0, c->stream, a);
     TVM_HIP_CHECK(c, hipGetLastError());
     return TVM_OK;
 }

@@ -33,6 +33,10 @@ import os
 import sys
 import time
 
+# this pool's host driver shares device memory between processes through dmabuf only: RCCL's setup of a multi-rank communicator
+# needs this before the HIP runtime starts, whoever launched the rank (the driver's torchrun or spawn_ranks below)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

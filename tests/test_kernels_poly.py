@@ -77,6 +77,38 @@ def test_quotient_segments(ctx, orc, log_q, log_ldt, n_rand):
     assert (got == want).all()
 
 
+@pytest.mark.parametrize("log_n,expansion,view_stride,n_cols", [(13, 1, 1, 5), (10, 4, 1, 5), (8, 16, 1, 5), (10, 8, 2, 5), (6, 4, 1, 5),
+                                                                 (10, 4, 1, 4)])
+def test_table_linear_combination_in_tiles(ctx, orc, log_n, expansion, view_stride, n_cols):
+    """tvm_table_linear_combination over tables stored coset-major in the order of the last LDE pass: the tiled kernel (16 rows x
+    128 (block, coset) pairs per workgroup, results handed through shared memory into runs of consecutive domain rows) for a
+    single coset (a rank's table at eight ranks), for 4 and 16 cosets, for a stride view, for a column count other than the
+    quotient-segment table's five (the form with loops as they come) -- and the plain kernel for a table too small for a tile --
+    against the weighted sum of the exported rows"""
+    import ctypes as C
+
+    from triton_vm_amd.master_table import MasterTable
+
+    rng = np.random.default_rng(log_n * 31 + expansion)
+    n, h = 1 << log_n, 3
+    trace_dom = ArithmeticDomain.of_length(n)
+    ev = ArithmeticDomain.of_length(expansion * n).with_offset(field.generator())
+    mt = MasterTable(ctx, orc.random_elements(rng, (n_cols, n, 3)), orc.random_elements(rng, (n_cols, h, 3)), trace_dom, ev, ev, 3)
+    mt.maybe_low_degree_extend_all_columns()
+    rows = mt.low_degree_extended_table()                      # [L, 5, 3] in domain order
+    w = orc.random_elements(rng, (n_cols, 3))
+    n_out = len(ev) // view_stride
+    out = ctx.alloc(3 * n_out)
+    ctx._check(ctx.lib.tvm_table_linear_combination(ctx.handle, C.c_void_p(mt._table), n_out, w.ctypes.data, out.ptr), "lincomb")
+    got = out.download((n_out, 3))
+    for i in range(n_out):
+        acc = np.zeros(3, np.uint64)
+        for c in range(n_cols):
+            acc = orc.xfe_add(acc, orc.xfe_mul(rows[i * view_stride, c], w[c]))
+        assert (got[i] == acc).all(), i
+    mt.clear_cache()
+
+
 @pytest.mark.parametrize("log_n,k", [(1, 2), (3, 1), (6, 4), (8, 2)])
 def test_deep_codeword(ctx, orc, log_n, k):
     rng = np.random.default_rng(log_n + k)

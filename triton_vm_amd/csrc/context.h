@@ -80,7 +80,9 @@ inline TabView tab_view(const TabLayout& l, u64 stride) {
     v.l = l;
     v.stride = stride;
     v.n_out = l.rows() / stride;
-    v.by_coset = l.X > 1 && stride <= l.X && l.X % stride == 0 && l.n2 > 1;
+    // (a single coset too: the table of a rank that owns one coset of the trace domain -- eight ranks at expansion 8 -- is stored
+    // in the order of the last LDE pass like any other; walking it in domain order read every word of a row from a line of its own)
+    v.by_coset = stride <= l.X && l.X % stride == 0 && l.n2 > 1;
     if (v.by_coset) {
         v.log_n = l.log_n1 + l.log_n2;
         v.log_xv = tab_ilog2(l.X / stride);

@@ -224,6 +224,86 @@ __global__ void k_table_lincomb(const u64* __restrict__ table, TabView view, int
     st_xfe(out + 3 * i, acc);
 }
 
+// The same over a table stored coset-major in the order of the last LDE pass (context.h: domain row X (j1 + n2 j2) + k is
+// storage row k pitch + j1 n1 + j2): consecutive storage rows are domain rows X n2 apart, so the kernel above -- storage order
+// in, domain order out -- scatters 24-byte results over the output (0.62 ms for 2^23 rows of 15 words where the table is read
+// in 0.15).  Here a workgroup takes a tile of 16 consecutive rows j2 (one 128-byte line per word) x 128 (block j1, coset k)
+// pairs, combines eight rows per work-item, and hands the results through shared memory: for each j2 the 128 pairs are 128
+// CONSECUTIVE domain rows (3 KB of output) when the view has at most eight cosets, runs of eight otherwise.
+#define TVM_LINCOMB_TILE_PAIRS 128
+// WORDS = fk * n_cols known at compile time (15: the five extension-field columns of the quotient-segment table): the words of a
+// row are loaded together and one row AHEAD of the arithmetic (with run-time loop bounds hipcc put each load right before its
+// use: fifteen exposed memory latencies per row, 0.6 ms for 2^23 rows); 0: any shape, loops as they come.
+template <int WORDS>
+__global__ void __launch_bounds__(256) k_table_lincomb_tiles(const u64* __restrict__ table, TabView view, int fk, u64 n_cols,
+                                                             const u64* __restrict__ w, u64* __restrict__ out) {
+    constexpr int RS = 3 * TVM_LINCOMB_TILE_PAIRS + 1;
+    __shared__ u64 so[16 * RS];
+    const TabLayout& l = view.l;
+    const int tid = threadIdx.x, p = tid & 15, q = tid >> 4;
+    const int log_kx = view.log_xv < 3 ? view.log_xv : 3, kx = 1 << log_kx;
+    const int j1_per_tile = TVM_LINCOMB_TILE_PAIRS >> log_kx;
+    // tile coordinates: j2 group fastest, then j1 group, then coset group
+    u64 b = blockIdx.x;
+    const u64 P = (b & ((l.n1 >> 4) - 1)) << 4;
+    b >>= l.log_n1 - 4;
+    const u64 tiles_j1 = l.n2 / j1_per_tile;
+    const u64 J = (b % tiles_j1) * j1_per_tile, k0 = (b / tiles_j1) << log_kx;
+    const u64 W = n_cols * (u64)fk;
+    auto row_of = [&](int it) {
+        const int pair = q + 16 * it;
+        const u64 j1 = J + (pair >> log_kx), kv = k0 + (pair & (kx - 1));
+        return kv * view.stride * l.pitch + j1 * l.n1 + P + p;
+    };
+    if constexpr (WORDS > 0) {
+        static_assert(WORDS % 3 == 0, "extension-field columns");
+        xfe wc[WORDS / 3];
+#pragma unroll
+        for (int c = 0; c < WORDS / 3; c++) wc[c] = ld_xfe(w + 3 * c);
+        u64 cur[WORDS], nxt[WORDS];
+        {
+            const u64 r0 = row_of(0);
+#pragma unroll
+            for (int v = 0; v < WORDS; v++) cur[v] = table[tvm_tab_idx(r0, v, WORDS)];
+        }
+#pragma unroll 1
+        for (int it = 0; it < TVM_LINCOMB_TILE_PAIRS / 16; it++) {
+            if (it + 1 < TVM_LINCOMB_TILE_PAIRS / 16) {
+                const u64 r1 = row_of(it + 1);
+#pragma unroll
+                for (int v = 0; v < WORDS; v++) nxt[v] = table[tvm_tab_idx(r1, v, WORDS)];
+            }
+            xfe acc = xfe_zero();
+#pragma unroll
+            for (int c = 0; c < WORDS / 3; c++) acc = xfe_add(acc, xfe_mul(xfe_make(cur[3 * c], cur[3 * c + 1], cur[3 * c + 2]), wc[c]));
+            u64* d = so + p * RS + 3 * (q + 16 * it);
+            d[0] = acc.c0, d[1] = acc.c1, d[2] = acc.c2;
+#pragma unroll
+            for (int v = 0; v < WORDS; v++) cur[v] = nxt[v];
+        }
+    } else {
+        for (int it = 0; it < TVM_LINCOMB_TILE_PAIRS / 16; it++) {
+            const u64 row = row_of(it);
+            xfe acc = xfe_zero();
+            for (u64 c = 0; c < n_cols; c++) {
+                const xfe wc = ld_xfe(w + 3 * c);
+                u64 e[3] = {0, 0, 0};
+                for (int k = 0; k < fk; k++) e[k] = table[tvm_tab_idx(row, c * fk + k, W)];
+                acc = xfe_add(acc, fk == 1 ? xfe_mul_bfe(wc, e[0]) : xfe_mul(xfe_make(e[0], e[1], e[2]), wc));
+            }
+            u64* d = so + p * RS + 3 * (q + 16 * it);
+            d[0] = acc.c0, d[1] = acc.c1, d[2] = acc.c2;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 16 * 3 * TVM_LINCOMB_TILE_PAIRS; e += 256) {
+        const int pp = e / (3 * TVM_LINCOMB_TILE_PAIRS), word = e % (3 * TVM_LINCOMB_TILE_PAIRS), pair = word / 3, comp = word % 3;
+        const u64 j = J + (pair >> log_kx) + ((P + pp) << l.log_n2);   // coset_index of the row
+        const u64 i = (j << view.log_xv) + k0 + (pair & (kx - 1));
+        out[3 * i + comp] = so[pp * RS + word];
+    }
+}
+
 // polynomial (XFE coefficients) at XFE points: partial[p][block] then a final pass
 __global__ void __launch_bounds__(TVM_RED_BLOCK) k_poly_eval_partial(const u64* __restrict__ co, u64 n,
                                                                      const u64* __restrict__ points,
@@ -406,7 +486,16 @@ int randomized_segments(tvm_ctx* c, const u64* d_q_coeffs, u64 q_len, const u64*
 }
 int table_lincomb(tvm_ctx* c, const u64* table, const TabLayout& layout, int fk, u64 n_cols, u64 stride, const u64* d_w, u64* d_out) {
     const TabView view = tab_view(layout, stride);
-    TVM_LAUNCH(k_table_lincomb, TVM_GRID(view.n_out, 256), dim3(256), 0, c->stream, table, view, fk, n_cols, d_w, d_out);
+    const u64 cosets = 1ull << view.log_xv;
+    const u64 j1_per_tile = TVM_LINCOMB_TILE_PAIRS / (cosets < 8 ? cosets : 8);
+    if (view.by_coset && layout.n1 >= 16 && layout.n2 >= j1_per_tile) {
+        const u64 tiles = view.n_out / (16 * TVM_LINCOMB_TILE_PAIRS);
+        if (fk == 3 && n_cols == 5)
+            TVM_LAUNCH(k_table_lincomb_tiles<15>, dim3((unsigned)tiles), dim3(256), 0, c->stream, table, view, fk, n_cols, d_w, d_out);
+        else
+            TVM_LAUNCH(k_table_lincomb_tiles<0>, dim3((unsigned)tiles), dim3(256), 0, c->stream, table, view, fk, n_cols, d_w, d_out);
+    } else
+        TVM_LAUNCH(k_table_lincomb, TVM_GRID(view.n_out, 256), dim3(256), 0, c->stream, table, view, fk, n_cols, d_w, d_out);
     TVM_HIP_CHECK(c, hipGetLastError());
     return TVM_OK;
 }

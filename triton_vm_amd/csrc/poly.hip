@@ -352,6 +352,9 @@ struct DeepArgs {
 // Four points per work-item, a quarter of the domain apart: x_{i + j n/4} = x_i w^j with w = gen^(n/4) a fourth root of unity, so
 // one power of the generator serves four points, and ONE inversion the 4 n_comp denominators of all of them (Montgomery's
 // trick; the denominators are recomputed on the way back instead of kept: sixteen prefix products are what the registers hold).
+// (Measured: the steps written out for four components -- no run-time indexing of the prefix products, which hipcc keeps in
+// 400 bytes of scratch here -- need 225 VGPRs and run 11 % slower, 1.07 vs 0.96 ms at 2^23 points; the kernel issues ~4700
+// instructions per point and is within 10 % of that issue time as it stands.)
 #define TVM_DEEP_POINTS 4
 __global__ void __launch_bounds__(256) k_deep(DeepArgs a) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;

@@ -18,7 +18,7 @@ def make_table(ctx, orc, rng, n, n_cols, h, fk):
 
 
 @pytest.mark.parametrize("fk,n_cols", [(1, 7), (3, 4), (1, 20)])
-@pytest.mark.parametrize("log_n,h", [(4, 5), (6, 9)])
+@pytest.mark.parametrize("log_n,h", [(4, 5), (6, 9), (8, 198), (8, 64), (8, 0)])
 def test_out_of_domain_rows(ctx, orc, fk, n_cols, log_n, h):
     rng = np.random.default_rng(fk * 100 + n_cols + log_n)
     mt, trace, rnd = make_table(ctx, orc, rng, 1 << log_n, n_cols, h, fk)

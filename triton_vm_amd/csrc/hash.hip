@@ -113,7 +113,11 @@ __global__ void __launch_bounds__(1024) k_merkle_top(u64* __restrict__ nodes, u6
     tip5_stage_lut(lut, threadIdx.x, blockDim.x);
     const int pos = (int)(threadIdx.x & 15), lane = (int)(threadIdx.x & 63);
     for (u64 lvl = widest; lvl >= 1; lvl >>= 1) {
-        for (u64 j0 = 0; j0 < lvl; j0 += blockDim.x / 16) {  // uniform trip count: every lane joins the rotations
+        for (u64 j0 = 0; j0 < lvl; j0 += blockDim.x / 16) {
+            // The rotations of tip5_permute_lanes stay inside a wavefront: every lane of a wavefront that has a parent joins
+            // them, a wavefront without one sits the level out (all sixteen wavefronts permuting clamped duplicates made every
+            // level cost what the widest one does: 62 us per tree, seventeen trees per proof).
+            if (j0 + ((threadIdx.x & ~63u) >> 4) >= lvl) continue;
             u64 j = j0 + (threadIdx.x >> 4);
             const bool live = j < lvl;
             if (!live) j = lvl - 1;

@@ -299,6 +299,11 @@ def simulate_ranks(ctx, host_lib, n_ranks, aet, padded_height, claim, kw):
     comms = native_host.LocalComms(host_lib, n_ranks, lockstep=True)
     ctxs = [type(ctx)(device=0, lib=ctx.lib) for _ in range(n_ranks)]
     out, errors = {}, []
+    # ONE copy of the replicated trace-side tables for the ranks of this process (triton_host.hpp, tvmh_comm::share): rank 0 fills,
+    # pads and extends, the others read its arrays -- 21.8 GB once instead of eight times at 2^22 rows, which is what lets BASELINE
+    # configs[2] (2^22 rows over 8 GPUs) run through this code path on one 288 GB device.  The replicated stages then show their
+    # time on rank 0 only; the slowest rank per stage -- what the projection sums -- is unchanged.
+    host_lib.tvmh_set_option(native_host.OPTION_SHARE_REPLICATED_TABLES, 1)
 
     def run(r, phase):
         try:
@@ -321,6 +326,7 @@ def simulate_ranks(ctx, host_lib, n_ranks, aet, padded_height, claim, kw):
                 raise RuntimeError(f"simulated rank failed: {errors[0]}")
             reports.append(comms.report())
     finally:
+        host_lib.tvmh_set_option(native_host.OPTION_SHARE_REPLICATED_TABLES, 0)
         comms.close()
         for c in ctxs:
             c.close()
@@ -344,6 +350,7 @@ def simulate_ranks(ctx, host_lib, n_ranks, aet, padded_height, claim, kw):
             "projected_exchange_ms": round(exchange_ms, 3), "projected_ms_per_proof": round(compute + exchange_ms, 3),
             "assumptions": f"{XGMI_EGRESS_GBPS:.0f} GB/s sustained per-rank egress over xGMI, {COLLECTIVE_LATENCY_US:.0f} us per collective call",
             "all_ranks_same_proof": all((p.size == proofs[0].size and (p == proofs[0]).all()) for p in proofs),
+            "replicated_tables": "one copy shared by the simulated ranks (rank 0 builds them; TVMH_OPTION_SHARE_REPLICATED_TABLES)",
             "proof": proofs[0],
             "note": "single-GPU LOCKSTEP run of the N-rank code path (one rank computes at a time, own context and stream per rank): per-rank "
                     "compute is measured, the exchanges are projected; not a multi-GPU measurement"}

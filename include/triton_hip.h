@@ -67,6 +67,14 @@ int32_t tvm_ctx_trim(tvm_ctx* ctx);
  * domain and the codeword completed by interpolation; bit-identical to the row-by-row evaluation on a valid trace,
  * different on an invalid one (where both yield a proof the verifier rejects). */
 #define TVM_OPTION_AIR_VALID_TRACE 1
+/* Tuning values (per context; they change launch shapes, never results).  TVM_OPTION_LDE_CHUNK_COLUMNS: columns per chunk of
+ * tvm_lde_table's three-pass transform, 0 (default) = 96 while the chunk's intermediates fit comfortably, else 32.
+ * TVM_OPTION_MERKLE_MIN_WORKGROUPS: tvm_merkle_tree gives a workgroup several groups of parents while at least this many
+ * workgroups remain (default 4096; 0 restores it) -- the tests lower it to reach that path with small trees.
+ * The library reads NO environment variable: a prover behind triton_vm::prove() must not change kernels on an inherited
+ * environment. */
+#define TVM_OPTION_LDE_CHUNK_COLUMNS 2
+#define TVM_OPTION_MERKLE_MIN_WORKGROUPS 3
 int32_t tvm_ctx_set_option(tvm_ctx* ctx, int32_t option, uint64_t value);
 /* Cap on the bytes this context may hold through tvm_malloc / table handles (0 = no cap).  Requests beyond it fail
  * with TVM_ERR_OUT_OF_MEMORY exactly like a full device: the knob a host uses to share a GPU, and what the tests use to
@@ -74,6 +82,11 @@ int32_t tvm_ctx_set_option(tvm_ctx* ctx, int32_t option, uint64_t value);
 int32_t tvm_ctx_set_memory_limit(tvm_ctx* ctx, size_t bytes);
 /* bytes currently held from the driver through this context (live blocks + cached blocks) */
 int32_t tvm_ctx_memory_held(const tvm_ctx* ctx, size_t* bytes);
+/* what this context could still obtain through tvm_malloc / table handles right now: the device's free memory plus the
+ * context's own cached blocks (they are given back before a request fails), capped by the memory limit; and the device's
+ * total.  Either pointer may be null.  The figure the host's memory policy plans with (master_table.rs:268-271: "does the
+ * cached extension fit?") instead of running into the failure. */
+int32_t tvm_ctx_memory_info(const tvm_ctx* ctx, size_t* available_bytes, size_t* device_total_bytes);
 int32_t tvm_memcpy_h2d(tvm_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int32_t tvm_memcpy_d2h(tvm_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 /* device to device, ordered on the context's stream, NOT synchronised (same device, or a peer-accessible one). */

@@ -61,6 +61,82 @@ def execution(kind, log2):
     return _TRACES[(kind, log2)]
 
 
+def _sharded_in_process(ctx, e, world, ldt, log2_expansion, split_all_trees, lockstep, seed):
+    """one proof of execution `e` over `world` in-process ranks of the sharded C++ host (one thread, context and stream per rank,
+    ONE copy of the replicated tables: TVMH_OPTION_SHARE_REPLICATED_TABLES) -> (every rank's proof words, rank 0's stats)"""
+    import threading
+
+    from triton_vm_amd import Context, native_host
+    from triton_vm_amd.master_table import aet_to_device
+
+    host = native_host.load_host_library()
+    resident = aet_to_device(ctx, e["aet"])
+    comms = native_host.LocalComms(host, world, lockstep=lockstep)
+    contexts = [Context(device=0, lib=ctx.lib) for _ in range(world)]
+    out, errors = [None] * world, []
+
+    def run(r):
+        try:
+            out[r] = native_host.prove_execution_sharded(contexts[r], host, comms.ptrs[r], resident, e["padded_height"], e["claim"], seed, jit_passes=1,
+                                                         log2_expansion=log2_expansion, ldt=ldt, split_tree_min_leaves=0 if split_all_trees else 1 << 21)
+        except BaseException as err:   # noqa: BLE001
+            errors.append((r, err))
+            comms.abort()
+
+    host.tvmh_set_option(native_host.OPTION_SHARE_REPLICATED_TABLES, 1)
+    try:
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=1200)
+        assert not errors, errors
+        assert all(not t.is_alive() for t in threads), "a rank hung"
+    finally:
+        host.tvmh_set_option(native_host.OPTION_SHARE_REPLICATED_TABLES, 0)
+        comms.close()
+        for c in contexts:
+            c.close()
+        del resident
+    return [o[0] for o in out], out[0][1]
+
+
+# (log2 padded height, low-degree test, log2 expansion, every tree split?, lockstep?) -- BASELINE configs[2] is the last line but one
+SHARDED_CASES = [
+    (16, "fri", 2, True, False),
+    (16, "stir", 2, True, False),
+    (16, "fri", 2, False, True),
+    (16, "fri", 4, True, False),
+    (20, "fri", 2, False, False),
+    (20, "stir", 2, False, True),
+]
+
+
+@pytest.mark.parametrize("log2,ldt,log2_expansion,split_all_trees,lockstep", SHARDED_CASES)
+def test_sharded_cpp_host_over_eight_ranks_equals_the_single_gpu_proof(gctx, log2, ldt, log2_expansion, split_all_trees, lockstep):
+    """The multi-GPU code path at real sizes (round 4's equality tests ran at 8 rows): prove_fib at 2^16 and 2^20 padded rows through
+    `tvmh_prove_execution_sharded` over EIGHT ranks -- multi-chunk table extensions, multi-workgroup kernels on one-coset tables, the
+    split-tree threshold of 2^21 leaves (at 2^20 rows: the three table trees and the first FRI rounds split, the later rounds
+    whole), the valid-trace AIR dealt over the ranks, FRI and STIR, LDT expansion 16 (two cosets per rank; the quotient domain is
+    the short one) -- must emit the single-GPU proof, word for word, on every rank.  stark.rs:805-1006, master_table.rs:470-503."""
+    from tests import test_proof_snapshot as snap
+    from triton_vm_amd import native_host
+
+    ctx = gctx
+    e = execution("fib", log2)
+    seed = snap.prover_seed(11)
+    host = native_host.load_host_library()
+    want = native_host.prove_execution(ctx, host, e["aet"], e["padded_height"], e["claim"], seed, log2_expansion=log2_expansion, ldt=ldt)
+    ctx.trim()
+    proofs, stats = _sharded_in_process(ctx, e, 8, ldt, log2_expansion, split_all_trees, lockstep, seed)
+    for rank, got in enumerate(proofs):
+        assert got.size == want.size and (got == want).all(), rank
+    assert stats["world"] == 8 and stats["passes"] == 1
+    assert stats["split_trees_built"] >= (3 if (split_all_trees or log2 >= 18) else 0)
+    assert stats["exchanges"]["main leaf digests"]["calls"] == 1
+    ctx.trim()
+
+
 @pytest.mark.parametrize("which,log2,ldt,log2_expansion,restated", CASES)
 def test_baseline_config_proves_and_verifies(gctx, orc, which, log2, ldt, log2_expansion, restated):
     from oracle import proof_decode, real_verifier
@@ -117,4 +193,27 @@ def test_baseline_config_proves_and_verifies(gctx, orc, which, log2, ldt, log2_e
         exact_proof = exact.prove().proof()
         exact.release()
         assert (exact_proof.words == proof.words).all()
+    ctx.trim()
+
+
+def test_configs2_height_over_eight_ranks_equals_the_single_gpu_proof(gctx):
+    """BASELINE configs[2] -- prove_fib at 2^22 padded rows over 8 ranks -- through the code that would serve it: eight in-process
+    ranks of the sharded C++ host in lockstep on this one GPU (21.8 GB of traces once, 8 x 20.4 GiB of one-coset tables), every
+    rank's proof word for word the single-GPU proof."""
+    from tests import test_proof_snapshot as snap
+    from triton_vm_amd import native_host
+
+    ctx = gctx
+    available, total = ctx.memory_info()
+    if total < (250 << 30):
+        pytest.skip("needs the 288 GB of an MI355X")
+    e = execution("fib", 22)
+    seed = snap.prover_seed(12)
+    host = native_host.load_host_library()
+    want = native_host.prove_execution(ctx, host, e["aet"], e["padded_height"], e["claim"], seed, ldt="fri")
+    ctx.trim()
+    proofs, stats = _sharded_in_process(ctx, e, 8, "fri", 2, False, True, seed)
+    for rank, got in enumerate(proofs):
+        assert got.size == want.size and (got == want).all(), rank
+    assert stats["split_trees_built"] >= 4
     ctx.trim()

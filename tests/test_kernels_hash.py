@@ -57,11 +57,13 @@ def test_ldt_view_is_strided_subset(ctx, orc):
 
 # 12: 16-lanes-per-parent levels, 17: all three level kernels, -17: the same with several groups of parents per workgroup
 @pytest.mark.parametrize("log_n", [0, 1, 4, 10, 12, 17, -17])
-def test_merkle_tree_sizes_and_codeword_tree(ctx, orc, log_n, monkeypatch):
+def test_merkle_tree_sizes_and_codeword_tree(ctx, orc, log_n, request):
     if abs(log_n) > 12 and ctx.kind == "emu":
         pytest.skip("2^17 leaves take minutes on the fiber emulation; the size runs on the GPU")
     if log_n < 0:
-        monkeypatch.setenv("TVM_MERKLE_MIN_WORKGROUPS", "64")   # 1024 groups of 64 parents on the widest level: 8 per workgroup
+        # TVM_OPTION_MERKLE_MIN_WORKGROUPS = 3: 1024 groups of 64 parents on the widest level -> 8 per workgroup
+        ctx._check(ctx.lib.tvm_ctx_set_option(ctx.handle, 3, 64), "tvm_ctx_set_option")
+        request.addfinalizer(lambda: ctx.lib.tvm_ctx_set_option(ctx.handle, 3, 0))
         log_n = -log_n
     rng = np.random.default_rng(log_n)
     n = 1 << log_n

@@ -168,6 +168,75 @@ def test_sharded_prove_execution_reproduces_the_reference_snapshot(ctx, orc, wor
         comms.close()
 
 
+@pytest.mark.parametrize("world,lockstep", [(2, True), (8, False)])
+def test_in_process_ranks_share_one_copy_of_the_replicated_tables(ctx, orc, world, lockstep):
+    """TVMH_OPTION_SHARE_REPLICATED_TABLES (triton_host.hpp, tvmh_comm::share): rank 0 fills, pads and extends, the other ranks of the
+    in-process communicator read its device arrays -- what lets bench.py --simulate-gpus put eight ranks of a 2^22-row proof on one
+    GPU.  Same proof (the reference's snapshot digest) on every rank, twice in a row (the second proof releases the first one's
+    tables), and the ranks other than 0 allocate no traces of their own."""
+    from tests import test_proof_snapshot as snap
+    from triton_vm_amd.proof_stream import Proof
+
+    if ctx.kind == "emu" and world > 2:
+        pytest.skip("eight ranks on the GPU only (CPU suite time)")
+    host = host_library(ctx)
+    aet, padded_height, claim, seed = _snapshot_inputs(orc)
+    comms = native_host.LocalComms(host, world, lockstep=lockstep)
+    contexts = [_new_context(ctx) for _ in range(world)]
+    host.tvmh_set_option(native_host.OPTION_SHARE_REPLICATED_TABLES, 1)
+    try:
+        for _ in range(2):
+            def rank_body(rank):
+                return native_host.prove_execution_sharded(contexts[rank], host, comms.ptrs[rank], aet, padded_height, claim, seed, jit_passes=1,
+                                                           split_tree_min_leaves=0, profile=True)
+
+            for words, stats in _run_ranks(world, rank_body, comms):
+                assert Proof(words).digest(ctx.lib) == snap.SNAPSHOT
+                assert stats["world"] == world and stats["split_trees_built"] >= 3
+        if lockstep:
+            report = comms.report()
+            fill = report["trace tables (fill, pad, randomizers)"]
+            assert fill[0] > 0 and "extend" in report
+    finally:
+        host.tvmh_set_option(native_host.OPTION_SHARE_REPLICATED_TABLES, 0)
+        comms.close()   # (drops the tables the group keeps: rank 0's context must still be open)
+        for c in contexts:
+            c.close()
+
+
+def test_memory_policy_with_a_communicator_is_decided_collectively(ctx, orc):
+    """jit_passes = 0 over a communicator: the ranks' free memory differs (here: rank 1 has a memory limit, rank 0 has none), and a
+    rank that restarted coset by coset on its own would issue collectives its peer does not expect.  Every rank plans with what ITS
+    context can obtain, one all-gather makes the largest pass count everybody's -- both ranks report the same pass count, more than
+    one, and the proof is the reference's."""
+    from tests import test_proof_snapshot as snap
+    from triton_vm_amd.proof_stream import Proof
+
+    host = host_library(ctx)
+    aet, padded_height, claim, seed = _snapshot_inputs(orc)
+    p = StarkParameters(padded_height.bit_length() - 1)
+    n, L = p.trace.length, p.ldt.length
+    world = 2
+    comms = native_host.LocalComms(host, world)
+    contexts = [_new_context(ctx) for _ in range(world)]
+    # rank 1 may hold its traces and a quarter of the extended rows (its share of the cached extension would be half of them)
+    contexts[1].set_memory_limit(contexts[1].memory_held() + 8 * (379 + 273) * (2 * n + L // 4))
+    try:
+        def rank_body(rank):
+            return native_host.prove_execution_sharded(contexts[rank], host, comms.ptrs[rank], aet, padded_height, claim, seed, jit_passes=0,
+                                                       split_tree_min_leaves=0)
+
+        results = _run_ranks(world, rank_body, comms)
+        passes = [stats["passes"] for _, stats in results]
+        assert passes[0] == passes[1] and passes[0] >= 2, passes
+        for words, _ in results:
+            assert Proof(words).digest(ctx.lib) == snap.SNAPSHOT
+    finally:
+        comms.close()
+        for c in contexts:
+            c.close()
+
+
 def test_memory_policy_of_the_cpp_host(ctx, orc):
     """master_table.rs:268-271, stark.rs:730-768: when the cached extension does not fit (the context's memory limit stands in
     for a full device) tvmh_prove_execution_sharded with jit_passes = 0 starts over coset by coset; the proof does not change"""

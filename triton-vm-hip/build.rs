@@ -12,6 +12,10 @@ fn main() {
     println!("cargo:rustc-link-search=native={}", dir.display());
     println!("cargo:rustc-link-lib=dylib=triton_hip");
     println!("cargo:rustc-link-lib=dylib=triton_host");
-    println!("cargo:rustc-link-lib=dylib=triton_rccl");   // the RCCL communicator of the multi-GPU prover (host/rccl_comm.cpp)
+    // the RCCL communicator of the multi-GPU prover (host/rccl_comm.cpp -> libtriton_rccl.so, which pulls in librccl): only with
+    // the `rccl` feature, so that a single-GPU box without RCCL builds and links the product
+    if env::var_os("CARGO_FEATURE_RCCL").is_some() {
+        println!("cargo:rustc-link-lib=dylib=triton_rccl");
+    }
     println!("cargo:rustc-link-arg=-Wl,-rpath,{}", dir.display());
 }

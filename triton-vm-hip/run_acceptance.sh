@@ -11,7 +11,7 @@ set -euo pipefail
 CHECKOUT=${1:?path to a TritonVM/triton-vm checkout}
 HERE=$(cd "$(dirname "$0")" && pwd)
 REPO=$(dirname "$HERE")
-python3 -c "import sys; sys.path.insert(0, '$REPO'); from triton_vm_amd.build import build, build_host, build_rccl; build(); build_host(); build_rccl()"
+python3 -c "import sys; sys.path.insert(0, '$REPO'); from triton_vm_amd.build import build, build_host, build_rccl, rccl_available; build(); build_host(); print(build_rccl() if rccl_available() else 'no RCCL here: libtriton_rccl.so skipped (cargo feature rccl stays off)')"
 cd "$CHECKOUT"
 git apply --check -p1 "$HERE/patches/triton-vm-hip.patch" && git apply -p1 "$HERE/patches/triton-vm-hip.patch"
 # point the dependency at this crate

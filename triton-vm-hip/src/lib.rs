@@ -500,6 +500,12 @@ pub struct TvmhComm {
     _private: [u8; 0],
 }
 
+/// Anything that owns a `tvmh_comm` (with the `rccl` feature: [`RcclComm`]).
+pub trait Communicator {
+    fn raw(&self) -> *const TvmhComm;
+}
+
+#[cfg(feature = "rccl")]
 #[link(name = "triton_rccl")]
 unsafe extern "C" {
     /// rank 0 draws the 128-byte `ncclUniqueId`; the launcher carries it to the other ranks
@@ -537,11 +543,20 @@ unsafe extern "C" {
     ) -> i32;
 }
 
-/// One rank's RCCL communicator (one process per GPU).
+/// One rank's RCCL communicator (one process per GPU).  Feature `rccl`.
+#[cfg(feature = "rccl")]
 pub struct RcclComm {
     raw: *mut TvmhComm,
 }
 
+#[cfg(feature = "rccl")]
+impl Communicator for RcclComm {
+    fn raw(&self) -> *const TvmhComm {
+        self.raw as *const TvmhComm
+    }
+}
+
+#[cfg(feature = "rccl")]
 impl RcclComm {
     pub fn unique_id() -> Result<[u8; 128]> {
         let mut id = [0_u8; 128];
@@ -560,6 +575,7 @@ impl RcclComm {
     }
 }
 
+#[cfg(feature = "rccl")]
 impl Drop for RcclComm {
     fn drop(&mut self) {
         unsafe { tvmh_rccl_comm_destroy(self.raw) }
@@ -571,7 +587,7 @@ impl Drop for RcclComm {
 #[allow(clippy::too_many_arguments)]
 pub fn prove_execution_sharded(
     ctx: &Context,
-    comm: Option<&RcclComm>,
+    comm: Option<&dyn Communicator>,
     jit_passes: u32,
     aet: &ExecutionTrace,
     padded_height: usize,
@@ -593,7 +609,7 @@ pub fn prove_execution_sharded(
         let status = unsafe {
             tvmh_prove_execution_sharded(
                 ctx.raw,
-                comm.map_or(ptr::null(), |c| c.raw as *const TvmhComm),
+                comm.map_or(ptr::null(), |c| c.raw()),
                 jit_passes,
                 1 << 21,
                 &raw,

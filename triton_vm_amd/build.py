@@ -97,8 +97,10 @@ def build_host(backend_lib=None, out=None):
     out = out or HOST_LIB
     assert os.path.dirname(os.path.abspath(out)) == os.path.dirname(os.path.abspath(backend_lib)), "host library next to its backend"
     srcs = [os.path.join(HERE, "host", "triton_host.cpp"), os.path.join(HERE, "host", "sharded_host.cpp")]
+    # (not the backend library's mtime: the host binds to it dynamically through the C ABI, which include/triton_hip.h states --
+    # a relinked backend with the same header does not make the host stale)
     deps = srcs + [os.path.join(HERE, "host", "triton_host.hpp"), os.path.join(HERE, "host", "host_internal.hpp"),
-                   os.path.join(ROOT, "include", "triton_hip.h"), backend_lib]
+                   os.path.join(ROOT, "include", "triton_hip.h")]
     if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
         return out
     import fcntl
@@ -117,6 +119,16 @@ def build_host(backend_lib=None, out=None):
 RCCL_LIB = os.path.join(HERE, "libtriton_rccl.so")
 
 
+class RcclUnavailable(RuntimeError):
+    """this machine has no RCCL headers / library: libtriton_rccl.so (the multi-GPU communicator only) cannot be built"""
+
+
+def rccl_available(rocm=None):
+    rocm = rocm or os.environ.get("ROCM_PATH", "/opt/rocm")
+    return os.path.exists(os.path.join(rocm, "include", "rccl", "rccl.h")) and any(
+        os.path.exists(os.path.join(rocm, "lib", n)) for n in ("librccl.so", "librccl.so.1"))
+
+
 def build_rccl(backend_lib=None):
     """The RCCL communicator of the multi-GPU prover (triton_vm_amd/host/rccl_comm.cpp): host code that enqueues RCCL
     collectives on the context's stream.  g++ against the ROCm headers; linked with the product library, librccl and
@@ -124,7 +136,10 @@ def build_rccl(backend_lib=None):
     backend_lib = backend_lib or build()
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
     src = os.path.join(HERE, "host", "rccl_comm.cpp")
-    deps = [src, os.path.join(HERE, "host", "triton_host.hpp"), os.path.join(ROOT, "include", "triton_hip.h"), backend_lib]
+    deps = [src, os.path.join(HERE, "host", "triton_host.hpp"), os.path.join(ROOT, "include", "triton_hip.h")]
+    if not rccl_available(rocm):
+        raise RcclUnavailable(f"no RCCL under {rocm} (include/rccl/rccl.h, lib/librccl.so): the multi-GPU communicator is not built; "
+                              "the single-GPU product (libtriton_hip.so, libtriton_host.so) does not need it")
     if os.path.exists(RCCL_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(RCCL_LIB) for d in deps):
         return RCCL_LIB
     import fcntl
@@ -142,4 +157,4 @@ def build_rccl(backend_lib=None):
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_host())
-    print(build_rccl())
+    print(build_rccl() if rccl_available() else "libtriton_rccl.so: skipped (no RCCL on this machine; only the multi-GPU communicator needs it)")

@@ -60,6 +60,7 @@ _SIGNATURES = {
     "tvm_ctx_set_option": (C.c_int32, [C.c_void_p, C.c_int32, C.c_uint64]),
     "tvm_ctx_set_memory_limit": (C.c_int32, [C.c_void_p, C.c_size_t]),
     "tvm_ctx_memory_held": (C.c_int32, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "tvm_ctx_memory_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "tvm_memcpy_h2d": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "tvm_memcpy_d2h": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "tvm_memcpy_d2d": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -232,6 +233,12 @@ class Context:
         n = C.c_size_t()
         self._check(self.lib.tvm_ctx_memory_held(self.handle, C.byref(n)), "tvm_ctx_memory_held")
         return n.value
+
+    def memory_info(self):
+        """-> (bytes this context could still obtain, the device's total bytes)"""
+        a, t = C.c_size_t(), C.c_size_t()
+        self._check(self.lib.tvm_ctx_memory_info(self.handle, C.byref(a), C.byref(t)), "tvm_ctx_memory_info")
+        return a.value, t.value
 
     def assume_valid_trace(self, on=True):
         """TVM_OPTION_AIR_VALID_TRACE: the tables come from a valid execution -- the quotient evaluation may use the

@@ -93,10 +93,31 @@ int32_t tvm_ctx_memory_held(const tvm_ctx* c, size_t* bytes) {
     *bytes = c->pool_bytes;
     return TVM_OK;
 }
+int32_t tvm_ctx_memory_info(const tvm_ctx* c, size_t* available_bytes, size_t* device_total_bytes) {
+    if (!c) return TVM_ERR_INVALID_ARGUMENT;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    size_t total = 0;
+    const size_t avail = pool_available(const_cast<tvm_ctx*>(c), &total);   // (binds the context's device; reads the pool only)
+    if (cur >= 0 && cur != c->device) (void)hipSetDevice(cur);
+    if (!total) return TVM_ERR_DEVICE;
+    if (available_bytes) *available_bytes = avail;
+    if (device_total_bytes) *device_total_bytes = total;
+    return TVM_OK;
+}
 int32_t tvm_ctx_set_option(tvm_ctx* c, int32_t option, uint64_t value) {
     if (!c) return TVM_ERR_INVALID_ARGUMENT;
     if (option == TVM_OPTION_AIR_VALID_TRACE) {
         c->air_valid_trace = value != 0;
+        return TVM_OK;
+    }
+    if (option == TVM_OPTION_LDE_CHUNK_COLUMNS) {
+        if (value > 4096) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "TVM_OPTION_LDE_CHUNK_COLUMNS: at most 4096");
+        c->lde_chunk_columns = (int)value;
+        return TVM_OK;
+    }
+    if (option == TVM_OPTION_MERKLE_MIN_WORKGROUPS) {
+        c->merkle_min_workgroups = value ? value : 4096;
         return TVM_OK;
     }
     return set_error(c, TVM_ERR_INVALID_ARGUMENT, "unknown option");
@@ -665,7 +686,7 @@ int32_t tvm_deep_codeword(tvm_ctx* c, uint32_t n_comp, const uint64_t* const* d_
 int32_t tvm_fri_commit_phase(tvm_ctx* c, const uint64_t* d_cw, tvm_domain dom, uint32_t n_rounds, const uint64_t* h_state,
                              uint64_t* const* d_codewords, uint64_t* const* d_nodes, uint64_t* h_roots, uint64_t* h_challenges) {
     if (!c || !d_cw || !valid_domain(dom) || !h_state || !d_nodes || !h_roots || (n_rounds && (!d_codewords || !h_challenges)) ||
-        n_rounds >= 64 || (dom.length >> n_rounds) < 1)   // every folded codeword has at least two elements
+        n_rounds >= 64 || (dom.length >> n_rounds) < 1)   // every fold halves a codeword of at least two elements: the last one has at least one
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "fri_commit_phase arguments");
     for (uint32_t r = 0; r <= n_rounds; r++)
         if (!d_nodes[r] || (r < n_rounds && !d_codewords[r])) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "fri_commit_phase: null buffer");

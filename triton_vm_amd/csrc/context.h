@@ -106,6 +106,8 @@ struct tvm_ctx {
     size_t pool_bytes = 0;                              // bytes held from the driver (live + cached)
     size_t pool_limit = 0;                              // tvm_ctx_set_memory_limit: 0 = whatever the device has
     bool air_valid_trace = false;                       // TVM_OPTION_AIR_VALID_TRACE (capi.hip: tvm_all_quotients_combined)
+    int lde_chunk_columns = 0;                          // TVM_OPTION_LDE_CHUNK_COLUMNS: 0 = chosen by lde_table (ntt.hip)
+    u64 merkle_min_workgroups = 4096;                   // TVM_OPTION_MERKLE_MIN_WORKGROUPS (hash.hip: merkle_tree_from_leaves)
     std::string last_error;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
@@ -120,6 +122,7 @@ int set_error(tvm_ctx* c, int code, const char* what);
 void* pool_alloc(tvm_ctx* c, size_t bytes);
 void pool_release(tvm_ctx* c, void* p);   // back to the cache (stream-ordered reuse)
 void pool_trim(tvm_ctx* c);               // cached blocks back to the driver (synchronises the stream)
+size_t pool_available(tvm_ctx* c, size_t* device_total);   // device free + own cache, capped by the context's limit
 // a pool block that goes back to the cache on every exit path of the function that holds it
 struct PoolBlock {
     tvm_ctx* c;

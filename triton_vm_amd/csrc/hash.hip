@@ -10,7 +10,6 @@
 // (tip5.h, "matrix-core form"); Merkle levels: one lane per parent while a level fills the chip, sixteen
 // lanes per parent below that.  Hashing is integer-ALU bound (38 + 28 permutations per
 // LDT row; ~60% of a permutation's instructions are the x^7 S-boxes), not HBM bound.
-#include <cstdlib>
 
 #include "context.h"
 #include "tip5.h"
@@ -227,8 +226,7 @@ int merkle_tree_from_leaves(tvm_ctx* c, u64* nodes, u64 n_leaves) {
     u64 lvl = n_leaves >> 1;
     for (; lvl > 32768; lvl >>= 1) {  // wide levels: four lanes per parent on the matrix cores (throughput form)
         const u64 groups = (lvl + 63) / 64;   // of 64 parents; up to 8 per workgroup while >= 4096 workgroups remain
-        const char* env = std::getenv("TVM_MERKLE_MIN_WORKGROUPS");   // (the CPU suite lowers it to reach this path)
-        const u64 min_wgs = env ? (u64)std::atoll(env) : 4096;
+        const u64 min_wgs = c->merkle_min_workgroups;   // 4096; TVM_OPTION_MERKLE_MIN_WORKGROUPS (the tests lower it to reach this path)
         const int reps = groups >= 8 * min_wgs ? 8 : groups >= 4 * min_wgs ? 4 : groups >= 2 * min_wgs ? 2 : 1;
         TVM_LAUNCH(k_merkle_level, dim3((unsigned)((groups + reps - 1) / reps)), dim3(256), 0, c->stream, nodes, lvl, lvl, reps);
     }

@@ -352,12 +352,10 @@ struct LdePass2Args {
     Pow2 tw_inter;       // w_N^e
     const u64* g_lo;     // [X][N1]: gamma_k^m2 / N
     const u64* g_hi;     // [X][N2]: gamma_k^(N1*m1)
-    const u64* g_lo_step;  // [N1]: (gamma_{k+1} / gamma_k)^m2       (k_lde_pass2_v2 walks the cosets with running
-    const u64* g_hi_step;  // [N2]: (gamma_{k+1} / gamma_k)^(N1*m1)    products: no table load inside its coset loop)
+    const u64* g_lo_step;  // [N1]: (gamma_{k+1} / gamma_k)^m2       (the row kernels walk the cosets with running
+    const u64* g_hi_step;  // [N2]: (gamma_{k+1} / gamma_k)^(N1*m1)    products: no table load inside their coset loop)
     u64 zk[TVM_LDE_MAX_COSETS];  // N * (gamma_k^N - 1)
     int std_roots;       // the trace domain's generator is the domains' own root of unity (shift twiddles, lds_ntt_group)
-    const u64* store_tw; // optional (k_lde_pass2_rows<10, 8>): the store phase's factors w_N^(m2 j1) gamma_k^m2 / N as a table in the
-                         // order the kernel reads them, [X][n1 / 8][16][512] (k_lde_store_table); null: running products
 };
 
 __global__ void __launch_bounds__(1024) k_lde_pass2(LdePass2Args a) {
@@ -433,7 +431,7 @@ struct LdePass3Args {
     int log_n1, log_n2;
     int n_cosets;
     int col0;            // first virtual column of the chunk
-    int tiles;           // k_lde_pass3_v2 / _v3: consecutive row tiles per workgroup
+    int tiles;           // k_lde_pass3_v3 / _rows: consecutive row tiles per workgroup
     int W;               // words per table row
     u64 L;
     u64 pitch;           // storage rows per coset
@@ -478,173 +476,19 @@ __global__ void __launch_bounds__(1024) k_lde_pass3(LdePass3Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Passes 2 and 3 for the production shape: tiles of 16 rows, one work-item per point of the LDS-resident
-// axis (blockDim.x == n2 resp. n1 >= 64).  Same results as k_lde_pass2 / k_lde_pass3; what changes is that
-// every index a work-item needs is either its own constant or uniform across the workgroup, so the scale
-// and store phases carry no per-element index arithmetic:
-//   * work-item tid owns position q = tid of all 16 rows: m1 = brev(tid) is its constant, m2 = brev(p0 + e)
-//     is uniform, and only work-items with m1*n1 < h ever see a randomizer coefficient;
-//   * gamma_k^m / N = gamma_k^(n1*m1) * (gamma_k^m2 / N): the first factor is applied before the column
-//     step (one load per coset, one multiplication per element), the second is a per-row constant, commutes
-//     with the column step and is merged into the inter-pass twiddle of the store phase, which itself is a
-//     running product  T(j1 + n2/16) = T(j1) * w_N^(m2*n2/16)  instead of two table loads per element.
-__global__ void __launch_bounds__(1024) k_lde_pass2_v2(LdePass2Args a) {
-    TVM_DYN_SMEM(u64, s);
-    const int tid = threadIdx.x, nt = blockDim.x;  // nt == n2
-    const u64 n1 = 1ull << a.log_n1;
-    const int n2 = 1 << a.log_n2;
-    const int RS = n2 + TVM_ROW_PAD;
-    const int vl = blockIdx.y, v = a.col0 + vl;
-    const u64 p0 = (u64)blockIdx.x * 16;
-    const u64 n = n1 << a.log_n2;
-    const u64* y = a.y + (u64)vl * n + p0 * n2;
-#pragma unroll
-    for (int e = 0; e < 16; e++) s[e * RS + tid] = TVM_LOAD_STREAM(&y[(u64)e * n2 + tid]);
-    tvm_lds_barrier();
-    // position q of row e: N * t[m1*n1 + m2], m1 = brev(q)
-    // (the production kernels are launched for the domains' own roots of unity only: shift twiddles, ROOT = 2 / 1)
-    if (a.log_n2 == 10) lds_ntt_fixed<false, 4, 10, 0, 4, 2>(s, a.tw_a2, tid, nt);
-    else if (a.log_n2 == 6) lds_ntt_fixed<false, 4, 6, 0, 4, 2>(s, a.tw_a2, tid, nt);  // 2^12 rows: the size the CPU suite runs
-    else lds_ntt<false, 4, 2>(s, a.log_n2, 4, 1, RS, a.tw_a2, tid, nt);
-
-    u64 coef[16];
-#pragma unroll
-    for (int e = 0; e < 16; e++) coef[e] = s[e * RS + tid];
-    // the forward twiddles w_N2^e (n2/2 words) live in LDS behind the tile for the X column steps that follow:
-    // an LDS read costs a fraction of the L1-hit latency of the same table in global memory
-    u64* tw_fwd = s + 16 * RS;
-    tw_fwd[tid] = a.tw_b1[tid];   // all n2 powers (nt == n2)
-    const u64 m1 = brev_bits((u32)tid, a.log_n2);
-    const bool has_rnd = m1 * n1 < a.h;  // a wavefront-uniform "no" for all but the first work-items
-    const u64* rnd = a.rnd + (u64)(v / a.fk) * a.h * a.fk + (v % a.fk);
-    // h <= n1 (every production shape): only the coefficients m < n1, i.e. m1 = 0 = position 0 of each row, see a randomizer.
-    // Work-item 0 parks its 16 coefficients in LDS, work-items 0..15 fetch the randomizer word of "their" row once, and in
-    // every coset work-item e writes  s[e][0] = t[m] + zk * r[m]  (gamma_k^(n1*0) = 1) instead of work-item 0: no global
-    // load and no divergent 16-element branch inside the coset loop -- the wavefront that ran it used to arrive last at
-    // every barrier of every coset.
-    const bool single = a.h <= n1;
-    u64* c0 = tw_fwd + n2;
-    u64* r0 = c0 + 16;
-    if (single) {
-        if (tid == 0) {
-#pragma unroll
-            for (int e = 0; e < 16; e++) c0[e] = coef[e];
-        }
-        if (tid < 16) {
-            const u64 m = brev_bits((u32)(p0 + tid), a.log_n1);
-            r0[tid] = m < a.h ? rnd[m * a.fk] : 0;
-        }
-    }
-    // store phase: this work-item writes row b = tid % 16, columns j1 = tid / 16 + i * n2/16, i < 16
-    const int b_out = tid & 15, j1_0 = tid >> 4;
-    const u64 m2_out = brev_bits((u32)(p0 + b_out), a.log_n1);
-    const int j1_step = n2 >> 4;                                          // 16 elements per work-item
-    const u64 t_step = pow2_get(a.tw_inter, (m2_out * (u64)j1_step) & (n - 1));  // w_N^(m2 * n2/16)
-    // The coset loop below issues no global load (except the few work-items that see randomizers): a load would
-    // have to be waited for, and the counter that waits for it also waits for every older store -- the stores of
-    // coset k would drain before the arithmetic of coset k + 1 instead of under it.  So the per-coset factors are
-    // running products: gamma_k = offset * g^k.
-    u64 gh = a.g_hi[m1];                                                  // gamma_0^(n1*m1)
-    const u64 gh_step = a.g_hi_step[m1];
-    u64 t_first = bfe_mul(pow2_get(a.tw_inter, m2_out * (u64)j1_0), a.g_lo[m2_out]);  // w_N^(m2*j1_0) * gamma_0^m2 / N
-    const u64 gl_step = a.g_lo_step[m2_out];
-    for (int k = 0; k < a.n_cosets; k++) {
-        tvm_lds_barrier();
-        if (single) {
-            if (tid != 0) {
-#pragma unroll
-                for (int e = 0; e < 16; e++) s[e * RS + tid] = bfe_mul(coef[e], gh);
-            }
-            if (tid < 16) s[tid * RS] = bfe_add(c0[tid], bfe_mul(a.zk[k], r0[tid]));
-        } else if (has_rnd) {
-            const u64 zk = a.zk[k];
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const u64 m = m1 * n1 + brev_bits((u32)(p0 + e), a.log_n1);
-                u64 c = coef[e];
-                if (m < a.h) c = bfe_add(c, bfe_mul(zk, rnd[m * a.fk]));
-                s[e * RS + tid] = bfe_mul(c, gh);
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 16; e++) s[e * RS + tid] = bfe_mul(coef[e], gh);
-        }
-        tvm_lds_barrier();
-        // coef[] stays live: 8-element groups
-        if (a.log_n2 == 10) lds_ntt_fixed<true, 3, 10, 0, 4, 1>(s, tw_fwd, tid, nt);
-        else if (a.log_n2 == 6) lds_ntt_fixed<true, 3, 6, 0, 4, 1>(s, tw_fwd, tid, nt);
-        else lds_ntt<true, 3, 1>(s, a.log_n2, 4, 1, RS, tw_fwd, tid, nt);
-        u64* z = a.z + ((u64)vl * a.n_cosets + k) * n + p0 + b_out;
-        u64 t = t_first;  // w_N^(m2*j1) * gamma_k^m2 / N at j1 = j1_0
-#pragma unroll 4
-        for (int i = 0; i < 16; i++) {
-            const int j1 = j1_0 + i * j1_step;
-            TVM_STORE_STREAM(&z[(u64)j1 * n1], bfe_mul(s[b_out * RS + j1], t));
-            t = bfe_mul(t, t_step);
-        }
-        gh = bfe_mul(gh, gh_step);
-        t_first = bfe_mul(t_first, gl_step);
-    }
-}
-
-// A workgroup walks a.tiles consecutive row tiles of its column: the 16 global loads of the next tile are issued
-// before the column step of the current one, so the read latency of a tile hides behind the arithmetic of the
-// previous tile instead of preceding it (one workgroup per CU: nobody else would cover it).
-__global__ void __launch_bounds__(1024) k_lde_pass3_v2(LdePass3Args a) {
-    TVM_DYN_SMEM(u64, s);
-    const int tid = threadIdx.x, nt = blockDim.x;  // nt == n1
-    const int n1 = 1 << a.log_n1;
-    const u64 n2 = 1ull << a.log_n2;
-    const int RS = n1 + TVM_ROW_PAD;
-    const u64 X = (u64)a.n_cosets;
-    const int log_x = 31 - __builtin_clz((unsigned)a.n_cosets);
-    // adjacent workgroups = adjacent table columns of the same 16 rows: together they write runs of
-    // chunk_cols * 128 contiguous bytes of the row-block-major table instead of lines 48 KiB apart
-    const int vl = blockIdx.x;
-    const u64* zc = a.z + (u64)vl * X * (n2 << a.log_n1) + tid;
-    u64* tw_fwd = s + 16 * RS;  // twiddles in LDS (see k_lde_pass2_v2)
-    tw_fwd[tid] = a.tw_b2[tid];   // all n1 powers (nt == n1)
-    // store phase: work-item tid writes position j2 = tid of all 16 rows (consecutive lanes = consecutive storage rows)
-    const u64 W = (u64)a.W;
-    u64* const out_t = a.table + ((((u64)(tid >> TVM_RB_LOG)) * W + (u64)(a.col0 + vl)) << TVM_RB_LOG) + (tid & (TVM_RB - 1));
-    u64 nxt[16];
-    u64 rho0 = (u64)blockIdx.y * a.tiles * 16;  // first local row of the tile
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-        const u64 rho = rho0 + e, j1 = rho >> log_x, k = rho & (X - 1);  // uniform; X is a power of two
-        nxt[e] = TVM_LOAD_STREAM(&zc[(k * n2 + j1) << a.log_n1]);
-    }
-    for (int it = 0; it < a.tiles; it++, rho0 += 16) {
-        if (it) tvm_lds_barrier();  // the stores of the previous tile have read s
-#pragma unroll
-        for (int e = 0; e < 16; e++) s[e * RS + tid] = nxt[e];
-        tvm_lds_barrier();
-        if (it + 1 < a.tiles) {
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const u64 rho = rho0 + 16 + e, j1 = rho >> log_x, k = rho & (X - 1);
-                nxt[e] = TVM_LOAD_STREAM(&zc[(k * n2 + j1) << a.log_n1]);
-            }
-        }
-        if (a.log_n1 == 10) lds_ntt_fixed<true, 4, 10, 0, 4, 1>(s, tw_fwd, tid, nt);
-        else if (a.log_n1 == 6) lds_ntt_fixed<true, 4, 6, 0, 4, 1>(s, tw_fwd, tid, nt);
-        else lds_ntt<true, 4, 1>(s, a.log_n1, 4, 1, RS, tw_fwd, tid, nt);
-        // row e of the tile is (k, j1): its storage rows start at k*pitch + j1*n1 (a multiple of 16)
-#pragma unroll 4
-        for (int e = 0; e < 16; e++) {
-            const u64 rho = rho0 + e, j1 = rho >> log_x, k = rho & (X - 1);
-            const u64 blk = (k * a.pitch + (j1 << a.log_n1)) >> TVM_RB_LOG;
-            TVM_STORE_STREAM(&out_t[(blk * W) << TVM_RB_LOG], s[e * RS + tid]);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // The same two passes for an LDS-resident axis LONGER than a workgroup: 2^LOGN points on 2^TLOG work-items, i.e.
 // PPT = 2^(LOGN - TLOG) positions per work-item and tiles of 16 / PPT rows, so that a work-item still owns 16 elements and
 // the tile still holds 16 * 2^TLOG words (2048-point axes on 1024 work-items with 8-row tiles: traces of 2^21 and 2^22
 // rows, which the production kernels above -- one position per work-item -- cannot take; 4096-point axes with 4-row tiles:
 // 2^23 and 2^24 rows; <7, 6> and <8, 6> are the same shapes at sizes the CPU suite can run).  Element e of a work-item: row e % ROWS, position tid + (e / ROWS) * 2^TLOG.
+// Same results as the generic k_lde_pass2 / k_lde_pass3; what the tile ownership buys is that every index a work-item needs is
+// either its own constant or uniform across the workgroup, so the scale and store phases carry no per-element index arithmetic:
+//   * a work-item owns the same positions q of all rows of the tile across the coset loop: m1 = brev(q) is its constant,
+//     m2 = brev(p0 + row) is uniform, and only work-items with m1*n1 < h ever see a randomizer coefficient;
+//   * gamma_k^m / N = gamma_k^(n1*m1) * (gamma_k^m2 / N): the first factor is applied before the column step (a running product
+//     over the cosets, one multiplication per element), the second is a per-row constant, commutes with the column step and is
+//     merged into the inter-pass twiddle of the store phase, which itself is a running product  T(j1 + step) = T(j1) * w_N^(m2*step)
+//     instead of two table loads per element.
 template <int LOGN, int TLOG>
 __global__ void __launch_bounds__(1 << TLOG) k_lde_pass2_v3(LdePass2Args a) {
     constexpr int NT = 1 << TLOG, RLOG = 4 - (LOGN - TLOG), ROWS = 1 << RLOG, PPT = 16 / ROWS;
@@ -666,7 +510,7 @@ __global__ void __launch_bounds__(1 << TLOG) k_lde_pass2_v3(LdePass2Args a) {
     u64 coef[16];
 #pragma unroll
     for (int e = 0; e < 16; e++) coef[e] = s[(e & (ROWS - 1)) * RS + tid + (e >> RLOG) * NT];
-    // the forward twiddles (all n2 powers) behind the tile (see k_lde_pass2_v2); a 4096-point axis leaves no room: global
+    // the forward twiddles (all n2 powers) behind the tile; a 4096-point axis leaves no room: global
     const u64* tw_fwd = a.tw_b1;
     if constexpr (LOGN < 12) {
         u64* tw_lds = s + ROWS * RS;
@@ -684,7 +528,7 @@ __global__ void __launch_bounds__(1 << TLOG) k_lde_pass2_v3(LdePass2Args a) {
     }
     const u64* rnd = a.rnd + (u64)(v / a.fk) * a.h * a.fk + (v % a.fk);
     // h <= n1: only position 0 of each row (work-item 0's first ROWS coefficients) sees a randomizer -- parked in LDS, written
-    // into the tile by work-items 0 .. ROWS-1 in every coset (see k_lde_pass2_v2): no global load in the coset loop
+    // into the tile by work-items 0 .. ROWS-1 in every coset: no global load in the coset loop
     const bool single = a.h <= n1;
     u64* c0 = s + ROWS * RS + (LOGN < 12 ? n2 : 0);
     u64* r0 = c0 + 16;
@@ -889,7 +733,7 @@ __global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass1_rows(Ntt2Args a) {
     }
 }
 
-// Pass 2: as k_lde_pass2_v2 (a work-item owns the same positions of all rows of the tile across the coset loop), but both
+// Pass 2: as k_lde_pass2_v3 (a work-item owns the same positions of all rows of the tile across the coset loop), but both
 // LDS-resident transforms run one row per wavefront (ROWS wavefronts, ROWS rows): three workgroup barriers per coset -- around
 // the scale phase and before the store phase, where data changes wavefronts -- instead of six.
 //   ROWS = 16: 1024 work-items, one position each, 148 KB of LDS: ONE workgroup per CU -- every barrier drains the CU.
@@ -897,8 +741,10 @@ __global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass1_rows(Ntt2Args a) {
 //              the other's butterflies; the stores are 64-byte runs (8 adjacent rows) instead of full lines.
 //   LOGN = 11 (round 4): rows of 2048 points, 8 rows = 156 KB of LDS, ONE workgroup of 8 wavefronts per CU (two per SIMD: 256 VGPRs),
 //              32 elements per work-item across the coset loop.
-//   TABLE (round 4): the store phase's factor w_N^(m2 j1) gamma_k^m2 / N comes from a table (a.store_tw) instead of a running product.
-template <int LOGN, int ROWS, bool TABLE = false>
+//   (Measured and not kept, round 4: 16-row tiles at 1024 points -- one workgroup per CU, +1 %; 2048-point rows -- two wavefronts per
+//   SIMD, +13 % against k_lde_pass2_v3<11, 10>; the store phase's factor from a table instead of a running product -- 8 % fewer
+//   VALU instructions, the same time; DESIGN.md section 9, items 10 and 11.  The variants are in the history, not in the tree.)
+template <int LOGN, int ROWS>
 __global__ void __launch_bounds__(64 * ROWS, LOGN == 10 ? 4 : 2) k_lde_pass2_rows(LdePass2Args a) {
     constexpr int n2 = 1 << LOGN, ROWW = TVM_ROW_WORDS(n2), NT = 64 * ROWS, PPT = n2 / NT, RLOG = ROWS == 16 ? 4 : 3, EPT = n2 / 64;
     static_assert((LOGN == 10 || LOGN == 11) && (ROWS == 16 || ROWS == 8), "one wavefront per row of 1024 or 2048 points");
@@ -934,7 +780,7 @@ __global__ void __launch_bounds__(64 * ROWS, LOGN == 10 ? 4 : 2) k_lde_pass2_row
         has_rnd |= m1[hh] * n1 < a.h;
     }
     const u64* rnd = a.rnd + (u64)(v / a.fk) * a.h * a.fk + (v % a.fk);
-    const bool single = a.h <= n1;   // see k_lde_pass2_v2
+    const bool single = a.h <= n1;   // the randomizers only touch position 0 of each row (see k_lde_pass2_v3)
     u64* c0 = tw_fwd + n2;
     u64* r0 = c0 + 16;
     if (single) {
@@ -950,12 +796,9 @@ __global__ void __launch_bounds__(64 * ROWS, LOGN == 10 ? 4 : 2) k_lde_pass2_row
     const int b_out = tid & (ROWS - 1), j1_0 = tid >> RLOG;
     const u64 m2_out = brev_bits((u32)(p0 + b_out), a.log_n1);
     constexpr int j1_step = NT >> RLOG;   // 64
-    u64 t_step = 0, t_first = 0, gl_step = 0;
-    if constexpr (!TABLE) {
-        t_step = pow2_get(a.tw_inter, (m2_out * (u64)j1_step) & (n - 1));
-        t_first = bfe_mul(pow2_get(a.tw_inter, m2_out * (u64)j1_0), a.g_lo[m2_out]);
-        gl_step = a.g_lo_step[m2_out];
-    }
+    const u64 t_step = pow2_get(a.tw_inter, (m2_out * (u64)j1_step) & (n - 1));
+    u64 t_first = bfe_mul(pow2_get(a.tw_inter, m2_out * (u64)j1_0), a.g_lo[m2_out]);
+    const u64 gl_step = a.g_lo_step[m2_out];
     for (int k = 0; k < a.n_cosets; k++) {
         tvm_lds_barrier();   // the store phase of the previous coset has read the tile
         if (single) {
@@ -980,20 +823,6 @@ __global__ void __launch_bounds__(64 * ROWS, LOGN == 10 ? 4 : 2) k_lde_pass2_row
         row_ntt<true, TVM_P2_MAXK, LOGN, 1>(s + w * ROWW, tw_fwd, lane);   // forward columns step of row w
         tvm_lds_barrier();
         u64* z = a.z + ((u64)vl * a.n_cosets + k) * n + p0 + b_out;
-        if constexpr (TABLE) {
-            // the factors from the table (shared by every column of the chunk: L2 / Infinity Cache hits after the first column),
-            // one coalesced load instead of the running product's multiplication
-            const u64* tq = a.store_tw + (((u64)k * gridDim.x + blockIdx.x) * EPT) * NT + tid;
-            // Measured in round 4 (profiles/r04_g_*, r04_h_*): 4.51 ms per 96-column chunk against 4.56-4.63 with the running product --
-            // the multiplication it removes (8 % of the kernel's VALU instructions) buys nothing, so pass 2 is not bound by its
-            // instruction count alone; with the loads batched ahead of the multiplications (4, 8 or 16 in flight) it is 15 % SLOWER
-            // (main table 36.4 against 31.5 ms).  Off by default (TVM_LDE_STORE_TABLE=1 selects it).
-#pragma unroll 4
-            for (int i = 0; i < EPT; i++) {
-                const int j1 = j1_0 + i * j1_step;
-                TVM_STORE_STREAM(&z[(u64)j1 * n1], bfe_mul(s[b_out * ROWW + TVM_ROW_SKEW(j1)], tq[(u64)i * NT]));
-            }
-        } else {
         u64 t = t_first;
 #pragma unroll 4
         for (int i = 0; i < EPT; i++) {
@@ -1001,10 +830,9 @@ __global__ void __launch_bounds__(64 * ROWS, LOGN == 10 ? 4 : 2) k_lde_pass2_row
             TVM_STORE_STREAM(&z[(u64)j1 * n1], bfe_mul(s[b_out * ROWW + TVM_ROW_SKEW(j1)], t));
             t = bfe_mul(t, t_step);
         }
-        }
 #pragma unroll
         for (int hh = 0; hh < PPT; hh++) gh[hh] = bfe_mul(gh[hh], gh_step[hh]);
-        if constexpr (!TABLE) t_first = bfe_mul(t_first, gl_step);
+        t_first = bfe_mul(t_first, gl_step);
     }
 }
 
@@ -1103,6 +931,21 @@ void pool_trim(tvm_ctx* c) {
     c->pool_free.clear();
 }
 
+// what a pool_alloc could still obtain: the device's free memory plus this context's cached blocks, capped by the limit
+size_t pool_available(tvm_ctx* c, size_t* device_total) {
+    size_t free_b = 0, total_b = 0;
+    if (!bind_device(c) || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+    size_t cached = 0;
+    for (const auto& kv : c->pool_free) cached += kv.first;
+    size_t avail = free_b + cached;
+    if (c->pool_limit) {
+        const size_t live = c->pool_bytes - cached;
+        avail = live >= c->pool_limit ? 0 : (avail < c->pool_limit - live ? avail : c->pool_limit - live);
+    }
+    if (device_total) *device_total = total_b;
+    return avail;
+}
+
 int set_error(tvm_ctx* c, int code, const char* what) {
     if (c) c->last_error = what;
     return code;
@@ -1135,37 +978,15 @@ static void set_lds_attributes() {
     (void)hipFuncSetAttribute((const void*)k_ntt2_pass2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    (void)hipFuncSetAttribute((const void*)k_lde_pass2_v2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    (void)hipFuncSetAttribute((const void*)k_lde_pass3_v2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    (void)hipFuncSetAttribute((const void*)k_lde_pass3_v3<10, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    (void)hipFuncSetAttribute((const void*)k_lde_pass3_v3<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<10, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<10, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    (void)hipFuncSetAttribute((const void*)k_lde_pass2_rows<10, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    (void)hipFuncSetAttribute((const void*)k_lde_pass2_rows<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    (void)hipFuncSetAttribute((const void*)k_lde_pass2_rows<11, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    (void)hipFuncSetAttribute((const void*)k_lde_pass2_rows<10, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<11, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass1_rows<10, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    (void)hipFuncSetAttribute((const void*)k_lde_pass1_rows<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass2_rows<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<11, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_v3<11, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    (void)hipFuncSetAttribute((const void*)k_lde_pass3_v3<11, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_v3<12, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_v3<12, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
 }
 
-// st[((k * tiles + tile) * 16 + i) * 512 + tid] = w_N^(m2 j1) * g_lo[k][m2] with m2 = brev(8 tile + tid % 8), j1 = tid / 8 + 64 i:
-// the factor the store phase of k_lde_pass2_rows<10, 8> applies to element (row tid % 8, position j1) of tile `tile` on coset k,
-// in the order its work-items read it (one 4 KB run per (k, tile, i))
-__global__ void k_lde_store_table(Pow2 tw_inter, const u64* __restrict__ g_lo, int log_n1, int log_n, u64 X, u64* __restrict__ out) {
-    const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u64 n1 = 1ull << log_n1, tiles = n1 >> 3;
-    if (e >= X * tiles * 16 * 512) return;
-    const u64 tid = e & 511, i = (e >> 9) & 15, tile = (e >> 13) % tiles, k = (e >> 13) / tiles;
-    const u64 m2 = brev_bits((u32)(tile * 8 + (tid & 7)), log_n1), j1 = (tid >> 3) + 64 * i;
-    out[e] = bfe_mul(pow2_get(tw_inter, (m2 * j1) & ((1ull << log_n) - 1)), g_lo[k * n1 + m2]);
-}
 // lo[k][i] = scale * gamma_k^i (i < n1), hi[k][i] = gamma_k^(n1*i) (i < n2), gamma_k = offset * gen^k
 __global__ void k_coset_tables(u64 offset, u64 gen, u64 X, u64 n1, u64 n2, u64 scale, u64* lo, u64* hi) {
     const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1315,11 +1136,15 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     const Split sp = split_for(N);
     const u64 n1 = 1ull << sp.log_n1, n2 = 1ull << sp.log_n2;
     const int W = (int)(n_cols * fk);
-    // columns per chunk: 96 while the chunk's intermediate (96 * L words) stays below 32 GiB, else 32.  Measured at 2^20 rows
-    // (main table, with 8 row tiles per pass-3 workgroup): 16 -> 48.0 ms, 32 -> 47.0, 96 -> 45.6, 192 -> 45.5, 379 -> 45.1; at 2^22
-    // rows (intermediate 25.8 GB; round 4, whole proof): 32 -> 836.9 ms, 64 -> 821.8, 96 -> 820.6; at 2^21 rows 398.1 -> 392.0
-    if (chunk_cols <= 0) chunk_cols = ((size_t)96 * X * n_rows * sizeof(u64) <= ((size_t)32 << 30)) ? 96 : 32;
-    if (std::getenv("TVM_LDE_CHUNK") && std::atoi(std::getenv("TVM_LDE_CHUNK")) > 0) chunk_cols = std::atoi(std::getenv("TVM_LDE_CHUNK"));  // experiment knob
+    // columns per chunk: 96 while the chunk's intermediates (96 * (1 + X) * N words, from the pool: they count against the
+    // context's memory limit) stay below 32 GiB AND below a third of what the context can still obtain, else 32.  Measured at 2^20
+    // rows (main table, with 8 row tiles per pass-3 workgroup): 16 -> 48.0 ms, 32 -> 47.0, 96 -> 45.6, 192 -> 45.5, 379 -> 45.1; at 2^22
+    // rows (intermediate 25.8 GB; round 4, whole proof): 32 -> 836.9 ms, 64 -> 821.8, 96 -> 820.6; at 2^21 rows 398.1 -> 392.0 --
+    // 2 % that are not worth the coset-wise fallback on a device (or under a limit) that 25.8 GB push over the edge.
+    // c->lde_chunk_columns (TVM_OPTION_LDE_CHUNK_COLUMNS) overrides.
+    const auto intermediates = [&](int cols) { return (size_t)cols * (1 + X) * n_rows * sizeof(u64); };
+    if (chunk_cols <= 0) chunk_cols = c->lde_chunk_columns;
+    if (chunk_cols <= 0) chunk_cols = (intermediates(96) <= ((size_t)36 << 30) && intermediates(96) <= pool_available(c, nullptr) / 3) ? 96 : 32;
 
     const u64 w = trace_gen, wi = bfe_inv(trace_gen);
     const u64 n_inv = bfe_inv(bfe_from_u64(N));
@@ -1343,7 +1168,6 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     p1.out_add = 0;
     p1.col0 = 0;
     const bool std_roots = classify_root(w, N) == 1;  // every ArithmeticDomain's generator is; any other root takes the generic kernels
-    static const bool lde_rows = !(std::getenv("TVM_LDE_ROWS") && std::atoi(std::getenv("TVM_LDE_ROWS")) == 0);  // experiment knob
     p1.root = std_roots ? 2 : 0;
 
     LdePass2Args p2;
@@ -1361,21 +1185,6 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     TVM_TRY(coset_tables(c, eval_offset, eval_gen, X, n1, n2, n_inv, &p2.g_lo, &p2.g_hi));
     p2.g_lo_step = pow_table(c, eval_gen, n1);
     p2.g_hi_step = pow_table(c, bfe_pow(eval_gen, n1), n2);
-    p2.store_tw = nullptr;
-    static const bool store_table = std::getenv("TVM_LDE_STORE_TABLE") && std::atoi(std::getenv("TVM_LDE_STORE_TABLE")) != 0;  // experiment knob
-    if (store_table && sp.log_n2 == 10 && n1 % 8 == 0 && X * N * sizeof(u64) <= ((size_t)256 << 20)) {
-        // X * N words (64 MB at 2^20 rows, expansion 8), cached per context like the other tables of a domain
-        auto key = std::make_tuple(eval_offset ^ 0x57AB1E57AB1Eull, eval_gen, (X << 56) | (n1 << 28) | n2);
-        auto it = c->tables.find(key);
-        u64* d = nullptr;
-        if (it != c->tables.end()) {
-            d = it->second;
-        } else if (hipMalloc((void**)&d, X * N * sizeof(u64)) == hipSuccess) {
-            TVM_LAUNCH(k_lde_store_table, dim3((unsigned)((X * N + 255) / 256)), dim3(256), 0, c->stream, p2.tw_inter, p2.g_lo, sp.log_n1, sp.log_n, X, d);
-            c->tables[key] = d;
-        }
-        p2.store_tw = d;
-    }
     const u64 n_mont = bfe_from_u64(N);
     for (u64 k = 0; k < X; k++) {
         const u64 gamma = bfe_mul(eval_offset, bfe_pow(eval_gen, k));
@@ -1396,9 +1205,18 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     if (!p1.tw1 || !p2.tw_a2 || !p2.tw_b1 || !p2.g_lo || !p2.g_hi || !p2.g_lo_step || !p2.g_hi_step || !p3.tw_b2)
         return set_error(c, TVM_ERR_OUT_OF_MEMORY, "lde tables");
 
-    u64* y = (u64*)scratch(c, 1, (size_t)chunk_cols * N * sizeof(u64));
-    u64* z = (u64*)scratch(c, 2, (size_t)chunk_cols * X * N * sizeof(u64));
-    if (!y || !z) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "lde scratch");
+    // the intermediates of one chunk: Y (pass 1 -> pass 2) and Z (pass 2 -> pass 3), pool blocks (the next call of the same
+    // shape gets the same blocks back from the cache, in stream order)
+    PoolBlock y_block(c), z_block(c);
+    u64* y = (u64*)y_block.alloc((size_t)chunk_cols * N * sizeof(u64));
+    u64* z = y ? (u64*)z_block.alloc((size_t)chunk_cols * X * N * sizeof(u64)) : nullptr;
+    if ((!y || !z) && chunk_cols > 32) {   // the wide chunk does not fit: the narrow one before giving up
+        chunk_cols = 32;
+        z_block.alloc(0);
+        y = (u64*)y_block.alloc((size_t)chunk_cols * N * sizeof(u64));
+        z = y ? (u64*)z_block.alloc((size_t)chunk_cols * X * N * sizeof(u64)) : nullptr;
+    }
+    if (!y || !z) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "lde intermediates");
     p1.tmp = y;
     p2.y = y;
     p2.z = z;
@@ -1412,15 +1230,11 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             const int B = 1 << a.batch_log;
             const int tile = (int)n1 << a.batch_log;
             dim3 grid((unsigned)((n2 + B - 1) / B), (unsigned)nc);
-            if (std_roots && lde_rows && sp.log_n1 == 10 && n2 % 16 == 0) {   // 1024-point axis: one row per wavefront
-                // 16-row tiles: 128-byte runs of the input.  8-row tiles (two workgroups per CU, see k_lde_pass2_rows) measured the
-                // same time and fetch every input line twice (16 instead of 8 B per cell, profiles/r03_q_pmc_lde.txt).
-                static const int p1_tile = std::getenv("TVM_LDE_PASS1_TILE") ? std::atoi(std::getenv("TVM_LDE_PASS1_TILE")) : 16;  // experiment knob
-                const u64 rows_r = p1_tile == 8 ? 8 : 16;
-                const size_t lds_r = (size_t)(rows_r * TVM_ROW_WORDS(n1) + n1) * sizeof(u64);
-                const dim3 g1r((unsigned)(n2 / rows_r), (unsigned)nc);
-                if (rows_r == 16) TVM_LAUNCH((k_lde_pass1_rows<10, 16>), g1r, dim3(1024), lds_r, c->stream, a);
-                else TVM_LAUNCH((k_lde_pass1_rows<10, 8>), g1r, dim3(512), lds_r, c->stream, a);
+            if (std_roots && sp.log_n1 == 10 && n2 % 16 == 0) {   // 1024-point axis: one row per wavefront
+                // 16-row tiles: 128-byte runs of the input.  (8-row tiles -- two workgroups per CU -- measured the same time and
+                // fetch every input line twice: 16 instead of 8 B per cell, profiles/r03_q_pmc_lde.txt.)
+                const size_t lds_r = (size_t)(16 * TVM_ROW_WORDS(n1) + n1) * sizeof(u64);
+                TVM_LAUNCH((k_lde_pass1_rows<10, 16>), dim3((unsigned)(n2 / 16), (unsigned)nc), dim3(1024), lds_r, c->stream, a);
             } else
                 TVM_LAUNCH(k_ntt2_pass1, grid, dim3(threads_for_tile(tile)), (size_t)tile * sizeof(u64), c->stream, a);
         }
@@ -1437,34 +1251,17 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             const u64 rows3 = 16 >> ppt_log;
             const size_t lds_v3 = (size_t)(rows3 * (n2 + TVM_ROW_PAD) + (sp.log_n2 < 12 ? n2 : 0) + 32) * sizeof(u64);
             const dim3 g2((unsigned)(n1 / rows3), (unsigned)nc);
-            // 2048-point rows, one per wavefront (k_lde_pass2_rows<11, 8>): OFF by default.  Measured in round 4 (profiles/r04_f_*): 8 rows
-            // fill a CU's LDS, so two wavefronts per SIMD instead of the tile kernel's four, and the carry chains of a field
-            // multiplication issue at 60-78 % of the rate with two: 24.5 ms per 96-column chunk at 2^22 rows against
-            // 21.6 ms for k_lde_pass2_v3<11, 10>; whole proof 2^21 rows 409.5 vs 397.9 ms, 2^22 rows 855.8 vs 840.2 (passes 2 and 3).
-            static const bool rows11 = std::getenv("TVM_LDE_ROWS11_PASS2") && std::atoi(std::getenv("TVM_LDE_ROWS11_PASS2")) != 0;  // experiment knob
-            if (std_roots && lde_rows && rows11 && sp.log_n2 == 11 && n1 % 8 == 0) {
-                // 2048-point axis (2^21 and 2^22 rows): one row per wavefront, 8 rows per workgroup (k_lde_pass2_rows<11, 8>)
-                const size_t lds_r = (size_t)(8 * TVM_ROW_WORDS(n2) + n2 + 32) * sizeof(u64);
-                TVM_LAUNCH((k_lde_pass2_rows<11, 8>), dim3((unsigned)(n1 / 8), (unsigned)nc), dim3(512), lds_r, c->stream, a);
-            } else
             if (std_roots && ppt_log && n1 % rows3 == 0) {
                 if (sp.log_n2 == 11) TVM_LAUNCH((k_lde_pass2_v3<11, 10>), g2, dim3(1024), lds_v3, c->stream, a);
                 else if (sp.log_n2 == 12) TVM_LAUNCH((k_lde_pass2_v3<12, 10>), g2, dim3(1024), lds_v3, c->stream, a);
                 else if (sp.log_n2 == 7) TVM_LAUNCH((k_lde_pass2_v3<7, 6>), g2, dim3(64), lds_v3, c->stream, a);
                 else TVM_LAUNCH((k_lde_pass2_v3<8, 6>), g2, dim3(64), lds_v3, c->stream, a);
             }
-            else if (std_roots && lde_rows && sp.log_n2 == 10 && n1 % 16 == 0) {
-                // 1024-point axis: one row per wavefront inside the LDS-resident transforms (k_lde_pass2_rows)
-                static const int p2_tile = std::getenv("TVM_LDE_PASS2_TILE") ? std::atoi(std::getenv("TVM_LDE_PASS2_TILE")) : 8;  // experiment knob
-                const u64 rows_r = p2_tile == 16 ? 16 : 8;
-                const size_t lds_r = (size_t)(rows_r * TVM_ROW_WORDS(n2) + n2 + 32) * sizeof(u64);
-                const dim3 g2r((unsigned)(n1 / rows_r), (unsigned)nc);
-                if (rows_r == 16) TVM_LAUNCH((k_lde_pass2_rows<10, 16>), g2r, dim3(1024), lds_r, c->stream, a);
-                else if (a.store_tw) TVM_LAUNCH((k_lde_pass2_rows<10, 8, true>), g2r, dim3(512), lds_r, c->stream, a);
-                else TVM_LAUNCH((k_lde_pass2_rows<10, 8>), g2r, dim3(512), lds_r, c->stream, a);
+            else if (std_roots && sp.log_n2 == 10 && n1 % 16 == 0) {
+                // 1024-point axis: one row per wavefront inside the LDS-resident transforms, 8-row tiles (k_lde_pass2_rows)
+                const size_t lds_r = (size_t)(8 * TVM_ROW_WORDS(n2) + n2 + 32) * sizeof(u64);
+                TVM_LAUNCH((k_lde_pass2_rows<10, 8>), dim3((unsigned)(n1 / 8), (unsigned)nc), dim3(512), lds_r, c->stream, a);
             }
-            else if (std_roots && a.batch_log == 4 && n2 >= 64 && n1 >= 16)  // production shape: one work-item per column of the tile
-                TVM_LAUNCH(k_lde_pass2_v2, grid, dim3((unsigned)n2), lds + (n2 + 32) * sizeof(u64), c->stream, a);
             else
                 TVM_LAUNCH(k_lde_pass2, grid, dim3(threads_for_tile(tile)), lds, c->stream, a);
         }
@@ -1478,65 +1275,28 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             const size_t lds = ((size_t)(n1 + TVM_ROW_PAD) << a.rows_log) * sizeof(u64);
             const int ppt_log = (sp.log_n1 == 11 || sp.log_n1 == 7) ? 1 : (sp.log_n1 == 12 || sp.log_n1 == 8) ? 2 : 0;
             const u64 rows3 = 16 >> ppt_log, tiles3 = X * n2 / rows3;  // see pass 2
-            static const int p3_rows = std::getenv("TVM_LDE_PASS3_ROWS") ? std::atoi(std::getenv("TVM_LDE_PASS3_ROWS")) : 8;  // experiment knob
             // (pass 3 has no coset loop and no workgroup barrier: here the 2048-point row form is 8 % faster than k_lde_pass3_v3<11, 10>,
             // 15.5 against 16.8 ms per 96 columns at 2^22 rows, even at two wavefronts per SIMD)
-            static const bool rows11_p3 = !(std::getenv("TVM_LDE_ROWS11") && std::atoi(std::getenv("TVM_LDE_ROWS11")) == 0);  // experiment knob
-            if (std_roots && lde_rows && rows11_p3 && sp.log_n1 == 11 && (X * n2) % 8 == 0) {
-                // 2048-point axis (2^22 rows): one (k, j1) row per wavefront, 8 wavefronts = one workgroup per CU (k_lde_pass3_rows<11, 8>)
+            if (std_roots && (sp.log_n1 == 10 || sp.log_n1 == 11) && (X * n2) % 8 == 0) {
+                // 1024- / 2048-point axis: one (k, j1) row per wavefront, no workgroup barrier (k_lde_pass3_rows): 8 wavefronts per
+                // workgroup -- 78 KB of LDS, two workgroups per CU at 1024 points (4 wavefronts per workgroup: +2 %, 16: +3 %,
+                // profiles/r03_g_lde_ab.txt); one workgroup per CU at 2048
                 const u64 tiles_w = X * n2 / 8;
                 a.tiles = tiles_w % 16 == 0 ? 16 : tiles_w % 8 == 0 ? 8 : tiles_w % 4 == 0 ? 4 : 1;
                 if (tiles_w / a.tiles >= 65536) return set_error(c, TVM_ERR_UNSUPPORTED, "lde: too many row tiles");
                 const size_t lds_w = (size_t)(8 * TVM_ROW_WORDS(n1) + n1) * sizeof(u64);
-                TVM_LAUNCH((k_lde_pass3_rows<11, 8>), dim3((unsigned)nc, (unsigned)(tiles_w / a.tiles)), dim3(512), lds_w, c->stream, a);
-            } else
-            if (std_roots && lde_rows && sp.log_n1 == 10 && (X * n2) % 8 == 0) {
-                // 1024-point axis: one (k, j1) row per wavefront, no workgroup barrier (k_lde_pass3_rows): 8 wavefronts per
-                // workgroup, 78 KB of LDS -- two workgroups per CU
-                static const int p3_waves = std::getenv("TVM_LDE_PASS3_WAVES") ? std::atoi(std::getenv("TVM_LDE_PASS3_WAVES")) : 8;  // experiment knob
-                const u64 waves = (p3_waves == 4 || p3_waves == 16) && (X * n2) % (u64)p3_waves == 0 ? (u64)p3_waves : 8;
-                const u64 tiles_w = X * n2 / waves;
-                a.tiles = tiles_w % 16 == 0 ? 16 : tiles_w % 8 == 0 ? 8 : tiles_w % 4 == 0 ? 4 : 1;
-                if (tiles_w / a.tiles >= 65536) return set_error(c, TVM_ERR_UNSUPPORTED, "lde: too many row tiles");
-                const size_t lds_w = (size_t)(waves * TVM_ROW_WORDS(n1) + n1) * sizeof(u64);
                 const dim3 g3((unsigned)nc, (unsigned)(tiles_w / a.tiles));
-                if (waves == 4) TVM_LAUNCH((k_lde_pass3_rows<10, 4>), g3, dim3(256), lds_w, c->stream, a);
-                else if (waves == 16) TVM_LAUNCH((k_lde_pass3_rows<10, 16>), g3, dim3(1024), lds_w, c->stream, a);
+                if (sp.log_n1 == 11) TVM_LAUNCH((k_lde_pass3_rows<11, 8>), g3, dim3(512), lds_w, c->stream, a);
                 else TVM_LAUNCH((k_lde_pass3_rows<10, 8>), g3, dim3(512), lds_w, c->stream, a);
-            } else
-            if (std_roots && sp.log_n1 == 10 && p3_rows == 4 && (X * n2) % 16 == 0) {
-                // 4-row tiles on 256 work-items, 37 KB of LDS: FOUR workgroups per CU.  Every row of a tile owns 1024 consecutive
-                // storage rows of the table (context.h), so the stores are full lines whatever the tile height.
-                const u64 tiles_q = X * n2 / 4;
-                a.tiles = tiles_q % 32 == 0 ? 32 : tiles_q % 8 == 0 ? 8 : 1;
-                if (tiles_q / a.tiles >= 65536) return set_error(c, TVM_ERR_UNSUPPORTED, "lde: too many row tiles");
-                const dim3 g3((unsigned)nc, (unsigned)(tiles_q / a.tiles));
-                const size_t lds_q = (size_t)(4 * (n1 + TVM_ROW_PAD) + n1) * sizeof(u64);
-                TVM_LAUNCH((k_lde_pass3_v3<10, 8>), g3, dim3(256), lds_q, c->stream, a);
-            } else
-            if (std_roots && sp.log_n1 == 10 && (X * n2) % 16 == 0 && X * n2 / 8 < 65536) {
-                // 1024-point axis (2^19 and 2^20 rows): 8-row tiles on 512 work-items, 70 KB of LDS -- TWO workgroups per CU, so
-                // that one's loads and stores run under the other's butterflies.  Pass 3 is the sum of ~9 ms of arithmetic
-                // and ~9 ms of memory time per 379 columns with one resident workgroup; main table 44.8 -> 42.8 ms
-                // (tiles per workgroup: 8 -> 43.1 ms, 16 -> 42.8 ms).  The 64-byte store runs of an 8-row tile pair up in L2.
-                const u64 tiles_h = X * n2 / 8;
-                a.tiles = tiles_h % 16 == 0 ? 16 : tiles_h % 8 == 0 ? 8 : tiles_h % 4 == 0 ? 4 : 1;
-                const dim3 g3((unsigned)nc, (unsigned)(tiles_h / a.tiles));
-                const size_t lds_h = (size_t)(8 * (n1 + TVM_ROW_PAD) + n1) * sizeof(u64);
-                TVM_LAUNCH((k_lde_pass3_v3<10, 9>), g3, dim3(512), lds_h, c->stream, a);
             } else
             if (std_roots && ppt_log && (X * n2) % 16 == 0) {
                 a.tiles = tiles3 % 8 == 0 ? 8 : tiles3 % 4 == 0 ? 4 : 1;
                 const dim3 g3((unsigned)nc, (unsigned)(tiles3 / a.tiles));
                 const size_t lds_v3 = (size_t)(rows3 * (n1 + TVM_ROW_PAD) + (sp.log_n1 < 12 ? n1 : 0)) * sizeof(u64);
                 if (g3.y >= 65536) return set_error(c, TVM_ERR_UNSUPPORTED, "lde: too many row tiles");
-                if (sp.log_n1 == 11) TVM_LAUNCH((k_lde_pass3_v3<11, 10>), g3, dim3(1024), lds_v3, c->stream, a);
-                else if (sp.log_n1 == 12) TVM_LAUNCH((k_lde_pass3_v3<12, 10>), g3, dim3(1024), lds_v3, c->stream, a);
+                if (sp.log_n1 == 12) TVM_LAUNCH((k_lde_pass3_v3<12, 10>), g3, dim3(1024), lds_v3, c->stream, a);
                 else if (sp.log_n1 == 7) TVM_LAUNCH((k_lde_pass3_v3<7, 6>), g3, dim3(64), lds_v3, c->stream, a);
                 else TVM_LAUNCH((k_lde_pass3_v3<8, 6>), g3, dim3(64), lds_v3, c->stream, a);
-            } else if (std_roots && a.rows_log == 4 && n1 >= 64 && (X * n2) % 16 == 0 && X * n2 / 16 < 65536) {
-                a.tiles = grid.x % 8 == 0 ? 8 : grid.x % 4 == 0 ? 4 : 1;  // 1 -> 49.2 ms, 2 -> 47.5, 4 -> 47.0, 8 -> 46.3 (2^20 rows)
-                TVM_LAUNCH(k_lde_pass3_v2, dim3(grid.y, grid.x / a.tiles), dim3((unsigned)n1), lds + n1 * sizeof(u64), c->stream, a);
             }
             else
                 TVM_LAUNCH(k_lde_pass3, grid, dim3(threads_for_tile(tile)), lds, c->stream, a);

@@ -10,7 +10,6 @@
 //
 // XFieldElement vectors are arrays of 3-word elements (c0,c1,c2), exactly the reference's layout.
 // All of these are streaming kernels: one pass over their operands, HBM bound.
-#include <cstdlib>
 
 #include "air_eval.h"   // AirAcc: sums of products with one reduction per coefficient at the end
 #include "context.h"
@@ -461,9 +460,7 @@ int out_of_domain_rows(tvm_ctx* c, int fk, const u64* trace, u64 n, u64 n_cols, 
     // rows in chunks of 2^15 (128 rows per work-item), columns in groups of G (2 columns: the accumulators' registers and the
     // wavefronts per SIMD they leave), points two at a time (2^13 for narrow tables so that the grid still fills the chip)
     // (measured at 2^20 rows, both points, main + aux: 4 / 2 columns per workgroup 4.58 ms, 2 / 2 4.07 ms)
-    static const int dot_g = std::getenv("TVM_DOT_G") ? std::atoi(std::getenv("TVM_DOT_G")) : 2;    // experiment knobs
-    static const int dot_gx = std::getenv("TVM_DOT_GX") ? std::atoi(std::getenv("TVM_DOT_GX")) : 1;
-    const u64 G = fk == 1 ? (dot_g == 4 ? 4 : 2) : (dot_gx == 2 ? 2 : 1);
+    const u64 G = fk == 1 ? 2 : 1;   // (4 main / 2 aux columns per workgroup: 4.58 against 4.07 ms, round 4)
     const u64 chunk_log = (n_cols + 1 + G - 1) / G >= 64 ? 15 : 13;
     const u64 rows_per_chunk = n < (1ull << chunk_log) ? n : (1ull << chunk_log);
     const u64 n_chunks = (n + rows_per_chunk - 1) / rows_per_chunk;
@@ -472,10 +469,8 @@ int out_of_domain_rows(tvm_ctx* c, int fk, const u64* trace, u64 n, u64 n_cols, 
     if (!partial) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "ood scratch");
     const dim3 grid((unsigned)((n_cols + 1 + G - 1) / G), (unsigned)n_chunks);
     for (int p0 = 0; p0 < n_points; p0 += TVM_DOT_P) {
-        if (fk == 1 && G == 2) TVM_LAUNCH((k_column_dot<1, 2>), grid, dim3(TVM_RED_BLOCK), 0, c->stream, trace, n, n_cols, u, p0, n_points, rows_per_chunk, n_chunks, partial);
-        else if (fk == 1) TVM_LAUNCH((k_column_dot<1, 4>), grid, dim3(TVM_RED_BLOCK), 0, c->stream, trace, n, n_cols, u, p0, n_points, rows_per_chunk, n_chunks, partial);
-        else if (G == 1) TVM_LAUNCH((k_column_dot<3, 1>), grid, dim3(TVM_RED_BLOCK), 0, c->stream, trace, n, n_cols, u, p0, n_points, rows_per_chunk, n_chunks, partial);
-        else TVM_LAUNCH((k_column_dot<3, 2>), grid, dim3(TVM_RED_BLOCK), 0, c->stream, trace, n, n_cols, u, p0, n_points, rows_per_chunk, n_chunks, partial);
+        if (fk == 1) TVM_LAUNCH((k_column_dot<1, 2>), grid, dim3(TVM_RED_BLOCK), 0, c->stream, trace, n, n_cols, u, p0, n_points, rows_per_chunk, n_chunks, partial);
+        else TVM_LAUNCH((k_column_dot<3, 1>), grid, dim3(TVM_RED_BLOCK), 0, c->stream, trace, n, n_cols, u, p0, n_points, rows_per_chunk, n_chunks, partial);
     }
     TVM_LAUNCH(k_sum_partials, dim3((unsigned)n_sums), dim3(TVM_RED_BLOCK), 0, c->stream, partial, n_chunks, num);
     TVM_LAUNCH(k_ood_finalize, dim3((unsigned)(n_cols * n_points)), dim3(64), 0, c->stream, num, rnd, fk, n, n_cols, h,

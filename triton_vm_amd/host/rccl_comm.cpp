@@ -32,12 +32,14 @@ int32_t fail(const char* what, ncclResult_t r) {
 
 int32_t rccl_all_gather(void* self, tvm_ctx* ctx, const uint64_t* d_send, uint64_t* d_recv, uint64_t words) {
     auto* c = (RcclComm*)self;
+    if (!c->comm) return fail("ncclAllGather on an aborted communicator", ncclInvalidUsage);
     const ncclResult_t r = ncclAllGather(d_send, d_recv, words, ncclUint64, c->comm, (hipStream_t)tvm_ctx_stream(ctx));
     return r == ncclSuccess ? TVM_OK : fail("ncclAllGather", r);
 }
 
 int32_t rccl_all_to_all(void* self, tvm_ctx* ctx, const uint64_t* d_send, uint64_t* d_recv, uint64_t words) {
     auto* c = (RcclComm*)self;
+    if (!c->comm) return fail("all-to-all on an aborted communicator", ncclInvalidUsage);
     hipStream_t stream = (hipStream_t)tvm_ctx_stream(ctx);
     ncclResult_t r = ncclGroupStart();
     for (uint32_t peer = 0; peer < c->vt.world && r == ncclSuccess; peer++) {
@@ -47,6 +49,15 @@ int32_t rccl_all_to_all(void* self, tvm_ctx* ctx, const uint64_t* d_send, uint64
     const ncclResult_t e = ncclGroupEnd();
     if (r == ncclSuccess) r = e;
     return r == ncclSuccess ? TVM_OK : fail("all-to-all (ncclSend / ncclRecv group)", r);
+}
+
+// tvmh_comm::abort: this rank failed in the middle of a proof.  Its queued collectives are cancelled and the communicator is
+// torn down without waiting for the peers (ncclCommDestroy would wait for them); the peers' pending collectives never complete,
+// which their launcher resolves the usual way -- this rank's process reports the error and the job is torn down.
+void rccl_abort(void* self) {
+    auto* c = (RcclComm*)self;
+    if (c->comm) (void)ncclCommAbort(c->comm);
+    c->comm = nullptr;
 }
 }  // namespace
 
@@ -78,7 +89,7 @@ extern "C" int32_t tvmh_rccl_comm_create(const uint8_t unique_id[128], uint32_t 
         return fail("ncclCommInitRank", r);
     }
     c->device = device;
-    c->vt = tvmh_comm{c, rank, world, rccl_all_gather, rccl_all_to_all, nullptr, nullptr, nullptr};
+    c->vt = tvmh_comm{c, rank, world, rccl_all_gather, rccl_all_to_all, nullptr, nullptr, nullptr, rccl_abort, nullptr};
     *out = &c->vt;
     return TVM_OK;
 }

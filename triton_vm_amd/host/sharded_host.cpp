@@ -834,13 +834,42 @@ struct CommSession {  // the communicator's begin / end hooks around one proof o
 };
 }  // namespace
 
+namespace {
+// The replicated trace-side tables of one proof, with a Context of their own: when the ranks of an in-process communicator share
+// them (tvmh_comm::share) the group keeps the object beyond the call that built it, and the buffers must not point at a
+// Context on that call's stack.
+struct SharedTables {
+    Context c;
+    ExecutionTables t;
+    SharedTables(tvm_ctx* raw, const StarkParameters& p, const tvm_aet& aet, const uint8_t seed[32], const std::function<void(const char*)>& lap)
+        : c(raw), t(c, p, aet, seed, lap) {}
+    static void drop(const void* self) { delete (const SharedTables*)self; }
+};
+
+// A conservative estimate of what one rank holds at the peak of a proof with `passes` passes (bytes): its traces, the cached
+// extension of its share of the rows (main, aux, quotient segments), the intermediates of one 96-column chunk of the table
+// extension, and the codewords / digests of the quotient and DEEP steps.
+u64 estimated_bytes(const StarkParameters& p, u64 world, u64 passes) {
+    const u64 n = p.trace.length, L = p.ldt.length, share = L / (world * passes), X = std::max<u64>(L / n / (world * passes), 1);
+    const u64 row_words = NUM_MAIN + 3 * NUM_AUX;
+    u64 words = row_words * n;                                   // the traces
+    words += (passes == 1 ? row_words + 15 : row_words) * share; // the cached extension (coset-wise passes keep one group at a time)
+    words += 96 * n * (1 + X);                                   // table extension: one chunk's intermediates
+    words += 5 * (L / world) * 3 + 3 * p.quotient.length * 4;    // leaf digests and their tree; quotient codeword, segments, combination
+    words += 10 * (L / world);                                   // the Merkle nodes over a rank's leaves (three trees, one at a time + tops)
+    // + a quarter and 48 MB for the pool's size classes (2 MB granules), the successor blocks of the tables and the small buffers:
+    // with a communicator an out-of-memory in the middle of a proof is fatal, one pass too many only costs time
+    return words * 10 + ((u64)48 << 20);
+}
+}  // namespace
+
 std::vector<u64> prove_execution_sharded(const Context& c, const StarkParameters& p, const tvmh_comm* comm, unsigned passes, const tvm_aet& aet,
                                          const Claim& claim, const uint8_t seed[32], bool profile, std::string* stats,
                                          u64 split_tree_min_leaves) {
     const u64 n = p.trace.length;
     const CommSession session(comm, c);
-    // TVMH_TRACE=1: host wall time of the phases of one proof on stderr (no stream synchronisation is added)
-    static const bool trace = std::getenv("TVMH_TRACE") != nullptr;
+    // TVMH_OPTION_TRACE: host wall time of the phases of one proof on stderr (no stream synchronisation is added)
+    const bool trace = tvmh_get_option(TVMH_OPTION_TRACE) != 0;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!trace) return;
@@ -848,16 +877,48 @@ std::vector<u64> prove_execution_sharded(const Context& c, const StarkParameters
         std::fprintf(stderr, "[tvmh sharded] %-32s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
+    const u64 world = comm ? comm->world : 1;
+    // in-process ranks may use ONE copy of the replicated tables (triton_host.hpp: tvmh_comm::share)
+    const bool shared = comm && comm->share && world > 1 && tvmh_get_option(TVMH_OPTION_SHARE_REPLICATED_TABLES);
+    auto rendezvous = [&](uint32_t op, const void* mine, const void** out) {
+        const int32_t status = comm->share(comm->self, c.raw(), op, mine, mine ? &SharedTables::drop : nullptr, out);
+        if (status != TVM_OK) throw Error(status, "the communicator's share hook failed (a rank left the proof)");
+    };
     auto attempt = [&](unsigned pass_count) {
         if (comm && comm->mark) comm->mark(comm->self, c.raw(), "trace tables (fill, pad, randomizers)");
         lap("entry");
-        const ExecutionTables t(c, p, aet, seed, [&](const char* what) { lap(what); });
-        ShardedProver prover(c, p, comm, pass_count, t.main_trace.ptr(), t.main_rnd.ptr(), t.aux_trace.ptr(), t.aux_rnd.ptr(),
-                             t.quotient_randomizer, claim);
+        std::unique_ptr<SharedTables> own;
+        const ExecutionTables* t = nullptr;
+        if (shared) {
+            // every rank has left the previous proof -> rank 0 drops that proof's tables, builds this one's and hands them over
+            rendezvous(TVMH_SHARE_RELEASE, nullptr, nullptr);
+            const void* obj = nullptr;
+            if (comm->rank == 0) {
+                own.reset(new SharedTables(c.raw(), p, aet, seed, [&](const char* what) { lap(what); }));
+                c.check(tvm_sync(c.raw()), "tvm_sync");   // the other ranks read the tables on their own streams
+                rendezvous(TVMH_SHARE_PUBLISH, own.get(), &obj);
+                own.release();                            // the group keeps it
+            } else {
+                rendezvous(TVMH_SHARE_PUBLISH, nullptr, &obj);
+            }
+            t = &((const SharedTables*)obj)->t;
+        } else {
+            own.reset(new SharedTables(c.raw(), p, aet, seed, [&](const char* what) { lap(what); }));
+            t = &own->t;
+        }
+        ShardedProver prover(c, p, comm, pass_count, t->main_trace.ptr(), t->main_rnd.ptr(), t->aux_trace.ptr(), t->aux_rnd.ptr(),
+                             t->quotient_randomizer, claim);
         prover.assume_valid_trace = !tvmh_get_option(TVMH_OPTION_EXACT_AIR);
         prover.profile = profile;
         prover.split_tree_min_leaves = split_tree_min_leaves;
-        prover.extend = [&](const std::vector<Xfe>& challenges) { t.extend(c, n, challenges); };
+        prover.extend = [&](const std::vector<Xfe>& challenges) {
+            if (!shared) return t->extend(c, n, challenges);
+            if (comm->rank == 0) {   // (every rank derives the same challenges: the transcripts are identical)
+                t->extend(c, n, challenges);
+                c.check(tvm_sync(c.raw()), "tvm_sync");
+            }
+            rendezvous(TVMH_SHARE_BARRIER, nullptr, nullptr);
+        };
         ProofStream stream = prover.prove();
         lap("prove (device drained)");
         std::vector<u64> proof = stream.proof();
@@ -869,17 +930,46 @@ std::vector<u64> prove_execution_sharded(const Context& c, const StarkParameters
         decltype(lap)& l;
         ~Done() { l("tables released, return"); }
     } done{lap};
-    if (passes) return attempt(passes);
+    // A rank that fails in the middle of a proof will not join the collectives its peers are waiting in: say so to the communicator
+    // (RCCL: ncclCommAbort; in-process: the waiting ranks leave with an error) before the error travels up.
+    auto guarded_attempt = [&](unsigned pass_count) {
+        try {
+            return attempt(pass_count);
+        } catch (...) {
+            if (comm && world > 1 && comm->abort) comm->abort(comm->self);
+            throw;
+        }
+    };
+    if (passes) return guarded_attempt(passes);
     // The reference's memory policy (master_table.rs:268-271, stark.rs:730-768): try the cached extension; if the device (or
     // the context's memory limit) cannot hold it, start over coset by coset with as few passes as fit.  The transcript is
-    // deterministic, so the restarted proof is the proof the cached path would have produced.  (With a communicator every
-    // rank must take the same decision: the ranks hold the same shares, so they run out of memory together.)
-    const u64 expansion = p.ldt.length / p.trace.length, world = comm ? comm->world : 1;
+    // deterministic, so the restarted proof is the proof the cached path would have produced.
+    const u64 expansion = p.ldt.length / p.trace.length;
+    auto may_double = [&](unsigned pass_count) { return pass_count * 2 * world <= expansion && p.quotient.length == p.ldt.length; };
+    if (world > 1) {
+        // With a communicator the decision has to be COLLECTIVE and taken BEFORE the first collective of the proof: a rank that ran
+        // out of memory on its own and restarted while its peers sat in an all-gather would issue mismatched collectives (the ranks'
+        // free memory differs: other tenants, fragmentation, per-context limits).  So every rank takes the smallest pass count
+        // whose estimated footprint fits what ITS context can still obtain (tvm_ctx_memory_info: device free + own cache, the
+        // memory limit included), one all-gather makes the largest of them everybody's, and an out-of-memory during the proof
+        // itself is an error (and an abort of the communicator), not a local retry.
+        size_t available = 0;
+        c.check(tvm_ctx_memory_info(c.raw(), &available, nullptr), "tvm_ctx_memory_info");
+        unsigned mine = 1;
+        while (estimated_bytes(p, world, mine) > available && may_double(mine)) mine *= 2;
+        DeviceBuffer send(c, 1), recv(c, world);
+        const u64 word = mine;
+        c.check(tvm_memcpy_h2d(c.raw(), send.ptr(), &word, 8), "tvm_memcpy_h2d");
+        const int32_t status = comm->all_gather(comm->self, c.raw(), send.ptr(), recv.ptr(), 1);
+        if (status != TVM_OK) throw Error(status, "pass-count agreement: the communicator reported " + std::string(tvm_status_string(status)));
+        const std::vector<u64> all = recv.download(0, world);
+        return guarded_attempt((unsigned)*std::max_element(all.begin(), all.end()));
+    }
     for (unsigned pass_count = 1;; pass_count *= 2) {
         try {
             return attempt(pass_count);
         } catch (const Error& e) {
-            if (e.status != TVM_ERR_OUT_OF_MEMORY || pass_count * 2 * world > expansion || p.quotient.length != p.ldt.length) throw;
+            if (e.status != TVM_ERR_OUT_OF_MEMORY || !may_double(pass_count)) throw;
         }
         (void)tvm_ctx_trim(c.raw());  // the failed attempt's buffers went back to the pool while unwinding: give them to the driver
     }
@@ -906,6 +996,11 @@ struct LocalGroup {
         uint32_t rank;
     };
     std::vector<Member> members;
+
+    // tvmh_comm::share: the object rank 0 published (the replicated tables of the current proof), dropped at the next release
+    const void* kept = nullptr;
+    void (*kept_drop)(const void*) = nullptr;
+    ~LocalGroup() { if (kept && kept_drop) kept_drop(kept); }
 
     bool broken = false;   // a rank failed: every waiting rank leaves its collective with an error instead of hanging
     bool barrier(std::unique_lock<std::mutex>& lock) {
@@ -940,6 +1035,14 @@ struct LocalGroup {
         turn = r + 1;
         cv.notify_all();
     }
+    // Lockstep runs put `world` ranks' working sets on ONE device (eight ranks of a 2^22-row proof: 21.8 GB of shared traces + 8 x
+    // (20.4 GiB of tables + intermediates)).  A rank that waits in a collective gives its pool's cached blocks back to the driver
+    // when the device runs short -- after its compute segment was closed, so the time is charged to no stage; a real multi-GPU
+    // run has a device per rank and never gets here.
+    static void trim_if_short(tvm_ctx* ctx) {
+        size_t available = 0, total = 0;
+        if (tvm_ctx_memory_info(ctx, &available, &total) == TVM_OK && available < total / 4) (void)tvm_ctx_trim(ctx);
+    }
 };
 
 int32_t local_collective(void* self, tvm_ctx* ctx, const uint64_t* d_send, uint64_t* d_recv, uint64_t words, bool all_to_all) {
@@ -948,7 +1051,12 @@ int32_t local_collective(void* self, tvm_ctx* ctx, const uint64_t* d_send, uint6
     const uint32_t r = mb->rank;
     int32_t status = tvm_sync(ctx);  // this rank's operands are complete
     std::unique_lock<std::mutex> lock(g.m);
-    if (g.lockstep) g.release(r);
+    if (g.lockstep) {
+        g.release(r);
+        lock.unlock();
+        LocalGroup::trim_if_short(ctx);
+        lock.lock();
+    }
     g.send[r] = d_send;
     if (!g.barrier(lock)) return TVM_ERR_DEVICE;
     std::vector<const uint64_t*> from = g.send;
@@ -963,6 +1071,45 @@ int32_t local_collective(void* self, tvm_ctx* ctx, const uint64_t* d_send, uint6
         g.acquire(r, lock);
     }
     return status;
+}
+// tvmh_comm::share (triton_host.hpp): a barrier (two, so that the lockstep turn passes as in a collective) around the hand-over
+int32_t local_share(void* self, tvm_ctx* ctx, uint32_t op, const void* mine, void (*drop)(const void*), const void** out) {
+    auto* mb = (LocalGroup::Member*)self;
+    LocalGroup& g = *mb->group;
+    const uint32_t r = mb->rank;
+    int32_t status = tvm_sync(ctx);  // this rank's use of the kept object (release) / its work on the new one (publish) is complete
+    std::unique_lock<std::mutex> lock(g.m);
+    if (g.lockstep) {
+        g.release(r);
+        lock.unlock();
+        LocalGroup::trim_if_short(ctx);
+        lock.lock();
+    }
+    if (!g.barrier(lock)) return TVM_ERR_DEVICE;
+    if (r == 0 && (op == TVMH_SHARE_RELEASE || (op == TVMH_SHARE_PUBLISH && mine))) {
+        const void* old = g.kept;
+        void (*old_drop)(const void*) = g.kept_drop;
+        g.kept = op == TVMH_SHARE_PUBLISH ? mine : nullptr;
+        g.kept_drop = op == TVMH_SHARE_PUBLISH ? drop : nullptr;
+        if (old && old_drop) {   // rank 0's thread, rank 0's context: every rank has passed the barrier, nobody reads it any more
+            lock.unlock();
+            old_drop(old);
+            lock.lock();
+        }
+    }
+    if (!g.barrier(lock)) return TVM_ERR_DEVICE;
+    if (out) *out = g.kept;
+    if (g.lockstep) {
+        if (r == 0) g.turn = 0, g.cv.notify_all();
+        g.acquire(r, lock);
+    }
+    return status;
+}
+void local_abort(void* self) {
+    LocalGroup& g = *((LocalGroup::Member*)self)->group;
+    std::unique_lock<std::mutex> lock(g.m);
+    g.broken = true;
+    g.cv.notify_all();
 }
 int32_t local_all_gather(void* self, tvm_ctx* ctx, const uint64_t* s, uint64_t* d, uint64_t w) { return local_collective(self, ctx, s, d, w, false); }
 int32_t local_all_to_all(void* self, tvm_ctx* ctx, const uint64_t* s, uint64_t* d, uint64_t w) { return local_collective(self, ctx, s, d, w, true); }
@@ -1011,17 +1158,14 @@ extern "C" int32_t tvmh_local_comms_create(uint32_t world, uint32_t lockstep, tv
     g->comms.resize(world);
     for (uint32_t r = 0; r < world; r++) {
         g->members[r] = {g, r};
-        g->comms[r] = tvmh_comm{&g->members[r], r, world, local_all_gather, local_all_to_all, local_begin, local_mark, local_end};
+        g->comms[r] = tvmh_comm{&g->members[r], r, world, local_all_gather, local_all_to_all, local_begin, local_mark, local_end, local_abort, local_share};
         out[r] = &g->comms[r];
     }
     return TVM_OK;
 }
 extern "C" void tvmh_local_comms_abort(tvmh_comm* any) {
     if (!any) return;
-    triton_vm::LocalGroup& g = *((triton_vm::LocalGroup::Member*)any->self)->group;
-    std::unique_lock<std::mutex> lock(g.m);
-    g.broken = true;
-    g.cv.notify_all();
+    triton_vm::local_abort(any->self);
 }
 extern "C" void tvmh_local_comms_destroy(tvmh_comm* first) {
     if (first) delete ((triton_vm::LocalGroup::Member*)first->self)->group;

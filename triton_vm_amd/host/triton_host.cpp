@@ -863,10 +863,10 @@ std::vector<u64> Stir::prove(const Context& c, const u64* d_codeword, ProofStrea
 
 // ------------------------------------------------------------------------------------------------ from an execution trace
 namespace {
-// TVMH_TRACE=1: wall time of the steps of prove_execution on stderr (each step drains the stream first)
+// TVMH_OPTION_TRACE: wall time of the steps of prove_execution on stderr (each step drains the stream first)
 struct Stopwatch {
     const Context& c;
-    const bool on = std::getenv("TVMH_TRACE") != nullptr;
+    const bool on = tvmh_get_option(TVMH_OPTION_TRACE) != 0;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), start = t0;
     ~Stopwatch() {
         if (on) std::fprintf(stderr, "[tvmh] %-28s %8.2f ms\n", "total", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - start).count());
@@ -988,11 +988,11 @@ std::vector<u64> prove_execution(const Context& c, const StarkParameters& p, con
 
 }  // namespace triton_vm
 
-static std::atomic<uint64_t> g_exact_air{0};
+static std::atomic<uint64_t> g_options[4] = {{0}, {0}, {0}, {0}};   // indexed by TVMH_OPTION_*
 extern "C" void tvmh_set_option(uint32_t option, uint64_t value) {
-    if (option == TVMH_OPTION_EXACT_AIR) g_exact_air.store(value);
+    if (option >= 1 && option <= 3) g_options[option].store(value);
 }
-extern "C" uint64_t tvmh_get_option(uint32_t option) { return option == TVMH_OPTION_EXACT_AIR ? g_exact_air.load() : 0; }
+extern "C" uint64_t tvmh_get_option(uint32_t option) { return option >= 1 && option <= 3 ? g_options[option].load() : 0; }
 
 extern "C" int32_t tvmh_prove(tvm_ctx* ctx, uint32_t log2_padded_height, uint64_t num_trace_randomizers,
                               uint64_t num_collinearity_checks, uint32_t log2_expansion, const uint64_t* d_main_trace,

@@ -246,7 +246,23 @@ typedef struct tvmh_comm {
     void (*begin)(void* self, tvm_ctx* ctx);
     void (*mark)(void* self, tvm_ctx* ctx, const char* stage);
     void (*end)(void* self, tvm_ctx* ctx);
+    /* optional (may be null): this rank failed outside a collective and will not take part in the ones its peers are waiting in.
+     * RCCL: ncclCommAbort -- the rank's own queued collectives are cancelled and its process can report the error (the launcher
+     * tears the job down); in-process communicators: every rank waiting in a collective leaves it with TVM_ERR_DEVICE. */
+    void (*abort)(void* self);
+    /* optional, ONLY for communicators whose ranks live in one process (may be null; null in rccl_comm.cpp): a barrier at which
+     * the ranks exchange one pointer to an object in their common address space, so that READ-ONLY replicated device data --
+     * the trace-side tables every rank would otherwise build and hold for itself -- exist once.  op TVMH_SHARE_RELEASE: barrier,
+     * then rank 0 drops the object the group keeps (every rank has left the proof that used it).  TVMH_SHARE_PUBLISH: rank 0
+     * hands over `mine` (its device work complete) and `drop`; the group keeps it until the next release or its own destruction,
+     * which must happen while rank 0's context is alive; every rank's *out is rank 0's object.  TVMH_SHARE_BARRIER: barrier only
+     * (*out = the kept object).  Used by bench.py --simulate-gpus (eight ranks of a 2^22-row proof on one GPU: 21.8 GB of traces
+     * once instead of eight times) under TVMH_OPTION_SHARE_REPLICATED_TABLES; a multi-process communicator never sees it. */
+    int32_t (*share)(void* self, tvm_ctx* ctx, uint32_t op, const void* mine, void (*drop)(const void*), const void** out);
 } tvmh_comm;
+#define TVMH_SHARE_BARRIER 0
+#define TVMH_SHARE_PUBLISH 1
+#define TVMH_SHARE_RELEASE 2
 }
 
 namespace triton_vm {
@@ -358,6 +374,14 @@ extern "C" int32_t tvmh_prove_execution(tvm_ctx* ctx, const tvm_aet* aet, uint32
 // by row on every point of the quotient domain, as the reference does (master_table.rs:1264-1363), instead of in valid-trace mode
 //  -- the same proof on a valid trace; bench.py times both.
 #define TVMH_OPTION_EXACT_AIR 1
+// TVMH_OPTION_SHARE_REPLICATED_TABLES != 0: the ranks of an IN-PROCESS communicator (one that has a `share` hook) use ONE copy of the
+// replicated trace-side tables -- rank 0 fills, pads and extends, the other ranks read its device arrays -- instead of one copy each.
+// For the single-GPU lockstep measurement of the N-rank code path at heights where N copies do not fit (bench.py --simulate-gpus
+// at 2^22 rows); the stage times of ranks 1..N-1 then lack the replicated stages, rank 0's has them.  Default 0.
+#define TVMH_OPTION_SHARE_REPLICATED_TABLES 2
+// TVMH_OPTION_TRACE != 0: host wall time of the steps of prove_execution (plain and sharded) on stderr.  Diagnostics only; the host
+// library, like the backend, reads no environment variable.
+#define TVMH_OPTION_TRACE 3
 extern "C" void tvmh_set_option(uint32_t option, uint64_t value);
 extern "C" uint64_t tvmh_get_option(uint32_t option);
 

@@ -192,7 +192,7 @@ TVM_D void lds_ntt_fixed(u64* s, const u64* __restrict__ tw, int tid, int nt) {
 #endif
 #define TVM_ROW_SKEW(p) ((p) + ((p) >> 4))
 #define TVM_ROW_WORDS(n) ((n) + ((n) >> 4) + 1)   // odd pitch: position p of the 16 rows of a tile falls into 16 different banks
-template <bool DIT, int K, int L, int LOGN, int ROOT>
+template <bool DIT, int K, int L, int LOGN, int ROOT, int TWB = TVM_TW_BATCH>
 TVM_D void row_ntt_group(u64* row, const u64* __restrict__ tw, int lane) {
     static_assert(ROOT == 1 || ROOT == 2, "the domains' own roots of unity only");
     constexpr int R = 1 << K, NG = 1 << (LOGN - K);
@@ -208,14 +208,14 @@ TVM_D void row_ntt_group(u64* row, const u64* __restrict__ tw, int lane) {
         u64 x[R];
 #pragma unroll
         for (int e = 0; e < R; e++) x[e] = p[TVM_ROW_SKEW(e << L)];
-        // (the twiddles are fetched TVM_TW_BATCH at a time: left alone, hipcc hoists all 2^K - 1 loads above the
+        // (the twiddles are fetched TWB at a time where the caller says so: left alone, hipcc hoists all 2^K - 1 loads above the
         // multiplications -- 30 VGPRs that the coset loop of pass 2 does not have)
         if constexpr (L > 0 && DIT) {
 #pragma unroll
             for (int e = 1; e < R; e++) {
                 x[e] = bfe_mul(x[e], tw[(j0 * brev_k(e, K)) << (LOGN - L - K)]);
-                if constexpr (TVM_TW_BATCH > 0) {
-                    if (e % TVM_TW_BATCH == 0) asm volatile("" ::: "memory");
+                if constexpr (TWB > 0) {
+                    if (e % TWB == 0) asm volatile("" ::: "memory");
                 }
             }
         }
@@ -224,8 +224,8 @@ TVM_D void row_ntt_group(u64* row, const u64* __restrict__ tw, int lane) {
 #pragma unroll
             for (int e = 1; e < R; e++) {
                 x[e] = bfe_mul(x[e], tw[(j0 * brev_k(e, K)) << (LOGN - L - K)]);
-                if constexpr (TVM_TW_BATCH > 0) {
-                    if (e % TVM_TW_BATCH == 0) asm volatile("" ::: "memory");
+                if constexpr (TWB > 0) {
+                    if (e % TWB == 0) asm volatile("" ::: "memory");
                 }
             }
         }
@@ -356,6 +356,10 @@ struct LdePass2Args {
     const u64* g_hi_step;  // [N2]: (gamma_{k+1} / gamma_k)^(N1*m1)    products: no table load inside their coset loop)
     u64 zk[TVM_LDE_MAX_COSETS];  // N * (gamma_k^N - 1)
     int std_roots;       // the trace domain's generator is the domains' own root of unity (shift twiddles, lds_ntt_group)
+    // k_lde_pass2_fused (1024-point axes) only:
+    const u64* g_hi_pos; // [X][N2]: gamma_k^(N1*brev(q)) at POSITION q of a row (g_hi in the order the row holds its coefficients)
+    const u64* f_tw;     // [N1 rows p][64 lanes][4 it][4 e]: w_N2^(g brev2(e)) * w_N^(brev(p) g), g = lane + 64 it (a lane's 16 values: one line)
+    const u64* u_tw;     // [X][N1 rows p][4]: (gamma_k^m2 / N) * w_N^(m2 * 256 e), m2 = brev(p)
 };
 
 __global__ void __launch_bounds__(1024) k_lde_pass2(LdePass2Args a) {
@@ -836,6 +840,125 @@ __global__ void __launch_bounds__(64 * ROWS, LOGN == 10 ? 4 : 2) k_lde_pass2_row
     }
 }
 
+// Pass 2 for 1024-point axes, round 5: every wavefront keeps ITS row from the inverse transform to the end of the coset loop.
+//   * The inverse rows step leaves position q of row w in the wavefront's own LDS words; lane l takes the 16 consecutive
+//     positions 16 l .. 16 l + 15 into VGPRs -- exactly the 16 points of its first forward butterfly group -- and keeps them
+//     across the coset loop.  The coset factor gamma_k^(n1 m1) is a table value at the POSITION (g_hi_pos, 8 KB per coset, four
+//     16-byte loads per lane) and the scaled coefficients go straight into the group's butterflies: the scale phase has no LDS
+//     round trip and no barrier (k_lde_pass2_rows wrote the scaled tile position-major and re-read it row-major between two
+//     barriers), and the randomizer term touches lane 0's first coefficient only (h <= n1: m1 = 0).
+//   * The inter-pass twiddle w_N^(m2 j1) gamma_k^m2 / N is folded into the LAST butterfly group (radix 4 over positions
+//     j1 = g + 256 e, g = lane + 64 it): w_N^(m2 g) is common to the four outputs of a butterfly, so it rides on the group's own
+//     twiddle step (f_tw: one table value per input, four multiplications where the step alone has three), and what is left,
+//     gamma_k^m2 / N * w_N^(256 m2 e), is uniform over the wavefront (u_tw: scalar loads).  2 multiplications per element for
+//     twiddle step + inter-pass twiddle where the running product of k_lde_pass2_rows' store phase paid 0.75 + 2.
+//   * The store phase is what is left of the transposition: a copy of the tile, row-major in LDS (written by the rows'
+//     wavefronts) to 64-byte runs of 8 adjacent rows in Z.  Two workgroup barriers per coset (rows complete / tile read), none
+//     inside a row's work.  Row pitch = 8 (mod 32) words: the store phase's 8 rows x 8 positions per wavefront fall into 64
+//     different banks (the odd pitch of TVM_ROW_WORDS put b + j1 = const into one).
+// 8 rows, 512 work-items, 78 KB of LDS: two workgroups per CU.
+#define TVM_P2F_ROWW 1096
+#ifndef TVM_P2F_TWB
+#define TVM_P2F_TWB 4   // twiddle loads in flight per batch in the middle group of the coset loop (registers)
+#endif
+template <int ROWS>
+__global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass2_fused(LdePass2Args a) {
+    constexpr int LOGN = 10, n2 = 1 << LOGN, ROWW = TVM_P2F_ROWW, NT = 64 * ROWS, RLOG = 3, Q4 = n2 / 4;
+    static_assert(ROWS == 8 && ROWW >= TVM_ROW_WORDS(n2) && ROWW % 32 == 8, "8-row tiles, bank-spread row pitch");
+    TVM_DYN_SMEM(u64, s);
+    const int tid = threadIdx.x, lane = tid & 63, w = tvm_uniform(tid >> 6);
+    const u64 n1 = 1ull << a.log_n1, n = n1 << LOGN;
+    const int vl = blockIdx.y, v = a.col0 + vl;
+    const u64 p0 = (u64)blockIdx.x * ROWS, p = p0 + (u64)w;
+    u64* const row = s + w * ROWW;
+    u64* const tw_fwd = s + ROWS * ROWW;   // all n2 powers of the forward root, behind the tile
+    {
+        const u64* y = a.y + (u64)vl * n + p * n2 + lane;
+        u64* const rowl = row + TVM_ROW_SKEW(lane);
+#pragma unroll
+        for (int e = 0; e < 16; e++) rowl[68 * e] = TVM_LOAD_STREAM(&y[64 * e]);   // position lane + 64 e (skew: + 4 e)
+    }
+    for (int i = tid; i < n2; i += NT) tw_fwd[i] = a.tw_b1[i];
+    tvm_wave_sync();
+    // inverse rows step: position q of the row then holds N * t[m1*n1 + m2], m1 = brev(q), m2 = brev(p)
+    row_ntt<false, 4, LOGN, 2>(row, a.tw_a2, lane);
+    u64 coef[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) coef[e] = row[17 * lane + e];   // TVM_ROW_SKEW(16 * lane + e) = 17 * lane + e
+    const u64 m2 = brev_bits((u32)p, a.log_n1);   // uniform over the wavefront
+    // lane 0: the randomizer coefficient that meets coefficient m = m2 (m1 = 0: position 0), re-read in every coset (one lane's load)
+    const u64* const rnd = a.rnd + ((u64)(v / a.fk) * a.h + (m2 < a.h ? m2 : 0)) * a.fk + (v % a.fk);
+    const bool has_rnd = m2 < a.h;
+    tvm_lds_barrier();   // the twiddle table is staged
+    for (int k = 0; k < a.n_cosets; k++) {
+        // (lane and work-item number through opaque moves: the addresses below are cheap to form and expensive to keep -- hoisted out
+        // of the coset loop they went to scratch)
+        const int ln = tvm_opaque(lane);
+        const u64x2* gh = (const u64x2*)(a.g_hi_pos + (u64)k * n2 + 16 * ln);
+        u64 x[16];
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            const u64x2 g2 = gh[e / 2];
+            x[e] = bfe_mul(coef[e], g2.x);
+            x[e + 1] = bfe_mul(coef[e + 1], g2.y);
+        }
+        if (has_rnd && ln == 0) x[0] = bfe_add(coef[0], bfe_mul(a.zk[k], *rnd));   // gamma_k^0 = 1 at position 0
+        ntt_pow2_points<4, true, false>(x);
+        {
+            u64* const out = row + 17 * ln;
+#pragma unroll
+            for (int e = 0; e < 16; e++) out[e] = x[e];
+        }
+        tvm_wave_sync();
+        row_ntt_group<true, 4, 4, LOGN, 1, TVM_P2F_TWB>(row, tw_fwd, ln);
+        u64 u[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) u[e] = a.u_tw[((u64)k * n1 + p) * 4 + e];
+        const u64x2* ft = (const u64x2*)(a.f_tw + (((p << 6) + ln) << 4));
+#pragma unroll
+        for (int it = 0; it < 4; it++) {   // layers 8 and 9 on positions g + 256 e, g = lane + 64 it, with the inter-pass twiddle
+            u64* const q = row + TVM_ROW_SKEW(ln + 64 * it);   // TVM_ROW_SKEW(g + 256 e) = TVM_ROW_SKEW(g) + 272 e
+            const u64x2 f01 = ft[2 * it], f23 = ft[2 * it + 1];
+            u64 y4[4] = {bfe_mul(q[0], f01.x), bfe_mul(q[Q4 + Q4 / 16], f01.y), bfe_mul(q[2 * (Q4 + Q4 / 16)], f23.x),
+                         bfe_mul(q[3 * (Q4 + Q4 / 16)], f23.y)};
+            ntt_pow2_points<2, true, false>(y4);
+#pragma unroll
+            for (int e = 0; e < 4; e++) q[(Q4 + Q4 / 16) * e] = bfe_mul(y4[e], u[e]);
+        }
+        tvm_lds_barrier();   // the rows are complete: the store phase reads across them
+        {
+            const int t2 = tvm_opaque(tid), b_out = t2 & (ROWS - 1), j1_0 = t2 >> RLOG;
+            u64* zk = a.z + ((u64)vl * a.n_cosets + k) * n + p0 + b_out;
+            const u64* src = s + b_out * ROWW;
+#pragma unroll 4
+            for (int i = 0; i < 16; i++) {
+                const int j1 = j1_0 + i * (NT >> RLOG);
+                TVM_STORE_STREAM(&zk[(u64)j1 * n1], src[TVM_ROW_SKEW(j1)]);
+            }
+        }
+        tvm_lds_barrier();   // the tile has been read: the next coset's first group overwrites the rows
+    }
+}
+
+// the tables of k_lde_pass2_fused (LdePass2Args): hi_pos[k][q] = hi[k][brev(q)]; f[((p*64 + lane)*4 + it)*4 + e] =
+// tw_n2[g * brev2(e)] * w_N^(brev(p) * g), g = lane + 64 it; u[(k*n1 + p)*4 + e] = lo[k][brev(p)] * w_N^(brev(p) * 256 e)
+__global__ void k_pass2_fused_tables(const u64* __restrict__ lo, const u64* __restrict__ hi, Pow2 tw_inter, const u64* __restrict__ tw_n2,
+                                     int log_n1, int log_n2, u64 X, u64* __restrict__ hi_pos, u64* __restrict__ f, u64* __restrict__ u) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 n1 = 1ull << log_n1, n2 = 1ull << log_n2, n = n1 * n2, quarter = n2 >> 2;
+    if (i < X * n2) hi_pos[i] = hi[(i / n2) * n2 + brev_bits((u32)(i % n2), log_n2)];
+    if (f && i < n) {
+        const u64 e = i & 3, it = (i >> 2) & 3, lane = (i >> 4) & 63, p = i >> 10, g = lane + 64 * it;
+        const u64 m2 = brev_bits((u32)p, log_n1);
+        f[i] = bfe_mul(tw_n2[(g * (u64)brev_k((int)e, 2)) & (n2 - 1)], pow2_get(tw_inter, (m2 * g) & (n - 1)));
+    }
+    if (i < X * n1 * 4) {
+        const u64 e = i & 3, p = (i >> 2) % n1, k = (i >> 2) / n1;
+        const u64 m2 = brev_bits((u32)p, log_n1);
+        u[i] = bfe_mul(lo[k * n1 + m2], pow2_get(tw_inter, (m2 * quarter * e) & (n - 1)));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // hipMalloc allocates on the calling thread's CURRENT device, which another context (or the application) may have
@@ -980,6 +1103,7 @@ static void set_lds_attributes() {
     (void)hipFuncSetAttribute((const void*)k_lde_pass3, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass1_rows<10, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_rows<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass2_fused<8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<11, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_v3<11, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -1012,6 +1136,36 @@ static int coset_tables(tvm_ctx* c, u64 offset, u64 gen, u64 X, u64 n1, u64 n2, 
     }
     *lo = d;
     *hi = d + X * n1;
+    return TVM_OK;
+}
+
+// the three tables of k_lde_pass2_fused, cached per context: f depends on the trace domain alone, hi_pos and u on the cosets too
+static int pass2_fused_tables(tvm_ctx* c, u64 trace_gen, u64 offset, u64 gen, u64 X, int log_n1, int log_n2, const u64* lo, const u64* hi,
+                              const Pow2& tw_inter, const u64* tw_n2, const u64** hi_pos, const u64** f, const u64** u) {
+    const u64 n1 = 1ull << log_n1, n2 = 1ull << log_n2, n = n1 * n2;
+    const auto key_f = std::make_tuple(trace_gen ^ 0xF05EDF05EDull, n1, n2);
+    const auto key_k = std::make_tuple(offset ^ 0xF05EDC05E7ull, gen, (X << 56) | (n1 << 28) | n2);
+    auto it_f = c->tables.find(key_f);
+    auto it_k = c->tables.find(key_k);
+    u64 *d_f = it_f != c->tables.end() ? it_f->second : nullptr, *d_k = it_k != c->tables.end() ? it_k->second : nullptr;
+    const bool new_f = !d_f, new_k = !d_k;
+    if (!bind_device(c)) return set_error(c, TVM_ERR_DEVICE, "bind device");
+    if (new_f && hipMalloc((void**)&d_f, n * sizeof(u64)) != hipSuccess) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "pass-2 twiddle table");
+    if (new_k && hipMalloc((void**)&d_k, X * (n2 + 4 * n1) * sizeof(u64)) != hipSuccess) {
+        if (new_f) (void)hipFree(d_f);
+        return set_error(c, TVM_ERR_OUT_OF_MEMORY, "pass-2 coset tables");
+    }
+    if (new_f || new_k) {
+        const u64 total = new_f ? (n > X * (n2 + 4 * n1) ? n : X * (n2 + 4 * n1)) : X * (n2 > 4 * n1 ? n2 : 4 * n1);
+        // (entries that exist already are simply written again with the same values when only one of the two is new)
+        TVM_LAUNCH(k_pass2_fused_tables, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, lo, hi, tw_inter, tw_n2, log_n1,
+                   log_n2, X, d_k, new_f ? d_f : (u64*)nullptr, d_k + X * n2);
+        if (new_f) c->tables[key_f] = d_f;
+        if (new_k) c->tables[key_k] = d_k;
+    }
+    *f = d_f;
+    *hi_pos = d_k;
+    *u = d_k + X * n2;
     return TVM_OK;
 }
 
@@ -1185,6 +1339,10 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     TVM_TRY(coset_tables(c, eval_offset, eval_gen, X, n1, n2, n_inv, &p2.g_lo, &p2.g_hi));
     p2.g_lo_step = pow_table(c, eval_gen, n1);
     p2.g_hi_step = pow_table(c, bfe_pow(eval_gen, n1), n2);
+    p2.g_hi_pos = p2.f_tw = p2.u_tw = nullptr;
+    if (std_roots && sp.log_n2 == 10 && n1 % 16 == 0 && h <= n1 && c->lde_pass2_form == 0)
+        TVM_TRY(pass2_fused_tables(c, w, eval_offset, eval_gen, X, sp.log_n1, sp.log_n2, p2.g_lo, p2.g_hi, p2.tw_inter, p2.tw_b1, &p2.g_hi_pos,
+                                   &p2.f_tw, &p2.u_tw));
     const u64 n_mont = bfe_from_u64(N);
     for (u64 k = 0; k < X; k++) {
         const u64 gamma = bfe_mul(eval_offset, bfe_pow(eval_gen, k));
@@ -1257,8 +1415,13 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
                 else if (sp.log_n2 == 7) TVM_LAUNCH((k_lde_pass2_v3<7, 6>), g2, dim3(64), lds_v3, c->stream, a);
                 else TVM_LAUNCH((k_lde_pass2_v3<8, 6>), g2, dim3(64), lds_v3, c->stream, a);
             }
+            else if (std_roots && sp.log_n2 == 10 && n1 % 16 == 0 && h <= n1 && c->lde_pass2_form == 0) {
+                // 1024-point axis: every wavefront keeps its row across the coset loop (k_lde_pass2_fused)
+                const size_t lds_r = (size_t)(8 * TVM_P2F_ROWW + n2) * sizeof(u64);
+                TVM_LAUNCH((k_lde_pass2_fused<8>), dim3((unsigned)(n1 / 8), (unsigned)nc), dim3(512), lds_r, c->stream, a);
+            }
             else if (std_roots && sp.log_n2 == 10 && n1 % 16 == 0) {
-                // 1024-point axis: one row per wavefront inside the LDS-resident transforms, 8-row tiles (k_lde_pass2_rows)
+                // ... or (more randomizers than n1, or TVM_OPTION_LDE_PASS2_FORM = 1) the position-major tile of rounds 3-4
                 const size_t lds_r = (size_t)(8 * TVM_ROW_WORDS(n2) + n2 + 32) * sizeof(u64);
                 TVM_LAUNCH((k_lde_pass2_rows<10, 8>), dim3((unsigned)(n1 / 8), (unsigned)nc), dim3(512), lds_r, c->stream, a);
             }

@@ -36,6 +36,25 @@ static inline void tvm_wave_sync() { emu::sync_wave(); }
 static __device__ __forceinline__ void tvm_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 #endif
 
+// tvm_uniform(v): v is the same in every lane of the wavefront (an index derived from the wavefront's number); says so to the
+// compiler, so that addresses built from it are scalar and the loads behind them scalar loads.
+#ifdef TVM_EMU
+#define tvm_uniform(v) (v)
+#else
+#define tvm_uniform(v) __builtin_amdgcn_readfirstlane(v)
+#endif
+
+// tvm_opaque(v): v, through a move the compiler cannot see through -- what is computed from the result is computed where it is
+// used, not hoisted out of the enclosing loop into registers that are then spilled.
+#ifdef TVM_EMU
+#define tvm_opaque(v) (v)
+#else
+static __device__ __forceinline__ int tvm_opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+#endif
+
 // Streaming accesses (non-temporal: the LDE's intermediates and table, written once and read a whole pass later, or read
 // once): measured -3 % on the LDE at 2^20 rows (main table 46.8 -> 45.2 ms); nothing for the VALU-bound row hashing.
 #if defined(TVM_EMU)
@@ -50,6 +69,10 @@ static __device__ __forceinline__ void tvm_wave_sync() { asm volatile("s_waitcnt
 
 typedef uint64_t u64;
 typedef uint32_t u32;
+
+struct alignas(16) u64x2 {   // two words moved by one 16-byte access (global_load_dwordx4)
+    u64 x, y;
+};
 
 #define TVM_HD __host__ __device__ __forceinline__
 #define TVM_D __device__ __forceinline__

@@ -858,6 +858,9 @@ __global__ void __launch_bounds__(64 * ROWS, LOGN == 10 ? 4 : 2) k_lde_pass2_row
 //     different banks (the odd pitch of TVM_ROW_WORDS put b + j1 = const into one).
 // 8 rows, 512 work-items, 78 KB of LDS: two workgroups per CU.
 #define TVM_P2F_ROWW 1096
+#ifndef TVM_P2F_X
+#define TVM_P2F_X 0
+#endif
 #ifndef TVM_P2F_TWB
 #define TVM_P2F_TWB 4   // twiddle loads in flight per batch in the middle group of the coset loop (registers)
 #endif
@@ -925,7 +928,16 @@ __global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass2_fused(LdePass2Args a
 #pragma unroll
             for (int e = 0; e < 4; e++) q[(Q4 + Q4 / 16) * e] = bfe_mul(y4[e], u[e]);
         }
+        // (TVM_P2F_X != 0: timing experiments with wrong results, tools/build_ntt_variants.py -- 1 no store phase: -11 %, 2 the same
+        // words as contiguous 64 KB blocks: -0 %, 3 no workgroup barriers: -3 %; profiles/r05_c_*.  Never in the product build.)
+#if TVM_P2F_X == 3
+        tvm_wave_sync();
+#else
         tvm_lds_barrier();   // the rows are complete: the store phase reads across them
+#endif
+#if TVM_P2F_X == 1
+        if (a.h == 0xDEADBEEFull)
+#endif
         {
             const int t2 = tvm_opaque(tid), b_out = t2 & (ROWS - 1), j1_0 = t2 >> RLOG;
             u64* zk = a.z + ((u64)vl * a.n_cosets + k) * n + p0 + b_out;
@@ -933,10 +945,18 @@ __global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass2_fused(LdePass2Args a
 #pragma unroll 4
             for (int i = 0; i < 16; i++) {
                 const int j1 = j1_0 + i * (NT >> RLOG);
+#if TVM_P2F_X == 2
+                TVM_STORE_STREAM(&a.z[((u64)vl * a.n_cosets + k) * n + p0 * n2 + (u64)i * NT + t2], src[TVM_ROW_SKEW(j1)]);
+#else
                 TVM_STORE_STREAM(&zk[(u64)j1 * n1], src[TVM_ROW_SKEW(j1)]);
+#endif
             }
         }
+#if TVM_P2F_X == 3
+        tvm_wave_sync();
+#else
         tvm_lds_barrier();   // the tile has been read: the next coset's first group overwrites the rows
+#endif
     }
 }
 

@@ -75,10 +75,6 @@ int32_t tvm_ctx_trim(tvm_ctx* ctx);
  * environment. */
 #define TVM_OPTION_LDE_CHUNK_COLUMNS 2
 #define TVM_OPTION_MERKLE_MIN_WORKGROUPS 3
-/* TVM_OPTION_LDE_PASS2_FORM: which kernel runs the middle pass of tvm_lde_table on 1024-point axes (2^19 / 2^20 rows):
- * 0 (default) every wavefront keeps its row across the coset loop (k_lde_pass2_fused), 1 the position-major tile of rounds 3-4
- * (k_lde_pass2_rows).  Same table either way; the A/B of profiles/r05_*. */
-#define TVM_OPTION_LDE_PASS2_FORM 4
 int32_t tvm_ctx_set_option(tvm_ctx* ctx, int32_t option, uint64_t value);
 /* Cap on the bytes this context may hold through tvm_malloc / table handles (0 = no cap).  Requests beyond it fail
  * with TVM_ERR_OUT_OF_MEMORY exactly like a full device: the knob a host uses to share a GPU, and what the tests use to

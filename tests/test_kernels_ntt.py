@@ -67,7 +67,7 @@ def test_lde_table_matches_oracle(ctx, orc, log_n, expansion, n_cols, h, fk):
 
 @pytest.mark.parametrize("log_n,fk,n_cols", [(20, 1, 2), (19, 3, 1), (21, 1, 1), pytest.param(22, 1, 1, marks=pytest.mark.gpu)])
 def test_lde_with_1024_point_axes(ctx, orc, log_n, fk, n_cols):
-    """The production kernels of tvm_lde_table (one transform row per wavefront, csrc/ntt.hip: k_lde_pass2_rows /
+    """The production kernels of tvm_lde_table (one transform row per wavefront, csrc/ntt.hip: k_lde_pass2_fused /
     k_lde_pass3_rows, taken for 1024-point axes: traces of 2^19 and 2^20 rows -- BASELINE config 1's height; since round 4 also for
     2048-point axes: 2^21 rows (pass 2) and, on the GPU, 2^22 rows -- BASELINE config 2's height -- in all passes that have them) on a few
     columns at full height, sampled rows against the oracle's extension of the same columns.  (On the emulation too: its

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 GPU visit B: the fused pass 2 of the LDE (k_lde_pass2_fused) against the position-major tile of rounds 3-4 (k_lde_pass2_rows,
-# TVM_OPTION_LDE_PASS2_FORM = 1): parity at full size, per-kernel times of one 96-column chunk and of the whole main table, counters.
+# a temporary context option, removed with that kernel after this visit): parity at full size, per-kernel times of one 96-column chunk and of the whole main table, counters.
 TAG=${1:-r05_b}
 mkdir -p gpurun_out
 export TMPDIR=/tmp

@@ -23,7 +23,7 @@ def main():
         ctx = Context(0, lib=load_library(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'triton_vm_amd', f'libtriton_hip_{variant}.so')))
     else:
         ctx = Context(0)
-    for opt, val in [kv.split("=") for kv in os.environ.get("TVM_PROBE_OPTIONS", "").split(",") if kv]:   # e.g. "4=1": TVM_OPTION_LDE_PASS2_FORM
+    for opt, val in [kv.split("=") for kv in os.environ.get("TVM_PROBE_OPTIONS", "").split(",") if kv]:   # e.g. "2=32": TVM_OPTION_LDE_CHUNK_COLUMNS
         ctx._check(ctx.lib.tvm_ctx_set_option(ctx.handle, int(opt), int(val)), "tvm_ctx_set_option")
     trace_dom = ArithmeticDomain.of_length(n)
     ev = ArithmeticDomain.of_length(8 * n).with_offset(field.generator())

@@ -187,9 +187,6 @@ TVM_D void lds_ntt_fixed(u64* s, const u64* __restrict__ tw, int tid, int nt) {
 #ifndef TVM_TW_BATCH
 #define TVM_TW_BATCH 0   // twiddle loads in flight per batch in row_ntt_group (0: let the compiler schedule them)
 #endif
-#ifndef TVM_P2_MAXK
-#define TVM_P2_MAXK 4   // butterfly layers per LDS round trip in the forward columns step of k_lde_pass2_rows
-#endif
 #define TVM_ROW_SKEW(p) ((p) + ((p) >> 4))
 #define TVM_ROW_WORDS(n) ((n) + ((n) >> 4) + 1)   // odd pitch: position p of the 16 rows of a tile falls into 16 different banks
 template <bool DIT, int K, int L, int LOGN, int ROOT, int TWB = TVM_TW_BATCH>
@@ -737,121 +734,22 @@ __global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass1_rows(Ntt2Args a) {
     }
 }
 
-// Pass 2: as k_lde_pass2_v3 (a work-item owns the same positions of all rows of the tile across the coset loop), but both
-// LDS-resident transforms run one row per wavefront (ROWS wavefronts, ROWS rows): three workgroup barriers per coset -- around
-// the scale phase and before the store phase, where data changes wavefronts -- instead of six.
-//   ROWS = 16: 1024 work-items, one position each, 148 KB of LDS: ONE workgroup per CU -- every barrier drains the CU.
-//   ROWS = 8:  512 work-items, two positions each, 78 KB of LDS: TWO workgroups per CU, one's barriers and tails run under
-//              the other's butterflies; the stores are 64-byte runs (8 adjacent rows) instead of full lines.
-//   LOGN = 11 (round 4): rows of 2048 points, 8 rows = 156 KB of LDS, ONE workgroup of 8 wavefronts per CU (two per SIMD: 256 VGPRs),
-//              32 elements per work-item across the coset loop.
-//   (Measured and not kept, round 4: 16-row tiles at 1024 points -- one workgroup per CU, +1 %; 2048-point rows -- two wavefronts per
-//   SIMD, +13 % against k_lde_pass2_v3<11, 10>; the store phase's factor from a table instead of a running product -- 8 % fewer
-//   VALU instructions, the same time; DESIGN.md section 9, items 10 and 11.  The variants are in the history, not in the tree.)
-template <int LOGN, int ROWS>
-__global__ void __launch_bounds__(64 * ROWS, LOGN == 10 ? 4 : 2) k_lde_pass2_rows(LdePass2Args a) {
-    constexpr int n2 = 1 << LOGN, ROWW = TVM_ROW_WORDS(n2), NT = 64 * ROWS, PPT = n2 / NT, RLOG = ROWS == 16 ? 4 : 3, EPT = n2 / 64;
-    static_assert((LOGN == 10 || LOGN == 11) && (ROWS == 16 || ROWS == 8), "one wavefront per row of 1024 or 2048 points");
-    TVM_DYN_SMEM(u64, s);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const u64 n1 = 1ull << a.log_n1;
-    const int vl = blockIdx.y, v = a.col0 + vl;
-    const u64 p0 = (u64)blockIdx.x * ROWS;
-    const u64 n = n1 << LOGN;
-    const u64* y = a.y + (u64)vl * n + p0 * n2;
-    int me[PPT];
-#pragma unroll
-    for (int hh = 0; hh < PPT; hh++) me[hh] = TVM_ROW_SKEW(tid + hh * NT);
-#pragma unroll
-    for (int e = 0; e < EPT; e++) s[(e & (ROWS - 1)) * ROWW + me[e >> RLOG]] = TVM_LOAD_STREAM(&y[(u64)(e & (ROWS - 1)) * n2 + tid + (e >> RLOG) * NT]);
-    u64* tw_fwd = s + ROWS * ROWW;   // all n2 powers of the forward root, behind the tile
-#pragma unroll
-    for (int hh = 0; hh < PPT; hh++) tw_fwd[tid + hh * NT] = a.tw_b1[tid + hh * NT];
-    tvm_lds_barrier();
-    // inverse rows step, row w by wavefront w: position q of row e then holds N * t[m1*n1 + m2], m1 = brev(q)
-    row_ntt<false, 4, LOGN, 2>(s + w * ROWW, a.tw_a2, lane);
-    tvm_lds_barrier();
-    u64 coef[EPT];   // element e: row e % ROWS, position tid + (e / ROWS) * NT
-#pragma unroll
-    for (int e = 0; e < EPT; e++) coef[e] = s[(e & (ROWS - 1)) * ROWW + me[e >> RLOG]];
-    u64 m1[PPT], gh[PPT], gh_step[PPT];
-    bool has_rnd = false;
-#pragma unroll
-    for (int hh = 0; hh < PPT; hh++) {
-        m1[hh] = brev_bits((u32)(tid + hh * NT), LOGN);
-        gh[hh] = a.g_hi[m1[hh]];
-        gh_step[hh] = a.g_hi_step[m1[hh]];
-        has_rnd |= m1[hh] * n1 < a.h;
-    }
-    const u64* rnd = a.rnd + (u64)(v / a.fk) * a.h * a.fk + (v % a.fk);
-    const bool single = a.h <= n1;   // the randomizers only touch position 0 of each row (see k_lde_pass2_v3)
-    u64* c0 = tw_fwd + n2;
-    u64* r0 = c0 + 16;
-    if (single) {
-        if (tid == 0) {
-#pragma unroll
-            for (int e = 0; e < ROWS; e++) c0[e] = coef[e];
-        }
-        if (tid < ROWS) {
-            const u64 m = brev_bits((u32)(p0 + tid), a.log_n1);
-            r0[tid] = m < a.h ? rnd[m * a.fk] : 0;
-        }
-    }
-    const int b_out = tid & (ROWS - 1), j1_0 = tid >> RLOG;
-    const u64 m2_out = brev_bits((u32)(p0 + b_out), a.log_n1);
-    constexpr int j1_step = NT >> RLOG;   // 64
-    const u64 t_step = pow2_get(a.tw_inter, (m2_out * (u64)j1_step) & (n - 1));
-    u64 t_first = bfe_mul(pow2_get(a.tw_inter, m2_out * (u64)j1_0), a.g_lo[m2_out]);
-    const u64 gl_step = a.g_lo_step[m2_out];
-    for (int k = 0; k < a.n_cosets; k++) {
-        tvm_lds_barrier();   // the store phase of the previous coset has read the tile
-        if (single) {
-#pragma unroll
-            for (int e = 0; e < EPT; e++)
-                if ((e >> RLOG) || tid) s[(e & (ROWS - 1)) * ROWW + me[e >> RLOG]] = bfe_mul(coef[e], gh[e >> RLOG]);
-            if (tid < ROWS) s[tid * ROWW] = bfe_add(c0[tid], bfe_mul(a.zk[k], r0[tid]));
-        } else if (has_rnd) {
-            const u64 zk = a.zk[k];
-#pragma unroll
-            for (int e = 0; e < EPT; e++) {
-                const u64 m = m1[e >> RLOG] * n1 + brev_bits((u32)(p0 + (e & (ROWS - 1))), a.log_n1);
-                u64 c = coef[e];
-                if (m < a.h) c = bfe_add(c, bfe_mul(zk, rnd[m * a.fk]));
-                s[(e & (ROWS - 1)) * ROWW + me[e >> RLOG]] = bfe_mul(c, gh[e >> RLOG]);
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < EPT; e++) s[(e & (ROWS - 1)) * ROWW + me[e >> RLOG]] = bfe_mul(coef[e], gh[e >> RLOG]);
-        }
-        tvm_lds_barrier();
-        row_ntt<true, TVM_P2_MAXK, LOGN, 1>(s + w * ROWW, tw_fwd, lane);   // forward columns step of row w
-        tvm_lds_barrier();
-        u64* z = a.z + ((u64)vl * a.n_cosets + k) * n + p0 + b_out;
-        u64 t = t_first;
-#pragma unroll 4
-        for (int i = 0; i < EPT; i++) {
-            const int j1 = j1_0 + i * j1_step;
-            TVM_STORE_STREAM(&z[(u64)j1 * n1], bfe_mul(s[b_out * ROWW + TVM_ROW_SKEW(j1)], t));
-            t = bfe_mul(t, t_step);
-        }
-#pragma unroll
-        for (int hh = 0; hh < PPT; hh++) gh[hh] = bfe_mul(gh[hh], gh_step[hh]);
-        t_first = bfe_mul(t_first, gl_step);
-    }
-}
-
 // Pass 2 for 1024-point axes, round 5: every wavefront keeps ITS row from the inverse transform to the end of the coset loop.
 //   * The inverse rows step leaves position q of row w in the wavefront's own LDS words; lane l takes the 16 consecutive
 //     positions 16 l .. 16 l + 15 into VGPRs -- exactly the 16 points of its first forward butterfly group -- and keeps them
 //     across the coset loop.  The coset factor gamma_k^(n1 m1) is a table value at the POSITION (g_hi_pos, 8 KB per coset, four
 //     16-byte loads per lane) and the scaled coefficients go straight into the group's butterflies: the scale phase has no LDS
-//     round trip and no barrier (k_lde_pass2_rows wrote the scaled tile position-major and re-read it row-major between two
-//     barriers), and the randomizer term touches lane 0's first coefficient only (h <= n1: m1 = 0).
+//     round trip and no barrier (the pass-2 kernel of rounds 3-4, k_lde_pass2_rows, wrote the scaled tile position-major and re-read
+//     it row-major between two barriers), and the randomizer term touches lane 0's first coefficient only (h <= n1: m1 = 0).
 //   * The inter-pass twiddle w_N^(m2 j1) gamma_k^m2 / N is folded into the LAST butterfly group (radix 4 over positions
 //     j1 = g + 256 e, g = lane + 64 it): w_N^(m2 g) is common to the four outputs of a butterfly, so it rides on the group's own
 //     twiddle step (f_tw: one table value per input, four multiplications where the step alone has three), and what is left,
 //     gamma_k^m2 / N * w_N^(256 m2 e), is uniform over the wavefront (u_tw: scalar loads).  2 multiplications per element for
 //     twiddle step + inter-pass twiddle where the running product of k_lde_pass2_rows' store phase paid 0.75 + 2.
+//   Measured against k_lde_pass2_rows on one box (profiles/r05_b_*, 96 columns at 2^20 rows): 8 % fewer VALU instructions, 29 % fewer
+//   LDS instructions, 36 instead of 200 bytes of scratch, WRITE_SIZE 66.5 instead of 77.9 B per cell, 4.72 against 4.78 ms on average
+//   (minimum 4.27 against 4.43): the four wavefronts per SIMD do not hide the table loads at their uses, and every variant that
+//   requests them earlier pays more in scratch than it gains (profiles/r05_d_*: 160 B -> 5.3 ms, 288 B -> 6.0 ms).
 //   * The store phase is what is left of the transposition: a copy of the tile, row-major in LDS (written by the rows'
 //     wavefronts) to 64-byte runs of 8 adjacent rows in Z.  Two workgroup barriers per coset (rows complete / tile read), none
 //     inside a row's work.  Row pitch = 8 (mod 32) words: the store phase's 8 rows x 8 positions per wavefront fall into 64
@@ -1122,7 +1020,6 @@ static void set_lds_attributes() {
     (void)hipFuncSetAttribute((const void*)k_lde_pass2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass1_rows<10, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    (void)hipFuncSetAttribute((const void*)k_lde_pass2_rows<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_fused<8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<11, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -1360,7 +1257,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     p2.g_lo_step = pow_table(c, eval_gen, n1);
     p2.g_hi_step = pow_table(c, bfe_pow(eval_gen, n1), n2);
     p2.g_hi_pos = p2.f_tw = p2.u_tw = nullptr;
-    if (std_roots && sp.log_n2 == 10 && n1 % 16 == 0 && h <= n1 && c->lde_pass2_form == 0)
+    if (std_roots && sp.log_n2 == 10 && n1 % 16 == 0 && h <= n1)
         TVM_TRY(pass2_fused_tables(c, w, eval_offset, eval_gen, X, sp.log_n1, sp.log_n2, p2.g_lo, p2.g_hi, p2.tw_inter, p2.tw_b1, &p2.g_hi_pos,
                                    &p2.f_tw, &p2.u_tw));
     const u64 n_mont = bfe_from_u64(N);
@@ -1435,15 +1332,11 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
                 else if (sp.log_n2 == 7) TVM_LAUNCH((k_lde_pass2_v3<7, 6>), g2, dim3(64), lds_v3, c->stream, a);
                 else TVM_LAUNCH((k_lde_pass2_v3<8, 6>), g2, dim3(64), lds_v3, c->stream, a);
             }
-            else if (std_roots && sp.log_n2 == 10 && n1 % 16 == 0 && h <= n1 && c->lde_pass2_form == 0) {
-                // 1024-point axis: every wavefront keeps its row across the coset loop (k_lde_pass2_fused)
+            else if (std_roots && sp.log_n2 == 10 && n1 % 16 == 0 && h <= n1) {
+                // 1024-point axis: every wavefront keeps its row across the coset loop (k_lde_pass2_fused); more trace randomizers than
+                // n1 (never the case for a STARK's parameters) take the generic kernel
                 const size_t lds_r = (size_t)(8 * TVM_P2F_ROWW + n2) * sizeof(u64);
                 TVM_LAUNCH((k_lde_pass2_fused<8>), dim3((unsigned)(n1 / 8), (unsigned)nc), dim3(512), lds_r, c->stream, a);
-            }
-            else if (std_roots && sp.log_n2 == 10 && n1 % 16 == 0) {
-                // ... or (more randomizers than n1, or TVM_OPTION_LDE_PASS2_FORM = 1) the position-major tile of rounds 3-4
-                const size_t lds_r = (size_t)(8 * TVM_ROW_WORDS(n2) + n2 + 32) * sizeof(u64);
-                TVM_LAUNCH((k_lde_pass2_rows<10, 8>), dim3((unsigned)(n1 / 8), (unsigned)nc), dim3(512), lds_r, c->stream, a);
             }
             else
                 TVM_LAUNCH(k_lde_pass2, grid, dim3(threads_for_tile(tile)), lds, c->stream, a);

@@ -236,7 +236,7 @@ def lde_roofline(lde_ms, n_rows, n_cols, expansion, share, counters, shape_match
     bytes_per_cell = 8 + 8 * expansion / share
     secs = lde_ms * 1e-3
     achieved = cells * bytes_per_cell / secs / 1e9
-    out = {"kernel": "main-table LDE: tvm_lde_table of 379 columns (k_lde_pass1_rows + k_lde_pass2_rows + k_lde_pass3_rows, column chunks of 96)",
+    out = {"kernel": "main-table LDE: tvm_lde_table of 379 columns (k_lde_pass1_rows + k_lde_pass2_fused + k_lde_pass3_rows, column chunks of 96)",
            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
            "launch_ms": round(lde_ms, 3), "algorithmic_bytes_per_launch": int(cells * bytes_per_cell), "traffic": None, "bound": "valu"}
     log_n = n_rows.bit_length() - 1
@@ -354,6 +354,39 @@ def simulate_ranks(ctx, host_lib, n_ranks, aet, padded_height, claim, kw):
             "proof": proofs[0],
             "note": "single-GPU LOCKSTEP run of the N-rank code path (one rank computes at a time, own context and stream per rank): per-rank "
                     "compute is measured, the exchanges are projected; not a multi-GPU measurement"}
+
+
+def column_split_bracket(sim, single_gpu_stage_ms, n_rows):
+    """north_star's OTHER sharding, priced from this run's measurements: the trace columns split over the ranks for the inverse
+    transforms (rank r interpolates W/R columns, the coefficients are all-gathered, every rank evaluates all columns on ITS cosets).
+    The coset sharding replicates the inverse transform of every column on every rank; its cost per rank is isolated from two
+    measured LDE times of the same table -- one coset (a rank of R) and X cosets (the single GPU): T_1 = I + F, T_X = I + X F.
+    The split removes (R - 1)/R of I and adds an all-gather of every coefficient: 652 words x N x 8 B x (R - 1)/R received per rank.
+    Both ends of the overlap assumption are stated: the exchange fully hidden behind the forward transforms and the hashing, and
+    fully exposed.  (Nothing here is built: the figures say whether it would pay -- DESIGN.md section 6.)"""
+    R = sim["ranks"]
+    stages = sim["stage_ms_per_rank"]
+    out = {}
+    try:
+        inv = {}
+        for name in ("main LDE", "aux LDE"):
+            t1, tx = max(stages[name]), single_gpu_stage_ms[name]
+            inv[name] = max(0.0, (R * t1 - tx) / (R - 1))
+        saved = sum(inv.values()) * (R - 1) / R
+        received = MASTER_WORDS * n_rows * 8 * (R - 1) // R
+        exchange_ms = received / (XGMI_EGRESS_GBPS * 1e6)
+        now = sim["slowest_rank_sum_ms"] + sim["projected_exchange_ms"]
+        hidden, exposed = now - saved, now - saved + exchange_ms
+        out = {"replicated_inverse_transform_ms_per_rank": {k: round(v, 3) for k, v in inv.items()}, "compute_saved_ms_per_rank": round(saved, 3),
+               "coefficient_bytes_received_per_rank": int(received), "exchange_ms_at_assumed_bandwidth": round(exchange_ms, 3),
+               "projected_ms_per_proof_now": round(now, 3), "projected_ms_exchange_fully_hidden": round(hidden, 3),
+               "projected_ms_exchange_fully_exposed": round(exposed, 3),
+               "fraction_of_exchange_that_must_be_hidden_to_break_even": round(max(0.0, min(1.0, 1 - saved / exchange_ms)), 3),
+               "note": "coset sharding (built, measured above) against a column split of the inverse transforms (priced, not built): the split "
+                       "pays only for the part of the all-gather that overlaps with compute"}
+    except (KeyError, ZeroDivisionError) as e:   # noqa: BLE001 (an extra)
+        out = {"error": str(e)}
+    return out
 
 
 def spawn_ranks(n):
@@ -763,6 +796,7 @@ def main():
                 sim = simulate_ranks(ctx, host_lib, n_sim, resident, padded_height, claim, kw)
                 sim["same_proof_as_single_gpu"] = bool(sim["proof"].size == last["proof"].size and (sim.pop("proof") == last["proof"]).all())
                 sim.pop("proof", None)
+                sim["column_split_bracket"] = column_split_bracket(sim, stage_ms, params.trace.length)
                 out["simulated_multi_gpu"] = sim
             except Exception as err:   # noqa: BLE001 (an extra: never lose the headline to it)
                 out["simulated_multi_gpu"] = {"error": str(err)[:400]}

@@ -129,6 +129,27 @@ int32_t tvm_intt(tvm_ctx* ctx, int32_t field_kind, uint64_t* d_data, uint64_t le
 int32_t tvm_lde_table(tvm_ctx* ctx, int32_t field_kind, const uint64_t* d_trace, uint64_t n_rows,
                       uint64_t n_cols, const uint64_t* d_randomizers, uint64_t num_trace_randomizers,
                       tvm_domain trace_domain, tvm_domain evaluation_domain, tvm_table** out);
+/* The same extension split at the coefficients -- the COLUMN sharding of SURVEY 8(e): a rank interpolates a range of columns,
+ * the coefficients are exchanged (an all-gather), every rank extends all columns onto its own part of the evaluation domain.
+ * A "virtual column" is one base-field component of a column (n_cols * field_kind of them, in the order (column, component)).
+ *   tvm_lde_column_coefficients   the inverse transforms of the virtual columns [first, first + n): n_rows words each into
+ *                                 d_coeffs[(v - first) * n_rows ...], in the library's COEFFICIENT FORM -- the scaled
+ *                                 coefficients in the order its extension kernels read them; opaque, position-independent
+ *                                 (a block of it can be moved anywhere), consumed only by tvm_lde_table_add_columns of the
+ *                                 same trace length.
+ *   tvm_lde_table_begin           a table handle like tvm_lde_table's, its columns not yet written
+ *   tvm_lde_table_add_columns     the virtual columns [first, first + n) of the table from their coefficient form, with the
+ *                                 trace randomizers of master_table.rs:392-403 (d_randomizers as in tvm_lde_table: all columns)
+ *   tvm_lde_table_end             once every column is written (the successor rows of the row-pair views)
+ * begin + add_columns over all columns + end == tvm_lde_table, word for word. */
+int32_t tvm_lde_column_coefficients(tvm_ctx* ctx, int32_t field_kind, const uint64_t* d_trace, uint64_t n_rows, uint64_t n_cols,
+                                    tvm_domain trace, uint64_t first_virtual_column, uint64_t n_virtual_columns, uint64_t* d_coeffs);
+int32_t tvm_lde_table_begin(tvm_ctx* ctx, int32_t field_kind, uint64_t n_rows, uint64_t n_cols, uint64_t num_trace_randomizers,
+                            tvm_domain trace, tvm_domain eval, tvm_table** out);
+int32_t tvm_lde_table_add_columns(tvm_ctx* ctx, tvm_table* table, const uint64_t* d_coeffs, uint64_t first_virtual_column,
+                                  uint64_t n_virtual_columns, const uint64_t* d_randomizers, uint64_t num_trace_randomizers,
+                                  tvm_domain trace, tvm_domain eval);
+int32_t tvm_lde_table_end(tvm_ctx* ctx, tvm_table* table);
 void tvm_table_free(tvm_ctx* ctx, tvm_table* table);
 uint64_t tvm_table_num_rows(const tvm_table* table);
 uint64_t tvm_table_num_columns(const tvm_table* table);

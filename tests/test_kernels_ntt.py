@@ -65,6 +65,34 @@ def test_lde_table_matches_oracle(ctx, orc, log_n, expansion, n_cols, h, fk):
     assert (mt.reveal_rows(idx) == want[idx]).all()
 
 
+@pytest.mark.parametrize("log_n,expansion,n_cols,h,fk,blocks,chunks", [
+    (3, 8, 5, 4, 1, 2, 1), (5, 1, 7, 3, 3, 8, 2), (6, 4, 33, 20, 1, 4, 3), (12, 2, 3, 70, 3, 2, 2),
+    (13, 1, 3, 198, 1, 8, 1), (14, 2, 2, 198, 3, 2, 1),   # two positions per work-item (the shape of 2^21 / 2^22-row traces)
+    (15, 1, 2, 20, 1, 2, 1),                               # four positions per work-item (2^23 / 2^24 rows)
+    (19, 1, 2, 198, 1, 2, 1),                              # one row per wavefront (k_lde_pass2_fused: 2^19 / 2^20 rows)
+    pytest.param(20, 1, 9, 198, 1, 8, 2, marks=pytest.mark.gpu), pytest.param(20, 8, 3, 198, 3, 2, 1, marks=pytest.mark.gpu),
+    pytest.param(22, 1, 3, 198, 1, 8, 1, marks=pytest.mark.gpu)])
+def test_lde_split_at_the_coefficients_gives_the_same_table(ctx, orc, log_n, expansion, n_cols, h, fk, blocks, chunks):
+    """tvm_lde_column_coefficients + tvm_lde_table_begin / _add_columns / _end (the column sharding of SURVEY 8(e): blocks of
+    columns interpolated separately, the table assembled chunk by chunk from the exchanged coefficient form) == tvm_lde_table, word
+    for word, on every pass-2 kernel: generic, two and four positions per work-item, one row per wavefront (2^20 rows, GPU)."""
+    rng = np.random.default_rng(log_n + 7 * n_cols + fk)
+    n = 1 << log_n
+    shape = lambda k: (n_cols, k) + ((3,) if fk == 3 else ())
+    trace, rnd = orc.random_elements(rng, shape(n)), orc.random_elements(rng, shape(h))
+    ev = ArithmeticDomain.of_length(n * expansion).with_offset(field.generator())
+    mt = MasterTable(ctx, trace, rnd, ArithmeticDomain.of_length(n), ev, ev, fk)
+    mt.maybe_low_degree_extend_all_columns()
+    rows = np.unique(np.concatenate([[0, 1, len(ev) - 1], rng.integers(0, len(ev), 500)])).astype(np.uint64)
+    want = mt.reveal_rows(rows) if log_n > 15 else mt.low_degree_extended_table()
+    mt.low_degree_extend_by_column_blocks(blocks, chunks)
+    got = mt.reveal_rows(rows) if log_n > 15 else mt.low_degree_extended_table()
+    assert (got == want).all()
+    if log_n <= 12:
+        assert (got == orc.lde_table(trace, rnd, odom(orc, ev), fk)).all()
+    mt.clear_cache()
+
+
 @pytest.mark.parametrize("log_n,fk,n_cols", [(20, 1, 2), (19, 3, 1), (21, 1, 1), pytest.param(22, 1, 1, marks=pytest.mark.gpu)])
 def test_lde_with_1024_point_axes(ctx, orc, log_n, fk, n_cols):
     """The production kernels of tvm_lde_table (one transform row per wavefront, csrc/ntt.hip: k_lde_pass2_fused /

@@ -75,6 +75,12 @@ _SIGNATURES = {
     "tvm_intt": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64]),
     "tvm_lde_table": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
                                   Domain, Domain, C.POINTER(C.c_void_p)]),
+    "tvm_lde_column_coefficients": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64, Domain, C.c_uint64, C.c_uint64,
+                                                C.c_void_p]),
+    "tvm_lde_table_begin": (C.c_int32, [C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, Domain, Domain, C.POINTER(C.c_void_p)]),
+    "tvm_lde_table_add_columns": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, Domain,
+                                              Domain]),
+    "tvm_lde_table_end": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "tvm_table_free": (None, [C.c_void_p, C.c_void_p]),
     "tvm_table_num_rows": (C.c_uint64, [C.c_void_p]),
     "tvm_table_num_columns": (C.c_uint64, [C.c_void_p]),

@@ -379,6 +379,64 @@ int32_t tvm_lde_table(tvm_ctx* c, int32_t fk, const uint64_t* d_trace, uint64_t 
     return TVM_OK;
 }
 
+// The same extension, split at the coefficients (the column sharding: SURVEY 8(e)).
+int32_t tvm_lde_column_coefficients(tvm_ctx* c, int32_t fk, const uint64_t* d_trace, uint64_t n_rows, uint64_t n_cols, tvm_domain trace_dom,
+                                    uint64_t first_virtual_column, uint64_t n_virtual_columns, uint64_t* d_coeffs) {
+    if (!c || !d_trace || !d_coeffs || !valid_fk(fk) || !valid_domain(trace_dom) || trace_dom.length != n_rows || n_cols == 0 ||
+        n_cols * fk > (1u << 20) || first_virtual_column + n_virtual_columns > n_cols * fk)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_lde_column_coefficients arguments");
+    if (trace_dom.offset != TVM_ONE) return set_error(c, TVM_ERR_UNSUPPORTED, "trace domain offset must be 1");
+    if (!n_virtual_columns) return TVM_OK;
+    const LdeSplit split{1, d_coeffs, (int)first_virtual_column, (int)n_virtual_columns};
+    return lde_table(c, fk, d_trace, n_rows, n_cols, nullptr, 0, trace_dom.generator, TVM_ONE, trace_dom.generator, n_rows, nullptr, 0, &split);
+}
+
+int32_t tvm_lde_table_begin(tvm_ctx* c, int32_t fk, uint64_t n_rows, uint64_t n_cols, uint64_t h, tvm_domain trace_dom, tvm_domain eval_dom,
+                            tvm_table** out) {
+    if (!c || !out) return TVM_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (!valid_fk(fk) || !valid_domain(trace_dom) || !valid_domain(eval_dom) || trace_dom.length != n_rows || n_cols == 0 ||
+        n_cols * fk > (1u << 20) || eval_dom.length < n_rows)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_lde_table_begin arguments");
+    if (trace_dom.offset != TVM_ONE) return set_error(c, TVM_ERR_UNSUPPORTED, "trace domain offset must be 1");
+    tvm_table* t = new (std::nothrow) tvm_table();
+    if (!t) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "table handle");
+    t->rows = eval_dom.length;
+    t->layout = lde_table_layout(n_rows, eval_dom.length);
+    t->has_successor_blocks = true;
+    t->n_cols = n_cols;
+    t->fk = fk;
+    t->W = (int)(n_cols * fk);
+    t->interpolant_len = n_rows + h;
+    t->data = (u64*)pool_alloc(c, t->bytes());
+    if (!t->data) {
+        delete t;
+        return set_error(c, TVM_ERR_OUT_OF_MEMORY, "LDE table allocation");
+    }
+    if (t->layout.storage_rows() % TVM_RB) {
+        const u64 full = t->layout.storage_rows() / TVM_RB * TVM_RB * (u64)t->W;
+        (void)hipMemsetAsync(t->data + full, 0, t->bytes() - full * sizeof(u64), c->stream);
+    }
+    *out = t;
+    return TVM_OK;
+}
+
+int32_t tvm_lde_table_add_columns(tvm_ctx* c, tvm_table* t, const uint64_t* d_coeffs, uint64_t first_virtual_column,
+                                  uint64_t n_virtual_columns, const uint64_t* d_rnd, uint64_t h, tvm_domain trace_dom, tvm_domain eval_dom) {
+    if (!c || !t || !d_coeffs || (h && !d_rnd) || !valid_domain(trace_dom) || !valid_domain(eval_dom) || eval_dom.length != t->rows ||
+        first_virtual_column + n_virtual_columns > (uint64_t)t->W || t->interpolant_len != trace_dom.length + h)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_lde_table_add_columns arguments");
+    if (!n_virtual_columns) return TVM_OK;
+    const LdeSplit split{2, const_cast<uint64_t*>(d_coeffs), (int)first_virtual_column, (int)n_virtual_columns};
+    return lde_table(c, t->fk, nullptr, trace_dom.length, t->n_cols, d_rnd, h, trace_dom.generator, eval_dom.offset, eval_dom.generator,
+                     eval_dom.length, t->data, 0, &split);
+}
+
+int32_t tvm_lde_table_end(tvm_ctx* c, tvm_table* t) {
+    if (!c || !t) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_lde_table_end arguments");
+    return fill_successor_blocks(c, t->data, t->layout, t->W);
+}
+
 void tvm_table_free(tvm_ctx* c, tvm_table* t) {
     if (!t) return;
     if (c && t->data) pool_release(c, t->data);

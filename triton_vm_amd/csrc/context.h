@@ -113,6 +113,14 @@ struct tvm_ctx {
 };
 
 namespace tvm {
+// the extension split at the coefficients, for the virtual columns [first_vcol, first_vcol + n_vcols) (a virtual column = one
+// base-field component of a column): mode 1 = inverse transforms only, the coefficient form -> coeffs ([n_vcols][n_rows] words);
+// mode 2 = forward only, from coeffs, into those columns of the table
+struct LdeSplit {
+    int mode;
+    u64* coeffs;
+    int first_vcol, n_vcols;
+};
 // t[i] = scale * base^i, i < count (Montgomery words); cached for the life of the context
 const u64* pow_table(tvm_ctx* c, u64 base, u64 count, u64 scale = TVM_ONE);
 // scratch slot `slot` of at least `bytes` bytes (grown on demand, contents undefined)

@@ -9,7 +9,7 @@ int ntt_columns(tvm_ctx* c, const u64* in, u64 in_len, int in_fk, u64 in_col_str
                 u64 out_mult);
 TabLayout lde_table_layout(u64 n_rows, u64 L);   // the layout lde_table writes (incl. the successor blocks)
 int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, const u64* rnd, u64 h, u64 trace_gen,
-              u64 eval_offset, u64 eval_gen, u64 L, u64* table, int chunk_cols);
+              u64 eval_offset, u64 eval_gen, u64 L, u64* table, int chunk_cols, const LdeSplit* split = nullptr);
 // hash.hip
 int hash_rows(tvm_ctx* c, const u64* table, const TabLayout& layout, int W, u64 stride, u64* digests);
 int merkle_tree_from_leaves(tvm_ctx* c, u64* nodes, u64 n_leaves);

@@ -334,6 +334,8 @@ __global__ void __launch_bounds__(1024) k_ntt2_pass2(Ntt2Args a) {
 // Master-table LDE, passes 2 and 3 (pass 1 is k_ntt2_pass1 with inverse tables).
 #define TVM_LDE_MAX_COSETS 32
 #define TVM_LDE_E 16  // coefficients a thread keeps in VGPRs across the coset loop
+#define TVM_LDE_INVERSE_ONLY 1
+#define TVM_LDE_FORWARD_ONLY 2
 
 struct LdePass2Args {
     const u64* y;        // [cols][N1 positions p][N2]
@@ -353,6 +355,11 @@ struct LdePass2Args {
     const u64* g_hi_step;  // [N2]: (gamma_{k+1} / gamma_k)^(N1*m1)    products: no table load inside their coset loop)
     u64 zk[TVM_LDE_MAX_COSETS];  // N * (gamma_k^N - 1)
     int std_roots;       // the trace domain's generator is the domains' own root of unity (shift twiddles, lds_ntt_group)
+    // The pass split at the coefficients (the column sharding of SURVEY 8(e): a rank interpolates ITS columns, the coefficients
+    // are exchanged, every rank extends all columns onto its cosets).  0: the whole pass.  TVM_LDE_INVERSE_ONLY: the inverse rows
+    // step, then the tile goes back to Y in place -- Y then holds N * t[m1*n1 + m2] at [position p of m2][position q of m1], the
+    // library's COEFFICIENT FORM of a column -- and the kernel returns.  TVM_LDE_FORWARD_ONLY: Y already holds that form.
+    int mode;
     // k_lde_pass2_fused (1024-point axes) only:
     const u64* g_hi_pos; // [X][N2]: gamma_k^(N1*brev(q)) at POSITION q of a row (g_hi in the order the row holds its coefficients)
     const u64* f_tw;     // [N1 rows p][64 lanes][4 it][4 e]: w_N2^(g brev2(e)) * w_N^(brev(p) g), g = lane + 64 it (a lane's 16 values: one line)
@@ -379,7 +386,15 @@ __global__ void __launch_bounds__(1024) k_lde_pass2(LdePass2Args a) {
     }
     tvm_lds_barrier();
     // inverse rows step: position q of row b now holds N * t[k1 + N1*k2], k2 = brev(q)
-    lds_ntt_rt<false>(a.std_roots ? 2 : 0, s, a.log_n2, a.batch_log, 1, RS, a.tw_a2, tid, nt);
+    if (a.mode != TVM_LDE_FORWARD_ONLY) lds_ntt_rt<false>(a.std_roots ? 2 : 0, s, a.log_n2, a.batch_log, 1, RS, a.tw_a2, tid, nt);
+    if (a.mode == TVM_LDE_INVERSE_ONLY) {
+        u64* yw = const_cast<u64*>(y);
+        for (int idx = tid; idx < tile; idx += nt) {
+            const int i2 = idx & (n2 - 1), b = idx >> a.log_n2;
+            if (p0 + b < n1) yw[(p0 + b) * n2 + i2] = s[b * RS + i2];
+        }
+        return;
+    }
 
     // The N coefficients of this tile stay in VGPRs for the whole coset loop (the only per-thread
     // state: 16 words); coset factors come from two small L2-resident tables per coset.
@@ -507,7 +522,16 @@ __global__ void __launch_bounds__(1 << TLOG) k_lde_pass2_v3(LdePass2Args a) {
         s[r * RS + q] = TVM_LOAD_STREAM(&y[(u64)r * n2 + q]);
     }
     tvm_lds_barrier();
-    lds_ntt_fixed<false, 4, LOGN, 0, RLOG, 2>(s, a.tw_a2, tid, NT);
+    if (a.mode != TVM_LDE_FORWARD_ONLY) lds_ntt_fixed<false, 4, LOGN, 0, RLOG, 2>(s, a.tw_a2, tid, NT);
+    if (a.mode == TVM_LDE_INVERSE_ONLY) {
+        u64* yw = const_cast<u64*>(y);
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int r = e & (ROWS - 1), q = tid + (e >> RLOG) * NT;
+            yw[(u64)r * n2 + q] = s[r * RS + q];
+        }
+        return;
+    }
     u64 coef[16];
 #pragma unroll
     for (int e = 0; e < 16; e++) coef[e] = s[(e & (ROWS - 1)) * RS + tid + (e >> RLOG) * NT];
@@ -782,7 +806,14 @@ __global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass2_fused(LdePass2Args a
     for (int i = tid; i < n2; i += NT) tw_fwd[i] = a.tw_b1[i];
     tvm_wave_sync();
     // inverse rows step: position q of the row then holds N * t[m1*n1 + m2], m1 = brev(q), m2 = brev(p)
-    row_ntt<false, 4, LOGN, 2>(row, a.tw_a2, lane);
+    if (a.mode != TVM_LDE_FORWARD_ONLY) row_ntt<false, 4, LOGN, 2>(row, a.tw_a2, lane);
+    if (a.mode == TVM_LDE_INVERSE_ONLY) {
+        u64* yw = const_cast<u64*>(a.y) + (u64)vl * n + p * n2 + lane;
+        const u64* const rowl = row + TVM_ROW_SKEW(lane);
+#pragma unroll
+        for (int e = 0; e < 16; e++) yw[64 * e] = rowl[68 * e];
+        return;
+    }
     u64 coef[16];
 #pragma unroll
     for (int e = 0; e < 16; e++) coef[e] = row[17 * lane + e];   // TVM_ROW_SKEW(16 * lane + e) = 17 * lane + e
@@ -1192,8 +1223,11 @@ int ntt_columns(tvm_ctx* c, const u64* in, u64 in_len, int in_fk, u64 in_col_str
 // master_table.rs:258-322.  trace: column-major [n_cols][n_rows][fk]; rnd: [n_cols][h][fk];
 // table: row-block-major over the storage rows of lde_table_layout(n_rows, L), n_cols*fk words per row (context.h); the
 // successor blocks are the caller's (fill_successor_blocks).
+// split (optional): the pass split at the coefficients for a range of virtual columns (LdeSplit, kernels.h) -- mode
+// TVM_LDE_INVERSE_ONLY writes the coefficient form of the range (n_rows words per virtual column) to split->coeffs and ignores
+// the evaluation domain (pass L = n_rows); TVM_LDE_FORWARD_ONLY reads it from there and writes the range's columns of the table.
 int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, const u64* rnd, u64 h, u64 trace_gen,
-              u64 eval_offset, u64 eval_gen, u64 L, u64* table, int chunk_cols) {
+              u64 eval_offset, u64 eval_gen, u64 L, u64* table, int chunk_cols, const LdeSplit* split) {
     if (!is_pow2(n_rows) || !is_pow2(L) || n_rows < 2 || L < n_rows || (fk != 1 && fk != 3))
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "lde: lengths must be powers of two, L >= n_rows >= 2");
     const u64 X = L / n_rows;
@@ -1207,6 +1241,10 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     const Split sp = split_for(N);
     const u64 n1 = 1ull << sp.log_n1, n2 = 1ull << sp.log_n2;
     const int W = (int)(n_cols * fk);
+    const int mode = split ? split->mode : 0;
+    const int first = split ? split->first_vcol : 0, last = split ? split->first_vcol + split->n_vcols : W;
+    if (split && (first < 0 || split->n_vcols < 0 || last > W || !split->coeffs || (mode != TVM_LDE_INVERSE_ONLY && mode != TVM_LDE_FORWARD_ONLY)))
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "lde: column range / mode of the split");
     // columns per chunk: 96 while the chunk's intermediates (96 * (1 + X) * N words, from the pool: they count against the
     // context's memory limit) stay below 32 GiB AND below a third of what the context can still obtain, else 32.  Measured at 2^20
     // rows (main table, with 8 row tiles per pass-3 workgroup): 16 -> 48.0 ms, 32 -> 47.0, 96 -> 45.6, 192 -> 45.5, 379 -> 45.1; at 2^22
@@ -1282,24 +1320,26 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
 
     // the intermediates of one chunk: Y (pass 1 -> pass 2) and Z (pass 2 -> pass 3), pool blocks (the next call of the same
     // shape gets the same blocks back from the cache, in stream order)
+    // (with a split, Y is the caller's coefficient array: one chunk's worth at a time; the inverse-only mode needs no Z)
     PoolBlock y_block(c), z_block(c);
-    u64* y = (u64*)y_block.alloc((size_t)chunk_cols * N * sizeof(u64));
-    u64* z = y ? (u64*)z_block.alloc((size_t)chunk_cols * X * N * sizeof(u64)) : nullptr;
+    u64* y = split ? split->coeffs : (u64*)y_block.alloc((size_t)chunk_cols * N * sizeof(u64));
+    u64* z = mode == TVM_LDE_INVERSE_ONLY ? y : y ? (u64*)z_block.alloc((size_t)chunk_cols * X * N * sizeof(u64)) : nullptr;
     if ((!y || !z) && chunk_cols > 32) {   // the wide chunk does not fit: the narrow one before giving up
         chunk_cols = 32;
         z_block.alloc(0);
-        y = (u64*)y_block.alloc((size_t)chunk_cols * N * sizeof(u64));
+        if (!split) y = (u64*)y_block.alloc((size_t)chunk_cols * N * sizeof(u64));
         z = y ? (u64*)z_block.alloc((size_t)chunk_cols * X * N * sizeof(u64)) : nullptr;
     }
     if (!y || !z) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "lde intermediates");
-    p1.tmp = y;
-    p2.y = y;
+    p2.mode = mode;
     p2.z = z;
     p3.z = z;
 
-    for (int col0 = 0; col0 < W; col0 += chunk_cols) {
-        const int nc = (W - col0 < chunk_cols) ? (W - col0) : chunk_cols;
-        {
+    for (int col0 = first; col0 < last; col0 += chunk_cols) {
+        const int nc = (last - col0 < chunk_cols) ? (last - col0) : chunk_cols;
+        p1.tmp = split ? y + (size_t)(col0 - first) * N : y;
+        p2.y = p1.tmp;
+        if (mode != TVM_LDE_FORWARD_ONLY) {
             Ntt2Args a = p1;
             a.col0 = col0;
             const int B = 1 << a.batch_log;
@@ -1341,7 +1381,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             else
                 TVM_LAUNCH(k_lde_pass2, grid, dim3(threads_for_tile(tile)), lds, c->stream, a);
         }
-        {
+        if (mode != TVM_LDE_INVERSE_ONLY) {
             LdePass3Args a = p3;
             a.col0 = col0;
             a.rows_log = batch_log_for(sp.log_n1);

@@ -48,6 +48,44 @@ class MasterTable:
                                                    self.trace_domain.c(), ev.c(), C.byref(h)), "tvm_lde_table")
         self._table = h.value
 
+    def low_degree_extend_by_column_blocks(self, n_blocks, n_chunks=1, exchange=None):
+        """The same table as maybe_low_degree_extend_all_columns, built the way the COLUMN sharding builds it (SURVEY 8(e);
+        include/triton_hip.h: tvm_lde_column_coefficients ...): the virtual columns are dealt to `n_blocks` owners in equal blocks
+        (the last one short), every owner's block is interpolated on its own and cut into `n_chunks` chunks, `exchange(chunk
+        buffers)` stands for the all-gather, and the table is assembled chunk by chunk from the gathered coefficients.  One
+        process plays every owner here (tests; the sharded C++ host does it over a communicator)."""
+        lib, ctx, n = self.ctx.lib, self.ctx, self.n_rows
+        W = self.n_cols * self.fk
+        cpc = -(-W // (n_blocks * n_chunks))          # virtual columns per (owner, chunk)
+        per = cpc * n_chunks
+        ev = self.evaluation_domain()
+        self.clear_cache()
+        blobs = []
+        for b in range(n_blocks):
+            first, count = min(b * per, W), max(0, min(W - b * per, per))
+            blob = ctx.alloc(per * n)
+            ctx._check(lib.tvm_lde_column_coefficients(ctx.handle, self.fk, self.d_trace.ptr, n, self.n_cols, self.trace_domain.c(), first, count,
+                                                       blob.ptr), "tvm_lde_column_coefficients")
+            blobs.append(blob)
+        if exchange is not None:
+            blobs = exchange(blobs)
+        h = C.c_void_p()
+        ctx._check(lib.tvm_lde_table_begin(ctx.handle, self.fk, n, self.n_cols, self.num_trace_randomizers, self.trace_domain.c(), ev.c(),
+                                           C.byref(h)), "tvm_lde_table_begin")
+        self._table = h.value
+        for c in range(n_chunks):
+            for b in range(n_blocks):
+                first = b * per + c * cpc
+                count = max(0, min(W - first, cpc))
+                if not count:
+                    continue
+                ctx._check(lib.tvm_lde_table_add_columns(ctx.handle, self._table, blobs[b].ptr + 8 * c * cpc * n, first, count,
+                                                         self.d_randomizers.ptr, self.num_trace_randomizers, self.trace_domain.c(), ev.c()),
+                           "tvm_lde_table_add_columns")
+        ctx._check(lib.tvm_lde_table_end(ctx.handle, self._table), "tvm_lde_table_end")
+        for blob in blobs:
+            blob.free()
+
     def clear_cache(self):
         if self._table:
             self.ctx.lib.tvm_table_free(self.ctx.handle, self._table)

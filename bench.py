@@ -285,7 +285,7 @@ XGMI_EGRESS_GBPS, COLLECTIVE_LATENCY_US = 300.0, 25.0   # assumptions of the pro
 #                                                          paper; 300 GB/s is what an all-to-all / all-gather is assumed to sustain
 
 
-def simulate_ranks(ctx, host_lib, n_ranks, aet, padded_height, claim, kw):
+def simulate_ranks(ctx, host_lib, n_ranks, aet, padded_height, claim, kw, column_chunks=0):
     """One proof as `n_ranks` ranks of the sharded C++ prover on ONE GPU, in lockstep: every rank has its own context and
     stream, the communicators are the in-process ones (collectives = rendezvous + device-to-device copies), and between two
     collectives only one rank computes at a time -- so each rank's stage times are measured without contention, which is what
@@ -304,6 +304,7 @@ def simulate_ranks(ctx, host_lib, n_ranks, aet, padded_height, claim, kw):
     # configs[2] (2^22 rows over 8 GPUs) run through this code path on one 288 GB device.  The replicated stages then show their
     # time on rank 0 only; the slowest rank per stage -- what the projection sums -- is unchanged.
     host_lib.tvmh_set_option(native_host.OPTION_SHARE_REPLICATED_TABLES, 1)
+    host_lib.tvmh_set_option(native_host.OPTION_COLUMN_SPLIT, column_chunks)   # > 0: the inverse transforms split by columns
 
     def run(r, phase):
         try:
@@ -327,6 +328,7 @@ def simulate_ranks(ctx, host_lib, n_ranks, aet, padded_height, claim, kw):
             reports.append(comms.report())
     finally:
         host_lib.tvmh_set_option(native_host.OPTION_SHARE_REPLICATED_TABLES, 0)
+        host_lib.tvmh_set_option(native_host.OPTION_COLUMN_SPLIT, 0)
         comms.close()
         for c in ctxs:
             c.close()
@@ -344,7 +346,20 @@ def simulate_ranks(ctx, host_lib, n_ranks, aet, padded_height, claim, kw):
     compute = sum(max(v) for v in stages.values())
     replicated = sum(max(v) for k, v in stages.items() if k in ("trace tables (fill, pad, randomizers)", "extend"))
     exchange_ms = sent / (XGMI_EGRESS_GBPS * 1e6) + calls * COLLECTIVE_LATENCY_US * 1e-3
-    return {"ranks": n_ranks, "measured_proofs": repeats, "stage_ms_per_rank": stages, "slowest_rank_sum_ms": round(compute, 3),
+    split = {}
+    if column_chunks:
+        # the column split's coefficient exchange runs on the communicator's own stream, chunk by chunk, under the extension of the
+        # chunks already there: how much of it hides is what a multi-GPU box would measure -- both ends are stated
+        coeff = sum(e["bytes_sent"] for k, e in exchanges.items() if k.endswith("coefficients"))
+        coeff_ms = coeff / (XGMI_EGRESS_GBPS * 1e6)
+        split = {"column_split": {"chunks_per_table": column_chunks, "coefficient_bytes_sent_per_rank": coeff,
+                                  "coefficient_exchange_ms_at_assumed_bandwidth": round(coeff_ms, 3),
+                                  "projected_ms_per_proof_exchange_fully_exposed": round(compute + exchange_ms, 3),
+                                  "projected_ms_per_proof_exchange_fully_hidden": round(compute + exchange_ms - coeff_ms, 3),
+                                  "note": "TVMH_OPTION_COLUMN_SPLIT: every rank interpolates its own columns, the coefficient forms are "
+                                          "all-gathered (MasterTable::low_degree_extend_over); `projected_ms_per_proof` below is the fully "
+                                          "exposed end"}}
+    return {"ranks": n_ranks, **split, "measured_proofs": repeats, "stage_ms_per_rank": stages, "slowest_rank_sum_ms": round(compute, 3),
             "slowest_rank_sum_ms_with_median_stage_times": round(median_sum, 3),
             "replicated_stages_ms": round(replicated, 3), "exchanges_of_rank_0": exchanges, "bytes_sent_per_rank": sent, "collective_calls": calls,
             "projected_exchange_ms": round(exchange_ms, 3), "projected_ms_per_proof": round(compute + exchange_ms, 3),
@@ -505,6 +520,9 @@ def main():
     ap.add_argument("--simulate-gpus", type=int, default=0, help="single GPU: run one proof as this many ranks of the sharded C++ prover in "
                     "LOCKSTEP (one rank computes at a time, communicators between the contexts of this process) and report, per stage, what "
                     "each rank computes -- the measured critical path of an N-GPU run, without N GPUs (DESIGN.md section 6)")
+    ap.add_argument("--column-split", type=int, default=0, help="sharded proof (--gpus N > 1, --simulate-gpus N): split the inverse transforms of the "
+                    "table extensions by columns over the ranks and exchange the coefficients in this many chunks per table "
+                    "(TVMH_OPTION_COLUMN_SPLIT; north_star's column sharding where it applies) instead of replicating them")
     ap.add_argument("--host", choices=["cpp", "python"], default="cpp",
                     help="host side that sequences the C-ABI calls of the timed step: the C++ mirror of Prover::prove "
                          "(triton_vm_amd/host/, the default where it applies: cached tables, one proof per GPU) or the "
@@ -548,6 +566,7 @@ def main():
         except Exception as e:  # no g++ on this machine: the Python mirror sequences the same C-ABI calls
             print(f"bench.py: C++ host library unavailable ({e}); timing the Python host", file=sys.stderr)
     if sharded and host_lib is not None:
+        host_lib.tvmh_set_option(native_host.OPTION_COLUMN_SPLIT, args.column_split)
         try:
             comm = make_comm(dist, device, rank, world, local_rank)
             ok = 1
@@ -793,10 +812,11 @@ def main():
         if host_lib is not None and n_sim > 1 and args.data == "real" and world == 1 and not sharded:
             ctx.trim()   # (the simulated ranks need the pool's cached blocks)
             try:
-                sim = simulate_ranks(ctx, host_lib, n_sim, resident, padded_height, claim, kw)
+                sim = simulate_ranks(ctx, host_lib, n_sim, resident, padded_height, claim, kw, args.column_split)
                 sim["same_proof_as_single_gpu"] = bool(sim["proof"].size == last["proof"].size and (sim.pop("proof") == last["proof"]).all())
                 sim.pop("proof", None)
-                sim["column_split_bracket"] = column_split_bracket(sim, stage_ms, params.trace.length)
+                if not args.column_split:
+                    sim["column_split_bracket"] = column_split_bracket(sim, stage_ms, params.trace.length)
                 out["simulated_multi_gpu"] = sim
             except Exception as err:   # noqa: BLE001 (an extra: never lose the headline to it)
                 out["simulated_multi_gpu"] = {"error": str(err)[:400]}

@@ -61,7 +61,7 @@ def execution(kind, log2):
     return _TRACES[(kind, log2)]
 
 
-def _sharded_in_process(ctx, e, world, ldt, log2_expansion, split_all_trees, lockstep, seed):
+def _sharded_in_process(ctx, e, world, ldt, log2_expansion, split_all_trees, lockstep, seed, column_chunks=0):
     """one proof of execution `e` over `world` in-process ranks of the sharded C++ host (one thread, context and stream per rank,
     ONE copy of the replicated tables: TVMH_OPTION_SHARE_REPLICATED_TABLES) -> (every rank's proof words, rank 0's stats)"""
     import threading
@@ -84,6 +84,7 @@ def _sharded_in_process(ctx, e, world, ldt, log2_expansion, split_all_trees, loc
             comms.abort()
 
     host.tvmh_set_option(native_host.OPTION_SHARE_REPLICATED_TABLES, 1)
+    host.tvmh_set_option(native_host.OPTION_COLUMN_SPLIT, column_chunks)
     try:
         threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
         for t in threads:
@@ -94,6 +95,7 @@ def _sharded_in_process(ctx, e, world, ldt, log2_expansion, split_all_trees, loc
         assert all(not t.is_alive() for t in threads), "a rank hung"
     finally:
         host.tvmh_set_option(native_host.OPTION_SHARE_REPLICATED_TABLES, 0)
+        host.tvmh_set_option(native_host.OPTION_COLUMN_SPLIT, 0)
         comms.close()
         for c in contexts:
             c.close()
@@ -101,24 +103,27 @@ def _sharded_in_process(ctx, e, world, ldt, log2_expansion, split_all_trees, loc
     return [o[0] for o in out], out[0][1]
 
 
-# (log2 padded height, low-degree test, log2 expansion, every tree split?, lockstep?) -- BASELINE configs[2] is the last line but one
+# (log2 padded height, low-degree test, log2 expansion, every tree split?, lockstep?, chunks of the column split -- 0: coset sharding alone)
 SHARDED_CASES = [
-    (16, "fri", 2, True, False),
-    (16, "stir", 2, True, False),
-    (16, "fri", 2, False, True),
-    (16, "fri", 4, True, False),
-    (20, "fri", 2, False, False),
-    (20, "stir", 2, False, True),
+    (16, "fri", 2, True, False, 0),
+    (16, "stir", 2, True, False, 0),
+    (16, "fri", 2, False, True, 0),
+    (16, "fri", 4, True, False, 0),
+    (16, "stir", 2, True, False, 1),
+    (20, "fri", 2, False, False, 0),
+    (20, "stir", 2, False, True, 0),
+    (20, "fri", 2, False, False, 2),
 ]
 
 
-@pytest.mark.parametrize("log2,ldt,log2_expansion,split_all_trees,lockstep", SHARDED_CASES)
-def test_sharded_cpp_host_over_eight_ranks_equals_the_single_gpu_proof(gctx, log2, ldt, log2_expansion, split_all_trees, lockstep):
+@pytest.mark.parametrize("log2,ldt,log2_expansion,split_all_trees,lockstep,column_chunks", SHARDED_CASES)
+def test_sharded_cpp_host_over_eight_ranks_equals_the_single_gpu_proof(gctx, log2, ldt, log2_expansion, split_all_trees, lockstep, column_chunks):
     """The multi-GPU code path at real sizes (round 4's equality tests ran at 8 rows): prove_fib at 2^16 and 2^20 padded rows through
     `tvmh_prove_execution_sharded` over EIGHT ranks -- multi-chunk table extensions, multi-workgroup kernels on one-coset tables, the
     split-tree threshold of 2^21 leaves (at 2^20 rows: the three table trees and the first FRI rounds split, the later rounds
     whole), the valid-trace AIR dealt over the ranks, FRI and STIR, LDT expansion 16 (two cosets per rank; the quotient domain is
-    the short one) -- must emit the single-GPU proof, word for word, on every rank.  stark.rs:805-1006, master_table.rs:470-503."""
+    the short one), and with the inverse transforms split by columns and the coefficients exchanged (north_star's column sharding,
+    TVMH_OPTION_COLUMN_SPLIT) -- must emit the single-GPU proof, word for word, on every rank.  stark.rs:805-1006, master_table.rs:470-503."""
     from tests import test_proof_snapshot as snap
     from triton_vm_amd import native_host
 
@@ -128,10 +133,11 @@ def test_sharded_cpp_host_over_eight_ranks_equals_the_single_gpu_proof(gctx, log
     host = native_host.load_host_library()
     want = native_host.prove_execution(ctx, host, e["aet"], e["padded_height"], e["claim"], seed, log2_expansion=log2_expansion, ldt=ldt)
     ctx.trim()
-    proofs, stats = _sharded_in_process(ctx, e, 8, ldt, log2_expansion, split_all_trees, lockstep, seed)
+    proofs, stats = _sharded_in_process(ctx, e, 8, ldt, log2_expansion, split_all_trees, lockstep, seed, column_chunks)
     for rank, got in enumerate(proofs):
         assert got.size == want.size and (got == want).all(), rank
     assert stats["world"] == 8 and stats["passes"] == 1
+    assert ("main coefficients" in stats["exchanges"]) == bool(column_chunks)   # the column split's exchange (TVMH_OPTION_COLUMN_SPLIT)
     assert stats["split_trees_built"] >= (3 if (split_all_trees or log2 >= 18) else 0)
     assert stats["exchanges"]["main leaf digests"]["calls"] == 1
     ctx.trim()

@@ -116,6 +116,36 @@ def test_sharded_cpp_proof_equals_single_gpu_proof(ctx, orc, world, split_trees,
         comms.close()
 
 
+@pytest.mark.parametrize("world,kind,chunks,lockstep", [(2, "fri", 1, False), (8, "fri", 2, True), (4, "stir", 3, False), (8, "fri16", 1, False)])
+def test_column_split_of_the_inverse_transforms_gives_the_same_proof(ctx, orc, world, kind, chunks, lockstep):
+    """TVMH_OPTION_COLUMN_SPLIT (north_star's column sharding where it applies: rank r interpolates ITS columns, the coefficient
+    forms are all-gathered in chunks, every rank extends all columns onto its cosets -- MasterTable::low_degree_extend_over) against
+    the single-GPU proof, word for word, and the exchange shows up in the rank's statistics."""
+    if ctx.kind == "emu" and world > 2:
+        pytest.skip("on the GPU only (CPU suite time)")
+    host = host_library(ctx)
+    p = _params(kind)
+    main_trace, aux_trace = _inputs(orc, p)
+    py, want = _single_proof(ctx, host, p, main_trace, aux_trace)
+    comms = native_host.LocalComms(host, world, lockstep=lockstep)
+    host.tvmh_set_option(native_host.OPTION_COLUMN_SPLIT, chunks)
+    try:
+        def rank_body(rank):
+            c = _new_context(ctx)
+            try:
+                mine = Prover(c, p, main_trace, aux_trace, seed=SEED)
+                return native_host.prove_sharded(c, host, comms.ptrs[rank], p, mine.main.d_trace, mine.main.d_randomizers, mine.aux.d_trace,
+                                                 mine.aux.d_randomizers, mine.quotient_randomizer, split_tree_min_leaves=0, stir_security_level=8)
+            finally:
+                c.close()
+
+        for rank, got in enumerate(_run_ranks(world, rank_body, comms)):
+            assert got.size == want.size and (got == want).all(), rank
+    finally:
+        host.tvmh_set_option(native_host.OPTION_COLUMN_SPLIT, 0)
+        comms.close()
+
+
 @pytest.mark.parametrize("passes", [2, 8])
 def test_coset_wise_cpp_proof_equals_cached_proof(ctx, orc, passes):
     """the just-in-time path (stark.rs:805-1006, master_table.rs:470-503, 556-609) in the C++ host, one rank"""

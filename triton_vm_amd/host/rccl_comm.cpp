@@ -18,10 +18,14 @@
 #include "triton_host.hpp"
 
 namespace {
+constexpr uint32_t SLOTS = 16;
 struct RcclComm {
     tvmh_comm vt;
     ncclComm_t comm = nullptr;
     int device = 0;
+    // all_gather_async: the communicator's own stream, one "operands ready" event, one "exchange done" event per slot
+    hipStream_t side = nullptr;
+    hipEvent_t ready = nullptr, done[SLOTS] = {};
 };
 thread_local char g_error[256] = "";
 
@@ -49,6 +53,33 @@ int32_t rccl_all_to_all(void* self, tvm_ctx* ctx, const uint64_t* d_send, uint64
     const ncclResult_t e = ncclGroupEnd();
     if (r == ncclSuccess) r = e;
     return r == ncclSuccess ? TVM_OK : fail("all-to-all (ncclSend / ncclRecv group)", r);
+}
+
+// tvmh_comm::all_gather_async / wait: the exchange runs on the communicator's own stream, behind an event that marks the work queued
+// on the context's stream so far (the operands), and the context's stream waits for the slot's "done" event only where the host says
+// so -- kernels queued in between run under the exchange.
+int32_t hip_fail(const char* what, hipError_t e) {
+    std::snprintf(g_error, sizeof g_error, "%s: %s", what, hipGetErrorString(e));
+    return TVM_ERR_DEVICE;
+}
+int32_t rccl_all_gather_async(void* self, tvm_ctx* ctx, const uint64_t* d_send, uint64_t* d_recv, uint64_t words, uint32_t slot) {
+    auto* c = (RcclComm*)self;
+    if (!c->comm) return fail("all_gather_async on an aborted communicator", ncclInvalidUsage);
+    if (slot >= SLOTS) return TVM_ERR_INVALID_ARGUMENT;
+    hipStream_t compute = (hipStream_t)tvm_ctx_stream(ctx);
+    hipError_t e = hipEventRecord(c->ready, compute);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->side, c->ready, 0);
+    if (e != hipSuccess) return hip_fail("all_gather_async (operands)", e);
+    const ncclResult_t r = ncclAllGather(d_send, d_recv, words, ncclUint64, c->comm, c->side);
+    if (r != ncclSuccess) return fail("ncclAllGather (own stream)", r);
+    e = hipEventRecord(c->done[slot], c->side);
+    return e == hipSuccess ? TVM_OK : hip_fail("all_gather_async (done event)", e);
+}
+int32_t rccl_wait(void* self, tvm_ctx* ctx, uint32_t slot) {
+    auto* c = (RcclComm*)self;
+    if (slot >= SLOTS) return TVM_ERR_INVALID_ARGUMENT;
+    const hipError_t e = hipStreamWaitEvent((hipStream_t)tvm_ctx_stream(ctx), c->done[slot], 0);
+    return e == hipSuccess ? TVM_OK : hip_fail("wait (exchange done)", e);
 }
 
 // tvmh_comm::abort: this rank failed in the middle of a proof.  Its queued collectives are cancelled and the communicator is
@@ -89,7 +120,12 @@ extern "C" int32_t tvmh_rccl_comm_create(const uint8_t unique_id[128], uint32_t 
         return fail("ncclCommInitRank", r);
     }
     c->device = device;
-    c->vt = tvmh_comm{c, rank, world, rccl_all_gather, rccl_all_to_all, nullptr, nullptr, nullptr, rccl_abort, nullptr};
+    bool own_stream = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess &&
+                      hipEventCreateWithFlags(&c->ready, hipEventDisableTiming) == hipSuccess;
+    for (uint32_t k = 0; k < SLOTS && own_stream; k++) own_stream = hipEventCreateWithFlags(&c->done[k], hipEventDisableTiming) == hipSuccess;
+    // (without a stream of its own the communicator simply offers no asynchronous exchange: the caller uses all_gather)
+    c->vt = tvmh_comm{c, rank, world, rccl_all_gather, rccl_all_to_all, nullptr, nullptr, nullptr, rccl_abort, nullptr,
+                      own_stream ? rccl_all_gather_async : nullptr, own_stream ? rccl_wait : nullptr};
     *out = &c->vt;
     return TVM_OK;
 }
@@ -97,6 +133,11 @@ extern "C" int32_t tvmh_rccl_comm_create(const uint8_t unique_id[128], uint32_t 
 extern "C" void tvmh_rccl_comm_destroy(tvmh_comm* comm) {
     if (!comm) return;
     auto* c = (RcclComm*)comm->self;
+    if (c->side) (void)hipStreamSynchronize(c->side);
     if (c->comm) (void)ncclCommDestroy(c->comm);
+    for (uint32_t k = 0; k < SLOTS; k++)
+        if (c->done[k]) (void)hipEventDestroy(c->done[k]);
+    if (c->ready) (void)hipEventDestroy(c->ready);
+    if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
 }

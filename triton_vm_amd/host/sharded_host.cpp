@@ -626,11 +626,15 @@ struct ShardedRun {
         MasterTable &main = sp.main_, &aux = sp.aux_;
 
         // 4-6: main table LDE, Merkle tree, challenges  (stark.rs:367-377)
+        // (TVMH_OPTION_COLUMN_SPLIT: the inverse transforms split by columns, the coefficients exchanged -- see extend_table)
+        const unsigned column_chunks = comm && R > 1 && P == 1 ? (unsigned)std::min<u64>(tvmh_get_option(TVMH_OPTION_COLUMN_SPLIT), 16) : 0;
+        auto extend_table = [&](MasterTable& mt, const char* what) {
+            mt.set_domains(ldt_rank, ldt_rank);
+            if (column_chunks) mt.low_degree_extend_over(comm, column_chunks, [&](u64 bytes) { count(what, bytes); });
+            else mt.maybe_low_degree_extend_all_columns();
+        };
         mark("main LDE");
-        if (P == 1) {
-            main.set_domains(ldt_rank, ldt_rank);
-            main.maybe_low_degree_extend_all_columns();
-        }
+        if (P == 1) extend_table(main, "main coefficients");
         mark("main Merkle");
         const Tree main_tree = commit_master_table(main, "main leaf digests");
         ps.enqueue("main root", main_tree.root().data(), 5);
@@ -640,10 +644,7 @@ struct ShardedRun {
 
         // 8-9: aux table
         mark("aux LDE");
-        if (P == 1) {
-            aux.set_domains(ldt_rank, ldt_rank);
-            aux.maybe_low_degree_extend_all_columns();
-        }
+        if (P == 1) extend_table(aux, "aux coefficients");
         mark("aux Merkle");
         const Tree aux_tree = commit_master_table(aux, "aux leaf digests");
         ps.enqueue("aux root", aux_tree.root().data(), 5);
@@ -1158,7 +1159,7 @@ extern "C" int32_t tvmh_local_comms_create(uint32_t world, uint32_t lockstep, tv
     g->comms.resize(world);
     for (uint32_t r = 0; r < world; r++) {
         g->members[r] = {g, r};
-        g->comms[r] = tvmh_comm{&g->members[r], r, world, local_all_gather, local_all_to_all, local_begin, local_mark, local_end, local_abort, local_share};
+        g->comms[r] = tvmh_comm{&g->members[r], r, world, local_all_gather, local_all_to_all, local_begin, local_mark, local_end, local_abort, local_share, nullptr, nullptr};
         out[r] = &g->comms[r];
     }
     return TVM_OK;

@@ -296,6 +296,39 @@ void MasterTable::maybe_low_degree_extend_all_columns() {
     c_.check(tvm_lde_table(c_.raw(), fk_, d_trace_, n_rows_, n_cols_, d_rnd_, h_, trace_.c(), evaluation_domain().c(), &table_),
              "tvm_lde_table");
 }
+void MasterTable::low_degree_extend_over(const tvmh_comm* comm, unsigned chunks, const std::function<void(u64)>& sent) {
+    if (!comm || !chunks || chunks > 16) throw Error(TVM_ERR_INVALID_ARGUMENT, "low_degree_extend_over: a communicator and 1 .. 16 chunks");
+    const u64 R = comm->world, me = comm->rank, W = n_cols_ * (u64)fk_, n = n_rows_;
+    const u64 cpc = (W + R * chunks - 1) / (R * chunks), per = cpc * chunks;   // virtual columns per (rank, chunk) / per rank
+    const ArithmeticDomain ev = evaluation_domain();
+    clear_cache();
+    // this rank's block, interpolated (the unused tail of a short last block travels as it is and is never read)
+    DeviceBuffer mine(c_, per * n);
+    const u64 first = std::min(me * per, W), count = std::min(W - first, per);
+    c_.check(tvm_lde_column_coefficients(c_.raw(), fk_, d_trace_, n, n_cols_, trace_.c(), first, count, mine.ptr()), "tvm_lde_column_coefficients");
+    std::vector<DeviceBuffer> all;
+    for (unsigned k = 0; k < chunks; k++) all.emplace_back(c_, R * cpc * n);
+    const bool async = comm->all_gather_async && comm->wait;
+    auto status = [&](int32_t st, const char* what) {
+        if (st != TVM_OK) throw Error(st, std::string(what) + ": the communicator reported " + tvm_status_string(st));
+    };
+    for (unsigned k = 0; k < chunks; k++) {
+        if (async) status(comm->all_gather_async(comm->self, c_.raw(), mine.ptr() + k * cpc * n, all[k].ptr(), cpc * n, k), "coefficients (all-gather)");
+        else status(comm->all_gather(comm->self, c_.raw(), mine.ptr() + k * cpc * n, all[k].ptr(), cpc * n), "coefficients (all-gather)");
+        if (sent) sent(cpc * n * 8 * (R - 1));
+    }
+    c_.check(tvm_lde_table_begin(c_.raw(), fk_, n, n_cols_, h_, trace_.c(), ev.c(), &table_), "tvm_lde_table_begin");
+    for (unsigned k = 0; k < chunks; k++) {
+        if (async) status(comm->wait(comm->self, c_.raw(), k), "coefficients (wait)");
+        for (u64 r = 0; r < R; r++) {
+            const u64 col0 = r * per + k * cpc;
+            if (col0 >= W) continue;
+            c_.check(tvm_lde_table_add_columns(c_.raw(), table_, all[k].ptr() + r * cpc * n, col0, std::min(W - col0, cpc), d_rnd_, h_, trace_.c(),
+                                               ev.c()), "tvm_lde_table_add_columns");
+        }
+    }
+    c_.check(tvm_lde_table_end(c_.raw(), table_), "tvm_lde_table_end");
+}
 void MasterTable::clear_cache() {
     if (table_) tvm_table_free(c_.raw(), table_);
     table_ = nullptr;
@@ -988,11 +1021,11 @@ std::vector<u64> prove_execution(const Context& c, const StarkParameters& p, con
 
 }  // namespace triton_vm
 
-static std::atomic<uint64_t> g_options[4] = {{0}, {0}, {0}, {0}};   // indexed by TVMH_OPTION_*
+static std::atomic<uint64_t> g_options[5] = {{0}, {0}, {0}, {0}, {0}};   // indexed by TVMH_OPTION_*
 extern "C" void tvmh_set_option(uint32_t option, uint64_t value) {
-    if (option >= 1 && option <= 3) g_options[option].store(value);
+    if (option >= 1 && option <= 4) g_options[option].store(value);
 }
-extern "C" uint64_t tvmh_get_option(uint32_t option) { return option >= 1 && option <= 3 ? g_options[option].load() : 0; }
+extern "C" uint64_t tvmh_get_option(uint32_t option) { return option >= 1 && option <= 4 ? g_options[option].load() : 0; }
 
 extern "C" int32_t tvmh_prove(tvm_ctx* ctx, uint32_t log2_padded_height, uint64_t num_trace_randomizers,
                               uint64_t num_collinearity_checks, uint32_t log2_expansion, const uint64_t* d_main_trace,

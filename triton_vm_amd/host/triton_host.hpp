@@ -20,6 +20,10 @@
 
 #include "triton_hip.h"
 
+extern "C" {
+typedef struct tvmh_comm tvmh_comm;   // the collectives of the sharded prover as a table of functions: defined below
+}
+
 namespace triton_vm {
 
 typedef uint64_t u64;
@@ -134,6 +138,12 @@ public:
     // the quotient / LDT domain this table is extended onto: a coset group of the real domains when the extended rows are
     // split over ranks or evaluated pass by pass (sharded_host.cpp); drops the cached extension
     void set_domains(ArithmeticDomain quotient, ArithmeticDomain ldt);
+    // maybe_low_degree_extend_all_columns the way the COLUMN sharding does it (include/triton_hip.h:
+    // tvm_lde_column_coefficients ...): this rank interpolates ITS block of virtual columns, the coefficient forms are all-gathered
+    // in `chunks` chunks -- all requested at once through all_gather_async where the communicator has it, so that the exchange
+    // of chunk c + 1 runs under the extension of chunk c -- and every column is extended onto this table's own evaluation domain.
+    // The same table as maybe_low_degree_extend_all_columns; sent(bytes) is told what each exchange sends.
+    void low_degree_extend_over(const tvmh_comm* comm, unsigned chunks, const std::function<void(u64)>& sent);
     // a second table object over the same trace and randomizer arrays, with no cached extension of its own
     MasterTable sibling() const { return MasterTable(c_, fk_, d_trace_, n_rows_, n_cols_, d_rnd_, h_, trace_, quotient_, ldt_); }
     // reveal_rows over the view of `view_rows` rows of the cached extension (its own LDT domain by default)
@@ -259,6 +269,12 @@ typedef struct tvmh_comm {
      * (*out = the kept object).  Used by bench.py --simulate-gpus (eight ranks of a 2^22-row proof on one GPU: 21.8 GB of traces
      * once instead of eight times) under TVMH_OPTION_SHARE_REPLICATED_TABLES; a multi-process communicator never sees it. */
     int32_t (*share)(void* self, tvm_ctx* ctx, uint32_t op, const void* mine, void (*drop)(const void*), const void** out);
+    /* optional (may be null: the caller then uses all_gather): an all-gather that does NOT occupy the context's stream -- ordered
+     * after the work queued on it so far, carried out on the communicator's own stream, and complete for the context's stream only
+     * once wait(slot) has been called -- so that several exchanges can be in flight under the kernels that consume the earlier
+     * ones (the coefficient exchange of the column split, chunk by chunk: MasterTable::low_degree_extend_over).  slot < 16. */
+    int32_t (*all_gather_async)(void* self, tvm_ctx* ctx, const uint64_t* d_send, uint64_t* d_recv, uint64_t words_per_rank, uint32_t slot);
+    int32_t (*wait)(void* self, tvm_ctx* ctx, uint32_t slot);
 } tvmh_comm;
 #define TVMH_SHARE_BARRIER 0
 #define TVMH_SHARE_PUBLISH 1
@@ -382,6 +398,12 @@ extern "C" int32_t tvmh_prove_execution(tvm_ctx* ctx, const tvm_aet* aet, uint32
 // TVMH_OPTION_TRACE != 0: host wall time of the steps of prove_execution (plain and sharded) on stderr.  Diagnostics only; the host
 // library, like the backend, reads no environment variable.
 #define TVMH_OPTION_TRACE 3
+// TVMH_OPTION_COLUMN_SPLIT = k > 0: the sharded prover splits the INVERSE transforms of the table extensions by columns over the
+// ranks and exchanges the coefficients in k chunks per table (MasterTable::low_degree_extend_over) instead of replicating them --
+// north_star's column sharding for the part of the front end where it applies.  Pays only for the part of the exchange that
+// overlaps with compute (at ~300 GB/s per rank moving a column's coefficients costs what recomputing them
+// costs); default 0 = the coset sharding alone.  k <= 16.
+#define TVMH_OPTION_COLUMN_SPLIT 4
 extern "C" void tvmh_set_option(uint32_t option, uint64_t value);
 extern "C" uint64_t tvmh_get_option(uint32_t option);
 

@@ -51,6 +51,7 @@ def load_host_library(backend_path=None, out=None):
 OPTION_EXACT_AIR = 1   # tvmh_set_option: prove_execution evaluates the AIR row by row instead of in valid-trace mode
 OPTION_SHARE_REPLICATED_TABLES = 2   # in-process ranks use ONE copy of the replicated trace-side tables (triton_host.hpp)
 OPTION_TRACE = 3   # host wall time of the steps of prove_execution on stderr
+OPTION_COLUMN_SPLIT = 4   # k > 0: the sharded prover splits the inverse transforms by columns, coefficients exchanged in k chunks
 
 
 # ---- communicators for the sharded C++ host (triton_host.hpp: tvmh_comm) -----------------------------------------------
@@ -59,12 +60,15 @@ _HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
 _MARK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_char_p)
 _ABORT = C.CFUNCTYPE(None, C.c_void_p)
 _SHARE = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p)
+_ASYNC = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32)
+_WAIT = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint32)
 
 
 class CommStruct(C.Structure):
     """struct tvmh_comm"""
     _fields_ = [("self", C.c_void_p), ("rank", C.c_uint32), ("world", C.c_uint32), ("all_gather", _COLLECTIVE), ("all_to_all", _COLLECTIVE),
-                ("begin", _HOOK), ("mark", _MARK), ("end", _HOOK), ("abort", _ABORT), ("share", _SHARE)]
+                ("begin", _HOOK), ("mark", _MARK), ("end", _HOOK), ("abort", _ABORT), ("share", _SHARE),
+                ("all_gather_async", _ASYNC), ("wait", _WAIT)]
 
 
 class LocalComms:
@@ -159,7 +163,7 @@ class CallbackComm:
             return _COLLECTIVE(call)
 
         self._keep = (wrap(all_gather), wrap(all_to_all))
-        self.struct = CommStruct(None, rank, world, self._keep[0], self._keep[1], _HOOK(), _MARK(), _HOOK(), _ABORT(), _SHARE())
+        self.struct = CommStruct(None, rank, world, self._keep[0], self._keep[1], _HOOK(), _MARK(), _HOOK(), _ABORT(), _SHARE(), _ASYNC(), _WAIT())
         self.ptr = C.addressof(self.struct)
 
 

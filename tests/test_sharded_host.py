@@ -116,7 +116,7 @@ def test_sharded_cpp_proof_equals_single_gpu_proof(ctx, orc, world, split_trees,
         comms.close()
 
 
-@pytest.mark.parametrize("world,kind,chunks,lockstep", [(2, "fri", 1, False), (8, "fri", 2, True), (4, "stir", 3, False), (8, "fri16", 1, False)])
+@pytest.mark.parametrize("world,kind,chunks,lockstep", [(2, "fri", 2, False), (8, "fri", 1, True), (4, "stir", 3, False), (8, "fri16", 2, False)])
 def test_column_split_of_the_inverse_transforms_gives_the_same_proof(ctx, orc, world, kind, chunks, lockstep):
     """TVMH_OPTION_COLUMN_SPLIT (north_star's column sharding where it applies: rank r interpolates ITS columns, the coefficient
     forms are all-gathered in chunks, every rank extends all columns onto its cosets -- MasterTable::low_degree_extend_over) against

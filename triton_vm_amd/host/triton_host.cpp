@@ -306,19 +306,24 @@ void MasterTable::low_degree_extend_over(const tvmh_comm* comm, unsigned chunks,
     DeviceBuffer mine(c_, per * n);
     const u64 first = std::min(me * per, W), count = std::min(W - first, per);
     c_.check(tvm_lde_column_coefficients(c_.raw(), fk_, d_trace_, n, n_cols_, trace_.c(), first, count, mine.ptr()), "tvm_lde_column_coefficients");
-    std::vector<DeviceBuffer> all;
-    for (unsigned k = 0; k < chunks; k++) all.emplace_back(c_, R * cpc * n);
     const bool async = comm->all_gather_async && comm->wait;
     auto status = [&](int32_t st, const char* what) {
         if (st != TVM_OK) throw Error(st, std::string(what) + ": the communicator reported " + tvm_status_string(st));
     };
-    for (unsigned k = 0; k < chunks; k++) {
+    // Two chunks' receive buffers at a time: the exchange of chunk k + 1 is requested before chunk k is extended (with an
+    // asynchronous communicator it runs under that extension), and a chunk's buffer goes back to the pool once its columns are
+    // written -- R * W / (R * chunks) columns of coefficients live per buffer, not all W.
+    std::vector<DeviceBuffer> all(chunks);
+    auto request = [&](unsigned k) {
+        all[k] = DeviceBuffer(c_, R * cpc * n);
         if (async) status(comm->all_gather_async(comm->self, c_.raw(), mine.ptr() + k * cpc * n, all[k].ptr(), cpc * n, k), "coefficients (all-gather)");
         else status(comm->all_gather(comm->self, c_.raw(), mine.ptr() + k * cpc * n, all[k].ptr(), cpc * n), "coefficients (all-gather)");
         if (sent) sent(cpc * n * 8 * (R - 1));
-    }
+    };
+    request(0);
     c_.check(tvm_lde_table_begin(c_.raw(), fk_, n, n_cols_, h_, trace_.c(), ev.c(), &table_), "tvm_lde_table_begin");
     for (unsigned k = 0; k < chunks; k++) {
+        if (k + 1 < chunks) request(k + 1);
         if (async) status(comm->wait(comm->self, c_.raw(), k), "coefficients (wait)");
         for (u64 r = 0; r < R; r++) {
             const u64 col0 = r * per + k * cpc;
@@ -326,6 +331,7 @@ void MasterTable::low_degree_extend_over(const tvmh_comm* comm, unsigned chunks,
             c_.check(tvm_lde_table_add_columns(c_.raw(), table_, all[k].ptr() + r * cpc * n, col0, std::min(W - col0, cpc), d_rnd_, h_, trace_.c(),
                                                ev.c()), "tvm_lde_table_add_columns");
         }
+        all[k].reset();   // (stream-ordered: the next request's exchange is ordered behind the kernels that read this buffer)
     }
     c_.check(tvm_lde_table_end(c_.raw(), table_), "tvm_lde_table_end");
 }

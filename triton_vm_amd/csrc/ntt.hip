@@ -780,6 +780,11 @@ __global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass1_rows(Ntt2Args a) {
 //     different banks (the odd pitch of TVM_ROW_WORDS put b + j1 = const into one).
 // 8 rows, 512 work-items, 78 KB of LDS: two workgroups per CU.
 #define TVM_P2F_ROWW 1096
+#define TVM_P2F_TW2_WORDS 272   // 16 x 17: the middle group's twiddles
+#define TVM_P2F_LDS_WORDS (8 * TVM_P2F_ROWW + TVM_P2F_TW2_WORDS + TVM_ROW_WORDS(1024) + 8)   // tile + twiddles + one coset's factors + a randomizer word per row: 79.2 KB
+#ifndef TVM_P2F_FT_EARLY
+#define TVM_P2F_FT_EARLY 2   // 16-byte loads of the last group's factors requested BEFORE the middle group (4 registers each)
+#endif
 #ifndef TVM_P2F_X
 #define TVM_P2F_X 0
 #endif
@@ -796,14 +801,19 @@ __global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass2_fused(LdePass2Args a
     const int vl = blockIdx.y, v = a.col0 + vl;
     const u64 p0 = (u64)blockIdx.x * ROWS, p = p0 + (u64)w;
     u64* const row = s + w * ROWW;
-    u64* const tw_fwd = s + ROWS * ROWW;   // all n2 powers of the forward root, behind the tile
+    // behind the tile: the 15 x 16 twiddles the middle butterfly group uses, tw2[17 j0 + e] = w_n2^(4 j0 brev4(e)) (pitch 17: the
+    // sixteen j0 of a wavefront in sixteen banks), and the coset factors of the current coset at their positions, skewed like a row
+    u64* const tw2 = s + ROWS * ROWW;
+    u64* const ghl = tw2 + TVM_P2F_TW2_WORDS;
     {
         const u64* y = a.y + (u64)vl * n + p * n2 + lane;
         u64* const rowl = row + TVM_ROW_SKEW(lane);
 #pragma unroll
         for (int e = 0; e < 16; e++) rowl[68 * e] = TVM_LOAD_STREAM(&y[64 * e]);   // position lane + 64 e (skew: + 4 e)
     }
-    for (int i = tid; i < n2; i += NT) tw_fwd[i] = a.tw_b1[i];
+    if (tid < 256) tw2[17 * (tid >> 4) + (tid & 15)] = a.tw_b1[((tid >> 4) * brev_bits((u32)(tid & 15), 4)) << 2];
+#pragma unroll
+    for (int hh = 0; hh < n2 / NT; hh++) ghl[TVM_ROW_SKEW(tid + hh * NT)] = a.g_hi_pos[tid + hh * NT];
     tvm_wave_sync();
     // inverse rows step: position q of the row then holds N * t[m1*n1 + m2], m1 = brev(q), m2 = brev(p)
     if (a.mode != TVM_LDE_FORWARD_ONLY) row_ntt<false, 4, LOGN, 2>(row, a.tw_a2, lane);
@@ -818,39 +828,61 @@ __global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass2_fused(LdePass2Args a
 #pragma unroll
     for (int e = 0; e < 16; e++) coef[e] = row[17 * lane + e];   // TVM_ROW_SKEW(16 * lane + e) = 17 * lane + e
     const u64 m2 = brev_bits((u32)p, a.log_n1);   // uniform over the wavefront
-    // lane 0: the randomizer coefficient that meets coefficient m = m2 (m1 = 0: position 0), re-read in every coset (one lane's load)
-    const u64* const rnd = a.rnd + ((u64)(v / a.fk) * a.h + (m2 < a.h ? m2 : 0)) * a.fk + (v % a.fk);
+    // lane 0: the randomizer coefficient that meets coefficient m = m2 (m1 = 0: position 0) -- parked in an LDS word of the row's own,
+    // re-read in every coset (a global load at its use stalled the wavefront, and with it the workgroup's barrier, once per coset:
+    // every 8-row tile has a row with m2 < 128)
     const bool has_rnd = m2 < a.h;
-    tvm_lds_barrier();   // the twiddle table is staged
+    u64* const r0 = ghl + TVM_ROW_WORDS(n2) + w;
+    if (lane == 0) *r0 = has_rnd ? a.rnd[((u64)(v / a.fk) * a.h + m2) * a.fk + (v % a.fk)] : 0;
+    tvm_lds_barrier();   // the twiddle tables and the first coset's factors are staged
     for (int k = 0; k < a.n_cosets; k++) {
         // (lane and work-item number through opaque moves: the addresses below are cheap to form and expensive to keep -- hoisted out
         // of the coset loop they went to scratch)
         const int ln = tvm_opaque(lane);
-        const u64x2* gh = (const u64x2*)(a.g_hi_pos + (u64)k * n2 + 16 * ln);
         u64 x[16];
+        {
+            const u64* const gh = ghl + 17 * ln;   // the coset's factors at positions 16 lane + e (staged by the workgroup, below)
 #pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-            const u64x2 g2 = gh[e / 2];
-            x[e] = bfe_mul(coef[e], g2.x);
-            x[e + 1] = bfe_mul(coef[e + 1], g2.y);
+            for (int e = 0; e < 16; e++) x[e] = bfe_mul(coef[e], gh[e]);
         }
-        if (has_rnd && ln == 0) x[0] = bfe_add(coef[0], bfe_mul(a.zk[k], *rnd));   // gamma_k^0 = 1 at position 0
+        if (has_rnd && ln == 0) x[0] = bfe_add(coef[0], bfe_mul(a.zk[k], *r0));   // gamma_k^0 = 1 at position 0
         ntt_pow2_points<4, true, false>(x);
         {
             u64* const out = row + 17 * ln;
 #pragma unroll
             for (int e = 0; e < 16; e++) out[e] = x[e];
         }
+        const u64x2* ft = (const u64x2*)(a.f_tw + (((p << 6) + ln) << 4));
+        u64x2 f[8];
+#pragma unroll
+        for (int j = 0; j < TVM_P2F_FT_EARLY; j++) f[j] = ft[j];   // the last group's first factors: in flight under the middle group
         tvm_wave_sync();
-        row_ntt_group<true, 4, 4, LOGN, 1, TVM_P2F_TWB>(row, tw_fwd, ln);
+        {   // layers 4 .. 7 (row_ntt_group<true, 4, 4>: one group per lane), the twiddle step from the compact table
+            const int j0 = ln & 15;
+            u64* const q = row + TVM_ROW_SKEW(((ln >> 4) << 8) | j0);   // positions base + 16 e: TVM_ROW_SKEW adds 17 e
+            const u64* const t2 = tw2 + 17 * j0;
+            u64 x2[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) x2[e] = q[17 * e];
+#pragma unroll
+            for (int e = 1; e < 16; e++) {
+                x2[e] = bfe_mul(x2[e], t2[e]);
+                if (e % TVM_P2F_TWB == 0) asm volatile("" ::: "memory");
+            }
+            ntt_pow2_points<4, true, false>(x2);
+#pragma unroll
+            for (int e = 0; e < 16; e++) q[17 * e] = x2[e];
+        }
+        tvm_wave_sync();
         u64 u[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) u[e] = a.u_tw[((u64)k * n1 + p) * 4 + e];
-        const u64x2* ft = (const u64x2*)(a.f_tw + (((p << 6) + ln) << 4));
+#pragma unroll
+        for (int j = TVM_P2F_FT_EARLY; j < 8; j++) f[j] = ft[j];
 #pragma unroll
         for (int it = 0; it < 4; it++) {   // layers 8 and 9 on positions g + 256 e, g = lane + 64 it, with the inter-pass twiddle
             u64* const q = row + TVM_ROW_SKEW(ln + 64 * it);   // TVM_ROW_SKEW(g + 256 e) = TVM_ROW_SKEW(g) + 272 e
-            const u64x2 f01 = ft[2 * it], f23 = ft[2 * it + 1];
+            const u64x2 f01 = f[2 * it], f23 = f[2 * it + 1];
             u64 y4[4] = {bfe_mul(q[0], f01.x), bfe_mul(q[Q4 + Q4 / 16], f01.y), bfe_mul(q[2 * (Q4 + Q4 / 16)], f23.x),
                          bfe_mul(q[3 * (Q4 + Q4 / 16)], f23.y)};
             ntt_pow2_points<2, true, false>(y4);
@@ -869,6 +901,12 @@ __global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass2_fused(LdePass2Args a
 #endif
         {
             const int t2 = tvm_opaque(tid), b_out = t2 & (ROWS - 1), j1_0 = t2 >> RLOG;
+            // the next coset's factors: requested here, parked in LDS at the end of the store phase (every wavefront has read this
+            // coset's before the barrier above) -- their latency hides behind the store phase and costs two registers
+            const bool more = k + 1 < a.n_cosets;
+            u64 g_next[n2 / NT];
+#pragma unroll
+            for (int hh = 0; hh < n2 / NT; hh++) g_next[hh] = more ? a.g_hi_pos[(u64)(k + 1) * n2 + t2 + hh * NT] : 0;
             u64* zk = a.z + ((u64)vl * a.n_cosets + k) * n + p0 + b_out;
             const u64* src = s + b_out * ROWW;
 #pragma unroll 4
@@ -879,6 +917,10 @@ __global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass2_fused(LdePass2Args a
 #else
                 TVM_STORE_STREAM(&zk[(u64)j1 * n1], src[TVM_ROW_SKEW(j1)]);
 #endif
+            }
+            if (more) {
+#pragma unroll
+                for (int hh = 0; hh < n2 / NT; hh++) ghl[TVM_ROW_SKEW(t2 + hh * NT)] = g_next[hh];
             }
         }
 #if TVM_P2F_X == 3
@@ -1375,7 +1417,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             else if (std_roots && sp.log_n2 == 10 && n1 % 16 == 0 && h <= n1) {
                 // 1024-point axis: every wavefront keeps its row across the coset loop (k_lde_pass2_fused); more trace randomizers than
                 // n1 (never the case for a STARK's parameters) take the generic kernel
-                const size_t lds_r = (size_t)(8 * TVM_P2F_ROWW + n2) * sizeof(u64);
+                const size_t lds_r = (size_t)TVM_P2F_LDS_WORDS * sizeof(u64);
                 TVM_LAUNCH((k_lde_pass2_fused<8>), dim3((unsigned)(n1 / 8), (unsigned)nc), dim3(512), lds_r, c->stream, a);
             }
             else

@@ -248,7 +248,7 @@ def lde_roofline(lde_ms, n_rows, n_cols, expansion, share, counters, shape_match
         insts = fam["wave_valu_instructions_per_trace_cell"] * cells
         hbm_counter_frac = traffic / secs / 1e9 / HBM_PEAK_GBPS
         valu_frac = insts * 64 / secs / 1e12 / VALU_PEAK_T
-        out.update(traffic=int(traffic), traffic_source=fam.get("source"),
+        out.update(traffic=int(traffic), traffic_source=fam.get("source"), traffic_source_commit=(counters or {}).get("commit"),
                    hbm={"algorithmic_gbps": round(achieved, 1), "algorithmic_frac": round(achieved / HBM_PEAK_GBPS, 4),
                         "counter_gbps": round(traffic / secs / 1e9, 1), "counter_frac": round(hbm_counter_frac, 4),
                         "traffic_over_algorithmic": round(traffic / (cells * bytes_per_cell), 2)},

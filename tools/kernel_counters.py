@@ -9,7 +9,7 @@ kernels, turned into the per-unit figures bench.py's roofline objects multiply u
   hash_rows   SQ_INSTS_VALU per row and Tip5 permutation (the probe's table has <cols> words per row: cols // 10 + 1 permutations),
               and the share of LDS-active cycles lost to bank conflicts
 
-Usage: python tools/kernel_counters.py <summary file> [columns per dispatch = 96] [log2 rows = 20]"""
+Usage: python tools/kernel_counters.py <summary file> [columns per dispatch = 96] [log2 rows = 20] [commit of the profiled tree]"""
 import json
 import re
 import sys
@@ -28,7 +28,7 @@ def blocks(txt):
     return out
 
 
-def main(path, cols=96, log2_rows=20, expansion=8):
+def main(path, cols=96, log2_rows=20, expansion=8, commit=None):
     b = blocks(open(path).read())
     cells = cols << log2_rows
     src = f"{path}: rocprofv3 --kernel-trace --pmc in separate passes (tools/pmc.sh) over `tools/probe.py {log2_rows} {cols} 0 1`"
@@ -44,7 +44,7 @@ def main(path, cols=96, log2_rows=20, expansion=8):
                      "lds_bank_conflict_share": round(c["SQ_LDS_BANK_CONFLICT"][0] / max(c["SQ_LDS_IDX_ACTIVE"][0], 1), 3)}
         total_bytes += f + w
         total_valu += v
-    out = {"lde": {"source": src, "columns_per_dispatch": cols, "hbm_bytes_per_trace_cell": round(total_bytes / cells, 1),
+    out = {"commit": commit, "lde": {"source": src, "columns_per_dispatch": cols, "hbm_bytes_per_trace_cell": round(total_bytes / cells, 1),
                    "wave_valu_instructions_per_trace_cell": round(total_valu / cells, 3), "kernels": lde}}
     h = b.get("k_hash_rows_mfma")
     if h and "SQ_INSTS_VALU" in h:
@@ -58,4 +58,6 @@ def main(path, cols=96, log2_rows=20, expansion=8):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 96, int(sys.argv[3]) if len(sys.argv) > 3 else 20)
+    # [4]: the commit of the tree the counters were taken on (the kernels that were profiled), recorded in the file
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 96, int(sys.argv[3]) if len(sys.argv) > 3 else 20,
+         commit=sys.argv[4] if len(sys.argv) > 4 else None)

@@ -75,6 +75,9 @@ int32_t tvm_ctx_trim(tvm_ctx* ctx);
  * environment. */
 #define TVM_OPTION_LDE_CHUNK_COLUMNS 2
 #define TVM_OPTION_MERKLE_MIN_WORKGROUPS 3
+/* TVM_OPTION_LDE_PASS2_TILES = 1: the middle pass of tvm_lde_table on 2048-point axes (2^21 / 2^22 rows) runs the position-major tile
+ * kernel (k_lde_pass2_v3) instead of k_lde_pass2_fused (and the generic kernel on 1024-point axes): the A/B switch of profiles/r05_*. */
+#define TVM_OPTION_LDE_PASS2_TILES 4
 int32_t tvm_ctx_set_option(tvm_ctx* ctx, int32_t option, uint64_t value);
 /* Cap on the bytes this context may hold through tvm_malloc / table handles (0 = no cap).  Requests beyond it fail
  * with TVM_ERR_OUT_OF_MEMORY exactly like a full device: the knob a host uses to share a GPU, and what the tests use to

@@ -116,6 +116,10 @@ int32_t tvm_ctx_set_option(tvm_ctx* c, int32_t option, uint64_t value) {
         c->lde_chunk_columns = (int)value;
         return TVM_OK;
     }
+    if (option == TVM_OPTION_LDE_PASS2_TILES) {
+        c->lde_pass2_tiles = value ? 1 : 0;
+        return TVM_OK;
+    }
     if (option == TVM_OPTION_MERKLE_MIN_WORKGROUPS) {
         c->merkle_min_workgroups = value ? value : 4096;
         return TVM_OK;

@@ -189,12 +189,15 @@ TVM_D void lds_ntt_fixed(u64* s, const u64* __restrict__ tw, int tid, int nt) {
 #endif
 #define TVM_ROW_SKEW(p) ((p) + ((p) >> 4))
 #define TVM_ROW_WORDS(n) ((n) + ((n) >> 4) + 1)   // odd pitch: position p of the 16 rows of a tile falls into 16 different banks
-template <bool DIT, int K, int L, int LOGN, int ROOT, int TWB = TVM_TW_BATCH>
+// LPR: lanes per row -- 64 (the row's own wavefront; tvm_wave_sync between groups) or 128 (two wavefronts share a row of 2048 points,
+// `lane` is the lane number within the pair, and the groups are separated by workgroup barriers: every wavefront of the workgroup runs
+// the same sequence)
+template <bool DIT, int K, int L, int LOGN, int ROOT, int TWB = TVM_TW_BATCH, int LPR = 64>
 TVM_D void row_ntt_group(u64* row, const u64* __restrict__ tw, int lane) {
     static_assert(ROOT == 1 || ROOT == 2, "the domains' own roots of unity only");
     constexpr int R = 1 << K, NG = 1 << (LOGN - K);
 #pragma unroll 1
-    for (int g = lane; g < NG; g += 64) {
+    for (int g = lane; g < NG; g += LPR) {
         const int j0 = g & ((1 << L) - 1);
         const int base = ((g >> L) << (L + K)) | j0;
         // skew(base + (e << L)) = skew(base) + skew(e << L): no carry into bit 4 -- for L >= 4 the second term is a multiple
@@ -229,15 +232,16 @@ TVM_D void row_ntt_group(u64* row, const u64* __restrict__ tw, int lane) {
 #pragma unroll
         for (int e = 0; e < R; e++) p[TVM_ROW_SKEW(e << L)] = x[e];
     }
-    tvm_wave_sync();
+    if constexpr (LPR == 64) tvm_wave_sync();
+    else tvm_lds_barrier();
 }
-template <bool DIT, int MAXK, int LOGN, int ROOT, int DONE = 0>
+template <bool DIT, int MAXK, int LOGN, int ROOT, int DONE = 0, int LPR = 64>
 TVM_D void row_ntt(u64* row, const u64* __restrict__ tw, int lane) {
     if constexpr (DONE < LOGN) {
         constexpr int k = (LOGN - DONE) >= MAXK ? MAXK : (LOGN - DONE);
         constexpr int l = DIT ? DONE : (LOGN - DONE - k);
-        row_ntt_group<DIT, k, l, LOGN, ROOT>(row, tw, lane);
-        row_ntt<DIT, MAXK, LOGN, ROOT, DONE + k>(row, tw, lane);
+        row_ntt_group<DIT, k, l, LOGN, ROOT, TVM_TW_BATCH, LPR>(row, tw, lane);
+        row_ntt<DIT, MAXK, LOGN, ROOT, DONE + k, LPR>(row, tw, lane);
     }
 }
 
@@ -779,9 +783,12 @@ __global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass1_rows(Ntt2Args a) {
 //     inside a row's work.  Row pitch = 8 (mod 32) words: the store phase's 8 rows x 8 positions per wavefront fall into 64
 //     different banks (the odd pitch of TVM_ROW_WORDS put b + j1 = const into one).
 // 8 rows, 512 work-items, 78 KB of LDS: two workgroups per CU.
-#define TVM_P2F_ROWW 1096
+#define TVM_P2F_ROWW(logn) ((logn) == 10 ? 1096 : 2184)   // >= TVM_ROW_WORDS, = 8 (mod 32)
 #define TVM_P2F_TW2_WORDS 272   // 16 x 17: the middle group's twiddles
-#define TVM_P2F_LDS_WORDS (8 * TVM_P2F_ROWW + TVM_P2F_TW2_WORDS + TVM_ROW_WORDS(1024) + 8)   // tile + twiddles + one coset's factors + a randomizer word per row: 79.2 KB
+#define TVM_P2F_LDS_WORDS(logn) (8 * TVM_P2F_ROWW(logn) + TVM_P2F_TW2_WORDS + TVM_ROW_WORDS(1 << (logn)) + 8)   // tile + twiddles + one coset's factors + a randomizer word per row: 79.2 / 159.4 KB
+#ifndef TVM_P2F_FT_EARLY_11
+#define TVM_P2F_FT_EARLY_11 0   // (2048-point rows: the radix-8 last group leaves no registers for them)
+#endif
 #ifndef TVM_P2F_FT_EARLY
 #define TVM_P2F_FT_EARLY 2   // 16-byte loads of the last group's factors requested BEFORE the middle group (4 registers each)
 #endif
@@ -791,57 +798,69 @@ __global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass1_rows(Ntt2Args a) {
 #ifndef TVM_P2F_TWB
 #define TVM_P2F_TWB 4   // twiddle loads in flight per batch in the middle group of the coset loop (registers)
 #endif
-template <int ROWS>
-__global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass2_fused(LdePass2Args a) {
-    constexpr int LOGN = 10, n2 = 1 << LOGN, ROWW = TVM_P2F_ROWW, NT = 64 * ROWS, RLOG = 3, Q4 = n2 / 4;
-    static_assert(ROWS == 8 && ROWW >= TVM_ROW_WORDS(n2) && ROWW % 32 == 8, "8-row tiles, bank-spread row pitch");
+// LOGN = 10: one wavefront per row, 512 work-items, 79 KB of LDS -- two workgroups per CU.  LOGN = 11 (round 5, the shape of 2^21 and
+// 2^22-row traces -- BASELINE configs[2]'s height): TWO wavefronts per row of 2048 points, 16 positions per lane as before, the butterfly
+// groups separated by workgroup barriers, the last group radix 8; 1024 work-items, 159 KB: one workgroup per CU (as the tile kernel
+// k_lde_pass2_v3<11, 10> it replaces, which kept the position-major tile, three multiplications outside the butterflies and 192 B of
+// scratch).
+template <int LOGN>
+__global__ void __launch_bounds__(LOGN == 10 ? 512 : 1024, 4) k_lde_pass2_fused(LdePass2Args a) {
+    constexpr int n2 = 1 << LOGN, ROWS = 8, LPR = n2 / 16, WPR = LPR / 64, NT = ROWS * LPR, RLOG = 3;
+    constexpr int ROWW = TVM_P2F_ROWW(LOGN), K3 = LOGN - 8, R3 = 1 << K3, ITS = 16 / R3, LSTEP = LPR + LPR / 16;
+    constexpr int FE = LOGN == 10 ? TVM_P2F_FT_EARLY : TVM_P2F_FT_EARLY_11;   // 16-byte loads of the last group's factors requested early
+    static_assert((LOGN == 10 || LOGN == 11) && ROWW >= TVM_ROW_WORDS(n2) && ROWW % 32 == 8, "1024 / 2048 points, bank-spread row pitch");
     TVM_DYN_SMEM(u64, s);
     const int tid = threadIdx.x, lane = tid & 63, w = tvm_uniform(tid >> 6);
+    const int r = w / WPR, rl = (w % WPR) * 64 + lane;   // this wavefront's row of the tile; the lane's number within the row
     const u64 n1 = 1ull << a.log_n1, n = n1 << LOGN;
     const int vl = blockIdx.y, v = a.col0 + vl;
-    const u64 p0 = (u64)blockIdx.x * ROWS, p = p0 + (u64)w;
-    u64* const row = s + w * ROWW;
-    // behind the tile: the 15 x 16 twiddles the middle butterfly group uses, tw2[17 j0 + e] = w_n2^(4 j0 brev4(e)) (pitch 17: the
-    // sixteen j0 of a wavefront in sixteen banks), and the coset factors of the current coset at their positions, skewed like a row
+    const u64 p0 = (u64)blockIdx.x * ROWS, p = p0 + (u64)r;
+    u64* const row = s + r * ROWW;
+    auto row_sync = [] {   // between two butterfly groups of a row: its lanes exchange data through the row's LDS words
+        if constexpr (WPR == 1) tvm_wave_sync();
+        else tvm_lds_barrier();
+    };
+    // behind the tile: the 15 x 16 twiddles the middle butterfly group uses, tw2[17 j0 + e] = w_n2^((j0 brev4(e)) << (LOGN - 8)) (pitch
+    // 17: sixteen j0 in sixteen banks), and the coset factors of the current coset at their positions, skewed like a row
     u64* const tw2 = s + ROWS * ROWW;
     u64* const ghl = tw2 + TVM_P2F_TW2_WORDS;
     {
-        const u64* y = a.y + (u64)vl * n + p * n2 + lane;
-        u64* const rowl = row + TVM_ROW_SKEW(lane);
+        const u64* y = a.y + (u64)vl * n + p * n2 + rl;
+        u64* const rowl = row + TVM_ROW_SKEW(rl);
 #pragma unroll
-        for (int e = 0; e < 16; e++) rowl[68 * e] = TVM_LOAD_STREAM(&y[64 * e]);   // position lane + 64 e (skew: + 4 e)
+        for (int e = 0; e < 16; e++) rowl[LSTEP * e] = TVM_LOAD_STREAM(&y[LPR * e]);   // position rl + LPR e
     }
-    if (tid < 256) tw2[17 * (tid >> 4) + (tid & 15)] = a.tw_b1[((tid >> 4) * brev_bits((u32)(tid & 15), 4)) << 2];
+    if (tid < 256) tw2[17 * (tid >> 4) + (tid & 15)] = a.tw_b1[((tid >> 4) * brev_bits((u32)(tid & 15), 4)) << (LOGN - 8)];
 #pragma unroll
     for (int hh = 0; hh < n2 / NT; hh++) ghl[TVM_ROW_SKEW(tid + hh * NT)] = a.g_hi_pos[tid + hh * NT];
-    tvm_wave_sync();
+    row_sync();
     // inverse rows step: position q of the row then holds N * t[m1*n1 + m2], m1 = brev(q), m2 = brev(p)
-    if (a.mode != TVM_LDE_FORWARD_ONLY) row_ntt<false, 4, LOGN, 2>(row, a.tw_a2, lane);
+    if (a.mode != TVM_LDE_FORWARD_ONLY) row_ntt<false, 4, LOGN, 2, 0, LPR>(row, a.tw_a2, rl);
     if (a.mode == TVM_LDE_INVERSE_ONLY) {
-        u64* yw = const_cast<u64*>(a.y) + (u64)vl * n + p * n2 + lane;
-        const u64* const rowl = row + TVM_ROW_SKEW(lane);
+        u64* yw = const_cast<u64*>(a.y) + (u64)vl * n + p * n2 + rl;
+        const u64* const rowl = row + TVM_ROW_SKEW(rl);
 #pragma unroll
-        for (int e = 0; e < 16; e++) yw[64 * e] = rowl[68 * e];
+        for (int e = 0; e < 16; e++) yw[LPR * e] = rowl[LSTEP * e];
         return;
     }
     u64 coef[16];
 #pragma unroll
-    for (int e = 0; e < 16; e++) coef[e] = row[17 * lane + e];   // TVM_ROW_SKEW(16 * lane + e) = 17 * lane + e
+    for (int e = 0; e < 16; e++) coef[e] = row[17 * rl + e];   // TVM_ROW_SKEW(16 * rl + e) = 17 * rl + e
     const u64 m2 = brev_bits((u32)p, a.log_n1);   // uniform over the wavefront
-    // lane 0: the randomizer coefficient that meets coefficient m = m2 (m1 = 0: position 0) -- parked in an LDS word of the row's own,
-    // re-read in every coset (a global load at its use stalled the wavefront, and with it the workgroup's barrier, once per coset:
-    // every 8-row tile has a row with m2 < 128)
+    // row-lane 0: the randomizer coefficient that meets coefficient m = m2 (m1 = 0: position 0) -- parked in an LDS word of the row's
+    // own, re-read in every coset (a global load at its use stalled the wavefront, and with it the workgroup's barrier, once per
+    // coset: every 8-row tile has a row with m2 < 128)
     const bool has_rnd = m2 < a.h;
-    u64* const r0 = ghl + TVM_ROW_WORDS(n2) + w;
-    if (lane == 0) *r0 = has_rnd ? a.rnd[((u64)(v / a.fk) * a.h + m2) * a.fk + (v % a.fk)] : 0;
+    u64* const r0 = ghl + TVM_ROW_WORDS(n2) + r;
+    if (rl == 0) *r0 = has_rnd ? a.rnd[((u64)(v / a.fk) * a.h + m2) * a.fk + (v % a.fk)] : 0;
     tvm_lds_barrier();   // the twiddle tables and the first coset's factors are staged
     for (int k = 0; k < a.n_cosets; k++) {
         // (lane and work-item number through opaque moves: the addresses below are cheap to form and expensive to keep -- hoisted out
         // of the coset loop they went to scratch)
-        const int ln = tvm_opaque(lane);
+        const int ln = tvm_opaque(rl);
         u64 x[16];
         {
-            const u64* const gh = ghl + 17 * ln;   // the coset's factors at positions 16 lane + e (staged by the workgroup, below)
+            const u64* const gh = ghl + 17 * ln;   // the coset's factors at positions 16 rl + e (staged by the workgroup, below)
 #pragma unroll
             for (int e = 0; e < 16; e++) x[e] = bfe_mul(coef[e], gh[e]);
         }
@@ -852,12 +871,12 @@ __global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass2_fused(LdePass2Args a
 #pragma unroll
             for (int e = 0; e < 16; e++) out[e] = x[e];
         }
-        const u64x2* ft = (const u64x2*)(a.f_tw + (((p << 6) + ln) << 4));
+        const u64x2* ft = (const u64x2*)(a.f_tw + (((p * LPR) + ln) << 4));
         u64x2 f[8];
 #pragma unroll
-        for (int j = 0; j < TVM_P2F_FT_EARLY; j++) f[j] = ft[j];   // the last group's first factors: in flight under the middle group
-        tvm_wave_sync();
-        {   // layers 4 .. 7 (row_ntt_group<true, 4, 4>: one group per lane), the twiddle step from the compact table
+        for (int j = 0; j < FE; j++) f[j] = ft[j];   // the last group's first factors: in flight under the middle group
+        row_sync();
+        {   // layers 4 .. 7 (row_ntt_group<true, 4, 4>: one group per row-lane), the twiddle step from the compact table
             const int j0 = ln & 15;
             u64* const q = row + TVM_ROW_SKEW(((ln >> 4) << 8) | j0);   // positions base + 16 e: TVM_ROW_SKEW adds 17 e
             const u64* const t2 = tw2 + 17 * j0;
@@ -873,21 +892,25 @@ __global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass2_fused(LdePass2Args a
 #pragma unroll
             for (int e = 0; e < 16; e++) q[17 * e] = x2[e];
         }
-        tvm_wave_sync();
-        u64 u[4];
+        row_sync();
+        u64 u[R3];
 #pragma unroll
-        for (int e = 0; e < 4; e++) u[e] = a.u_tw[((u64)k * n1 + p) * 4 + e];
+        for (int e = 0; e < R3; e++) u[e] = a.u_tw[((u64)k * n1 + p) * R3 + e];
 #pragma unroll
-        for (int j = TVM_P2F_FT_EARLY; j < 8; j++) f[j] = ft[j];
+        for (int j = FE; j < 8; j++) f[j] = ft[j];
 #pragma unroll
-        for (int it = 0; it < 4; it++) {   // layers 8 and 9 on positions g + 256 e, g = lane + 64 it, with the inter-pass twiddle
-            u64* const q = row + TVM_ROW_SKEW(ln + 64 * it);   // TVM_ROW_SKEW(g + 256 e) = TVM_ROW_SKEW(g) + 272 e
-            const u64x2 f01 = f[2 * it], f23 = f[2 * it + 1];
-            u64 y4[4] = {bfe_mul(q[0], f01.x), bfe_mul(q[Q4 + Q4 / 16], f01.y), bfe_mul(q[2 * (Q4 + Q4 / 16)], f23.x),
-                         bfe_mul(q[3 * (Q4 + Q4 / 16)], f23.y)};
-            ntt_pow2_points<2, true, false>(y4);
+        for (int it = 0; it < ITS; it++) {   // layers 8 .. LOGN - 1 on positions g + 256 e, g = rl + LPR it, with the inter-pass twiddle
+            u64* const q = row + TVM_ROW_SKEW(ln + LPR * it);   // TVM_ROW_SKEW(g + 256 e) = TVM_ROW_SKEW(g) + 272 e
+            u64 y8[R3];
 #pragma unroll
-            for (int e = 0; e < 4; e++) q[(Q4 + Q4 / 16) * e] = bfe_mul(y4[e], u[e]);
+            for (int e = 0; e < R3; e += 2) {
+                const u64x2 fe = f[(it * R3 + e) / 2];
+                y8[e] = bfe_mul(q[272 * e], fe.x);
+                y8[e + 1] = bfe_mul(q[272 * (e + 1)], fe.y);
+            }
+            ntt_pow2_points<K3, true, false>(y8);
+#pragma unroll
+            for (int e = 0; e < R3; e++) q[272 * e] = bfe_mul(y8[e], u[e]);
         }
         // (TVM_P2F_X != 0: timing experiments with wrong results, tools/build_ntt_variants.py -- 1 no store phase: -11 %, 2 the same
         // words as contiguous 64 KB blocks: -0 %, 3 no workgroup barriers: -3 %; profiles/r05_c_*.  Never in the product build.)
@@ -931,22 +954,26 @@ __global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass2_fused(LdePass2Args a
     }
 }
 
-// the tables of k_lde_pass2_fused (LdePass2Args): hi_pos[k][q] = hi[k][brev(q)]; f[((p*64 + lane)*4 + it)*4 + e] =
-// tw_n2[g * brev2(e)] * w_N^(brev(p) * g), g = lane + 64 it; u[(k*n1 + p)*4 + e] = lo[k][brev(p)] * w_N^(brev(p) * 256 e)
+// the tables of k_lde_pass2_fused (LdePass2Args), for rows of n2 = 1024 or 2048 points: LPR = n2 / 16 lanes per row, the last
+// butterfly group of radix R3 = n2 / 256 in 16 / R3 iterations.  hi_pos[k][q] = hi[k][brev(q)];
+// f[((p*LPR + rl)*16 + it*R3 + e] = tw_n2[g * brev(e)] * w_N^(brev(p) * g), g = rl + LPR it;
+// u[(k*n1 + p)*R3 + e] = lo[k][brev(p)] * w_N^(brev(p) * 256 e)
 __global__ void k_pass2_fused_tables(const u64* __restrict__ lo, const u64* __restrict__ hi, Pow2 tw_inter, const u64* __restrict__ tw_n2,
                                      int log_n1, int log_n2, u64 X, u64* __restrict__ hi_pos, u64* __restrict__ f, u64* __restrict__ u) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u64 n1 = 1ull << log_n1, n2 = 1ull << log_n2, n = n1 * n2, quarter = n2 >> 2;
+    const u64 n1 = 1ull << log_n1, n2 = 1ull << log_n2, n = n1 * n2;
+    const int k3 = log_n2 - 8;
+    const u64 r3 = 1ull << k3, lpr = n2 >> 4;
     if (i < X * n2) hi_pos[i] = hi[(i / n2) * n2 + brev_bits((u32)(i % n2), log_n2)];
     if (f && i < n) {
-        const u64 e = i & 3, it = (i >> 2) & 3, lane = (i >> 4) & 63, p = i >> 10, g = lane + 64 * it;
+        const u64 e = i & (r3 - 1), it = (i >> k3) & ((16 >> k3) - 1), rl = (i >> 4) & (lpr - 1), p = i >> log_n2, g = rl + lpr * it;
         const u64 m2 = brev_bits((u32)p, log_n1);
-        f[i] = bfe_mul(tw_n2[(g * (u64)brev_k((int)e, 2)) & (n2 - 1)], pow2_get(tw_inter, (m2 * g) & (n - 1)));
+        f[i] = bfe_mul(tw_n2[(g * (u64)brev_bits((u32)e, k3)) & (n2 - 1)], pow2_get(tw_inter, (m2 * g) & (n - 1)));
     }
-    if (i < X * n1 * 4) {
-        const u64 e = i & 3, p = (i >> 2) % n1, k = (i >> 2) / n1;
+    if (i < X * n1 * r3) {
+        const u64 e = i & (r3 - 1), p = (i >> k3) % n1, k = (i >> k3) / n1;
         const u64 m2 = brev_bits((u32)p, log_n1);
-        u[i] = bfe_mul(lo[k * n1 + m2], pow2_get(tw_inter, (m2 * quarter * e) & (n - 1)));
+        u[i] = bfe_mul(lo[k * n1 + m2], pow2_get(tw_inter, (m2 * 256 * e) & (n - 1)));
     }
 }
 
@@ -1093,7 +1120,8 @@ static void set_lds_attributes() {
     (void)hipFuncSetAttribute((const void*)k_lde_pass2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass1_rows<10, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    (void)hipFuncSetAttribute((const void*)k_lde_pass2_fused<8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass2_fused<10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass2_fused<11>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<11, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_v3<11, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -1141,12 +1169,13 @@ static int pass2_fused_tables(tvm_ctx* c, u64 trace_gen, u64 offset, u64 gen, u6
     const bool new_f = !d_f, new_k = !d_k;
     if (!bind_device(c)) return set_error(c, TVM_ERR_DEVICE, "bind device");
     if (new_f && hipMalloc((void**)&d_f, n * sizeof(u64)) != hipSuccess) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "pass-2 twiddle table");
-    if (new_k && hipMalloc((void**)&d_k, X * (n2 + 4 * n1) * sizeof(u64)) != hipSuccess) {
+    const u64 r3 = n2 >> 8;   // radix of the last butterfly group
+    if (new_k && hipMalloc((void**)&d_k, X * (n2 + r3 * n1) * sizeof(u64)) != hipSuccess) {
         if (new_f) (void)hipFree(d_f);
         return set_error(c, TVM_ERR_OUT_OF_MEMORY, "pass-2 coset tables");
     }
     if (new_f || new_k) {
-        const u64 total = new_f ? (n > X * (n2 + 4 * n1) ? n : X * (n2 + 4 * n1)) : X * (n2 > 4 * n1 ? n2 : 4 * n1);
+        const u64 total = new_f ? (n > X * (n2 + r3 * n1) ? n : X * (n2 + r3 * n1)) : X * (n2 > r3 * n1 ? n2 : r3 * n1);
         // (entries that exist already are simply written again with the same values when only one of the two is new)
         TVM_LAUNCH(k_pass2_fused_tables, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, lo, hi, tw_inter, tw_n2, log_n1,
                    log_n2, X, d_k, new_f ? d_f : (u64*)nullptr, d_k + X * n2);
@@ -1337,7 +1366,8 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     p2.g_lo_step = pow_table(c, eval_gen, n1);
     p2.g_hi_step = pow_table(c, bfe_pow(eval_gen, n1), n2);
     p2.g_hi_pos = p2.f_tw = p2.u_tw = nullptr;
-    if (std_roots && sp.log_n2 == 10 && n1 % 16 == 0 && h <= n1)
+    const bool fused = std_roots && (sp.log_n2 == 10 || sp.log_n2 == 11) && n1 % 16 == 0 && h <= n1 && c->lde_pass2_tiles == 0;
+    if (fused)
         TVM_TRY(pass2_fused_tables(c, w, eval_offset, eval_gen, X, sp.log_n1, sp.log_n2, p2.g_lo, p2.g_hi, p2.tw_inter, p2.tw_b1, &p2.g_hi_pos,
                                    &p2.f_tw, &p2.u_tw));
     const u64 n_mont = bfe_from_u64(N);
@@ -1408,17 +1438,18 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             const u64 rows3 = 16 >> ppt_log;
             const size_t lds_v3 = (size_t)(rows3 * (n2 + TVM_ROW_PAD) + (sp.log_n2 < 12 ? n2 : 0) + 32) * sizeof(u64);
             const dim3 g2((unsigned)(n1 / rows3), (unsigned)nc);
-            if (std_roots && ppt_log && n1 % rows3 == 0) {
+            if (fused) {
+                // 1024- / 2048-point axis: every wavefront (pair of wavefronts) keeps its row across the coset loop (k_lde_pass2_fused);
+                // more trace randomizers than n1 (never the case for a STARK's parameters) take the kernels below
+                const size_t lds_r = (size_t)TVM_P2F_LDS_WORDS(sp.log_n2) * sizeof(u64);
+                if (sp.log_n2 == 10) TVM_LAUNCH((k_lde_pass2_fused<10>), dim3((unsigned)(n1 / 8), (unsigned)nc), dim3(512), lds_r, c->stream, a);
+                else TVM_LAUNCH((k_lde_pass2_fused<11>), dim3((unsigned)(n1 / 8), (unsigned)nc), dim3(1024), lds_r, c->stream, a);
+            }
+            else if (std_roots && ppt_log && n1 % rows3 == 0) {
                 if (sp.log_n2 == 11) TVM_LAUNCH((k_lde_pass2_v3<11, 10>), g2, dim3(1024), lds_v3, c->stream, a);
                 else if (sp.log_n2 == 12) TVM_LAUNCH((k_lde_pass2_v3<12, 10>), g2, dim3(1024), lds_v3, c->stream, a);
                 else if (sp.log_n2 == 7) TVM_LAUNCH((k_lde_pass2_v3<7, 6>), g2, dim3(64), lds_v3, c->stream, a);
                 else TVM_LAUNCH((k_lde_pass2_v3<8, 6>), g2, dim3(64), lds_v3, c->stream, a);
-            }
-            else if (std_roots && sp.log_n2 == 10 && n1 % 16 == 0 && h <= n1) {
-                // 1024-point axis: every wavefront keeps its row across the coset loop (k_lde_pass2_fused); more trace randomizers than
-                // n1 (never the case for a STARK's parameters) take the generic kernel
-                const size_t lds_r = (size_t)TVM_P2F_LDS_WORDS * sizeof(u64);
-                TVM_LAUNCH((k_lde_pass2_fused<8>), dim3((unsigned)(n1 / 8), (unsigned)nc), dim3(512), lds_r, c->stream, a);
             }
             else
                 TVM_LAUNCH(k_lde_pass2, grid, dim3(threads_for_tile(tile)), lds, c->stream, a);

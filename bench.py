@@ -716,8 +716,14 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         share = world if sharded else (args.jit_passes or 1)
         counters = kernel_counters()
-        roofline = lde_roofline(lde_avg_ms, params.trace.length, 379, params.ldt.length // params.trace.length, share, counters,
-                                share == 1 and args.log2_expansion == 2 and args.log2_rows == 20)   # (the counters were taken on this shape)
+        expansion = params.ldt.length // params.trace.length
+        shape_key = f"2p{args.log2_rows}_x{expansion}"
+        if counters and share == 1 and shape_key in counters.get("shapes", {}):   # counters taken on this shape (tools/kernel_counters.py)
+            counters = counters["shapes"][shape_key]
+            shape_ok = True
+        else:
+            shape_ok = share == 1 and args.log2_expansion == 2 and args.log2_rows == 20   # (the default counters were taken on this shape)
+        roofline = lde_roofline(lde_avg_ms, params.trace.length, 379, expansion, share, counters, shape_ok)
         if args.data == "real":
             workload_text = (f"Prover::prove(claim, aet) for real: {args.program} program run for {e['cycles']} cycles (public input "
                              f"{e['index']}), padded height 2^{args.log2_rows}, 379 main + 91 aux columns (652 words/row); Stark::default() parameters with "

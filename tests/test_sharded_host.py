@@ -82,7 +82,9 @@ def _run_ranks(world, body, comms=None):
     return results
 
 
-ON_THE_EMULATION_TOO = {(2, True, "fri", True), (8, True, "fri", False), (2, True, "fri16", False)}   # (CPU suite time; all of them on the GPU)
+# (CPU suite time; all of them on the GPU.  (4, False, "fri", False): the whole-tree path with a communicator -- gather_rows, then
+# whole_tree and tvm_fri_commit_phase -- which tests/test_sharded_prover.py leaves to this file)
+ON_THE_EMULATION_TOO = {(2, True, "fri", True), (8, True, "fri", False), (2, True, "fri16", False), (4, False, "fri", False)}
 
 
 @pytest.mark.parametrize("world,split_trees,kind,lockstep", [(2, True, "fri", True), (4, False, "fri", False), (8, True, "fri", False), (8, True, "fri", True),

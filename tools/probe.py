@@ -26,7 +26,8 @@ def main():
     for opt, val in [kv.split("=") for kv in os.environ.get("TVM_PROBE_OPTIONS", "").split(",") if kv]:   # e.g. "2=32": TVM_OPTION_LDE_CHUNK_COLUMNS
         ctx._check(ctx.lib.tvm_ctx_set_option(ctx.handle, int(opt), int(val)), "tvm_ctx_set_option")
     trace_dom = ArithmeticDomain.of_length(n)
-    ev = ArithmeticDomain.of_length(8 * n).with_offset(field.generator())
+    expansion = int(os.environ.get("TVM_PROBE_EXPANSION", "8"))   # |evaluation domain| / |trace domain| (32: FRI log-blowup 4)
+    ev = ArithmeticDomain.of_length(expansion * n).with_offset(field.generator())
     L = len(ev)
     for name, fk, n_cols in (("main", 1, n_main), ("aux", 3, n_aux)):
         if not n_cols:
@@ -50,7 +51,7 @@ def main():
             ctx.lib.tvm_table_free(ctx.handle, t)
             print(json.dumps({"table": name, "log_n": log_n, "cols": n_cols, "rep": rep, "lde_ms": round(ms_lde, 3),
                               "hash_ms": round(ms_hash, 3), "merkle_ms": round(ms_merkle, 3),
-                              "lde_GBps_algorithmic": round(cells * 72 / ms_lde / 1e6, 1),
+                              "lde_GBps_algorithmic": round(cells * (8 + 8 * expansion) / ms_lde / 1e6, 1),
                               "hash_Mperm_per_s": round(L * (n_cols * fk // 10 + 1) / ms_hash / 1e3, 1)}), flush=True)
         d_trace.free(); d_rnd.free(); d_nodes.free()
     ctx.close()

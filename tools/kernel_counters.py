@@ -36,7 +36,7 @@ def main(path, cols=96, log2_rows=20, expansion=8, commit=None, shape=None):
         (f" with TVM_PROBE_EXPANSION={expansion}" if expansion != 8 else "")
     lde, total_bytes, total_valu = {}, 0.0, 0.0
     for name, c in b.items():
-        if not re.match(r"k_lde_pass[123]", name) or "FETCH_SIZE" not in c:
+        if not re.match(r"k_lde_pass[123]|k_ntt2_pass1", name) or "FETCH_SIZE" not in c:   # (k_ntt2_pass1: pass 1 where no row kernel applies)
             continue
         n_disp = c["SQ_INSTS_VALU"][1]
         f, w = 2 * c["FETCH_SIZE"][0] * 1024 * n_disp, c["WRITE_SIZE"][0] * 1024 * n_disp

@@ -815,6 +815,10 @@ __global__ void __launch_bounds__(LOGN == 10 ? 512 : 1024, 4) k_lde_pass2_fused(
     const u64 n1 = 1ull << a.log_n1, n = n1 << LOGN;
     const int vl = blockIdx.y, v = a.col0 + vl;
     const u64 p0 = (u64)blockIdx.x * ROWS, p = p0 + (u64)r;
+    // (grid x = tile, y = column.  With the columns side by side instead -- so that the workgroups running together share their rows'
+    // factor table in L2: it streams through once per coset and column, 76 B per cell fetched at 2^22 rows where 8 are due,
+    // profiles/r05_j_pmc_lde_hash_2p22.txt -- the kernel takes the same time at 2^22 rows (20.75 against 20.92 ms) and 1 % longer at
+    // 2^20: the Infinity Cache serves the table, the fetches were never what the kernel waited for; profiles/r05_k_*.)
     u64* const row = s + r * ROWW;
     auto row_sync = [] {   // between two butterfly groups of a row: its lanes exchange data through the row's LDS words
         if constexpr (WPR == 1) tvm_wave_sync();
@@ -930,17 +934,24 @@ __global__ void __launch_bounds__(LOGN == 10 ? 512 : 1024, 4) k_lde_pass2_fused(
             u64 g_next[n2 / NT];
 #pragma unroll
             for (int hh = 0; hh < n2 / NT; hh++) g_next[hh] = more ? a.g_hi_pos[(u64)(k + 1) * n2 + t2 + hh * NT] : 0;
-            u64* zk = a.z + ((u64)vl * a.n_cosets + k) * n + p0 + b_out;
+#if TVM_P2F_X == 2
+            u64* zk = a.z + ((u64)vl * a.n_cosets + k) * n + p0 * n2;
             const u64* src = s + b_out * ROWW;
 #pragma unroll 4
-            for (int i = 0; i < 16; i++) {
-                const int j1 = j1_0 + i * (NT >> RLOG);
-#if TVM_P2F_X == 2
-                TVM_STORE_STREAM(&a.z[((u64)vl * a.n_cosets + k) * n + p0 * n2 + (u64)i * NT + t2], src[TVM_ROW_SKEW(j1)]);
+            for (int i = 0; i < 16; i++) TVM_STORE_STREAM(&zk[(u64)i * NT + t2], src[TVM_ROW_SKEW(j1_0 + i * (NT >> RLOG))]);
 #else
-                TVM_STORE_STREAM(&zk[(u64)j1 * n1], src[TVM_ROW_SKEW(j1)]);
-#endif
+            // a lane copies TWO adjacent rows of a position with one 16-byte store: 8 store instructions per lane and coset instead of
+            // 16 for the same 64-byte runs (-3 % of the kernel, profiles/r05_k_*)
+            (void)b_out, (void)j1_0;
+            const int bp = t2 & (ROWS / 2 - 1), j1_p = t2 >> (RLOG - 1);
+            u64* zk = a.z + ((u64)vl * a.n_cosets + k) * n + p0 + 2 * bp;
+            const u64* src = s + 2 * bp * ROWW;
+#pragma unroll 4
+            for (int i = 0; i < 8; i++) {
+                const int j1 = j1_p + i * (NT >> (RLOG - 1));
+                TVM_STORE_STREAM_X2(&zk[(u64)j1 * n1], src[TVM_ROW_SKEW(j1)], src[ROWW + TVM_ROW_SKEW(j1)]);
             }
+#endif
             if (more) {
 #pragma unroll
                 for (int hh = 0; hh < n2 / NT; hh++) ghl[TVM_ROW_SKEW(t2 + hh * NT)] = g_next[hh];

@@ -60,9 +60,13 @@ static __device__ __forceinline__ int tvm_opaque(int v) {
 #if defined(TVM_EMU)
 #define TVM_STORE_STREAM(ptr, value) (*(ptr) = (value))
 #define TVM_LOAD_STREAM(ptr) (*(ptr))
+#define TVM_STORE_STREAM_X2(ptr, a, b) ((ptr)[0] = (a), (ptr)[1] = (b))
 #else
 #define TVM_STORE_STREAM(ptr, value) __builtin_nontemporal_store((value), (ptr))
 #define TVM_LOAD_STREAM(ptr) __builtin_nontemporal_load(ptr)
+typedef unsigned long tvm_u64v2 __attribute__((ext_vector_type(2)));
+// two adjacent words (16-byte aligned) in one streaming store
+#define TVM_STORE_STREAM_X2(ptr, a, b) __builtin_nontemporal_store(tvm_u64v2{(a), (b)}, (tvm_u64v2*)(ptr))
 #endif
 
 #include <cstdint>

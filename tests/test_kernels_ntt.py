@@ -93,7 +93,7 @@ def test_lde_split_at_the_coefficients_gives_the_same_table(ctx, orc, log_n, exp
     mt.clear_cache()
 
 
-@pytest.mark.parametrize("log_n,fk,n_cols", [(20, 1, 2), (19, 3, 1), (21, 1, 1), pytest.param(22, 1, 1, marks=pytest.mark.gpu)])
+@pytest.mark.parametrize("log_n,fk,n_cols", [(20, 1, 2), (19, 3, 1), (21, 1, 1), (22, 1, 1)])
 def test_lde_with_1024_point_axes(ctx, orc, log_n, fk, n_cols):
     """The production kernels of tvm_lde_table (one transform row per wavefront, csrc/ntt.hip: k_lde_pass2_fused /
     k_lde_pass3_rows, taken for 1024-point axes: traces of 2^19 and 2^20 rows -- BASELINE config 1's height; since round 4 also for

@@ -728,35 +728,38 @@ __global__ void __launch_bounds__(64 * WAVES, LOGN == 10 ? 4 : 2) k_lde_pass3_ro
 // and the store applies the inter-pass twiddle w_N^-(i2 * k1) as a running product over k1 = brev(position) -- the positions
 // of a work-item are visited in bit-reversed order so that k1 advances by one -- instead of two table loads per element.
 template <int LOGN, int ROWS>
-__global__ void __launch_bounds__(64 * ROWS, 4) k_lde_pass1_rows(Ntt2Args a) {
-    constexpr int n1 = 1 << LOGN, ROWW = TVM_ROW_WORDS(n1), NT = 64 * ROWS, RLOG = ROWS == 16 ? 4 : 3;
-    static_assert(LOGN == 10 && (ROWS == 16 || ROWS == 8), "one wavefront per row of 1024 points");
+__global__ void __launch_bounds__((1 << (LOGN - 4)) * ROWS, 4) k_lde_pass1_rows(Ntt2Args a) {
+    // LOGN = 10: one wavefront per row, 16 rows (128-byte runs of the input).  LOGN = 11 (round 5; 2^22 and 2^23-row traces): TWO
+    // wavefronts per row of 2048 points, 8 rows (LDS holds no more of them: 64-byte runs), the butterfly groups separated by
+    // workgroup barriers (row_ntt_group, LPR = 128) -- instead of the generic k_ntt2_pass1.
+    constexpr int n1 = 1 << LOGN, ROWW = TVM_ROW_WORDS(n1), LPR = n1 / 16, WPR = LPR / 64, NT = LPR * ROWS, RLOG = ROWS == 16 ? 4 : 3;
+    static_assert((LOGN == 10 && (ROWS == 16 || ROWS == 8)) || (LOGN == 11 && ROWS == 8), "one or two wavefronts per row of 1024 / 2048 points");
     TVM_DYN_SMEM(u64, s);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const u64 n2 = 1ull << a.log_n2;
     const int vl = blockIdx.y, v = a.col0 + vl;
     const u64 i2_0 = (u64)blockIdx.x * ROWS;
-    const int b = tid & (ROWS - 1), q0 = tid >> RLOG;   // this work-item loads / stores row b, positions q0 + 64 * it
+    const int b = tid & (ROWS - 1), q0 = tid >> RLOG;   // this work-item loads / stores row b, positions q0 + LPR * it
     const u64* in = a.in + (u64)(v / a.in_fk) * a.in_col_stride + (v % a.in_fk) + (i2_0 + b) * a.in_fk;
 #pragma unroll
     for (int it = 0; it < 16; it++) {
-        const int i1 = q0 + 64 * it;
+        const int i1 = q0 + LPR * it;
         s[b * ROWW + TVM_ROW_SKEW(i1)] = TVM_LOAD_STREAM(&in[(u64)i1 * n2 * a.in_fk]);
     }
     u64* tw_lds = s + ROWS * ROWW;
     for (int i = tid; i < n1; i += NT) tw_lds[i] = a.tw1[i];   // all n1 powers of the inverse root
     tvm_lds_barrier();
-    row_ntt<false, 4, LOGN, 2>(s + w * ROWW, tw_lds, lane);
+    row_ntt<false, 4, LOGN, 2, 0, LPR>(s + (w / WPR) * ROWW, tw_lds, (w % WPR) * 64 + lane);
     tvm_lds_barrier();
-    // position p = q0 + 64 * brev4(c) holds index k1 = brev(p) = brev6(q0) * 16 + c
+    // position p = q0 + LPR * brev4(c) holds index k1 = brev(p) = brev(q0) * 16 + c
     const u64 i2 = i2_0 + b;
-    const u64 k1_0 = (u64)brev_bits((u32)q0, 6) << 4;
+    const u64 k1_0 = (u64)brev_bits((u32)q0, LOGN - 4) << 4;
     u64 t = pow2_get(a.tw_inter, (i2 * k1_0) & ((n2 << LOGN) - 1));
     const u64 t_step = pow2_get(a.tw_inter, i2);
     u64* tmp = a.tmp + (u64)vl * a.tmp_col_stride + i2;
 #pragma unroll 4
     for (int c = 0; c < 16; c++) {
-        const int p = q0 + 64 * (int)brev_bits((u32)c, 4);
+        const int p = q0 + LPR * (int)brev_bits((u32)c, 4);
         TVM_STORE_STREAM(&tmp[(u64)p * n2], bfe_mul(s[b * ROWW + TVM_ROW_SKEW(p)], t));
         t = bfe_mul(t, t_step);
     }
@@ -1131,6 +1134,7 @@ static void set_lds_attributes() {
     (void)hipFuncSetAttribute((const void*)k_lde_pass2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass1_rows<10, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass1_rows<11, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_fused<10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_fused<11>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -1433,6 +1437,9 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
                 // fetch every input line twice: 16 instead of 8 B per cell, profiles/r03_q_pmc_lde.txt.)
                 const size_t lds_r = (size_t)(16 * TVM_ROW_WORDS(n1) + n1) * sizeof(u64);
                 TVM_LAUNCH((k_lde_pass1_rows<10, 16>), dim3((unsigned)(n2 / 16), (unsigned)nc), dim3(1024), lds_r, c->stream, a);
+            } else if (std_roots && sp.log_n1 == 11 && n2 % 8 == 0 && c->lde_pass2_tiles == 0) {   // 2048-point axis: two wavefronts per row
+                const size_t lds_r = (size_t)(8 * TVM_ROW_WORDS(n1) + n1) * sizeof(u64);
+                TVM_LAUNCH((k_lde_pass1_rows<11, 8>), dim3((unsigned)(n2 / 8), (unsigned)nc), dim3(1024), lds_r, c->stream, a);
             } else
                 TVM_LAUNCH(k_ntt2_pass1, grid, dim3(threads_for_tile(tile)), (size_t)tile * sizeof(u64), c->stream, a);
         }

@@ -24,6 +24,14 @@ for STAGE in 2 1; do
     TRITON_HIP_STAGE=$STAGE cargo test --release -p triton-vm --features hip -- "$T"
   done
 done
+# the same acceptance tests through the sharded / coset-wise entry point (tvmh_prove_execution_sharded, comm = NULL): under the memory
+# policy (0) and coset by coset in two passes (2) -- the proof must not change, so the snapshot tests pass unchanged
+for PASSES in 0 2; do
+  echo "== feature hip, stage 2 through tvmh_prove_execution_sharded, jit_passes = $PASSES"
+  for T in $TESTS; do
+    TRITON_HIP_SHARDED_ENTRY=$PASSES cargo test --release -p triton-vm --features hip -- "$T"
+  done
+done
 # STIR, the reference's automatic low-degree test from 2^16 padded rows on (stark.rs:1944-1951) -- the one part of the proof no
 # reference-held value pins (both proof-hash snapshots are FRI-sized): prove_fib at 2^16 rows through the device backend, the
 # UNMODIFIED verifier must accept.  FIBONACCI_INDEX 6500 -> ~65 000 cycles -> padded height 2^16; the bench's own
@@ -42,6 +50,7 @@ RS
 for STAGE in 2 1; do
   TRITON_HIP_STAGE=$STAGE cargo test --release -p triton-vm --features hip --test hip_stir_acceptance
 done
+TRITON_HIP_SHARDED_ENTRY=0 cargo test --release -p triton-vm --features hip --test hip_stir_acceptance
 # the headline benchmark, CPU vs device, same box; then the same at 2^16 rows, where Stark::default() is STIR
 cargo bench -p triton-vm --bench prove_fib --no-default-features
 cargo bench -p triton-vm --bench prove_fib --no-default-features --features hip

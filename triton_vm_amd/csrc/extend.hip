@@ -713,8 +713,9 @@ __global__ void __launch_bounds__(EXT_SCAN_THREADS) k_ext_scan_apply(ExtendArgs 
     if (kind == EXT_KIND_SKIP) return;
     const int tid = threadIdx.x;
     const u64 r0 = ((u64)blockIdx.x * EXT_SCAN_THREADS + tid) * EXT_SCAN_K;
-    ExtMap el[EXT_SCAN_K];
+    ExtMap el[EXT_SCAN_K];   // (both loops fully unrolled, no early exit: indexed dynamically the array lived in scratch, 208 B per lane)
     ExtMap m = ext_identity();
+#pragma unroll
     for (int k = 0; k < EXT_SCAN_K; k++) {
         el[k] = r0 + k < a.n ? ext_load(a, kind, col, slot, r0 + k) : ext_identity();
         m = ext_compose(kind, el[k], m);
@@ -722,10 +723,12 @@ __global__ void __launch_bounds__(EXT_SCAN_THREADS) k_ext_scan_apply(ExtendArgs 
     ext_block_scan(kind, m, lds, tid, EXT_SCAN_THREADS);
     ExtMap carry = ext_lds_get(agg + 6 * ((u64)col * n_tiles + blockIdx.x), 0);
     if (tid > 0) carry = ext_compose(kind, ext_lds_get(lds, tid - 1), carry);
+#pragma unroll
     for (int k = 0; k < EXT_SCAN_K; k++) {
-        if (r0 + k >= a.n) break;
-        carry = ext_compose(kind, el[k], carry);
-        ext_put(a, col, r0 + k, ext_apply(kind, carry));
+        if (r0 + k < a.n) {
+            carry = ext_compose(kind, el[k], carry);
+            ext_put(a, col, r0 + k, ext_apply(kind, carry));
+        }
     }
 }
 

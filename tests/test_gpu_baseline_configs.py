@@ -210,9 +210,10 @@ def test_configs2_height_over_eight_ranks_equals_the_single_gpu_proof(gctx):
     from triton_vm_amd import native_host
 
     ctx = gctx
+    ctx.trim()
     available, total = ctx.memory_info()
-    if total < (250 << 30):
-        pytest.skip("needs the 288 GB of an MI355X")
+    if total < (250 << 30) or available < (255 << 30):   # 21.8 GB of traces + 8 x (20.4 GiB of tables + intermediates) on ONE device
+        pytest.skip(f"needs (nearly all of) the 288 GB of an MI355X: {available >> 30} GiB obtainable of {total >> 30}")
     e = execution("fib", 22)
     seed = snap.prover_seed(12)
     host = native_host.load_host_library()

@@ -212,7 +212,7 @@ def test_configs2_height_over_eight_ranks_equals_the_single_gpu_proof(gctx):
     ctx = gctx
     ctx.trim()
     available, total = ctx.memory_info()
-    if total < (250 << 30) or available < (255 << 30):   # 21.8 GB of traces + 8 x (20.4 GiB of tables + intermediates) on ONE device
+    if total < (250 << 30) or available < (235 << 30):   # 21.8 GB of traces + 8 x (20.4 GiB of tables + intermediates) on ONE device (268 GiB)
         pytest.skip(f"needs (nearly all of) the 288 GB of an MI355X: {available >> 30} GiB obtainable of {total >> 30}")
     e = execution("fib", 22)
     seed = snap.prover_seed(12)

@@ -458,6 +458,7 @@ struct LdePass3Args {
     const u64* tw_b2;    // w_N1^e
     int rows_log;        // rows per workgroup tile
     int std_roots;       // see LdePass2Args
+    const u64* fb_tw;    // k_lde_pass3_halves: the second half's last-group factors (k_pass3_halves_table)
 };
 
 __global__ void __launch_bounds__(1024) k_lde_pass3(LdePass3Args a) {
@@ -721,6 +722,109 @@ __global__ void __launch_bounds__(64 * WAVES, LOGN == 10 ? 4 : 2) k_lde_pass3_ro
             TVM_STORE_STREAM(&out_l[((blk + 4 * e) * W) << TVM_RB_LOG], rowl[68 * e]);
         tvm_wave_sync();   // (the next tile overwrites the row)
     }
+}
+
+// Pass 3 on 2048-point rows (2^22 and 2^23-row traces) as TWO 1024-point halves through ONE 1024-word LDS region per wavefront (round 5).
+// k_lde_pass3_rows<11, 8> keeps a whole row of 2048 points in LDS: 17 KB per wavefront, eight of them fill a CU, two wavefronts per SIMD
+// -- and runs 36 % less efficiently per element than the 1024-point kernel at four.  A decimation-in-time transform of 2048 points in
+// bit-reversed order is two independent 1024-point transforms of its halves (layers 0 .. 9 never cross the middle, and their twiddles
+// w_(2^(l+1))^(pos mod 2^l) do not know which half they are in) followed by ONE layer across the halves, X[j], X[j + 1024] = A[j] +-
+// w_2048^j B[j].  So: half A through the wavefront's LDS region (row_ntt, as for 1024-point rows), its 16 results per lane back in
+// VGPRs; half B through the same region, with w_2048^j folded into its last butterfly group the way pass 2 folds the inter-pass
+// twiddle -- w_2048^(g + 256 e) = w_2048^g * w_8^e: the first factor rides on the group's input twiddles (fb_tw: 1024 row-independent
+// values, read at their use), the second is a power of two -- and the last layer is an addition and a subtraction.  8.7 KB of LDS per
+// wavefront: two workgroups of eight per CU, four wavefronts per SIMD, 128 VGPRs.
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, 4) k_lde_pass3_halves(LdePass3Args a) {
+    constexpr int LOGH = 10, nh = 1 << LOGH, ROWW = TVM_ROW_WORDS(nh);
+    TVM_DYN_SMEM(u64, s);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const u64 n2 = 1ull << a.log_n2;
+    const u64 X = (u64)a.n_cosets;
+    const int log_x = 31 - __builtin_clz((unsigned)a.n_cosets);
+    const int vl = blockIdx.x;
+    u64* const row = s + w * ROWW;
+    u64* tw_lds = s + WAVES * ROWW;
+    for (int i = tid; i < nh; i += 64 * WAVES) tw_lds[i] = a.tw_b2[2 * i];   // all 1024 powers of w_1024 = w_2048^2
+    __syncthreads();   // the only workgroup barrier
+    const u64 W = (u64)a.W;
+    u64 rho = ((u64)blockIdx.y * a.tiles) * WAVES + w;
+    {   // the first row's half A into the region
+        const u64 j1 = rho >> log_x, k = rho & (X - 1);
+        const u64* const z_row = a.z + ((((u64)vl * X + k) * n2 + j1) << 11) + lane;
+        u64* const rl = row + TVM_ROW_SKEW(lane);
+#pragma unroll
+        for (int e = 0; e < 16; e++) rl[68 * e] = TVM_LOAD_STREAM(&z_row[64 * e]);
+    }
+    for (int it = 0; it < a.tiles; it++, rho += WAVES) {
+        const u64 j1 = rho >> log_x, k = rho & (X - 1);
+        const int ln = tvm_opaque(lane);   // (addresses formed where they are used: kept across the loop they went to scratch)
+        const u64* const z_row = a.z + ((((u64)vl * X + k) * n2 + j1) << 11) + ln;
+        u64* const rl = row + TVM_ROW_SKEW(ln);
+        tvm_wave_sync();   // half A is in the region (parked there at the end of the previous row's work)
+        u64 in_b[16];      // half B: requested now, in flight under A's transform
+#pragma unroll
+        for (int e = 0; e < 16; e++) in_b[e] = TVM_LOAD_STREAM(&z_row[nh + 64 * e]);
+        row_ntt_group<true, 4, 0, LOGH, 1, 4>(row, tw_lds, ln);
+        row_ntt_group<true, 4, 4, LOGH, 1, 4>(row, tw_lds, ln);
+        row_ntt_group<true, 2, 8, LOGH, 1, 4>(row, tw_lds, ln);
+        u64 ra[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) ra[e] = rl[68 * e];
+        tvm_wave_sync();
+        // half B
+#pragma unroll
+        for (int e = 0; e < 16; e++) rl[68 * e] = in_b[e];
+        tvm_wave_sync();
+        row_ntt_group<true, 4, 0, LOGH, 1, 4>(row, tw_lds, ln);
+        row_ntt_group<true, 4, 4, LOGH, 1, 4>(row, tw_lds, ln);
+        // the next row's half A is requested once this row's results have left the region and parked there at once: requested any
+        // earlier (before the last group, before the stores) it costs 108 B of scratch and 17 % of the kernel (15.8 against 13.5 ms
+        // per chunk, profiles/r05_o_*); carried across the loop's back edge in registers it went to scratch as well
+        const bool more = it + 1 < a.tiles;
+        u64 nxt[16];
+        auto request_next = [&] {
+            const u64 r2 = rho + WAVES, j1n = r2 >> log_x, kn = r2 & (X - 1);
+            const u64* const z_next = a.z + ((((u64)vl * X + kn) * n2 + j1n) << 11) + tvm_opaque(lane);
+#pragma unroll
+            for (int e = 0; e < 16; e++) nxt[e] = TVM_LOAD_STREAM(&z_next[64 * e]);
+        };
+        const u64x2* const fb = (const u64x2*)(a.fb_tw + 16 * ln);   // the lane's 16 factors: one line
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {   // layers 8 and 9 of the half on positions g + 256 e, g = lane + 64 g4, times w_2048^(g + 256 e)
+            u64* const q = row + TVM_ROW_SKEW(ln + 64 * g4);   // TVM_ROW_SKEW(g + 256 e) = TVM_ROW_SKEW(g) + 272 e
+            const u64x2 f01 = fb[2 * g4], f23 = fb[2 * g4 + 1];
+            u64 y[4] = {bfe_mul(q[0], f01.x), bfe_mul(q[272], f01.y), bfe_mul(q[544], f23.x), bfe_mul(q[816], f23.y)};
+            ntt_pow2_points<2, true, false>(y);
+            q[0] = y[0];
+            q[272] = bfe_neg(bfe_mul_pow2<24>(y[1]));    // w_8   = 2^120 = -2^24
+            q[544] = bfe_mul_pow2<48>(y[2]);             // w_8^2 = 2^48
+            q[816] = bfe_neg(bfe_mul_pow2<72>(y[3]));    // w_8^3 = 2^168 = -2^72
+        }
+        tvm_wave_sync();
+        const u64 blk = (k * a.pitch + (j1 << 11)) >> TVM_RB_LOG;   // the row's first 16-row block of the table
+        u64* const out_l = a.table + ((((u64)(ln >> TVM_RB_LOG)) * W + (u64)(a.col0 + vl)) << TVM_RB_LOG) + (ln & (TVM_RB - 1));
+#pragma unroll 4
+        for (int e = 0; e < 16; e++) {   // j2 = lane + 64 e and j2 + 1024: consecutive lanes = consecutive storage rows
+            const u64 b = rl[68 * e];
+            TVM_STORE_STREAM(&out_l[((blk + 4 * e) * W) << TVM_RB_LOG], bfe_add(ra[e], b));
+            TVM_STORE_STREAM(&out_l[((blk + 64 + 4 * e) * W) << TVM_RB_LOG], bfe_sub(ra[e], b));
+        }
+        tvm_wave_sync();   // (the region has been read)
+        if (more) {
+            request_next();
+#pragma unroll
+            for (int e = 0; e < 16; e++) rl[68 * e] = nxt[e];
+        }
+    }
+}
+
+// fb[lane*16 + g4*4 + e] = w_1024^(g brev2(e)) * w_2048^g, g = lane + 64 g4 (k_lde_pass3_halves)
+__global__ void k_pass3_halves_table(const u64* __restrict__ tw_2048, u64* __restrict__ fb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 1024) return;
+    const int e = i & 3, g4 = (i >> 2) & 3, lane = i >> 4, g = lane + 64 * g4;
+    fb[i] = bfe_mul(tw_2048[(2 * g * brev_k(e, 2)) & 2047], tw_2048[g]);
 }
 
 // Pass 1 (the inverse transform's column step) in the same form: a tile is 16 adjacent columns i2 of the N1 x N2 view, i.e.
@@ -1139,6 +1243,7 @@ static void set_lds_attributes() {
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_fused<11>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<11, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass3_halves<8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_v3<11, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_v3<12, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_v3<12, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -1402,6 +1507,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     p3.pitch = lde_table_layout(N, L).pitch;
     p3.std_roots = std_roots ? 1 : 0;
     p3.tw_b2 = pow_table(c, bfe_pow(w, n2), n1);
+    p3.fb_tw = nullptr;
     if (!p1.tw1 || !p2.tw_a2 || !p2.tw_b1 || !p2.g_lo || !p2.g_hi || !p2.g_lo_step || !p2.g_hi_step || !p3.tw_b2)
         return set_error(c, TVM_ERR_OUT_OF_MEMORY, "lde tables");
 
@@ -1493,7 +1599,21 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
                 if (tiles_w / a.tiles >= 65536) return set_error(c, TVM_ERR_UNSUPPORTED, "lde: too many row tiles");
                 const size_t lds_w = (size_t)(8 * TVM_ROW_WORDS(n1) + n1) * sizeof(u64);
                 const dim3 g3((unsigned)nc, (unsigned)(tiles_w / a.tiles));
-                if (sp.log_n1 == 11) TVM_LAUNCH((k_lde_pass3_rows<11, 8>), g3, dim3(512), lds_w, c->stream, a);
+                if (sp.log_n1 == 11 && c->lde_pass2_tiles == 0) {
+                    // 2048-point rows as two 1024-point halves through one LDS region per wavefront (k_lde_pass3_halves)
+                    const auto key = std::make_tuple(bfe_pow(w, n2) ^ 0xFB7AB1EFB7ull, (u64)2048, (u64)0);
+                    auto found = c->tables.find(key);
+                    u64* fb = found != c->tables.end() ? found->second : nullptr;
+                    if (!fb) {
+                        if (!bind_device(c) || hipMalloc((void**)&fb, 1024 * sizeof(u64)) != hipSuccess)
+                            return set_error(c, TVM_ERR_OUT_OF_MEMORY, "pass-3 twiddle table");
+                        TVM_LAUNCH(k_pass3_halves_table, dim3(4), dim3(256), 0, c->stream, a.tw_b2, fb);
+                        c->tables[key] = fb;
+                    }
+                    a.fb_tw = fb;
+                    const size_t lds_h = (size_t)(8 * TVM_ROW_WORDS(1024) + 1024) * sizeof(u64);
+                    TVM_LAUNCH((k_lde_pass3_halves<8>), g3, dim3(512), lds_h, c->stream, a);
+                } else if (sp.log_n1 == 11) TVM_LAUNCH((k_lde_pass3_rows<11, 8>), g3, dim3(512), lds_w, c->stream, a);
                 else TVM_LAUNCH((k_lde_pass3_rows<10, 8>), g3, dim3(512), lds_w, c->stream, a);
             } else
             if (std_roots && ppt_log && (X * n2) % 16 == 0) {

@@ -305,6 +305,13 @@ def simulate_ranks(ctx, host_lib, n_ranks, aet, padded_height, claim, kw, column
     # time on rank 0 only; the slowest rank per stage -- what the projection sums -- is unchanged.
     host_lib.tvmh_set_option(native_host.OPTION_SHARE_REPLICATED_TABLES, 1)
     host_lib.tvmh_set_option(native_host.OPTION_COLUMN_SPLIT, column_chunks)   # > 0: the inverse transforms split by columns
+    if padded_height >= 1 << 22:
+        # n_ranks working sets on ONE device leave no room for 96-column chunks of intermediates per rank (6.4 GB each at 2^22 rows): with
+        # them the ranks give their cached blocks back and fetch them again in every proof, and a rank's 12.7 GB table allocation took
+        # 190 ms in one run (profiles/r05_q_*).  32-column chunks (TVM_OPTION_LDE_CHUNK_COLUMNS; 2 % slower extension) keep the lockstep run
+        # inside the device; a real rank has a device of its own and the default chunk width.
+        for c in ctxs:
+            c._check(c.lib.tvm_ctx_set_option(c.handle, 2, 32), "tvm_ctx_set_option")
 
     def run(r, phase):
         try:

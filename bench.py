@@ -707,6 +707,19 @@ def main():
             prof.release()
             del prof
     barrier()
+    # `stage_ms` above is the Python mirror's profile (its host work between launches sits inside the stages).  The production host's
+    # own stage times of one more proof, through its sharded entry with no communicator and one pass (the same kernels in the same
+    # order; the stream drained at every stage boundary): what the C++ host spends per stage.
+    stage_ms_cpp = None
+    if rank == 0 and world == 1 and host_lib is not None and args.data == "real" and not cpp_stats:
+        try:
+            _, st = native_host.prove_execution_sharded(ctx, host_lib, None, resident, padded_height, claim, PROVER_SEED, jit_passes=1,
+                                                        profile=True, **kw)   # first call: allocations
+            _, st = native_host.prove_execution_sharded(ctx, host_lib, None, resident, padded_height, claim, PROVER_SEED, jit_passes=1,
+                                                        profile=True, **kw)
+            stage_ms_cpp = {k: round(v, 3) for k, v in dict(st["stage_ms"]).items()}
+        except Exception as e:  # noqa: BLE001  (reported, never fatal for the line)
+            stage_ms_cpp = {"error": str(e)[:200]}
     lde_avg_ms = hash_avg_ms = None
     if rank == 0:
         share = world if sharded else (args.jit_passes or 1)
@@ -768,6 +781,7 @@ def main():
             "roofline_valu": hash_roofline(hash_avg_ms, hash_rows, 379, counters),
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "stage_wall_ms": {k: round(v, 3) for k, v in stage_wall.items()},
+            **({"stage_ms_cpp_host": stage_ms_cpp} if stage_ms_cpp is not None else {}),
             "profiled_prove_wall_ms": round(t_prof, 3),
         }
         if verified is not None:

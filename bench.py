@@ -517,6 +517,9 @@ def main():
                     "BASELINE config 5's FRI log-blowup (the quotient domain is then the short domain)")
     ap.add_argument("--ldt", choices=["fri", "stir", "auto"], default="fri",
                     help="low-degree test: fri (what BASELINE.json names), stir, or auto = Stark::ldt's rule (STIR from 2^16 rows on)")
+    ap.add_argument("--memory-policy", action="store_true",
+                    help="real data, single GPU: the C++ host's sharded entry with jit_passes = 0 -- the reference's policy (master_table.rs:268-271): "
+                         "the cached extension, and if the device cannot hold it, coset-wise with as few passes as fit (2^23 rows)")
     ap.add_argument("--jit-passes", type=int, default=0, help="synthetic data, single GPU: evaluate the extended tables coset-wise in this "
                     "many passes (triton_vm_amd/jit.py, the reference's JIT path) instead of caching them")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent proofs per GPU instead of one sharded proof")
@@ -562,6 +565,7 @@ def main():
 
     ctx = make_context(local_rank)
     sharded = (world > 1 or args.sharded) and not args.replicas
+    coset_wise = bool(args.jit_passes or args.memory_policy)   # the C++ host's sharded entry with no communicator
     ldt = None if args.ldt == "auto" else args.ldt
     effective_ldt = ldt or ("fri" if args.log2_rows < 16 else "stir")
     host_lib, comm = None, None
@@ -609,7 +613,7 @@ def main():
         kw = dict(log2_expansion=args.log2_expansion, ldt=ldt)
 
         def prove_from(aet, profile=False):
-            if host_lib is not None and (sharded or args.jit_passes):
+            if host_lib is not None and (sharded or coset_wise):
                 last["proof"], last["stats"] = native_host.prove_execution_sharded(
                     ctx, host_lib, comm.ptr if comm is not None else None, aet, padded_height, claim, PROVER_SEED,
                     jit_passes=args.jit_passes or (1 if sharded else 0), split_tree_min_leaves=split_min, profile=profile, **kw)
@@ -650,7 +654,7 @@ def main():
             prover = Prover(ctx, params, seed=1000 + rank)
         cells_per_step = params.padded_height * MASTER_WORDS * (1 if sharded else world)
         step, host = prover.prove, "python"
-        if host_lib is not None and (sharded or args.jit_passes):
+        if host_lib is not None and (sharded or coset_wise):
             step = lambda: native_host.prove_sharded(ctx, host_lib, comm.ptr if comm is not None else None, params, prover.main.d_trace,   # noqa: E731
                                                      prover.main.d_randomizers, prover.aux.d_trace, prover.aux.d_randomizers,
                                                      prover.quotient_randomizer, jit_passes=args.jit_passes or 1, split_tree_min_leaves=split_min)
@@ -678,7 +682,7 @@ def main():
                     "revealed_rows": len(accepted_at), "proof_words": int(last["proof"].size), "seconds": round(time.perf_counter() - t0, 2)}
     barrier()
     stage_ms, stage_wall, t_prof, rank_stats = {}, {}, 0.0, None
-    cpp_stats = host_lib is not None and (sharded or args.jit_passes) and args.data == "real"
+    cpp_stats = host_lib is not None and (sharded or coset_wise) and args.data == "real"
     if cpp_stats:   # the sharded / coset-wise C++ host times its own stages (stream drained at every stage boundary)
         t_prof = time.perf_counter()
         prove_from(resident, profile=True)
@@ -688,7 +692,7 @@ def main():
             rank_stats = [None] * world
             dist.all_gather_object(rank_stats, last["stats"])
         stage_ms = dict(rank_stats[0]["stage_ms"])
-    elif (rank == 0 or sharded) and not (host_lib is not None and (sharded or args.jit_passes)):  # a sharded prove() contains collectives: every rank has to take part
+    elif (rank == 0 or sharded) and not (host_lib is not None and (sharded or coset_wise)):  # a sharded prove() contains collectives: every rank has to take part
         if args.data == "real":
             if sharded:
                 from triton_vm_amd.sharded import ShardedProver
@@ -722,7 +726,8 @@ def main():
             stage_ms_cpp = {"error": str(e)[:200]}
     lde_avg_ms = hash_avg_ms = None
     if rank == 0:
-        share = world if sharded else (args.jit_passes or 1)
+        passes_used = int((rank_stats or [{}])[0].get("passes", 0) or 0) if not sharded else 0   # what the memory policy settled on
+        share = world if sharded else (passes_used or args.jit_passes or 1)
         kp = params
         if share > 1:   # a rank (or a coset-wise pass) extends onto its share of the rows
             from triton_vm_amd.sharded import local_domain
@@ -734,7 +739,7 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        share = world if sharded else (args.jit_passes or 1)
+        share = world if sharded else (passes_used or args.jit_passes or 1)
         counters = kernel_counters()
         expansion = params.ldt.length // params.trace.length
         shape_key = f"2p{args.log2_rows}_x{expansion}"
@@ -775,8 +780,9 @@ def main():
                        "padded_rows": params.padded_height, "master_words": MASTER_WORDS, "ldt": effective_ldt,
                        "ldt_domain": params.ldt.length, "parallelism": (f"one proof over {world} GPUs: coset sharding of the extended tables, all-to-all of leaf "
                                        "digests, all-gather of the quotient codeword" if sharded else f"{world} independent proofs, one per GPU" if world > 1
-                                       else f"single GPU, tables evaluated coset-wise in {args.jit_passes} passes (nothing cached)"
-                                       if args.jit_passes else "single GPU")},
+                                       else f"single GPU, tables evaluated coset-wise in {share} passes (nothing cached)"
+                                       + (" -- chosen by the host's memory policy (jit_passes = 0: the cached path first)" if args.memory_policy and not args.jit_passes else "")
+                                       if coset_wise and share > 1 else "single GPU")},
             "roofline": roofline,
             "roofline_valu": hash_roofline(hash_avg_ms, hash_rows, 379, counters),
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
@@ -786,6 +792,10 @@ def main():
         }
         if verified is not None:
             out["verified"] = verified
+        if args.memory_policy and not sharded:
+            out["memory_policy"] = {"entry": "tvmh_prove_execution_sharded(comm = NULL, jit_passes = 0)", "passes": share,
+                                    "note": "every proof starts with the cached path and, where the device cannot hold it, starts over coset-wise "
+                                            "(master_table.rs:268-271, stark.rs:730-768); the failed attempts are inside ms_per_step"}
         if rank_stats is not None:   # per rank: stage times of one profiled proof and the bytes each collective sent
             out["ranks"] = rank_stats
         if args.data == "real":
@@ -794,7 +804,7 @@ def main():
         if stage_ms.get("AIR quotients", 0.0) > (80.0 if args.log2_rows == 20 and world == 1 else 1e9):
             # the unexplained slow mode of the AIR kernels seen on 2 of ~40 boxes in round 2: leave evidence
             out["air_slow_mode"] = {"stage_ms": stage_ms["AIR quotients"], "smi": smi_snapshot()}
-        extras = world == 1 and not sharded and not args.jit_passes and not args.no_extras
+        extras = world == 1 and not sharded and not coset_wise and not args.no_extras
         if extras and args.data == "real":
             # (1) the same step with the execution trace in host memory (what a host that keeps the AET in RAM pays)
             t = timed_steps(lambda: prove_from(e["aet"]), 3, 1, ctx.sync)

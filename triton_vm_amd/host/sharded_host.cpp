@@ -866,7 +866,7 @@ u64 estimated_bytes(const StarkParameters& p, u64 world, u64 passes) {
 
 std::vector<u64> prove_execution_sharded(const Context& c, const StarkParameters& p, const tvmh_comm* comm, unsigned passes, const tvm_aet& aet,
                                          const Claim& claim, const uint8_t seed[32], bool profile, std::string* stats,
-                                         u64 split_tree_min_leaves) {
+                                         u64 split_tree_min_leaves, unsigned policy_first_passes) {
     const u64 n = p.trace.length;
     const CommSession session(comm, c);
     // TVMH_OPTION_TRACE: host wall time of the phases of one proof on stderr (no stream synchronisation is added)
@@ -966,13 +966,28 @@ std::vector<u64> prove_execution_sharded(const Context& c, const StarkParameters
         const std::vector<u64> all = recv.download(0, world);
         return guarded_attempt((unsigned)*std::max_element(all.begin(), all.end()));
     }
-    for (unsigned pass_count = 1;; pass_count *= 2) {
+    // One rank: the attempts themselves find out what fits (an out-of-memory unwinds, the pool goes back to the driver, the proof starts
+    // over with more passes) -- but not blindly.  (a) A pass count whose footprint cannot fit even by the plain estimate (the
+    // conservative one without its quarter of headroom) is not attempted: at 2^23 rows the cached path would allocate for seconds
+    // before it fails.  (b) A coset-wise pass count has to fit by the CONSERVATIVE estimate: the passes allocate and release their
+    // group's tables again and again, and on a device that the working set just about fills the pool cannot keep any of them (measured,
+    // 2^23 rows on one MI355X: 2 passes "fit" and take 27 s per proof, hipMalloc of 100-GiB blocks in every pass; profiles/r05_t_*).
+    size_t available = 0;
+    c.check(tvm_ctx_memory_info(c.raw(), &available, nullptr), "tvm_ctx_memory_info");
+    auto fits = [&](unsigned pass_count) {
+        const u64 conservative = estimated_bytes(p, 1, pass_count);
+        return (pass_count == 1 ? conservative / 10 * 8 : conservative) <= available;
+    };
+    unsigned pass_count = policy_first_passes ? policy_first_passes : 1;   // (tvmh_prove_execution arrives here after ITS cached path failed: 2)
+    while (!fits(pass_count) && may_double(pass_count)) pass_count *= 2;
+    for (;;) {
         try {
             return attempt(pass_count);
         } catch (const Error& e) {
             if (e.status != TVM_ERR_OUT_OF_MEMORY || !may_double(pass_count)) throw;
         }
         (void)tvm_ctx_trim(c.raw());  // the failed attempt's buffers went back to the pool while unwinding: give them to the driver
+        do pass_count *= 2; while (!fits(pass_count) && may_double(pass_count));
     }
 }
 

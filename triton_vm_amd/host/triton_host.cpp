@@ -1095,16 +1095,8 @@ extern "C" int32_t tvmh_prove_execution(tvm_ctx* ctx, const tvm_aet* aet, uint32
         }
         if (out_of_memory) {
             (void)tvm_ctx_trim(c.raw());
-            const unsigned expansion = (unsigned)(p.ldt.length / p.trace.length);
-            for (unsigned passes = 2;; passes *= 2) {
-                try {
-                    proof = prove_execution_sharded(c, p, nullptr, passes, *aet, claim, randomness_seed);
-                    break;
-                } catch (const Error& e) {
-                    if (e.status != TVM_ERR_OUT_OF_MEMORY || passes * 2 > expansion) throw;
-                }
-                (void)tvm_ctx_trim(c.raw());
-            }
+            // the policy of the sharded entry from two passes on (sharded_host.cpp: pass counts by estimate, retries on out-of-memory)
+            proof = prove_execution_sharded(c, p, nullptr, 0, *aet, claim, randomness_seed, false, nullptr, 1ull << 21, 2);
         }
         if (proof_words) *proof_words = proof.size();
         if (h_proof && capacity >= proof.size()) std::memcpy(h_proof, proof.data(), proof.size() * sizeof(u64));

@@ -325,10 +325,13 @@ private:
 
 // Prover::prove(claim, aet) over the ranks of `comm` (null: this process alone) with `passes` passes per rank; passes == 0
 // is the reference's memory policy (master_table.rs:268-271, stark.rs:730-768): the cached path, and if the device (or the
-// context's memory limit) cannot hold it, the coset-wise path with as few passes as fit.  stats: optional, see ShardedProver.
+// context's memory limit) cannot hold it, the coset-wise path with as few passes as fit WITH headroom (a pass count is attempted when its
+// estimated footprint fits what the context can obtain, tvm_ctx_memory_info; an out-of-memory starts over with more).  stats: optional,
+// see ShardedProver.
 std::vector<u64> prove_execution_sharded(const Context& c, const StarkParameters& p, const tvmh_comm* comm, unsigned passes,
                                          const tvm_aet& aet, const Claim& claim, const uint8_t seed[32], bool profile = false,
-                                         std::string* stats = nullptr, u64 split_tree_min_leaves = 1ull << 21);
+                                         std::string* stats = nullptr, u64 split_tree_min_leaves = 1ull << 21,
+                                         unsigned policy_first_passes = 1);   // passes == 0 on one rank: the first pass count the policy considers
 
 }  // namespace triton_vm
 

@@ -1,7 +1,9 @@
 // rccl_comm.cpp -> libtriton_rccl.so: the tvmh_comm (triton_host.hpp) of the multi-GPU prover over RCCL / xGMI.
 //
-// One process per GPU.  Every collective is enqueued on the CONTEXT's stream (tvm_ctx_stream), behind the kernels that
-// produce its operands and ahead of those that consume its result: no host synchronisation, no second stream, no event.
+// One process per GPU.  The collectives of the default proof are enqueued on the CONTEXT's stream (tvm_ctx_stream), behind the
+// kernels that produce their operands and ahead of those that consume their results: no host synchronisation, no second stream,
+// no event.  (The opt-in column split's coefficient exchange is the exception: all_gather_async / wait below, on a stream of the
+// communicator's own, so that it can run under the kernels queued after it.)
 // The exchanges of a proof are few and large (leaf digests L x 40 B / R per rank by all-to-all,
 // the quotient codeword L x 24 B by all-gather, FRI codewords by all-to-all), so they are issued as single RCCL calls --
 // xGMI is point-to-point (7 links per GPU), an all-to-all is R - 1 concurrent peer transfers, one per link.

@@ -1,5 +1,5 @@
-"""MEASUREMENT: one execution trace, the C++ host's sharded entry with no communicator at several pass counts (0 = the memory policy).
-usage: python tools/jit_passes_probe.py <log2 rows> <passes,passes,...> [repeats]      e.g.  23 0,4,8,2
+"""TEST-SIDE MEASUREMENT (it runs the oracle-side VM for its workload, like bench.py does): one execution trace, the C++ host's sharded entry with no communicator at several pass counts (0 = the memory policy).
+usage: python tests/jit_passes_probe.py <log2 rows> <passes,passes,...> [repeats]      e.g.  23 0,4,8,2
 Prints one JSON object: per pass count the milliseconds of each proof, the pass count the host used, and whether every proof is
 word for word the first one."""
 import json

@@ -148,3 +148,21 @@ def test_bench_lockstep_measurement_of_the_multi_gpu_code_path():
     assert sim["ranks"] == 4 and sim["all_ranks_same_proof"] and sim["same_proof_as_single_gpu"], sim.get("error")
     assert len(sim["stage_ms_per_rank"]["AIR quotients"]) == 4 and sim["bytes_sent_per_rank"] > 0
     assert sim["projected_ms_per_proof"] > 0 and sim["slowest_rank_sum_ms"] > 0
+
+
+def test_bench_memory_policy():
+    """`bench.py --memory-policy` (the C++ host's sharded entry with jit_passes = 0 on one GPU: the reference's policy,
+    master_table.rs:268-271) -- on the emulation, where the trace fits: one pass, the proof verified, the host's own stage times"""
+    import json
+    import subprocess
+
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_on_emulation.py"), "--steps", "1", "--warmup", "0", "--log2-rows", "9",
+           "--no-cpu-baseline", "--no-extras", "--memory-policy"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1800)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["memory_policy"]["passes"] == 1 and rec["verified"]["accepted"] and rec["config"]["parallelism"] == "single GPU"
+    assert set(rec["stage_ms"]) >= {"main LDE", "main Merkle", "AIR quotients", "FRI"}   # (the sharded entry's own stage times)

@@ -112,3 +112,23 @@ def test_lde_with_1024_point_axes(ctx, orc, log_n, fk, n_cols):
     want = orc.lde_table(trace, rnd, orc.Domain(ev.offset, ev.generator, ev.length), fk)
     assert (got == want[rows.astype(np.int64)]).all()
     mt.clear_cache()
+
+
+@pytest.mark.parametrize("log_n,h", [(19, 1), (19, 512), (19, 513), (21, 1024), (21, 1025)])
+def test_lde_with_1024_point_axes_at_the_randomizer_bound(ctx, orc, log_n, h):
+    """k_lde_pass2_fused is taken while the randomizer polynomial has no more coefficients than a transform row has points
+    (h <= n1: its term then touches the first coefficient group only; csrc/ntt.hip's dispatcher); one more and the tile kernel takes
+    over.  2^19 rows = 512 x 1024 (one wavefront per row) and 2^21 rows = 1024 x 2048 (two): h = 1, h = n1 and h = n1 + 1 against the
+    oracle's extension, sampled rows."""
+    fk, n_cols = 1, 1
+    rng = np.random.default_rng(1000 + h)
+    n = 1 << log_n
+    trace, rnd = orc.random_elements(rng, (n_cols, n)), orc.random_elements(rng, (n_cols, h))
+    ev = ArithmeticDomain.of_length(8 * n).with_offset(field.generator())
+    mt = MasterTable(ctx, trace, rnd, ArithmeticDomain.of_length(n), ev, ev, fk)
+    mt.maybe_low_degree_extend_all_columns()
+    rows = np.unique(np.concatenate([[0, 1, 7, 8, 8 * n - 1], rng.integers(0, 8 * n, 2000)])).astype(np.uint64)
+    got = mt.reveal_rows(rows)
+    want = orc.lde_table(trace, rnd, orc.Domain(ev.offset, ev.generator, ev.length), fk)
+    assert (got == want[rows.astype(np.int64)]).all()
+    mt.clear_cache()

@@ -132,3 +132,32 @@ def test_lde_with_1024_point_axes_at_the_randomizer_bound(ctx, orc, log_n, h):
     want = orc.lde_table(trace, rnd, orc.Domain(ev.offset, ev.generator, ev.length), fk)
     assert (got == want[rows.astype(np.int64)]).all()
     mt.clear_cache()
+
+
+@pytest.mark.parametrize("log_n,n_cols", [(6, 7), (12, 7), (19, 3), (21, 2)])
+def test_lde_tuning_options_never_change_the_table(ctx, orc, log_n, n_cols, request):
+    """include/triton_hip.h: TVM_OPTION_LDE_CHUNK_COLUMNS and TVM_OPTION_LDE_PASS2_TILES "change launch shapes, never results" --
+    chunks of 1 / 3 / 4096 columns (ragged last chunks; bench.py sets 32 for the lockstep ranks at 2^22 rows) and the tile kernel
+    instead of the row kernels on 2048-point axes (2^21 rows), against the default extension of the same table."""
+    rng = np.random.default_rng(77 + log_n)
+    n, h = 1 << log_n, min(198, 1 << log_n)
+    trace, rnd = orc.random_elements(rng, (n_cols, n)), orc.random_elements(rng, (n_cols, h))
+    ev = ArithmeticDomain.of_length(4 * n).with_offset(field.generator())
+    rows = np.unique(np.concatenate([[0, 1, 4 * n - 1], rng.integers(0, 4 * n, 600)])).astype(np.uint64)
+    set_option = lambda option, value: ctx._check(ctx.lib.tvm_ctx_set_option(ctx.handle, option, value), "tvm_ctx_set_option")
+    request.addfinalizer(lambda: (ctx.lib.tvm_ctx_set_option(ctx.handle, 2, 0), ctx.lib.tvm_ctx_set_option(ctx.handle, 4, 0)))
+
+    def table():
+        mt = MasterTable(ctx, trace, rnd, ArithmeticDomain.of_length(n), ev, ev, 1)
+        mt.maybe_low_degree_extend_all_columns()
+        got = mt.reveal_rows(rows)
+        mt.clear_cache()
+        return got
+
+    want = table()
+    if log_n <= 12:
+        assert (want == orc.lde_table(trace, rnd, orc.Domain(ev.offset, ev.generator, ev.length), 1)[rows.astype(np.int64)]).all()
+    for chunk, tiles in ((1, 0), (3, 0), (4096, 0), (0, 1), (3, 1)):
+        set_option(2, chunk)
+        set_option(4, tiles)
+        assert (table() == want).all(), (chunk, tiles)

@@ -1445,6 +1445,8 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     const auto intermediates = [&](int cols) { return (size_t)cols * (1 + X) * n_rows * sizeof(u64); };
     if (chunk_cols <= 0) chunk_cols = c->lde_chunk_columns;
     if (chunk_cols <= 0) chunk_cols = (intermediates(96) <= ((size_t)36 << 30) && intermediates(96) <= pool_available(c, nullptr) / 3) ? 96 : 32;
+    // (a chunk wider than the columns there are buys nothing; not below 96, so that narrow tables keep sharing the blocks of the wide ones)
+    if (chunk_cols > 96 && chunk_cols > last - first) chunk_cols = last - first > 96 ? last - first : 96;
 
     const u64 w = trace_gen, wi = bfe_inv(trace_gen);
     const u64 n_inv = bfe_inv(bfe_from_u64(N));

@@ -533,6 +533,8 @@ def main():
     ap.add_argument("--column-split", type=int, default=0, help="sharded proof (--gpus N > 1, --simulate-gpus N): split the inverse transforms of the "
                     "table extensions by columns over the ranks and exchange the coefficients in this many chunks per table "
                     "(TVMH_OPTION_COLUMN_SPLIT; north_star's column sharding where it applies) instead of replicating them")
+    ap.add_argument("--hash-lut16", type=int, default=0, help="A/B switch: row hashing with the two-byte S-box table in LDS (TVM_OPTION_HASH_LUT16 = this "
+                    "many persistent workgroups; 256 = one per CU of an MI355X); 0 = the byte-table kernel")
     ap.add_argument("--host", choices=["cpp", "python"], default="cpp",
                     help="host side that sequences the C-ABI calls of the timed step: the C++ mirror of Prover::prove "
                          "(triton_vm_amd/host/, the default where it applies: cached tables, one proof per GPU) or the "
@@ -564,6 +566,8 @@ def main():
     from triton_vm_amd.prover import Prover, StarkParameters, stark_parameters
 
     ctx = make_context(local_rank)
+    if args.hash_lut16:
+        ctx._check(ctx.lib.tvm_ctx_set_option(ctx.handle, 5, args.hash_lut16), "tvm_ctx_set_option")
     sharded = (world > 1 or args.sharded) and not args.replicas
     coset_wise = bool(args.jit_passes or args.memory_policy)   # the C++ host's sharded entry with no communicator
     ldt = None if args.ldt == "auto" else args.ldt

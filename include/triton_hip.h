@@ -78,6 +78,10 @@ int32_t tvm_ctx_trim(tvm_ctx* ctx);
 /* TVM_OPTION_LDE_PASS2_TILES = 1: the middle pass of tvm_lde_table on 2048-point axes (2^21 / 2^22 rows) runs the position-major tile
  * kernel (k_lde_pass2_v3) instead of k_lde_pass2_fused (and the generic kernel on 1024-point axes): the A/B switch of profiles/r05_*. */
 #define TVM_OPTION_LDE_PASS2_TILES 4
+/* TVM_OPTION_HASH_LUT16 = G > 0: row hashing (tvm_hash_rows, tvm_table_merkle_tree) of >= 256 G rows runs k_hash_rows_lut16 -- the S-box
+ * two bytes at a time from a 128 KB LDS table, G persistent workgroups (one per CU: 256 on an MI355X) -- instead of the byte-table
+ * kernel.  Same digests; the A/B switch of profiles/r06_*. */
+#define TVM_OPTION_HASH_LUT16 5
 int32_t tvm_ctx_set_option(tvm_ctx* ctx, int32_t option, uint64_t value);
 /* Cap on the bytes this context may hold through tvm_malloc / table handles (0 = no cap).  Requests beyond it fail
  * with TVM_ERR_OUT_OF_MEMORY exactly like a full device: the knob a host uses to share a GPU, and what the tests use to
@@ -97,6 +101,23 @@ int32_t tvm_memcpy_d2d(tvm_ctx* ctx, void* d_dst, const void* d_src, size_t byte
 /* the hipStream_t every call of this context is ordered on (so that a collective library -- RCCL -- can be enqueued
  * behind the kernels that produce its operands and ahead of those that consume its results; triton_vm_amd/host/rccl_comm.cpp) */
 void* tvm_ctx_stream(const tvm_ctx* ctx);
+/* The context's SIDE LANE: a second stream (created on first use) for exchanges that run UNDER the kernels of the context's stream --
+ * the coefficient exchange of the column split (MasterTable::low_degree_extend_over, triton_vm_amd/host/triton_host.cpp) and its
+ * communicators (rccl_comm.cpp enqueues ncclAllGather on it; the in-process communicator of sharded_host.cpp copies on it).  Ordering is
+ * by events only, no host synchronisation:
+ *   tvm_side_begin       the side lane waits for everything queued on the context's stream so far (the exchange's operands);
+ *   tvm_side_memcpy_d2d  a device-to-device copy on the side lane;
+ *   tvm_side_mark(slot)  records "everything queued on the side lane so far is done" in slot < TVM_SIDE_SLOTS;
+ *   tvm_side_wait(slot)  the context's stream waits for that mark -- which also orders the pool's reuse of a freed block behind
+ *                        the exchange that read or wrote it (a mark never recorded is no wait);
+ *   tvm_side_sync        the HOST waits for the side lane (in-process communicators: a peer's copies out of this rank's buffer). */
+#define TVM_SIDE_SLOTS 16
+void* tvm_ctx_side_stream(tvm_ctx* ctx); /* NULL if it cannot be created */
+int32_t tvm_side_begin(tvm_ctx* ctx);
+int32_t tvm_side_memcpy_d2d(tvm_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
+int32_t tvm_side_mark(tvm_ctx* ctx, uint32_t slot);
+int32_t tvm_side_wait(tvm_ctx* ctx, uint32_t slot);
+int32_t tvm_side_sync(tvm_ctx* ctx);
 
 /* HIP-event stopwatch on the context's stream (bench.py's live kernel timing) */
 int32_t tvm_timer_start(tvm_ctx* ctx);

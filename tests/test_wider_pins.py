@@ -48,15 +48,17 @@ def test_stir_proof_of_the_second_snapshot_program_has_not_drifted(orc):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("log2_rows", [12, 14])
-def test_device_proof_equals_the_oracle_provers_at_larger_heights(orc, log2_rows):
-    """prove_fib padded to 2^12 and 2^14 rows: every word of the device proof (Python host and C++ host) equals the oracle
-    prover's -- the prover that reproduces the reference's two proof digests"""
+@pytest.mark.parametrize("kind", ["fib", "u32", "ram", "sponge"])
+def test_device_proof_equals_the_oracle_provers_at_larger_heights(orc, kind, log2_rows):
+    """prove_fib -- and the u32 / ram / sponge loops of BASELINE.json's configs[3] and [4], whose U32, RAM (Bezout coefficients), hash,
+    cascade and lookup tables are NOT small here (round 6) -- padded to 2^12 and 2^14 rows: every word of the device proof (Python
+    host and C++ host) equals the oracle prover's -- the prover that reproduces the reference's two proof digests"""
     from oracle import real_prover
     from oracle.vm import workload
     from triton_vm_amd import Context, native_host
     from triton_vm_amd.prover import Claim, Prover
 
-    e = workload.execution("fib", log2_rows)
+    e = workload.execution(kind, log2_rows)
     want = real_prover.prove(e["program"], [e["index"]], seed_u64=snap.SEED_U64)
     seed = snap.prover_seed(snap.SEED_U64)
     claim = Claim(e["program_digest"], e["public_input"], e["public_output"])

@@ -29,7 +29,7 @@ done
 for PASSES in 0 2; do
   echo "== feature hip, stage 2 through tvmh_prove_execution_sharded, jit_passes = $PASSES"
   for T in $TESTS; do
-    TRITON_HIP_SHARDED_ENTRY=$PASSES cargo test --release -p triton-vm --features hip -- "$T"
+    TRITON_HIP_SHARDED_ENTRY=$PASSES cargo test --release -p triton-vm --features hip,triton-vm-hip/acceptance-sharded-entry -- "$T"
   done
 done
 # STIR, the reference's automatic low-degree test from 2^16 padded rows on (stark.rs:1944-1951) -- the one part of the proof no
@@ -50,7 +50,7 @@ RS
 for STAGE in 2 1; do
   TRITON_HIP_STAGE=$STAGE cargo test --release -p triton-vm --features hip --test hip_stir_acceptance
 done
-TRITON_HIP_SHARDED_ENTRY=0 cargo test --release -p triton-vm --features hip --test hip_stir_acceptance
+TRITON_HIP_SHARDED_ENTRY=0 cargo test --release -p triton-vm --features hip,triton-vm-hip/acceptance-sharded-entry --test hip_stir_acceptance
 # the headline benchmark, CPU vs device, same box; then the same at 2^16 rows, where Stark::default() is STIR
 cargo bench -p triton-vm --bench prove_fib --no-default-features
 cargo bench -p triton-vm --bench prove_fib --no-default-features --features hip

@@ -449,12 +449,18 @@ pub fn prove_execution(
     public_input: &[u64],
     public_output: &[u64],
 ) -> Result<Vec<u64>> {
-    // Acceptance switch of run_acceptance.sh (a test harness setting of this shim, not of the libraries, which read no environment):
-    // TRITON_HIP_SHARDED_ENTRY routes the same call through `tvmh_prove_execution_sharded` with no communicator -- the entry point of
-    // the multi-GPU / coset-wise prover under the reference's memory policy -- so that the reference's own tests (proof-hash
-    // snapshots, prove_and_verify_*) check that code path too; its value is the pass count (0 = the memory policy).
+    // Acceptance switch of run_acceptance.sh, compiled in ONLY under the cargo feature `acceptance-sharded-entry` (off by default: a
+    // prover behind triton_vm::prove() must not change code paths because of an inherited environment -- the libraries read none, and
+    // neither does this crate as shipped).  With the feature, TRITON_HIP_SHARDED_ENTRY=<passes> routes the same call through
+    // `tvmh_prove_execution_sharded` with no communicator -- the entry point of the multi-GPU / coset-wise prover under the
+    // reference's memory policy (0 = the policy decides) -- so that the reference's own tests check that code path too; a value that
+    // does not parse is an error, not a silent 0.
+    #[cfg(feature = "acceptance-sharded-entry")]
     if let Some(passes) = std::env::var_os("TRITON_HIP_SHARDED_ENTRY") {
-        let jit_passes = passes.to_str().and_then(|p| p.parse::<u32>().ok()).unwrap_or(0);
+        let jit_passes = passes
+            .to_str()
+            .and_then(|p| p.parse::<u32>().ok())
+            .unwrap_or_else(|| panic!("TRITON_HIP_SHARDED_ENTRY must be a pass count (0 = the memory policy), got {passes:?}"));
         return prove_execution_sharded(
             ctx, None, jit_passes, aet, padded_height, security_level, log2_expansion, ldt, randomness_seed, program_digest, public_input,
             public_output,

@@ -65,6 +65,12 @@ _SIGNATURES = {
     "tvm_memcpy_d2h": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "tvm_memcpy_d2d": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "tvm_ctx_stream": (C.c_void_p, [C.c_void_p]),
+    "tvm_ctx_side_stream": (C.c_void_p, [C.c_void_p]),
+    "tvm_side_begin": (C.c_int32, [C.c_void_p]),
+    "tvm_side_memcpy_d2d": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "tvm_side_mark": (C.c_int32, [C.c_void_p, C.c_uint32]),
+    "tvm_side_wait": (C.c_int32, [C.c_void_p, C.c_uint32]),
+    "tvm_side_sync": (C.c_int32, [C.c_void_p]),
     "tvm_timer_start": (C.c_int32, [C.c_void_p]),
     "tvm_timer_stop": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float)]),
     "tvm_synthetic_fill": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),

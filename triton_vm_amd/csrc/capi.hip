@@ -61,6 +61,13 @@ void tvm_ctx_destroy(tvm_ctx* c) {
     for (auto& kv : c->pool_live) hipFree(kv.first);
     if (c->ev_start) hipEventDestroy(c->ev_start);
     if (c->ev_stop) hipEventDestroy(c->ev_stop);
+    if (c->side) {
+        hipStreamSynchronize(c->side);
+        hipStreamDestroy(c->side);
+    }
+    if (c->side_ready) hipEventDestroy(c->side_ready);
+    for (hipEvent_t e : c->side_done)
+        if (e) hipEventDestroy(e);
     if (c->owns_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -120,6 +127,11 @@ int32_t tvm_ctx_set_option(tvm_ctx* c, int32_t option, uint64_t value) {
         c->lde_pass2_tiles = value ? 1 : 0;
         return TVM_OK;
     }
+    if (option == TVM_OPTION_HASH_LUT16) {
+        if (value > 65535) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "TVM_OPTION_HASH_LUT16: at most 65535 workgroups");
+        c->hash_lut16 = (int)value;
+        return TVM_OK;
+    }
     if (option == TVM_OPTION_MERKLE_MIN_WORKGROUPS) {
         c->merkle_min_workgroups = value ? value : 4096;
         return TVM_OK;
@@ -149,6 +161,55 @@ int32_t tvm_memcpy_d2d(tvm_ctx* c, void* dst, const void* src, size_t bytes) {
     return TVM_OK;
 }
 void* tvm_ctx_stream(const tvm_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+// ---- the side lane (include/triton_hip.h)
+static_assert(TVM_SIDE_SLOTS == 16, "tvm_ctx::side_done has sixteen slots");
+static bool side_lane(tvm_ctx* c) {
+    if (c->side) return true;
+    int cur = -1;   // streams belong to the device that is current when they are created (see bind_device, ntt.hip)
+    if ((hipGetDevice(&cur) != hipSuccess || cur != c->device) && hipSetDevice(c->device) != hipSuccess) return false;
+    hipStream_t s = nullptr;
+    hipEvent_t ready = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return false;
+    if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess) {
+        hipStreamDestroy(s);
+        return false;
+    }
+    c->side = s;
+    c->side_ready = ready;
+    return true;
+}
+void* tvm_ctx_side_stream(tvm_ctx* c) { return c && side_lane(c) ? (void*)c->side : nullptr; }
+int32_t tvm_side_begin(tvm_ctx* c) {
+    if (!c) return TVM_ERR_INVALID_ARGUMENT;
+    if (!side_lane(c)) return tvm::set_error(c, TVM_ERR_DEVICE, "tvm_side_begin: no second stream");
+    TVM_HIP_CHECK(c, hipEventRecord(c->side_ready, c->stream));
+    TVM_HIP_CHECK(c, hipStreamWaitEvent(c->side, c->side_ready, 0));
+    return TVM_OK;
+}
+int32_t tvm_side_memcpy_d2d(tvm_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c || (bytes && (!dst || !src))) return TVM_ERR_INVALID_ARGUMENT;
+    if (!side_lane(c)) return tvm::set_error(c, TVM_ERR_DEVICE, "tvm_side_memcpy_d2d: no second stream");
+    if (bytes) TVM_HIP_CHECK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->side));
+    return TVM_OK;
+}
+int32_t tvm_side_mark(tvm_ctx* c, uint32_t slot) {
+    if (!c || slot >= TVM_SIDE_SLOTS) return TVM_ERR_INVALID_ARGUMENT;
+    if (!side_lane(c)) return tvm::set_error(c, TVM_ERR_DEVICE, "tvm_side_mark: no second stream");
+    if (!c->side_done[slot]) TVM_HIP_CHECK(c, hipEventCreateWithFlags(&c->side_done[slot], hipEventDisableTiming));
+    TVM_HIP_CHECK(c, hipEventRecord(c->side_done[slot], c->side));
+    return TVM_OK;
+}
+int32_t tvm_side_wait(tvm_ctx* c, uint32_t slot) {
+    if (!c || slot >= TVM_SIDE_SLOTS) return TVM_ERR_INVALID_ARGUMENT;
+    if (c->side_done[slot]) TVM_HIP_CHECK(c, hipStreamWaitEvent(c->stream, c->side_done[slot], 0));   // (never marked: nothing to wait for)
+    return TVM_OK;
+}
+int32_t tvm_side_sync(tvm_ctx* c) {
+    if (!c) return TVM_ERR_INVALID_ARGUMENT;
+    if (c->side) TVM_HIP_CHECK(c, hipStreamSynchronize(c->side));
+    return TVM_OK;
+}
 
 int32_t tvm_timer_start(tvm_ctx* c) {
     if (!c) return TVM_ERR_INVALID_ARGUMENT;
@@ -387,7 +448,7 @@ int32_t tvm_lde_table(tvm_ctx* c, int32_t fk, const uint64_t* d_trace, uint64_t 
 int32_t tvm_lde_column_coefficients(tvm_ctx* c, int32_t fk, const uint64_t* d_trace, uint64_t n_rows, uint64_t n_cols, tvm_domain trace_dom,
                                     uint64_t first_virtual_column, uint64_t n_virtual_columns, uint64_t* d_coeffs) {
     if (!c || !d_trace || !d_coeffs || !valid_fk(fk) || !valid_domain(trace_dom) || trace_dom.length != n_rows || n_cols == 0 ||
-        n_cols * fk > (1u << 20) || first_virtual_column + n_virtual_columns > n_cols * fk)
+        n_cols * fk > (1u << 20) || first_virtual_column > n_cols * fk || n_virtual_columns > n_cols * fk - first_virtual_column)
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_lde_column_coefficients arguments");
     if (trace_dom.offset != TVM_ONE) return set_error(c, TVM_ERR_UNSUPPORTED, "trace domain offset must be 1");
     if (!n_virtual_columns) return TVM_OK;
@@ -421,24 +482,52 @@ int32_t tvm_lde_table_begin(tvm_ctx* c, int32_t fk, uint64_t n_rows, uint64_t n_
         const u64 full = t->layout.storage_rows() / TVM_RB * TVM_RB * (u64)t->W;
         (void)hipMemsetAsync(t->data + full, 0, t->bytes() - full * sizeof(u64), c->stream);
     }
+    t->lde_split_open = true;
+    t->lde_trace_len = n_rows;
+    t->lde_trace_gen = trace_dom.generator;
+    t->lde_eval_offset = eval_dom.offset;
+    t->lde_eval_gen = eval_dom.generator;
+    t->lde_written.assign((size_t)t->W, 0);
     *out = t;
     return TVM_OK;
 }
 
 int32_t tvm_lde_table_add_columns(tvm_ctx* c, tvm_table* t, const uint64_t* d_coeffs, uint64_t first_virtual_column,
                                   uint64_t n_virtual_columns, const uint64_t* d_rnd, uint64_t h, tvm_domain trace_dom, tvm_domain eval_dom) {
-    if (!c || !t || !d_coeffs || (h && !d_rnd) || !valid_domain(trace_dom) || !valid_domain(eval_dom) || eval_dom.length != t->rows ||
-        first_virtual_column + n_virtual_columns > (uint64_t)t->W || t->interpolant_len != trace_dom.length + h)
+    if (!c || !t || !d_coeffs || (h && !d_rnd) || !valid_domain(trace_dom) || !valid_domain(eval_dom))
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_lde_table_add_columns arguments");
+    // only a table that tvm_lde_table_begin made and tvm_lde_table_end has not closed (its layout has the successor blocks pass 3
+    // and fill_successor_blocks write into), and only with the domains that were given to begin
+    if (!t->lde_split_open || !t->has_successor_blocks)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_lde_table_add_columns: not a table under construction (tvm_lde_table_begin)");
+    if (trace_dom.offset != TVM_ONE) return set_error(c, TVM_ERR_UNSUPPORTED, "trace domain offset must be 1");
+    if (trace_dom.length != t->lde_trace_len || trace_dom.generator != t->lde_trace_gen || eval_dom.length != t->rows ||
+        eval_dom.offset != t->lde_eval_offset || eval_dom.generator != t->lde_eval_gen || t->interpolant_len != trace_dom.length + h)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_lde_table_add_columns: other domains / randomizer count than tvm_lde_table_begin's");
+    const uint64_t W = (uint64_t)t->W;
+    if (first_virtual_column > W || n_virtual_columns > W - first_virtual_column)   // (no wrap-around in the sum)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_lde_table_add_columns: columns beyond the table");
     if (!n_virtual_columns) return TVM_OK;
     const LdeSplit split{2, const_cast<uint64_t*>(d_coeffs), (int)first_virtual_column, (int)n_virtual_columns};
-    return lde_table(c, t->fk, nullptr, trace_dom.length, t->n_cols, d_rnd, h, trace_dom.generator, eval_dom.offset, eval_dom.generator,
-                     eval_dom.length, t->data, 0, &split);
+    const int rc = lde_table(c, t->fk, nullptr, trace_dom.length, t->n_cols, d_rnd, h, trace_dom.generator, eval_dom.offset, eval_dom.generator,
+                             eval_dom.length, t->data, 0, &split);
+    if (rc == TVM_OK)
+        for (uint64_t v = first_virtual_column; v < first_virtual_column + n_virtual_columns; v++) t->lde_written[(size_t)v] = 1;
+    return rc;
 }
 
 int32_t tvm_lde_table_end(tvm_ctx* c, tvm_table* t) {
     if (!c || !t) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_lde_table_end arguments");
-    return fill_successor_blocks(c, t->data, t->layout, t->W);
+    if (!t->lde_split_open || !t->has_successor_blocks)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_lde_table_end: not a table under construction (tvm_lde_table_begin)");
+    for (size_t v = 0; v < t->lde_written.size(); v++)
+        if (!t->lde_written[v]) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_lde_table_end: a column was never written (tvm_lde_table_add_columns)");
+    const int rc = fill_successor_blocks(c, t->data, t->layout, t->W);
+    if (rc == TVM_OK) {
+        t->lde_split_open = false;
+        t->lde_written.clear();
+    }
+    return rc;
 }
 
 void tvm_table_free(tvm_ctx* c, tvm_table* t) {

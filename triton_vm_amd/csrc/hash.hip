@@ -58,6 +58,44 @@ __global__ void __launch_bounds__(TVM_HASH_BLOCK, 6) k_hash_rows_mfma(const u64*
     }
 }
 
+// The same with the S-box two bytes at a time (tip5.h: tip5_lut16_*): 128 KB of LDS for the table, ONE persistent workgroup of
+// sixteen wavefronts per CU that builds it once and then walks its groups of 256 rows.  Dynamic LDS only: the table sits at LDS
+// address TIP5_LUT16_LDS_OFFSET, which the lookups' addresses assume.
+__global__ void __launch_bounds__(1024) k_hash_rows_lut16(const u64* __restrict__ table, TabView view, int W, u64* __restrict__ digests,
+                                                         u64 n_groups) {
+    TVM_DYN_SMEM(int, ctab);   // 3200 bytes of the first 4 KB; the table behind them
+    unsigned short* const lut16 = (unsigned short*)((unsigned char*)ctab + TIP5_LUT16_LDS_OFFSET);
+    static_assert(TIP5_ROUNDS * TIP5_MFMA_POSITIONS * 16 * sizeof(int) <= TIP5_LUT16_LDS_OFFSET, "the accumulator inputs fit in front of the table");
+    const int tid = threadIdx.x;
+    for (int i = tid; i < TIP5_ROUNDS * TIP5_MFMA_POSITIONS * 16; i += blockDim.x) ctab[i] = d_tip5_mfma_table.v[i];
+    tip5_lut16_build(lut16, tid, blockDim.x);
+    __syncthreads();
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const Tip5MfmaOperands a = tip5_mfma_matrix_operands(lane);
+    const int n_perms = W / TIP5_RATE + 1;
+    for (u64 grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const u64 t = (grp * 16 + (u64)(tid >> 6)) * 16 + n;
+        const bool live = t < view.n_out;  // every lane of a wavefront takes part in the matrix instructions
+        u64 row, r;
+        view.locate(live ? t : view.n_out - 1, row, r);
+        const u64* base = table + (row >> TVM_RB_LOG) * (u64)W * TVM_RB + (row & (TVM_RB - 1));
+        u64 st[4] = {0, 0, 0, 0};
+        for (int perm = 0; perm < n_perms; perm++) {
+#pragma unroll
+            for (int t3 = 0; t3 < 3; t3++) {
+                const int q = g + 4 * t3;
+                const int wi = perm * TIP5_RATE + q;
+                if (q < TIP5_RATE) st[t3] = wi < W ? TVM_LOAD_STREAM(&base[(u64)wi * TVM_RB]) : (wi == W ? TVM_ONE : 0);
+            }
+            tip5_permute_mfma<true>(st, a, g, (const unsigned char*)lut16, ctab);
+        }
+        if (live) {
+            digests[r * 5 + g] = st[0];
+            if (g == 0) digests[r * 5 + 4] = st[1];
+        }
+    }
+}
+
 // nodes[i] = hash_pair(nodes[2i], nodes[2i+1]) for i in [first, first + count): the matrix-core form of the
 // permutation (four lanes per parent, sixteen parents per wavefront; tip5.h), for the levels that fill the chip.
 __global__ void __launch_bounds__(256, 6) k_merkle_level(u64* __restrict__ nodes, u64 first, u64 count, int reps) {
@@ -212,6 +250,19 @@ __global__ void k_columns_to_table(const u64* __restrict__ cols, u64 col_stride,
 int hash_rows(tvm_ctx* c, const u64* table, const TabLayout& layout, int W, u64 stride, u64* digests) {
     if (!stride || layout.rows() % stride) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "hash_rows: stride must divide the number of rows");
     const TabView view = tab_view(layout, stride);
+    if (c->hash_lut16 && view.n_out >= 256ull * (u64)c->hash_lut16) {   // (a launch with less than one group of 256 rows per workgroup takes the byte form)
+        static bool attr_done = false;
+        const size_t lds = TIP5_LUT16_LDS_OFFSET + 65536 * sizeof(unsigned short);
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)k_hash_rows_lut16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done = true;
+        }
+        const u64 n_groups = (view.n_out + 255) / 256;
+        const u64 grid = n_groups < (u64)c->hash_lut16 ? n_groups : (u64)c->hash_lut16;
+        TVM_LAUNCH(k_hash_rows_lut16, dim3((unsigned)grid), dim3(1024), lds, c->stream, table, view, W, digests, n_groups);
+        TVM_HIP_CHECK(c, hipGetLastError());
+        return TVM_OK;
+    }
     const u64 rows_per_block = TVM_HASH_BLOCK / 4;
     TVM_LAUNCH(k_hash_rows_mfma, dim3((unsigned)((view.n_out + rows_per_block - 1) / rows_per_block)), dim3(TVM_HASH_BLOCK), 0, c->stream,
                table, view, W, digests);

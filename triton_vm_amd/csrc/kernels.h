@@ -1,5 +1,6 @@
 // kernels.h -- host-callable entry points of the kernel translation units (namespace tvm).
 #pragma once
+#include <vector>
 #include "context.h"
 
 namespace tvm {
@@ -71,5 +72,10 @@ struct tvm_table {
     int W = 0;            // base-field words per row = n_cols * fk
     u64 interpolant_len = 0;  // tables made by tvm_lde_table: every column is a polynomial with at most this many
                               // coefficients (trace length + trace randomizers); 0 = unknown
+    // tables under construction by tvm_lde_table_begin / _add_columns / _end (the column split): the domains given to begin, and which
+    // virtual columns have been written -- add_columns and end refuse any other handle, other domains, and an incomplete table
+    bool lde_split_open = false;
+    u64 lde_trace_len = 0, lde_trace_gen = 0, lde_eval_offset = 0, lde_eval_gen = 0;
+    std::vector<unsigned char> lde_written;
     size_t bytes() const { return (size_t)tvm_tab_words(layout.storage_rows(), (u64)W) * sizeof(u64); }
 };

@@ -899,9 +899,6 @@ __global__ void __launch_bounds__((1 << (LOGN - 4)) * ROWS, 4) k_lde_pass1_rows(
 #ifndef TVM_P2F_FT_EARLY
 #define TVM_P2F_FT_EARLY 2   // 16-byte loads of the last group's factors requested BEFORE the middle group (4 registers each)
 #endif
-#ifndef TVM_P2F_X
-#define TVM_P2F_X 0
-#endif
 #ifndef TVM_P2F_TWB
 #define TVM_P2F_TWB 4   // twiddle loads in flight per batch in the middle group of the coset loop (registers)
 #endif
@@ -1023,16 +1020,9 @@ __global__ void __launch_bounds__(LOGN == 10 ? 512 : 1024, 4) k_lde_pass2_fused(
 #pragma unroll
             for (int e = 0; e < R3; e++) q[272 * e] = bfe_mul(y8[e], u[e]);
         }
-        // (TVM_P2F_X != 0: timing experiments with wrong results, tools/build_ntt_variants.py -- 1 no store phase: -11 %, 2 the same
-        // words as contiguous 64 KB blocks: -0 %, 3 no workgroup barriers: -3 %; profiles/r05_c_*.  Never in the product build.)
-#if TVM_P2F_X == 3
-        tvm_wave_sync();
-#else
+        // (timing experiments of round 5 with deliberately wrong results -- no store phase: -11 %, the same words as contiguous 64 KB
+        // blocks: -0 %, no workgroup barriers: -3 %; profiles/r05_c_* -- are in the history, commit a103ba1, not in this source)
         tvm_lds_barrier();   // the rows are complete: the store phase reads across them
-#endif
-#if TVM_P2F_X == 1
-        if (a.h == 0xDEADBEEFull)
-#endif
         {
             const int t2 = tvm_opaque(tid), b_out = t2 & (ROWS - 1), j1_0 = t2 >> RLOG;
             // the next coset's factors: requested here, parked in LDS at the end of the store phase (every wavefront has read this
@@ -1041,12 +1031,6 @@ __global__ void __launch_bounds__(LOGN == 10 ? 512 : 1024, 4) k_lde_pass2_fused(
             u64 g_next[n2 / NT];
 #pragma unroll
             for (int hh = 0; hh < n2 / NT; hh++) g_next[hh] = more ? a.g_hi_pos[(u64)(k + 1) * n2 + t2 + hh * NT] : 0;
-#if TVM_P2F_X == 2
-            u64* zk = a.z + ((u64)vl * a.n_cosets + k) * n + p0 * n2;
-            const u64* src = s + b_out * ROWW;
-#pragma unroll 4
-            for (int i = 0; i < 16; i++) TVM_STORE_STREAM(&zk[(u64)i * NT + t2], src[TVM_ROW_SKEW(j1_0 + i * (NT >> RLOG))]);
-#else
             // a lane copies TWO adjacent rows of a position with one 16-byte store: 8 store instructions per lane and coset instead of
             // 16 for the same 64-byte runs (-3 % of the kernel, profiles/r05_k_*)
             (void)b_out, (void)j1_0;
@@ -1058,17 +1042,12 @@ __global__ void __launch_bounds__(LOGN == 10 ? 512 : 1024, 4) k_lde_pass2_fused(
                 const int j1 = j1_p + i * (NT >> (RLOG - 1));
                 TVM_STORE_STREAM_X2(&zk[(u64)j1 * n1], src[TVM_ROW_SKEW(j1)], src[ROWW + TVM_ROW_SKEW(j1)]);
             }
-#endif
             if (more) {
 #pragma unroll
                 for (int hh = 0; hh < n2 / NT; hh++) ghl[TVM_ROW_SKEW(t2 + hh * NT)] = g_next[hh];
             }
         }
-#if TVM_P2F_X == 3
-        tvm_wave_sync();
-#else
         tvm_lds_barrier();   // the tile has been read: the next coset's first group overwrites the rows
-#endif
     }
 }
 

@@ -353,8 +353,65 @@ TVM_D void tip5_mfma_recombine(const tvm_v4i (&d)[TIP5_MFMA_POSITIONS], u64 (&st
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// The split-and-lookup S-box TWO BYTES AT A TIME (round 6): a 65536-entry table of 16-bit words in LDS (128 KB: one workgroup of
+// sixteen wavefronts per CU), entry i = the lowered looked-up bytes of the two bytes of i.  A word then costs four lookups instead
+// of eight, each address is two plain 32-bit instructions -- (x << 1) & 0x1fffe, (x >> 15) & 0x1fffe -- and the loads assemble the
+// result themselves (ds_read_u16_d16 / _d16_hi write one half of a register and keep the other): 8 VALU instructions per word where
+// the byte form takes 16 (eight extractions, eight to put the bytes together again; hipcc does not pick the d16_hi form by itself).
+// The table MUST start at LDS address TIP5_LUT16_LDS_OFFSET (the kernel has no static LDS in front of its dynamic block, whose first
+// 4 KB hold the accumulator-input table: within reach of immediate offsets, which the table is not): the asm below says so.
+#define TIP5_LUT16_LDS_OFFSET 4096
+#define TIP5_STR2(x) #x
+#define TIP5_STR(x) TIP5_STR2(x)
+struct Tip5Lut16Pending { u32 lo, hi; };
+TVM_D void tip5_lut16_build(unsigned short* lut16, int tid, int nt) {
+    for (int i = tid; i < 32768; i += nt) {   // two entries per store
+        const u32 b0 = d_tip5_lut[(2 * i) & 0xFF] ^ 0x80u, b0n = d_tip5_lut[(2 * i + 1) & 0xFF] ^ 0x80u, b1 = d_tip5_lut[(2 * i) >> 8] ^ 0x80u;
+        ((u32*)lut16)[i] = (b1 << 8 | b0) | ((b1 << 8 | b0n) << 16);
+    }
+}
+// request the four lookups of a word; tip5_lut16_finish waits for them.  Between the two the compiler schedules what it likes: LDS
+// results return in order, so its own waits (which do not count these loads) are never too weak.
+TVM_D Tip5Lut16Pending tip5_lut16_request(u64 x, const unsigned short* lut16) {
+    Tip5Lut16Pending p;
+#if defined(TVM_FIELD_ASM)
+    (void)lut16;
+    u32 a0, a1, a2, a3;
+    const u32 mask = 0x1FFFEu;
+    asm volatile("v_lshlrev_b32_e32 %[a0], 1, %[xl]\n\t"
+                 "v_lshrrev_b32_e32 %[a1], 15, %[xl]\n\t"
+                 "v_lshlrev_b32_e32 %[a2], 1, %[xh]\n\t"
+                 "v_lshrrev_b32_e32 %[a3], 15, %[xh]\n\t"
+                 "v_and_b32_e32 %[a0], %[m], %[a0]\n\t"
+                 "v_and_b32_e32 %[a1], %[m], %[a1]\n\t"
+                 "v_and_b32_e32 %[a2], %[m], %[a2]\n\t"
+                 "v_and_b32_e32 %[a3], %[m], %[a3]\n\t"
+                 "ds_read_u16_d16 %[lo], %[a0] offset:" TIP5_STR(TIP5_LUT16_LDS_OFFSET) "\n\t"
+                 "ds_read_u16_d16 %[hi], %[a2] offset:" TIP5_STR(TIP5_LUT16_LDS_OFFSET) "\n\t"
+                 "ds_read_u16_d16_hi %[lo], %[a1] offset:" TIP5_STR(TIP5_LUT16_LDS_OFFSET) "\n\t"
+                 "ds_read_u16_d16_hi %[hi], %[a3] offset:" TIP5_STR(TIP5_LUT16_LDS_OFFSET)
+                 : [lo] "=&v"(p.lo), [hi] "=&v"(p.hi), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3)
+                 : [xl] "v"((u32)x), [xh] "v"((u32)(x >> 32)), [m] "s"(mask));
+#else
+    const u32 xl = (u32)x, xh = (u32)(x >> 32);
+    p.lo = (u32)lut16[xl & 0xFFFF] | ((u32)lut16[xl >> 16] << 16);
+    p.hi = (u32)lut16[xh & 0xFFFF] | ((u32)lut16[xh >> 16] << 16);
+#endif
+    return p;
+}
+TVM_D void tip5_lut16_finish(Tip5Lut16Pending& p) {
+#if defined(TVM_FIELD_ASM)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p.lo), "+v"(p.hi));
+#else
+    (void)p;
+#endif
+}
+
 // st[t] = word g + 4t of the state of permutation n; every lane of the wavefront must take part.  `lut` is the S-box table
 // LOWERED by 128 (tip5_stage_lut_lowered): the looked-up word goes to the matrix cores only, where bytes travel that way.
+// LUT16: `lut` is the 65536-entry table of tip5_lut16_build at LDS address TIP5_LUT16_LDS_OFFSET instead.
+template <bool LUT16 = false>
 TVM_D void tip5_permute_mfma(u64 (&st)[4], const Tip5MfmaOperands& m, int g, const unsigned char* lut, const int* ctab) {
     for (int r = 0; r < TIP5_ROUNDS; r++) {
         // accumulator inputs first: their LDS latency hides behind the S-box layer
@@ -365,13 +422,21 @@ TVM_D void tip5_permute_mfma(u64 (&st)[4], const Tip5MfmaOperands& m, int g, con
 #pragma unroll
             for (int v = 0; v < 4; v++) d[c][v] = cp[v];
         }
-        st[0] = tip5_sbox_lookup(st[0], lut);
+        Tip5Lut16Pending pending;
+        if constexpr (LUT16) pending = tip5_lut16_request(st[0], (const unsigned short*)lut);   // in flight under the power maps
+        else st[0] = tip5_sbox_lookup(st[0], lut);
 #pragma unroll
         for (int t = 1; t < 4; t++) st[t] = tip5_pow7(st[t]);
         const u32 pad = 0x80808080u;  // bytes travel lowered by 128
         tvm_v4i lo, hi;
-        lo[0] = (int)(u32)st[0];
-        hi[0] = (int)(u32)(st[0] >> 32);
+        if constexpr (LUT16) {
+            tip5_lut16_finish(pending);
+            lo[0] = (int)pending.lo;
+            hi[0] = (int)pending.hi;
+        } else {
+            lo[0] = (int)(u32)st[0];
+            hi[0] = (int)(u32)(st[0] >> 32);
+        }
 #pragma unroll
         for (int t = 1; t < 4; t++) {
             lo[t] = (int)((u32)st[t] ^ pad);

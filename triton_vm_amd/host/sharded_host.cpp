@@ -897,8 +897,12 @@ std::vector<u64> prove_execution_sharded(const Context& c, const StarkParameters
             if (comm->rank == 0) {
                 own.reset(new SharedTables(c.raw(), p, aet, seed, [&](const char* what) { lap(what); }));
                 c.check(tvm_sync(c.raw()), "tvm_sync");   // the other ranks read the tables on their own streams
-                rendezvous(TVMH_SHARE_PUBLISH, own.get(), &obj);
-                own.release();                            // the group keeps it
+                // Ownership passes to the group the moment it installs the pointer -- which the hook reports through *out even
+                // when it then returns an error (a peer left between its two barriers): own must let go exactly then, or the group's
+                // kept_drop and this unique_ptr would both free the tables.
+                const int32_t handed = comm->share(comm->self, c.raw(), TVMH_SHARE_PUBLISH, own.get(), &SharedTables::drop, &obj);
+                if (obj == own.get()) own.release();      // the group keeps it
+                if (handed != TVM_OK) throw Error(handed, "the communicator's share hook failed (a rank left the proof)");
             } else {
                 rendezvous(TVMH_SHARE_PUBLISH, nullptr, &obj);
             }
@@ -1061,11 +1065,15 @@ struct LocalGroup {
     }
 };
 
-int32_t local_collective(void* self, tvm_ctx* ctx, const uint64_t* d_send, uint64_t* d_recv, uint64_t words, bool all_to_all) {
+// side_slot < 0: the exchange on the context's stream, complete when the call returns.  side_slot >= 0 (tvmh_comm::all_gather_async):
+// the same rendezvous, but the copies go on the context's SIDE LANE (include/triton_hip.h: tvm_side_*) behind the work queued on the
+// context's stream so far and are marked in that slot -- the calls the RCCL communicator makes around ncclAllGather -- and the call
+// returns with the copies in flight; local_wait completes it.
+int32_t local_collective(void* self, tvm_ctx* ctx, const uint64_t* d_send, uint64_t* d_recv, uint64_t words, bool all_to_all, int side_slot = -1) {
     auto* mb = (LocalGroup::Member*)self;
     LocalGroup& g = *mb->group;
     const uint32_t r = mb->rank;
-    int32_t status = tvm_sync(ctx);  // this rank's operands are complete
+    int32_t status = tvm_sync(ctx);  // this rank's operands are complete (the peers read them on streams no event of this rank orders)
     std::unique_lock<std::mutex> lock(g.m);
     if (g.lockstep) {
         g.release(r);
@@ -1077,11 +1085,36 @@ int32_t local_collective(void* self, tvm_ctx* ctx, const uint64_t* d_send, uint6
     if (!g.barrier(lock)) return TVM_ERR_DEVICE;
     std::vector<const uint64_t*> from = g.send;
     lock.unlock();
-    for (uint32_t peer = 0; peer < g.world && status == TVM_OK; peer++)
-        status = tvm_memcpy_d2d(ctx, d_recv + (uint64_t)peer * words, from[peer] + (all_to_all ? (uint64_t)r * words : 0), words * 8);
-    if (status == TVM_OK) status = tvm_sync(ctx);
+    if (side_slot >= 0 && status == TVM_OK) status = tvm_side_begin(ctx);
+    for (uint32_t peer = 0; peer < g.world && status == TVM_OK; peer++) {
+        uint64_t* dst = d_recv + (uint64_t)peer * words;
+        const uint64_t* src = from[peer] + (all_to_all ? (uint64_t)r * words : 0);
+        status = side_slot >= 0 ? tvm_side_memcpy_d2d(ctx, dst, src, words * 8) : tvm_memcpy_d2d(ctx, dst, src, words * 8);
+    }
+    if (status == TVM_OK) status = side_slot >= 0 ? tvm_side_mark(ctx, (uint32_t)side_slot) : tvm_sync(ctx);
     lock.lock();
-    if (!g.barrier(lock)) return TVM_ERR_DEVICE;  // nobody reuses its send buffer before everybody has read it
+    // synchronous: nobody reuses its send buffer before everybody has read it.  On the side lane the reads are still in flight: the
+    // barrier only hands the turn on, local_wait's barrier is the one that protects the send buffers.
+    if (!g.barrier(lock)) return TVM_ERR_DEVICE;
+    if (g.lockstep) {
+        if (r == 0) g.turn = 0, g.cv.notify_all();
+        g.acquire(r, lock);
+    }
+    return status;
+}
+// tvmh_comm::wait: the context's stream waits for the slot's mark (its kernels may read the received words), the HOST for this rank's
+// side lane (its copies out of the peers' send buffers are done), and a barrier tells every rank that its own send buffer has been
+// read by everybody -- the caller may release it.
+int32_t local_wait(void* self, tvm_ctx* ctx, uint32_t slot) {
+    auto* mb = (LocalGroup::Member*)self;
+    LocalGroup& g = *mb->group;
+    const uint32_t r = mb->rank;
+    int32_t status = tvm_side_wait(ctx, slot);
+    const int32_t drained = tvm_side_sync(ctx);
+    if (status == TVM_OK) status = drained;
+    std::unique_lock<std::mutex> lock(g.m);
+    if (g.lockstep) g.release(r);
+    if (!g.barrier(lock)) return TVM_ERR_DEVICE;
     if (g.lockstep) {
         if (r == 0) g.turn = 0, g.cv.notify_all();
         g.acquire(r, lock);
@@ -1107,6 +1140,7 @@ int32_t local_share(void* self, tvm_ctx* ctx, uint32_t op, const void* mine, voi
         void (*old_drop)(const void*) = g.kept_drop;
         g.kept = op == TVMH_SHARE_PUBLISH ? mine : nullptr;
         g.kept_drop = op == TVMH_SHARE_PUBLISH ? drop : nullptr;
+        if (out) *out = g.kept;  // from here on the group owns `mine`: the publisher learns it even if the barrier below fails
         if (old && old_drop) {   // rank 0's thread, rank 0's context: every rank has passed the barrier, nobody reads it any more
             lock.unlock();
             old_drop(old);
@@ -1129,6 +1163,10 @@ void local_abort(void* self) {
 }
 int32_t local_all_gather(void* self, tvm_ctx* ctx, const uint64_t* s, uint64_t* d, uint64_t w) { return local_collective(self, ctx, s, d, w, false); }
 int32_t local_all_to_all(void* self, tvm_ctx* ctx, const uint64_t* s, uint64_t* d, uint64_t w) { return local_collective(self, ctx, s, d, w, true); }
+int32_t local_all_gather_async(void* self, tvm_ctx* ctx, const uint64_t* s, uint64_t* d, uint64_t w, uint32_t slot) {
+    if (slot >= TVM_SIDE_SLOTS) return TVM_ERR_INVALID_ARGUMENT;
+    return local_collective(self, ctx, s, d, w, false, (int)slot);
+}
 void local_begin(void* self, tvm_ctx*) {
     auto* mb = (LocalGroup::Member*)self;
     LocalGroup& g = *mb->group;
@@ -1174,7 +1212,8 @@ extern "C" int32_t tvmh_local_comms_create(uint32_t world, uint32_t lockstep, tv
     g->comms.resize(world);
     for (uint32_t r = 0; r < world; r++) {
         g->members[r] = {g, r};
-        g->comms[r] = tvmh_comm{&g->members[r], r, world, local_all_gather, local_all_to_all, local_begin, local_mark, local_end, local_abort, local_share, nullptr, nullptr};
+        g->comms[r] = tvmh_comm{&g->members[r], r, world, local_all_gather, local_all_to_all, local_begin, local_mark, local_end, local_abort, local_share,
+                                local_all_gather_async, local_wait};
         out[r] = &g->comms[r];
     }
     return TVM_OK;

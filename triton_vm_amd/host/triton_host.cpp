@@ -314,8 +314,20 @@ void MasterTable::low_degree_extend_over(const tvmh_comm* comm, unsigned chunks,
     // asynchronous communicator it runs under that extension), and a chunk's buffer goes back to the pool once its columns are
     // written -- R * W / (R * chunks) columns of coefficients live per buffer, not all W.
     std::vector<DeviceBuffer> all(chunks);
+    // An exchange on the communicator's side lane reads `mine` and writes all[k] outside the order of the context's stream -- the
+    // order the pool reuses freed blocks in.  Whatever way this function is left (a failed launch, a failed peer), every requested
+    // exchange is waited for BEFORE the buffers below go back to the pool: wait() puts the side lane's mark into the context's stream.
+    struct Outstanding {
+        const tvmh_comm* comm;
+        tvm_ctx* ctx;
+        uint32_t requested = 0, waited = 0;   // slots [waited, requested) are in flight
+        ~Outstanding() {
+            for (uint32_t k = waited; k < requested; k++) (void)comm->wait(comm->self, ctx, k);
+        }
+    } outstanding{comm, c_.raw()};
     auto request = [&](unsigned k) {
         all[k] = DeviceBuffer(c_, R * cpc * n);
+        if (async) outstanding.requested = k + 1;   // (counted before the call: a request that failed half-way may have queued its exchange)
         if (async) status(comm->all_gather_async(comm->self, c_.raw(), mine.ptr() + k * cpc * n, all[k].ptr(), cpc * n, k), "coefficients (all-gather)");
         else status(comm->all_gather(comm->self, c_.raw(), mine.ptr() + k * cpc * n, all[k].ptr(), cpc * n), "coefficients (all-gather)");
         if (sent) sent(cpc * n * 8 * (R - 1));
@@ -324,7 +336,10 @@ void MasterTable::low_degree_extend_over(const tvmh_comm* comm, unsigned chunks,
     c_.check(tvm_lde_table_begin(c_.raw(), fk_, n, n_cols_, h_, trace_.c(), ev.c(), &table_), "tvm_lde_table_begin");
     for (unsigned k = 0; k < chunks; k++) {
         if (k + 1 < chunks) request(k + 1);
-        if (async) status(comm->wait(comm->self, c_.raw(), k), "coefficients (wait)");
+        if (async) {
+            outstanding.waited = k + 1;
+            status(comm->wait(comm->self, c_.raw(), k), "coefficients (wait)");
+        }
         for (u64 r = 0; r < R; r++) {
             const u64 col0 = r * per + k * cpc;
             if (col0 >= W) continue;

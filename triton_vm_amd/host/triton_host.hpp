@@ -265,7 +265,8 @@ typedef struct tvmh_comm {
      * the trace-side tables every rank would otherwise build and hold for itself -- exist once.  op TVMH_SHARE_RELEASE: barrier,
      * then rank 0 drops the object the group keeps (every rank has left the proof that used it).  TVMH_SHARE_PUBLISH: rank 0
      * hands over `mine` (its device work complete) and `drop`; the group keeps it until the next release or its own destruction,
-     * which must happen while rank 0's context is alive; every rank's *out is rank 0's object.  TVMH_SHARE_BARRIER: barrier only
+     * which must happen while rank 0's context is alive; every rank's *out is rank 0's object -- and rank 0's *out == mine says "the
+     * group has taken ownership" EVEN IF the call then returns an error (the publisher must not free it).  TVMH_SHARE_BARRIER: barrier only
      * (*out = the kept object).  Used by bench.py --simulate-gpus (eight ranks of a 2^22-row proof on one GPU: 21.8 GB of traces
      * once instead of eight times) under TVMH_OPTION_SHARE_REPLICATED_TABLES; a multi-process communicator never sees it. */
     int32_t (*share)(void* self, tvm_ctx* ctx, uint32_t op, const void* mine, void (*drop)(const void*), const void** out);

@@ -213,6 +213,108 @@ def cpu_baseline(log2_rows, log2_expansion=2):
                       "NOT the Rust prover (no cargo in this image): a reported baseline, not a speed-up claim"}
 
 
+def cpu_baseline_full(log2_rows, log2_expansion=2):
+    """`--cpu-baseline full`: the same port (oracle/tvm_oracle_fast.c, OpenMP) over the WHOLE work of one prove() at this height -- every
+    column of both tables extended, every row of the three tables hashed, the three table trees and the FRI round trees built, the AIR on
+    every quotient-domain row, DEEP and every FRI fold -- timed stage by stage, nothing scaled.  To stay inside a host's memory the
+    tables are produced and consumed in blocks (64 columns for the extension, 2^20 rows for the hashing, 2^15 rows for the AIR), and a
+    block's CONTENT is synthetic and reused (the cost of these stages does not depend on the values): it is a timing of all of the
+    work, not a proof.  About 70 s on 16 cores at 2^20 rows; the result is committed under profiles/ and cited by the default line."""
+    import ctypes
+
+    import numpy as np
+
+    from oracle import oracle as orc
+
+    fast = orc.fast
+    orc.lib()
+    cores = available_cores()
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except OSError:
+        pass
+    n = 1 << log2_rows
+    X = 2 << log2_expansion
+    L = X * n
+    rng = np.random.default_rng(1)
+    g = orc.lib().orc_bfe_generator()
+    t = {}
+
+    def timed(name, fn):
+        t0 = time.perf_counter()
+        out = fn()
+        t[name] = t.get(name, 0.0) + time.perf_counter() - t0
+        return out
+
+    # low-degree extension: 652 base-field columns, 64 at a time (the block is discarded: the hashing below reads a synthetic one)
+    ev = orc.domain_of_length(L, offset=g)
+    cols_done = 0
+    while cols_done < MASTER_WORDS:
+        c = min(64, MASTER_WORDS - cols_done)
+        trace, rnd = orc.random_elements(rng, (c, n)), orc.random_elements(rng, (c, 198))
+        timed("lde", lambda: fast.lde_table(trace, rnd, ev))
+        cols_done += c
+    del trace, rnd
+    # row hashing: every row of the main (379 words), auxiliary (273) and quotient-segment (15) tables, 2^20 rows at a time
+    rows_blk = min(L, 1 << 20)
+    digests = None
+    for width in (379, 273, 15):
+        block = orc.random_elements(rng, (rows_blk, width))
+        for _ in range(L // rows_blk):
+            digests = timed("hash_rows", lambda: fast.hash_rows(block))
+        del block
+    # Merkle trees: three table trees of L leaves and the FRI rounds' trees (L, L/2, ... leaves: another 2 L leaves' worth)
+    leaves = np.tile(digests, (L // digests.shape[0], 1)) if digests.shape[0] < L else digests
+    for _ in range(3):
+        timed("merkle", lambda: fast.merkle_tree(leaves))
+    m = L
+    while m >= 1024:
+        timed("merkle", lambda: fast.merkle_tree(leaves[:m]))
+        m //= 2
+    del leaves, digests
+    # AIR: all constraints and zerofiers on every row of the quotient domain, 2^15 rows at a time
+    q_s = min(L, 1 << 15)
+    main_rows, aux_rows = orc.random_elements(rng, (q_s, 379)), orc.random_elements(rng, (q_s, 91, 3))
+    ch, w = orc.random_elements(rng, (63, 3)), orc.random_elements(rng, (604, 3))
+    tr_s, qd_s = orc.domain_of_length(q_s // 8), orc.domain_of_length(q_s, offset=g)
+    for _ in range(L // q_s):
+        timed("air", lambda: fast.quotients_combined(main_rows, aux_rows, tr_s, qd_s, ch, w))
+    # DEEP (4 components on the LDT domain) and the FRI folds (L, L/2, ... points)
+    cw = orc.random_elements(rng, (L, 3))
+    pt, val = orc.random_elements(rng, 3), orc.random_elements(rng, 3)
+    for _ in range(4):
+        timed("deep", lambda: fast.deep_codeword(cw, ev, pt, val))
+    m = L
+    while m >= 1024:
+        d_m = orc.domain_of_length(m, offset=g)
+        cw_m = cw[:m]
+        timed("fri_fold", lambda: orc.fri_split_and_fold(cw_m, d_m, pt))
+        m //= 2
+    total = sum(t.values())
+    return {"value": round(n * MASTER_WORDS / total, 1), "unit": "trace-cells/s", "cores": cores, "kind": "port", "mode": "full",
+            "host_threads_reported_by_os": os.cpu_count(), "prove_seconds": round(total, 1), "stage_seconds": {k: round(v, 2) for k, v in t.items()},
+            "sample": f"oracle/tvm_oracle_fast.c (C, OpenMP, {cores} threads) over ALL the work of one prove() at 2^{log2_rows} rows, nothing scaled: "
+                      f"{MASTER_WORDS} columns extended onto the {X}x domain, {L} rows of the 379- / 273- / 15-word tables hashed, the table and FRI "
+                      f"trees, the AIR on {L} quotient rows, DEEP and the folds ({total:.0f} s; blocks of synthetic content, reused).  An optimised "
+                      "restatement, NOT the Rust prover (no cargo in this image): a reported baseline, not a speed-up claim"}
+
+
+def cpu_baseline_full_on_record(log2_rows):
+    """the committed result of `--cpu-baseline full` at this height (profiles/r*_cpu_baseline_full_2p<rows>.json: the newest), or None"""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_cpu_baseline_full_2p{log2_rows}.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            rec = json.load(f)
+        return {"file": os.path.relpath(files[-1], ROOT), "value": rec["value"], "unit": rec["unit"], "cores": rec["cores"],
+                "prove_seconds": rec["prove_seconds"], "stage_seconds": rec["stage_seconds"]}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def kernel_counters():
     """profiles/kernel_counters.json: per-dispatch hardware counters of the SHIPPED hot kernels (rocprofv3 --pmc in separate passes,
     tools/pmc.sh -> tools/kernel_counters.py; the file names its source profile and command)"""
@@ -238,7 +340,10 @@ def lde_roofline(lde_ms, n_rows, n_cols, expansion, share, counters, shape_match
     achieved = cells * bytes_per_cell / secs / 1e9
     out = {"kernel": "main-table LDE: tvm_lde_table of 379 columns (k_lde_pass1_rows + k_lde_pass2_fused + k_lde_pass3_rows, column chunks of 96)",
            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-           "launch_ms": round(lde_ms, 3), "algorithmic_bytes_per_launch": int(cells * bytes_per_cell), "traffic": None, "bound": "valu"}
+           "launch_ms": round(lde_ms, 3), "algorithmic_bytes_per_launch": int(cells * bytes_per_cell), "traffic": None, "bound": "valu",
+           "launch_ms_measured": "live in this run with HIP events on the context's stream (tvm_timer_*), over tvm_lde_table on a synthetic table of the "
+                                 "same shape AFTER the timed proofs (hot_kernel_timings), not inside them; stage_ms_cpp_host['main LDE'] is the same "
+                                 "call inside a proof"}
     log_n = n_rows.bit_length() - 1
     butterflies = cells * (1 + expansion / share) * log_n / 2          # one inverse + expansion/share forward transforms per column
     out["work"] = {"butterflies_per_s": round(butterflies / secs, 1), "unit": "radix-2 butterflies/s (log2(n)/2 per point and transform)"}
@@ -404,8 +509,9 @@ def column_split_bracket(sim, single_gpu_stage_ms, n_rows):
                "projected_ms_per_proof_now": round(now, 3), "projected_ms_exchange_fully_hidden": round(hidden, 3),
                "projected_ms_exchange_fully_exposed": round(exposed, 3),
                "fraction_of_exchange_that_must_be_hidden_to_break_even": round(max(0.0, min(1.0, 1 - saved / exchange_ms)), 3),
-               "note": "coset sharding (built, measured above) against a column split of the inverse transforms (priced, not built): the split "
-                       "pays only for the part of the all-gather that overlaps with compute"}
+               "note": "coset sharding (the default, measured above) against the column split of the inverse transforms -- BUILT since round 5 "
+                       "(TVMH_OPTION_COLUMN_SPLIT, --column-split; measured in the lockstep harness, unverified over RCCL): the split pays "
+                       "only for the part of the all-gather that overlaps with compute"}
     except (KeyError, ZeroDivisionError) as e:   # noqa: BLE001 (an extra)
         out = {"error": str(e)}
     return out
@@ -510,6 +616,9 @@ def main():
                     help="real data: prove_fib (BASELINE configs[1], the default), the u32 loop (configs[3]), the sponge loop (configs[4] "
                          "with --log2-expansion 4), the RAM loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", choices=["sample", "full"], default="sample",
+                    help="sample (default): 10-30 s of sampled stage work scaled to prove(); full: the port over ALL the work of one prove(), "
+                         "~70 s on 16 cores at 2^20 rows (the committed result, profiles/*cpu_baseline_full*.json, is cited by the default line)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (PCIe-inclusive, synthetic hot path, STIR)")
     ap.add_argument("--trace-randomizers", type=int, default=198, help="synthetic data: Stark::default() with FRI has 198 (stark.rs:2083-2089)")
     ap.add_argument("--queries", type=int, default=173, help="synthetic data: FRI collinearity checks at 160 bits, expansion 4: 173")
@@ -533,8 +642,6 @@ def main():
     ap.add_argument("--column-split", type=int, default=0, help="sharded proof (--gpus N > 1, --simulate-gpus N): split the inverse transforms of the "
                     "table extensions by columns over the ranks and exchange the coefficients in this many chunks per table "
                     "(TVMH_OPTION_COLUMN_SPLIT; north_star's column sharding where it applies) instead of replicating them")
-    ap.add_argument("--hash-lut16", type=int, default=0, help="A/B switch: row hashing with the two-byte S-box table in LDS (TVM_OPTION_HASH_LUT16 = this "
-                    "many persistent workgroups; 256 = one per CU of an MI355X); 0 = the byte-table kernel")
     ap.add_argument("--host", choices=["cpp", "python"], default="cpp",
                     help="host side that sequences the C-ABI calls of the timed step: the C++ mirror of Prover::prove "
                          "(triton_vm_amd/host/, the default where it applies: cached tables, one proof per GPU) or the "
@@ -566,8 +673,6 @@ def main():
     from triton_vm_amd.prover import Prover, StarkParameters, stark_parameters
 
     ctx = make_context(local_rank)
-    if args.hash_lut16:
-        ctx._check(ctx.lib.tvm_ctx_set_option(ctx.handle, 5, args.hash_lut16), "tvm_ctx_set_option")
     sharded = (world > 1 or args.sharded) and not args.replicas
     coset_wise = bool(args.jit_passes or args.memory_policy)   # the C++ host's sharded entry with no communicator
     ldt = None if args.ldt == "auto" else args.ldt
@@ -869,7 +974,9 @@ def main():
             out["valid_trace_mode"] = {"option": "TVM_OPTION_AIR_VALID_TRACE", "ms_per_step": round(1e3 * t / 3, 3),
                                        "value": round(cells_per_step * 3 / t, 1), "unit": "trace-cells/s"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.log2_rows, args.log2_expansion)
+            out["cpu_baseline"] = (cpu_baseline_full if args.cpu_baseline == "full" else cpu_baseline)(args.log2_rows, args.log2_expansion)
+            if args.cpu_baseline != "full":
+                out["cpu_baseline"]["full_run_on_record"] = cpu_baseline_full_on_record(args.log2_rows)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

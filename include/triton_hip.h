@@ -78,10 +78,6 @@ int32_t tvm_ctx_trim(tvm_ctx* ctx);
 /* TVM_OPTION_LDE_PASS2_TILES = 1: the middle pass of tvm_lde_table on 2048-point axes (2^21 / 2^22 rows) runs the position-major tile
  * kernel (k_lde_pass2_v3) instead of k_lde_pass2_fused (and the generic kernel on 1024-point axes): the A/B switch of profiles/r05_*. */
 #define TVM_OPTION_LDE_PASS2_TILES 4
-/* TVM_OPTION_HASH_LUT16 = G > 0: row hashing (tvm_hash_rows, tvm_table_merkle_tree) of >= 256 G rows runs k_hash_rows_lut16 -- the S-box
- * two bytes at a time from a 128 KB LDS table, G persistent workgroups (one per CU: 256 on an MI355X) -- instead of the byte-table
- * kernel.  Same digests; the A/B switch of profiles/r06_*. */
-#define TVM_OPTION_HASH_LUT16 5
 int32_t tvm_ctx_set_option(tvm_ctx* ctx, int32_t option, uint64_t value);
 /* Cap on the bytes this context may hold through tvm_malloc / table handles (0 = no cap).  Requests beyond it fail
  * with TVM_ERR_OUT_OF_MEMORY exactly like a full device: the knob a host uses to share a GPU, and what the tests use to

@@ -41,28 +41,6 @@ def test_row_hashes_of_short_tables(ctx, orc, n, expansion):
     assert (mt.hash_all_ldt_domain_rows() == orc.hash_rows(table)).all()
 
 
-@pytest.mark.parametrize("n,expansion,n_cols,fk,groups", [(256, 4, 23, 1, 2), (128, 8, 4, 3, 3), (512, 4, 10, 1, 8)])
-def test_row_hashes_with_the_two_byte_sbox_table(ctx, orc, n, expansion, n_cols, fk, groups, request):
-    """TVM_OPTION_HASH_LUT16: the persistent row-hashing kernel with the 65536-entry S-box table in LDS (k_hash_rows_lut16) gives the
-    digests of the byte-table kernel and of the oracle; `groups` workgroups walk the groups of 256 rows (more groups than workgroups,
-    a last group with idle wavefronts when the row count says so)."""
-    rng = np.random.default_rng(n + groups)
-    h = 3
-    shape_t = (n_cols, n) + ((3,) if fk == 3 else ())
-    shape_r = (n_cols, h) + ((3,) if fk == 3 else ())
-    trace, rnd = orc.random_elements(rng, shape_t), orc.random_elements(rng, shape_r)
-    ev = ArithmeticDomain.of_length(n * expansion).with_offset(field.generator())
-    mt = MasterTable(ctx, trace, rnd, ArithmeticDomain.of_length(n), ev, ev, fk)
-    mt.maybe_low_degree_extend_all_columns()
-    plain = mt.hash_all_ldt_domain_rows()
-    ctx._check(ctx.lib.tvm_ctx_set_option(ctx.handle, 5, groups), "tvm_ctx_set_option")
-    request.addfinalizer(lambda: ctx.lib.tvm_ctx_set_option(ctx.handle, 5, 0))
-    two_bytes = mt.hash_all_ldt_domain_rows()
-    assert (two_bytes == plain).all()
-    table = orc.lde_table(trace, rnd, odom(orc, ev), fk)
-    assert (two_bytes == orc.hash_rows(table.reshape(len(ev), -1))).all()
-
-
 def test_ldt_view_is_strided_subset(ctx, orc):
     """ldt domain shorter than the evaluation domain: rows at stride (master_table.rs:792-801)."""
     rng = np.random.default_rng(3)

@@ -93,7 +93,8 @@ def test_lde_split_at_the_coefficients_gives_the_same_table(ctx, orc, log_n, exp
     mt.clear_cache()
 
 
-@pytest.mark.parametrize("log_n,fk,n_cols", [(20, 1, 2), (19, 3, 1), (21, 1, 1), (22, 1, 1)])
+@pytest.mark.parametrize("log_n,fk,n_cols", [(20, 1, 2), (19, 3, 1), (21, 1, 1), (22, 1, 1),
+                                             (16, 1, 3), (17, 3, 1), (18, 1, 2)])   # round 6: 256- and 512-point rows (k_lde_pass2_fused<8 | 9> ...)
 def test_lde_with_1024_point_axes(ctx, orc, log_n, fk, n_cols):
     """The production kernels of tvm_lde_table (one transform row per wavefront, csrc/ntt.hip: k_lde_pass2_fused /
     k_lde_pass3_rows, taken for 1024-point axes: traces of 2^19 and 2^20 rows -- BASELINE config 1's height; since round 4 also for
@@ -134,7 +135,7 @@ def test_lde_with_1024_point_axes_at_the_randomizer_bound(ctx, orc, log_n, h):
     mt.clear_cache()
 
 
-@pytest.mark.parametrize("log_n,n_cols", [(6, 7), (12, 7), (19, 3), (21, 2)])
+@pytest.mark.parametrize("log_n,n_cols", [(6, 7), (12, 7), (16, 2), (17, 2), (19, 3), (21, 2)])
 def test_lde_tuning_options_never_change_the_table(ctx, orc, log_n, n_cols, request):
     """include/triton_hip.h: TVM_OPTION_LDE_CHUNK_COLUMNS and TVM_OPTION_LDE_PASS2_TILES "change launch shapes, never results" --
     chunks of 1 / 3 / 4096 columns (ragged last chunks; bench.py sets 32 for the lockstep ranks at 2^22 rows) and the tile kernel

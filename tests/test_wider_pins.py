@@ -48,11 +48,12 @@ def test_stir_proof_of_the_second_snapshot_program_has_not_drifted(orc):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("log2_rows", [12, 14])
-@pytest.mark.parametrize("kind", ["fib", "u32", "ram", "sponge"])
+@pytest.mark.parametrize("kind", ["fib", "u32", "ram"])   # (the sponge loop fills the cascade table: its padded height is 2^16 at least -- minutes of oracle prover)
 def test_device_proof_equals_the_oracle_provers_at_larger_heights(orc, kind, log2_rows):
-    """prove_fib -- and the u32 / ram / sponge loops of BASELINE.json's configs[3] and [4], whose U32, RAM (Bezout coefficients), hash,
-    cascade and lookup tables are NOT small here (round 6) -- padded to 2^12 and 2^14 rows: every word of the device proof (Python
-    host and C++ host) equals the oracle prover's -- the prover that reproduces the reference's two proof digests"""
+    """prove_fib -- and the u32 / ram loops of BASELINE.json's configs[3], whose U32 and RAM tables (Bezout coefficients) are NOT small
+    here (round 6) -- padded to 2^12 and 2^14 rows: every word of the device proof (Python host and C++ host) equals the oracle
+    prover's -- the prover that reproduces the reference's two proof digests.  (The hash-heavy sponge loop of configs[4] cannot be
+    this small: it fills the cascade table, 2^16 rows at least; tests/test_gpu_baseline_configs.py proves and verifies it at 2^20.)"""
     from oracle import real_prover
     from oracle.vm import workload
     from triton_vm_amd import Context, native_host

@@ -127,11 +127,6 @@ int32_t tvm_ctx_set_option(tvm_ctx* c, int32_t option, uint64_t value) {
         c->lde_pass2_tiles = value ? 1 : 0;
         return TVM_OK;
     }
-    if (option == TVM_OPTION_HASH_LUT16) {
-        if (value > 65535) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "TVM_OPTION_HASH_LUT16: at most 65535 workgroups");
-        c->hash_lut16 = (int)value;
-        return TVM_OK;
-    }
     if (option == TVM_OPTION_MERKLE_MIN_WORKGROUPS) {
         c->merkle_min_workgroups = value ? value : 4096;
         return TVM_OK;

@@ -108,7 +108,6 @@ struct tvm_ctx {
     bool air_valid_trace = false;                       // TVM_OPTION_AIR_VALID_TRACE (capi.hip: tvm_all_quotients_combined)
     int lde_chunk_columns = 0;                          // TVM_OPTION_LDE_CHUNK_COLUMNS: 0 = chosen by lde_table (ntt.hip)
     int lde_pass2_tiles = 0;                            // TVM_OPTION_LDE_PASS2_TILES: 1 = the tile kernels instead of k_lde_pass2_fused (A/B)
-    int hash_lut16 = 0;                                 // TVM_OPTION_HASH_LUT16: workgroups of k_hash_rows_lut16 (0 = the byte-table kernel)
     u64 merkle_min_workgroups = 4096;                   // TVM_OPTION_MERKLE_MIN_WORKGROUPS (hash.hip: merkle_tree_from_leaves)
     std::string last_error;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;

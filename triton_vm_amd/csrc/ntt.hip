@@ -189,9 +189,10 @@ TVM_D void lds_ntt_fixed(u64* s, const u64* __restrict__ tw, int tid, int nt) {
 #endif
 #define TVM_ROW_SKEW(p) ((p) + ((p) >> 4))
 #define TVM_ROW_WORDS(n) ((n) + ((n) >> 4) + 1)   // odd pitch: position p of the 16 rows of a tile falls into 16 different banks
-// LPR: lanes per row -- 64 (the row's own wavefront; tvm_wave_sync between groups) or 128 (two wavefronts share a row of 2048 points,
+// LPR: lanes per row -- 64 (the row's own wavefront; tvm_wave_sync between groups), 128 (two wavefronts share a row of 2048 points,
 // `lane` is the lane number within the pair, and the groups are separated by workgroup barriers: every wavefront of the workgroup runs
-// the same sequence)
+// the same sequence), or 32 / 16 (round 6: rows of 512 / 256 points, two / four of them per wavefront, `lane` the number within the
+// row's lanes; still wavefront-private: tvm_wave_sync)
 template <bool DIT, int K, int L, int LOGN, int ROOT, int TWB = TVM_TW_BATCH, int LPR = 64>
 TVM_D void row_ntt_group(u64* row, const u64* __restrict__ tw, int lane) {
     static_assert(ROOT == 1 || ROOT == 2, "the domains' own roots of unity only");
@@ -232,7 +233,7 @@ TVM_D void row_ntt_group(u64* row, const u64* __restrict__ tw, int lane) {
 #pragma unroll
         for (int e = 0; e < R; e++) p[TVM_ROW_SKEW(e << L)] = x[e];
     }
-    if constexpr (LPR == 64) tvm_wave_sync();
+    if constexpr (LPR <= 64) tvm_wave_sync();
     else tvm_lds_barrier();
 }
 template <bool DIT, int MAXK, int LOGN, int ROOT, int DONE = 0, int LPR = 64>
@@ -680,10 +681,13 @@ __global__ void __launch_bounds__(1 << TLOG) k_lde_pass3_v3(LdePass3Args a) {
 // tiles of WAVES rows, every wavefront with the loads of its next row in flight under the butterflies of the current one.
 // (2048-point rows, round 4: 32 elements per lane, 17 KB of LDS per wavefront -- eight wavefronts fill a CU's LDS, two per SIMD, so
 // the kernel may use 256 VGPRs and keeps the next row's 32 loads in flight)
+// LOGN = 9 / 8 (round 6: the axes of 2^16 .. 2^19-row traces, which ran the generic tile kernel k_lde_pass3 until then): still one row per
+// wavefront -- 8 / 4 points per lane -- with radix-8 butterfly groups, so that every group of a 512-point row has a butterfly for
+// every lane (3 + 3 + 3 layers; 256 points: 3 + 3 + 2, half the lanes idle in the first two groups).
 template <int LOGN, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES, LOGN == 10 ? 4 : 2) k_lde_pass3_rows(LdePass3Args a) {   // 1024 points: room for 4 wavefronts per SIMD (128 VGPRs)
-    constexpr int n1 = 1 << LOGN, ROWW = TVM_ROW_WORDS(n1), E = n1 / 64;
-    static_assert(E == 16 || E == 32, "16 or 32 elements per lane");
+__global__ void __launch_bounds__(64 * WAVES, LOGN <= 10 ? 4 : 2) k_lde_pass3_rows(LdePass3Args a) {   // up to 1024 points: room for 4 wavefronts per SIMD (128 VGPRs)
+    constexpr int n1 = 1 << LOGN, ROWW = TVM_ROW_WORDS(n1), E = n1 / 64, MAXK = LOGN >= 10 ? 4 : 3;
+    static_assert(E == 4 || E == 8 || E == 16 || E == 32, "4 .. 32 elements per lane");
     TVM_DYN_SMEM(u64, s);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const u64 n2 = 1ull << a.log_n2;
@@ -714,10 +718,10 @@ __global__ void __launch_bounds__(64 * WAVES, LOGN == 10 ? 4 : 2) k_lde_pass3_ro
 #pragma unroll
             for (int e = 0; e < E; e++) nxt[e] = TVM_LOAD_STREAM(&zc[((k * n2 + j1) << LOGN) + 64 * e]);
         }
-        row_ntt<true, 4, LOGN, 1>(row, tw_lds, lane);
+        row_ntt<true, MAXK, LOGN, 1>(row, tw_lds, lane);
         const u64 j1 = rho >> log_x, k = rho & (X - 1);
         const u64 blk = (k * a.pitch + (j1 << LOGN)) >> TVM_RB_LOG;   // the row's first 16-row block of the table
-#pragma unroll 4
+#pragma unroll (E < 4 ? E : 4)
         for (int e = 0; e < E; e++)   // j2 = lane + 64 e: consecutive lanes = consecutive storage rows, 4 full lines per store
             TVM_STORE_STREAM(&out_l[((blk + 4 * e) * W) << TVM_RB_LOG], rowl[68 * e]);
         tvm_wave_sync();   // (the next tile overwrites the row)
@@ -836,10 +840,11 @@ __global__ void __launch_bounds__((1 << (LOGN - 4)) * ROWS, 4) k_lde_pass1_rows(
     // LOGN = 10: one wavefront per row, 16 rows (128-byte runs of the input).  LOGN = 11 (round 5; 2^22 and 2^23-row traces): TWO
     // wavefronts per row of 2048 points, 8 rows (LDS holds no more of them: 64-byte runs), the butterfly groups separated by
     // workgroup barriers (row_ntt_group, LPR = 128) -- instead of the generic k_ntt2_pass1.
-    constexpr int n1 = 1 << LOGN, ROWW = TVM_ROW_WORDS(n1), LPR = n1 / 16, WPR = LPR / 64, NT = LPR * ROWS, RLOG = ROWS == 16 ? 4 : 3;
-    static_assert((LOGN == 10 && (ROWS == 16 || ROWS == 8)) || (LOGN == 11 && ROWS == 8), "one or two wavefronts per row of 1024 / 2048 points");
+    // LOGN = 9 / 8 (round 6; 2^16 .. 2^19-row traces): 32 / 16 lanes per row, two / four rows per wavefront, 16 rows.
+    constexpr int n1 = 1 << LOGN, ROWW = TVM_ROW_WORDS(n1), LPR = n1 / 16, NT = LPR * ROWS, RLOG = ROWS == 16 ? 4 : 3;
+    static_assert((LOGN >= 8 && LOGN <= 10 && (ROWS == 16 || ROWS == 8)) || (LOGN == 11 && ROWS == 8), "16 .. 128 lanes per row of 256 .. 2048 points");
     TVM_DYN_SMEM(u64, s);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x;
     const u64 n2 = 1ull << a.log_n2;
     const int vl = blockIdx.y, v = a.col0 + vl;
     const u64 i2_0 = (u64)blockIdx.x * ROWS;
@@ -853,7 +858,7 @@ __global__ void __launch_bounds__((1 << (LOGN - 4)) * ROWS, 4) k_lde_pass1_rows(
     u64* tw_lds = s + ROWS * ROWW;
     for (int i = tid; i < n1; i += NT) tw_lds[i] = a.tw1[i];   // all n1 powers of the inverse root
     tvm_lds_barrier();
-    row_ntt<false, 4, LOGN, 2, 0, LPR>(s + (w / WPR) * ROWW, tw_lds, (w % WPR) * 64 + lane);
+    row_ntt<false, 4, LOGN, 2, 0, LPR>(s + (tid / LPR) * ROWW, tw_lds, tid % LPR);
     tvm_lds_barrier();
     // position p = q0 + LPR * brev4(c) holds index k1 = brev(p) = brev(q0) * 16 + c
     const u64 i2 = i2_0 + b;
@@ -890,7 +895,7 @@ __global__ void __launch_bounds__((1 << (LOGN - 4)) * ROWS, 4) k_lde_pass1_rows(
 //     inside a row's work.  Row pitch = 8 (mod 32) words: the store phase's 8 rows x 8 positions per wavefront fall into 64
 //     different banks (the odd pitch of TVM_ROW_WORDS put b + j1 = const into one).
 // 8 rows, 512 work-items, 78 KB of LDS: two workgroups per CU.
-#define TVM_P2F_ROWW(logn) ((logn) == 10 ? 1096 : 2184)   // >= TVM_ROW_WORDS, = 8 (mod 32)
+#define TVM_P2F_ROWW(logn) ((logn) == 8 ? 296 : (logn) == 9 ? 552 : (logn) == 10 ? 1096 : 2184)   // >= TVM_ROW_WORDS, = 8 (mod 32)
 #define TVM_P2F_TW2_WORDS 272   // 16 x 17: the middle group's twiddles
 #define TVM_P2F_LDS_WORDS(logn) (8 * TVM_P2F_ROWW(logn) + TVM_P2F_TW2_WORDS + TVM_ROW_WORDS(1 << (logn)) + 8)   // tile + twiddles + one coset's factors + a randomizer word per row: 79.2 / 159.4 KB
 #ifndef TVM_P2F_FT_EARLY_11
@@ -907,15 +912,24 @@ __global__ void __launch_bounds__((1 << (LOGN - 4)) * ROWS, 4) k_lde_pass1_rows(
 // groups separated by workgroup barriers, the last group radix 8; 1024 work-items, 159 KB: one workgroup per CU (as the tile kernel
 // k_lde_pass2_v3<11, 10> it replaces, which kept the position-major tile, three multiplications outside the butterflies and 192 B of
 // scratch).
+// LOGN = 9 / 8 (round 6: the 512- / 256-point axes of 2^16 .. 2^19-row traces, on which pass 2 ran the generic tile kernel k_lde_pass2 --
+// 344 B of scratch, 2.4 times the time per cell -- or, at 256 points, the 64-work-item stand-in k_lde_pass2_v3<8, 6>): 32 / 16 lanes
+// per row, TWO / FOUR rows per wavefront (everything between two butterfly groups of a row stays inside its wavefront, as at 1024
+// points), the last group radix 2 / nothing but the inter-pass factors; 256 / 128 work-items, 42 / 23 KB of LDS.
 template <int LOGN>
-__global__ void __launch_bounds__(LOGN == 10 ? 512 : 1024, 4) k_lde_pass2_fused(LdePass2Args a) {
+__global__ void __launch_bounds__(8 << (LOGN - 4), 4) k_lde_pass2_fused(LdePass2Args a) {
     constexpr int n2 = 1 << LOGN, ROWS = 8, LPR = n2 / 16, WPR = LPR / 64, NT = ROWS * LPR, RLOG = 3;
     constexpr int ROWW = TVM_P2F_ROWW(LOGN), K3 = LOGN - 8, R3 = 1 << K3, ITS = 16 / R3, LSTEP = LPR + LPR / 16;
-    constexpr int FE = LOGN == 10 ? TVM_P2F_FT_EARLY : TVM_P2F_FT_EARLY_11;   // 16-byte loads of the last group's factors requested early
-    static_assert((LOGN == 10 || LOGN == 11) && ROWW >= TVM_ROW_WORDS(n2) && ROWW % 32 == 8, "1024 / 2048 points, bank-spread row pitch");
+    constexpr int FE = LOGN == 11 ? TVM_P2F_FT_EARLY_11 : TVM_P2F_FT_EARLY;   // 16-byte loads of the last group's factors requested early
+    static_assert(LOGN >= 8 && LOGN <= 11 && ROWW >= TVM_ROW_WORDS(n2) && ROWW % 32 == 8, "256 .. 2048 points, bank-spread row pitch");
     TVM_DYN_SMEM(u64, s);
-    const int tid = threadIdx.x, lane = tid & 63, w = tvm_uniform(tid >> 6);
-    const int r = w / WPR, rl = (w % WPR) * 64 + lane;   // this wavefront's row of the tile; the lane's number within the row
+    const int tid = threadIdx.x;
+    // this lane's row of the tile and its number within the row's lanes (a row per wavefront, per pair of wavefronts, or -- below
+    // 1024 points -- per 32 / 16 lanes; with whole wavefronts per row the row number is uniform, and told so)
+    int r;
+    if constexpr (WPR >= 1) r = tvm_uniform(tid >> 6) / WPR;
+    else r = tid / LPR;
+    const int rl = tid % LPR;
     const u64 n1 = 1ull << a.log_n1, n = n1 << LOGN;
     const int vl = blockIdx.y, v = a.col0 + vl;
     const u64 p0 = (u64)blockIdx.x * ROWS, p = p0 + (u64)r;
@@ -925,7 +939,7 @@ __global__ void __launch_bounds__(LOGN == 10 ? 512 : 1024, 4) k_lde_pass2_fused(
     // 2^20: the Infinity Cache serves the table, the fetches were never what the kernel waited for; profiles/r05_k_*.)
     u64* const row = s + r * ROWW;
     auto row_sync = [] {   // between two butterfly groups of a row: its lanes exchange data through the row's LDS words
-        if constexpr (WPR == 1) tvm_wave_sync();
+        if constexpr (WPR <= 1) tvm_wave_sync();
         else tvm_lds_barrier();
     };
     // behind the tile: the 15 x 16 twiddles the middle butterfly group uses, tw2[17 j0 + e] = w_n2^((j0 brev4(e)) << (LOGN - 8)) (pitch
@@ -938,7 +952,7 @@ __global__ void __launch_bounds__(LOGN == 10 ? 512 : 1024, 4) k_lde_pass2_fused(
 #pragma unroll
         for (int e = 0; e < 16; e++) rowl[LSTEP * e] = TVM_LOAD_STREAM(&y[LPR * e]);   // position rl + LPR e
     }
-    if (tid < 256) tw2[17 * (tid >> 4) + (tid & 15)] = a.tw_b1[((tid >> 4) * brev_bits((u32)(tid & 15), 4)) << (LOGN - 8)];
+    for (int i = tid; i < 256; i += NT) tw2[17 * (i >> 4) + (i & 15)] = a.tw_b1[((i >> 4) * brev_bits((u32)(i & 15), 4)) << (LOGN - 8)];
 #pragma unroll
     for (int hh = 0; hh < n2 / NT; hh++) ghl[TVM_ROW_SKEW(tid + hh * NT)] = a.g_hi_pos[tid + hh * NT];
     row_sync();
@@ -1011,12 +1025,11 @@ __global__ void __launch_bounds__(LOGN == 10 ? 512 : 1024, 4) k_lde_pass2_fused(
             u64* const q = row + TVM_ROW_SKEW(ln + LPR * it);   // TVM_ROW_SKEW(g + 256 e) = TVM_ROW_SKEW(g) + 272 e
             u64 y8[R3];
 #pragma unroll
-            for (int e = 0; e < R3; e += 2) {
-                const u64x2 fe = f[(it * R3 + e) / 2];
-                y8[e] = bfe_mul(q[272 * e], fe.x);
-                y8[e + 1] = bfe_mul(q[272 * (e + 1)], fe.y);
+            for (int e = 0; e < R3; e++) {
+                const int j = it * R3 + e;   // (a constant after unrolling: the factor's place in the eight 16-byte loads)
+                y8[e] = bfe_mul(q[272 * e], (j & 1) ? f[j >> 1].y : f[j >> 1].x);
             }
-            ntt_pow2_points<K3, true, false>(y8);
+            if constexpr (K3 > 0) ntt_pow2_points<K3, true, false>(y8);
 #pragma unroll
             for (int e = 0; e < R3; e++) q[272 * e] = bfe_mul(y8[e], u[e]);
         }
@@ -1216,10 +1229,16 @@ static void set_lds_attributes() {
     (void)hipFuncSetAttribute((const void*)k_ntt2_pass2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass1_rows<8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass1_rows<9, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass1_rows<10, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass1_rows<11, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass2_fused<8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass2_fused<9>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_fused<10>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass2_fused<11>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<9, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_rows<11, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     (void)hipFuncSetAttribute((const void*)k_lde_pass3_halves<8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -1467,7 +1486,9 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     p2.g_lo_step = pow_table(c, eval_gen, n1);
     p2.g_hi_step = pow_table(c, bfe_pow(eval_gen, n1), n2);
     p2.g_hi_pos = p2.f_tw = p2.u_tw = nullptr;
-    const bool fused = std_roots && (sp.log_n2 == 10 || sp.log_n2 == 11) && n1 % 16 == 0 && h <= n1 && c->lde_pass2_tiles == 0;
+    // (256- and 512-point axes -- 2^16 .. 2^19-row traces -- since round 6; TVM_OPTION_LDE_PASS2_TILES restores the tile kernels on all of them)
+    const bool short_rows = c->lde_pass2_tiles == 0;   // the row kernels of passes 1 and 3 on 256- / 512-point axes, likewise
+    const bool fused = std_roots && sp.log_n2 >= 8 && sp.log_n2 <= 11 && n1 % 16 == 0 && h <= n1 && c->lde_pass2_tiles == 0;
     if (fused)
         TVM_TRY(pass2_fused_tables(c, w, eval_offset, eval_gen, X, sp.log_n1, sp.log_n2, p2.g_lo, p2.g_hi, p2.tw_inter, p2.tw_b1, &p2.g_hi_pos,
                                    &p2.f_tw, &p2.u_tw));
@@ -1519,6 +1540,11 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             const int B = 1 << a.batch_log;
             const int tile = (int)n1 << a.batch_log;
             dim3 grid((unsigned)((n2 + B - 1) / B), (unsigned)nc);
+            if (std_roots && short_rows && (sp.log_n1 == 8 || sp.log_n1 == 9) && n2 % 16 == 0) {   // 256 / 512 points: four / two rows per wavefront
+                const size_t lds_r = (size_t)(16 * TVM_ROW_WORDS(n1) + n1) * sizeof(u64);
+                if (sp.log_n1 == 8) TVM_LAUNCH((k_lde_pass1_rows<8, 16>), dim3((unsigned)(n2 / 16), (unsigned)nc), dim3(256), lds_r, c->stream, a);
+                else TVM_LAUNCH((k_lde_pass1_rows<9, 16>), dim3((unsigned)(n2 / 16), (unsigned)nc), dim3(512), lds_r, c->stream, a);
+            } else
             if (std_roots && sp.log_n1 == 10 && n2 % 16 == 0) {   // 1024-point axis: one row per wavefront
                 // 16-row tiles: 128-byte runs of the input.  (8-row tiles -- two workgroups per CU -- measured the same time and
                 // fetch every input line twice: 16 instead of 8 B per cell, profiles/r03_q_pmc_lde.txt.)
@@ -1547,7 +1573,9 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
                 // 1024- / 2048-point axis: every wavefront (pair of wavefronts) keeps its row across the coset loop (k_lde_pass2_fused);
                 // more trace randomizers than n1 (never the case for a STARK's parameters) take the kernels below
                 const size_t lds_r = (size_t)TVM_P2F_LDS_WORDS(sp.log_n2) * sizeof(u64);
-                if (sp.log_n2 == 10) TVM_LAUNCH((k_lde_pass2_fused<10>), dim3((unsigned)(n1 / 8), (unsigned)nc), dim3(512), lds_r, c->stream, a);
+                if (sp.log_n2 == 8) TVM_LAUNCH((k_lde_pass2_fused<8>), dim3((unsigned)(n1 / 8), (unsigned)nc), dim3(128), lds_r, c->stream, a);
+                else if (sp.log_n2 == 9) TVM_LAUNCH((k_lde_pass2_fused<9>), dim3((unsigned)(n1 / 8), (unsigned)nc), dim3(256), lds_r, c->stream, a);
+                else if (sp.log_n2 == 10) TVM_LAUNCH((k_lde_pass2_fused<10>), dim3((unsigned)(n1 / 8), (unsigned)nc), dim3(512), lds_r, c->stream, a);
                 else TVM_LAUNCH((k_lde_pass2_fused<11>), dim3((unsigned)(n1 / 8), (unsigned)nc), dim3(1024), lds_r, c->stream, a);
             }
             else if (std_roots && ppt_log && n1 % rows3 == 0) {
@@ -1571,7 +1599,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             const u64 rows3 = 16 >> ppt_log, tiles3 = X * n2 / rows3;  // see pass 2
             // (pass 3 has no coset loop and no workgroup barrier: here the 2048-point row form is 8 % faster than k_lde_pass3_v3<11, 10>,
             // 15.5 against 16.8 ms per 96 columns at 2^22 rows, even at two wavefronts per SIMD)
-            if (std_roots && (sp.log_n1 == 10 || sp.log_n1 == 11) && (X * n2) % 8 == 0) {
+            if (std_roots && (sp.log_n1 == 10 || sp.log_n1 == 11 || (short_rows && (sp.log_n1 == 8 || sp.log_n1 == 9))) && (X * n2) % 8 == 0) {
                 // 1024- / 2048-point axis: one (k, j1) row per wavefront, no workgroup barrier (k_lde_pass3_rows): 8 wavefronts per
                 // workgroup -- 78 KB of LDS, two workgroups per CU at 1024 points (4 wavefronts per workgroup: +2 %, 16: +3 %,
                 // profiles/r03_g_lde_ab.txt); one workgroup per CU at 2048
@@ -1595,6 +1623,8 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
                     const size_t lds_h = (size_t)(8 * TVM_ROW_WORDS(1024) + 1024) * sizeof(u64);
                     TVM_LAUNCH((k_lde_pass3_halves<8>), g3, dim3(512), lds_h, c->stream, a);
                 } else if (sp.log_n1 == 11) TVM_LAUNCH((k_lde_pass3_rows<11, 8>), g3, dim3(512), lds_w, c->stream, a);
+                else if (sp.log_n1 == 8) TVM_LAUNCH((k_lde_pass3_rows<8, 8>), g3, dim3(512), lds_w, c->stream, a);
+                else if (sp.log_n1 == 9) TVM_LAUNCH((k_lde_pass3_rows<9, 8>), g3, dim3(512), lds_w, c->stream, a);
                 else TVM_LAUNCH((k_lde_pass3_rows<10, 8>), g3, dim3(512), lds_w, c->stream, a);
             } else
             if (std_roots && ppt_log && (X * n2) % 16 == 0) {

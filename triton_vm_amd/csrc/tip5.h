@@ -353,99 +353,118 @@ TVM_D void tip5_mfma_recombine(const tvm_v4i (&d)[TIP5_MFMA_POSITIONS], u64 (&st
 #endif
 }
 
-// ------------------------------------------------------------------------------------------------
-// The split-and-lookup S-box TWO BYTES AT A TIME (round 6): a 65536-entry table of 16-bit words in LDS (128 KB: one workgroup of
-// sixteen wavefronts per CU), entry i = the lowered looked-up bytes of the two bytes of i.  A word then costs four lookups instead
-// of eight, each address is two plain 32-bit instructions -- (x << 1) & 0x1fffe, (x >> 15) & 0x1fffe -- and the loads assemble the
-// result themselves (ds_read_u16_d16 / _d16_hi write one half of a register and keep the other): 8 VALU instructions per word where
-// the byte form takes 16 (eight extractions, eight to put the bytes together again; hipcc does not pick the d16_hi form by itself).
-// The table MUST start at LDS address TIP5_LUT16_LDS_OFFSET (the kernel has no static LDS in front of its dynamic block, whose first
-// 4 KB hold the accumulator-input table: within reach of immediate offsets, which the table is not): the asm below says so.
-#define TIP5_LUT16_LDS_OFFSET 4096
-#define TIP5_STR2(x) #x
-#define TIP5_STR(x) TIP5_STR2(x)
-struct Tip5Lut16Pending { u32 lo, hi; };
-TVM_D void tip5_lut16_build(unsigned short* lut16, int tid, int nt) {
-    for (int i = tid; i < 32768; i += nt) {   // two entries per store
-        const u32 b0 = d_tip5_lut[(2 * i) & 0xFF] ^ 0x80u, b0n = d_tip5_lut[(2 * i + 1) & 0xFF] ^ 0x80u, b1 = d_tip5_lut[(2 * i) >> 8] ^ 0x80u;
-        ((u32*)lut16)[i] = (b1 << 8 | b0) | ((b1 << 8 | b0n) << 16);
-    }
-}
-// request the four lookups of a word; tip5_lut16_finish waits for them.  Between the two the compiler schedules what it likes: LDS
-// results return in order, so its own waits (which do not count these loads) are never too weak.
-TVM_D Tip5Lut16Pending tip5_lut16_request(u64 x, const unsigned short* lut16) {
-    Tip5Lut16Pending p;
-#if defined(TVM_FIELD_ASM)
-    (void)lut16;
-    u32 a0, a1, a2, a3;
-    const u32 mask = 0x1FFFEu;
-    asm volatile("v_lshlrev_b32_e32 %[a0], 1, %[xl]\n\t"
-                 "v_lshrrev_b32_e32 %[a1], 15, %[xl]\n\t"
-                 "v_lshlrev_b32_e32 %[a2], 1, %[xh]\n\t"
-                 "v_lshrrev_b32_e32 %[a3], 15, %[xh]\n\t"
-                 "v_and_b32_e32 %[a0], %[m], %[a0]\n\t"
-                 "v_and_b32_e32 %[a1], %[m], %[a1]\n\t"
-                 "v_and_b32_e32 %[a2], %[m], %[a2]\n\t"
-                 "v_and_b32_e32 %[a3], %[m], %[a3]\n\t"
-                 "ds_read_u16_d16 %[lo], %[a0] offset:" TIP5_STR(TIP5_LUT16_LDS_OFFSET) "\n\t"
-                 "ds_read_u16_d16 %[hi], %[a2] offset:" TIP5_STR(TIP5_LUT16_LDS_OFFSET) "\n\t"
-                 "ds_read_u16_d16_hi %[lo], %[a1] offset:" TIP5_STR(TIP5_LUT16_LDS_OFFSET) "\n\t"
-                 "ds_read_u16_d16_hi %[hi], %[a3] offset:" TIP5_STR(TIP5_LUT16_LDS_OFFSET)
-                 : [lo] "=&v"(p.lo), [hi] "=&v"(p.hi), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3)
-                 : [xl] "v"((u32)x), [xh] "v"((u32)(x >> 32)), [m] "s"(mask));
-#else
-    const u32 xl = (u32)x, xh = (u32)(x >> 32);
-    p.lo = (u32)lut16[xl & 0xFFFF] | ((u32)lut16[xl >> 16] << 16);
-    p.hi = (u32)lut16[xh & 0xFFFF] | ((u32)lut16[xh >> 16] << 16);
+// (Round 6, measured and not adopted -- commit 71bc48c: the split-and-lookup S-box two bytes at a time from a 65536-entry table in
+// LDS.  250 instead of 260 VALU instructions per round, but 128 KB of LDS mean one workgroup of sixteen wavefronts per CU, and at four
+// wavefronts per SIMD instead of six the wait states of the carry chains are no longer hidden: 52.8 against 44.3 ms for the main
+// table's rows, profiles/r06_b_kernels_*.  The d16 loads that would assemble the result for free zero the other half of their
+// register under SRAM-ECC, which is why hipcc never selects them.)
+// The same for two words of a lane, v = V0 and V0 + 1 (a lean tip5_round_mfma -- the last round of a permutation whose rate words the
+// next absorb overwrites -- owes the words 2, 3 only).  Two chains instead of four: the distance between a carry's producer and its
+// consumer comes from wait states.
+#ifndef TVM_TIP5_PAIRED_TAIL
+#define TVM_TIP5_PAIRED_TAIL 0   // 1: every round recombines as two pairs, the first pair skipped in a lean round (A/B, profiles/r06_*)
 #endif
-    return p;
-}
-TVM_D void tip5_lut16_finish(Tip5Lut16Pending& p) {
-#if defined(TVM_FIELD_ASM)
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p.lo), "+v"(p.hi));
+template <int V0>
+TVM_D void tip5_mfma_recombine_pair(const tvm_v4i (&d)[TIP5_MFMA_POSITIONS], u64 (&st)[4]) {
+    u64 t[2];
+    u32 pl[2];
+    u32 w8 = 1u << 8, w16 = 1u << 16, w24 = 1u << 24;
+#ifdef TVM_FIELD_ASM
+    asm("" : "+s"(w8), "+s"(w16), "+s"(w24));
+#endif
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int v = V0 + i;
+        u64 p0 = (u64)(u32)d[1][v] * w8;
+        p0 += (u64)(u32)d[2][v] * w16;
+        p0 += (u64)(u32)d[3][v] * w24;
+        p0 += (u32)d[0][v];
+        u64 p1 = (u64)(u32)d[5][v] * w8;
+        p1 += (u64)(u32)d[6][v] * w16;
+        p1 += (u64)(u32)d[7][v] * w24;
+        p1 += (u32)d[4][v];
+        const u32 h = (u32)(p1 >> 32) + (u32)d[8][v] + ((u32)d[9][v] << 8);
+        t[i] = (u64)h * 0xFFFFFFFFu + p0;
+        pl[i] = (u32)p1;
+    }
+#ifdef TVM_FIELD_ASM
+    u32 sh0, sh1, zl0, zl1, zh0, zh1;
+    u64 k0, k1, c1;
+    asm("v_add_co_u32_e64 %[sh0], %[k0], %[th0], %[pl0]\n\t"
+        "v_add_co_u32_e64 %[sh1], %[k1], %[th1], %[pl1]\n\t"
+        "v_add_co_u32_e64 %[zl0], vcc, -1, %[tl0]\n\t"
+        "v_add_co_u32_e64 %[zl1], %[c1], -1, %[tl1]\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e64 %[zh0], vcc, 0, %[sh0], vcc\n\t"
+        "v_addc_co_u32_e64 %[zh1], %[c1], 0, %[sh1], %[c1]\n\t"
+        "s_nop 1\n\t"
+        "s_or_b64 vcc, vcc, %[k0]\n\t"
+        "s_or_b64 %[c1], %[c1], %[k1]\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e64 %[zl0], %[tl0], %[zl0], vcc\n\t"
+        "v_cndmask_b32_e64 %[zl1], %[tl1], %[zl1], %[c1]\n\t"
+        "v_cndmask_b32_e64 %[sh0], %[sh0], %[zh0], vcc\n\t"
+        "v_cndmask_b32_e64 %[sh1], %[sh1], %[zh1], %[c1]"
+        : [sh0] "=&v"(sh0), [sh1] "=&v"(sh1), [zl0] "=&v"(zl0), [zl1] "=&v"(zl1), [zh0] "=&v"(zh0), [zh1] "=&v"(zh1), [k0] "=&s"(k0),
+          [k1] "=&s"(k1), [c1] "=&s"(c1)
+        : [tl0] "v"((u32)t[0]), [th0] "v"((u32)(t[0] >> 32)), [pl0] "v"(pl[0]), [tl1] "v"((u32)t[1]), [th1] "v"((u32)(t[1] >> 32)),
+          [pl1] "v"(pl[1])
+        : "vcc", "scc");
+    st[V0] = ((u64)sh0 << 32) | zl0;
+    st[V0 + 1] = ((u64)sh1 << 32) | zl1;
 #else
-    (void)p;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const u64 s = t[i] + ((u64)pl[i] << 32), z = s + TVM_EPS;
+        st[V0 + i] = ((s < t[i]) | (z < s)) ? z : s;
+    }
 #endif
 }
 
-// st[t] = word g + 4t of the state of permutation n; every lane of the wavefront must take part.  `lut` is the S-box table
-// LOWERED by 128 (tip5_stage_lut_lowered): the looked-up word goes to the matrix cores only, where bytes travel that way.
-// LUT16: `lut` is the 65536-entry table of tip5_lut16_build at LDS address TIP5_LUT16_LDS_OFFSET instead.
-template <bool LUT16 = false>
-TVM_D void tip5_permute_mfma(u64 (&st)[4], const Tip5MfmaOperands& m, int g, const unsigned char* lut, const int* ctab) {
-    for (int r = 0; r < TIP5_ROUNDS; r++) {
-        // accumulator inputs first: their LDS latency hides behind the S-box layer
-        tvm_v4i d[TIP5_MFMA_POSITIONS];
+// One round on the state of tip5_permute_mfma.  st[t] = word g + 4t of the state of permutation n; every lane of the wavefront must
+// take part.  `lut` is the S-box table LOWERED by 128 (tip5_stage_lut_lowered): the looked-up word goes to the matrix cores only, where
+// bytes travel that way.
+// lean: the round's results for the words 0 .. 7 (st[0], st[1] of every lane) are NOT produced -- the caller overwrites them: in a
+// sponge that absorbs in overwrite mode the rate part of the state after a permutation is replaced by the next block, so the LAST
+// round of every permutation but the final one owes only the words 8 .. 15 (st[2] is a rate word for g < 2 and is computed all the
+// same: the lanes of a wavefront run one instruction stream).
+// (`lean` is uniform over the wavefront -- a scalar branch around the tail of ONE round body; compiled as separate copies of the round
+// the kernel spilled 88 bytes)
+TVM_D void tip5_round_mfma(u64 (&st)[4], const Tip5MfmaOperands& m, int g, const unsigned char* lut, const int* ctab, int r, bool lean) {
+    // accumulator inputs first: their LDS latency hides behind the S-box layer
+    tvm_v4i d[TIP5_MFMA_POSITIONS];
 #pragma unroll
-        for (int c = 0; c < TIP5_MFMA_POSITIONS; c++) {
-            const int* cp = ctab + ((r * TIP5_MFMA_POSITIONS + c) * 4 + g) * 4;
+    for (int c = 0; c < TIP5_MFMA_POSITIONS; c++) {
+        const int* cp = ctab + ((r * TIP5_MFMA_POSITIONS + c) * 4 + g) * 4;
 #pragma unroll
-            for (int v = 0; v < 4; v++) d[c][v] = cp[v];
-        }
-        Tip5Lut16Pending pending;
-        if constexpr (LUT16) pending = tip5_lut16_request(st[0], (const unsigned short*)lut);   // in flight under the power maps
-        else st[0] = tip5_sbox_lookup(st[0], lut);
-#pragma unroll
-        for (int t = 1; t < 4; t++) st[t] = tip5_pow7(st[t]);
-        const u32 pad = 0x80808080u;  // bytes travel lowered by 128
-        tvm_v4i lo, hi;
-        if constexpr (LUT16) {
-            tip5_lut16_finish(pending);
-            lo[0] = (int)pending.lo;
-            hi[0] = (int)pending.hi;
-        } else {
-            lo[0] = (int)(u32)st[0];
-            hi[0] = (int)(u32)(st[0] >> 32);
-        }
-#pragma unroll
-        for (int t = 1; t < 4; t++) {
-            lo[t] = (int)((u32)st[t] ^ pad);
-            hi[t] = (int)((u32)(st[t] >> 32) ^ pad);
-        }
-#pragma unroll
-        for (int s = 0; s < TIP5_MFMA_SHIFTS; s++) d[s] = TVM_MFMA_I8(m.a[s], lo, d[s]);
-#pragma unroll
-        for (int s = 0; s < TIP5_MFMA_SHIFTS; s++) d[s + 4] = TVM_MFMA_I8(m.a[s], hi, d[s + 4]);
-        tip5_mfma_recombine(d, st);
+        for (int v = 0; v < 4; v++) d[c][v] = cp[v];
     }
+    st[0] = tip5_sbox_lookup(st[0], lut);
+#pragma unroll
+    for (int t = 1; t < 4; t++) st[t] = tip5_pow7(st[t]);
+    const u32 pad = 0x80808080u;  // bytes travel lowered by 128
+    tvm_v4i lo, hi;
+    lo[0] = (int)(u32)st[0];
+    hi[0] = (int)(u32)(st[0] >> 32);
+#pragma unroll
+    for (int t = 1; t < 4; t++) {
+        lo[t] = (int)((u32)st[t] ^ pad);
+        hi[t] = (int)((u32)(st[t] >> 32) ^ pad);
+    }
+#pragma unroll
+    for (int s = 0; s < TIP5_MFMA_SHIFTS; s++) d[s] = TVM_MFMA_I8(m.a[s], lo, d[s]);
+#pragma unroll
+    for (int s = 0; s < TIP5_MFMA_SHIFTS; s++) d[s + 4] = TVM_MFMA_I8(m.a[s], hi, d[s + 4]);
+#if TVM_TIP5_PAIRED_TAIL
+    // the tail as two pairs of words, the first of them optional (one instruction stream up to the branch, nothing but the pair
+    // behind it: as two alternative tails the kernel spilled)
+    tip5_mfma_recombine_pair<2>(d, st);
+    if (!lean) tip5_mfma_recombine_pair<0>(d, st);
+#else
+    (void)lean;
+    tip5_mfma_recombine(d, st);
+#endif
+}
+TVM_D void tip5_permute_mfma(u64 (&st)[4], const Tip5MfmaOperands& m, int g, const unsigned char* lut, const int* ctab) {
+    for (int r = 0; r < TIP5_ROUNDS; r++) tip5_round_mfma(st, m, g, lut, ctab, r, false);
 }

@@ -25,17 +25,10 @@ namespace tvm {
 // the matrix cores (tip5_permute_mfma): four lanes per row, sixteen rows per wavefront.  Lane (n, g) absorbs the
 // words g, g + 4 (and g + 8 for g < 2) of each block of ten: with consecutive rows in a wavefront (stride 1) every
 // load instruction touches four full 128-byte lines of the row-block-major table.
-#ifndef TVM_HASH_LEAN
-#define TVM_HASH_LEAN 1   // 0: the last round of a permutation recombines the rate words all the same (A/B)
-#endif
-#ifndef TVM_HASH_WAVES
-#define TVM_HASH_WAVES 6   // wavefronts per SIMD the register budget of k_hash_rows_mfma is set for
-#endif
-__global__ void __launch_bounds__(TVM_HASH_BLOCK, TVM_HASH_WAVES) k_hash_rows_mfma(const u64* __restrict__ table, TabView view, int W,
+__global__ void __launch_bounds__(TVM_HASH_BLOCK, 6) k_hash_rows_mfma(const u64* __restrict__ table, TabView view, int W,
                                                                     u64* __restrict__ digests) {
     __shared__ unsigned char lut[256];
     __shared__ int ctab[TIP5_ROUNDS * TIP5_MFMA_POSITIONS * 16];
-    __shared__ u32 stage[TVM_HASH_BLOCK / 64][3][128];   // per wavefront: the next block's three words per lane, as low and high halves
     const int tid = threadIdx.x;
     for (int i = tid; i < TIP5_ROUNDS * TIP5_MFMA_POSITIONS * 16; i += blockDim.x) ctab[i] = d_tip5_mfma_table.v[i];
     tip5_stage_lut_lowered(lut, tid, blockDim.x);
@@ -50,58 +43,18 @@ __global__ void __launch_bounds__(TVM_HASH_BLOCK, TVM_HASH_WAVES) k_hash_rows_mf
     const Tip5MfmaOperands a = tip5_mfma_matrix_operands(lane);
     u64 st[4] = {0, 0, 0, 0};
     const int n_perms = W / TIP5_RATE + 1;
-    // Block `perm` of the row, this lane's words q = g, g + 4 (and g + 8 for g < 2): overwrite-mode absorb, padding 1 then 0s.
-    // Round 6 (tools/ubench/tip5_floor.hip measured the row hashing 7 % above its bare permutations): a block is REQUESTED a whole
-    // permutation ahead -- after the first round of the permutation before it -- into the wavefront's staging words in LDS (LDS-DMA
-    // loads, platform.h: no register holds it meanwhile; the kernel runs at its register cap), and COLLECTED at the end of that
-    // permutation's last round, which is LEAN (tip5.h): the rate words it would produce are overwritten by the block, so they are not
-    // recombined (34 of a permutation's 1300 VALU instructions).  Before, the loads sat at the top of the permutation and the
-    // wavefront sat out their latency.
-    u32* const staged = &stage[tvm_uniform(tid >> 6)][0][0];
-    // (lane number through an opaque move: the addresses below are cheap to form and expensive to keep -- hoisted out of the round
-    // loop they went to scratch and took one of the matrix operands with them)
-    auto request = [&](int perm) {
-        const int ln = tvm_opaque(lane), gg = ln >> 4;
-#pragma unroll
-        for (int t3 = 0; t3 < 3; t3++) {
-            const int q = gg + 4 * t3, wi = perm * TIP5_RATE + q;
-            if (q < TIP5_RATE && wi < W) tvm_stage_word(&base[(u64)wi * TVM_RB], staged + 128 * t3, ln);
-        }
-    };
-    auto collect = [&](int perm) {
-        const int ln = tvm_opaque(lane), gg = ln >> 4;
-        tvm_stage_wait();
-#pragma unroll
-        for (int t3 = 0; t3 < 3; t3++) {
-            const int q = gg + 4 * t3, wi = perm * TIP5_RATE + q;
-            if (q < TIP5_RATE) st[t3] = wi < W ? tvm_staged_word(staged + 128 * t3, ln) : (wi == W ? TVM_ONE : 0);
-        }
-    };
-#pragma unroll
-    for (int t3 = 0; t3 < 3; t3++) {   // the first block: straight into the registers
-        const int q = g + 4 * t3;
-        if (q < TIP5_RATE) st[t3] = q < W ? TVM_LOAD_STREAM(&base[(u64)q * TVM_RB]) : (q == W ? TVM_ONE : 0);
-    }
     for (int perm = 0; perm < n_perms; perm++) {
-        const bool more = perm + 1 < n_perms;
-        for (int r = 0; r < TIP5_ROUNDS; r++) {
-            const bool lean = more && r + 1 == TIP5_ROUNDS;
-            tip5_round_mfma(st, a, g, lut, ctab, r, TVM_HASH_LEAN && lean);
-            if (more && r == 0) request(perm + 1);   // (the staging words' previous contents were consumed by this round)
-            if (lean) collect(perm + 1);
+#pragma unroll
+        for (int t3 = 0; t3 < 3; t3++) {
+            const int q = g + 4 * t3;  // word of the state, overwritten if it is in the rate part
+            const int wi = perm * TIP5_RATE + q;
+            if (q < TIP5_RATE) st[t3] = wi < W ? TVM_LOAD_STREAM(&base[(u64)wi * TVM_RB]) : (wi == W ? TVM_ONE : 0);  // padding: 1 then 0s
         }
+        tip5_permute_mfma(st, a, g, lut, ctab);
     }
-    // (where the digest goes: located AGAIN, from the work-item number through an opaque move -- two registers fewer across the
-    // permutations than keeping the index)
-    {
-        const int tid2 = tvm_opaque(tid), n2 = tid2 & 15, g2 = (tid2 & 63) >> 4;
-        const u64 t2 = ((u64)blockIdx.x * (TVM_HASH_BLOCK / 64) + (tid2 >> 6)) * 16 + n2;
-        if (t2 < view.n_out) {
-            u64 row2, r2;
-            view.locate(t2, row2, r2);
-            digests[r2 * 5 + g2] = st[0];
-            if (g2 == 0) digests[r2 * 5 + 4] = st[1];
-        }
+    if (live) {
+        digests[r * 5 + g] = st[0];
+        if (g == 0) digests[r * 5 + 4] = st[1];
     }
 }
 

@@ -80,28 +80,3 @@ struct alignas(16) u64x2 {   // two words moved by one 16-byte access (global_lo
 
 #define TVM_HD __host__ __device__ __forceinline__
 #define TVM_D __device__ __forceinline__
-
-// tvm_stage_word: this lane's 8-byte word at `gptr` -> the wavefront's staging words in LDS, WITHOUT passing through a register
-// (gfx950's LDS-DMA loads: global_load_lds_dword writes lane l's dword to M0 + offset + 4 l): the low halves of the 64 lanes at
-// stage[0 .. 63], the high halves at stage[64 .. 127].  `stage` is uniform over the wavefront.  Lanes that are switched off neither
-// load nor write.  tvm_stage_wait: every staged word of this wavefront has arrived (vmcnt(0)); read it back with tvm_staged_word.
-// What this buys k_hash_rows_mfma (hash.hip): the next block of a row is requested a whole permutation before it is absorbed, and
-// no VGPR holds it in the meantime -- the kernel runs at its register cap.
-#ifdef TVM_EMU
-static inline void tvm_stage_word(const u64* gptr, u32* stage, int lane) {
-    stage[lane] = (u32)*gptr;
-    stage[64 + lane] = (u32)(*gptr >> 32);
-}
-static inline void tvm_stage_wait() {}
-#else
-static __device__ __forceinline__ void tvm_stage_word(const u64* gptr, u32* stage, int lane) {
-    (void)lane;
-    typedef __attribute__((address_space(1))) const void* global_ptr;
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    __builtin_amdgcn_global_load_lds((global_ptr)gptr, (lds_ptr)stage, 4, 0, 0);
-    // (the instruction's immediate offset goes to BOTH addresses: the high half of the word, 4 bytes on, lands 4 bytes behind M0)
-    __builtin_amdgcn_global_load_lds((global_ptr)gptr, (lds_ptr)(stage + 63), 4, 4, 0);
-}
-static __device__ __forceinline__ void tvm_stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-#endif
-TVM_D u64 tvm_staged_word(const u32* stage, int lane) { return ((u64)stage[64 + lane] << 32) | stage[lane]; }

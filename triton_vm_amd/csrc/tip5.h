@@ -353,118 +353,47 @@ TVM_D void tip5_mfma_recombine(const tvm_v4i (&d)[TIP5_MFMA_POSITIONS], u64 (&st
 #endif
 }
 
-// (Round 6, measured and not adopted -- commit 71bc48c: the split-and-lookup S-box two bytes at a time from a 65536-entry table in
-// LDS.  250 instead of 260 VALU instructions per round, but 128 KB of LDS mean one workgroup of sixteen wavefronts per CU, and at four
-// wavefronts per SIMD instead of six the wait states of the carry chains are no longer hidden: 52.8 against 44.3 ms for the main
-// table's rows, profiles/r06_b_kernels_*.  The d16 loads that would assemble the result for free zero the other half of their
-// register under SRAM-ECC, which is why hipcc never selects them.)
-// The same for two words of a lane, v = V0 and V0 + 1 (a lean tip5_round_mfma -- the last round of a permutation whose rate words the
-// next absorb overwrites -- owes the words 2, 3 only).  Two chains instead of four: the distance between a carry's producer and its
-// consumer comes from wait states.
-#ifndef TVM_TIP5_PAIRED_TAIL
-#define TVM_TIP5_PAIRED_TAIL 0   // 1: every round recombines as two pairs, the first pair skipped in a lean round (A/B, profiles/r06_*)
-#endif
-template <int V0>
-TVM_D void tip5_mfma_recombine_pair(const tvm_v4i (&d)[TIP5_MFMA_POSITIONS], u64 (&st)[4]) {
-    u64 t[2];
-    u32 pl[2];
-    u32 w8 = 1u << 8, w16 = 1u << 16, w24 = 1u << 24;
-#ifdef TVM_FIELD_ASM
-    asm("" : "+s"(w8), "+s"(w16), "+s"(w24));
-#endif
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int v = V0 + i;
-        u64 p0 = (u64)(u32)d[1][v] * w8;
-        p0 += (u64)(u32)d[2][v] * w16;
-        p0 += (u64)(u32)d[3][v] * w24;
-        p0 += (u32)d[0][v];
-        u64 p1 = (u64)(u32)d[5][v] * w8;
-        p1 += (u64)(u32)d[6][v] * w16;
-        p1 += (u64)(u32)d[7][v] * w24;
-        p1 += (u32)d[4][v];
-        const u32 h = (u32)(p1 >> 32) + (u32)d[8][v] + ((u32)d[9][v] << 8);
-        t[i] = (u64)h * 0xFFFFFFFFu + p0;
-        pl[i] = (u32)p1;
-    }
-#ifdef TVM_FIELD_ASM
-    u32 sh0, sh1, zl0, zl1, zh0, zh1;
-    u64 k0, k1, c1;
-    asm("v_add_co_u32_e64 %[sh0], %[k0], %[th0], %[pl0]\n\t"
-        "v_add_co_u32_e64 %[sh1], %[k1], %[th1], %[pl1]\n\t"
-        "v_add_co_u32_e64 %[zl0], vcc, -1, %[tl0]\n\t"
-        "v_add_co_u32_e64 %[zl1], %[c1], -1, %[tl1]\n\t"
-        "s_nop 0\n\t"
-        "v_addc_co_u32_e64 %[zh0], vcc, 0, %[sh0], vcc\n\t"
-        "v_addc_co_u32_e64 %[zh1], %[c1], 0, %[sh1], %[c1]\n\t"
-        "s_nop 1\n\t"
-        "s_or_b64 vcc, vcc, %[k0]\n\t"
-        "s_or_b64 %[c1], %[c1], %[k1]\n\t"
-        "s_nop 1\n\t"
-        "v_cndmask_b32_e64 %[zl0], %[tl0], %[zl0], vcc\n\t"
-        "v_cndmask_b32_e64 %[zl1], %[tl1], %[zl1], %[c1]\n\t"
-        "v_cndmask_b32_e64 %[sh0], %[sh0], %[zh0], vcc\n\t"
-        "v_cndmask_b32_e64 %[sh1], %[sh1], %[zh1], %[c1]"
-        : [sh0] "=&v"(sh0), [sh1] "=&v"(sh1), [zl0] "=&v"(zl0), [zl1] "=&v"(zl1), [zh0] "=&v"(zh0), [zh1] "=&v"(zh1), [k0] "=&s"(k0),
-          [k1] "=&s"(k1), [c1] "=&s"(c1)
-        : [tl0] "v"((u32)t[0]), [th0] "v"((u32)(t[0] >> 32)), [pl0] "v"(pl[0]), [tl1] "v"((u32)t[1]), [th1] "v"((u32)(t[1] >> 32)),
-          [pl1] "v"(pl[1])
-        : "vcc", "scc");
-    st[V0] = ((u64)sh0 << 32) | zl0;
-    st[V0 + 1] = ((u64)sh1 << 32) | zl1;
-#else
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const u64 s = t[i] + ((u64)pl[i] << 32), z = s + TVM_EPS;
-        st[V0 + i] = ((s < t[i]) | (z < s)) ? z : s;
-    }
-#endif
-}
-
-// One round on the state of tip5_permute_mfma.  st[t] = word g + 4t of the state of permutation n; every lane of the wavefront must
-// take part.  `lut` is the S-box table LOWERED by 128 (tip5_stage_lut_lowered): the looked-up word goes to the matrix cores only, where
-// bytes travel that way.
-// lean: the round's results for the words 0 .. 7 (st[0], st[1] of every lane) are NOT produced -- the caller overwrites them: in a
-// sponge that absorbs in overwrite mode the rate part of the state after a permutation is replaced by the next block, so the LAST
-// round of every permutation but the final one owes only the words 8 .. 15 (st[2] is a rate word for g < 2 and is computed all the
-// same: the lanes of a wavefront run one instruction stream).
-// (`lean` is uniform over the wavefront -- a scalar branch around the tail of ONE round body; compiled as separate copies of the round
-// the kernel spilled 88 bytes)
-TVM_D void tip5_round_mfma(u64 (&st)[4], const Tip5MfmaOperands& m, int g, const unsigned char* lut, const int* ctab, int r, bool lean) {
-    // accumulator inputs first: their LDS latency hides behind the S-box layer
-    tvm_v4i d[TIP5_MFMA_POSITIONS];
-#pragma unroll
-    for (int c = 0; c < TIP5_MFMA_POSITIONS; c++) {
-        const int* cp = ctab + ((r * TIP5_MFMA_POSITIONS + c) * 4 + g) * 4;
-#pragma unroll
-        for (int v = 0; v < 4; v++) d[c][v] = cp[v];
-    }
-    st[0] = tip5_sbox_lookup(st[0], lut);
-#pragma unroll
-    for (int t = 1; t < 4; t++) st[t] = tip5_pow7(st[t]);
-    const u32 pad = 0x80808080u;  // bytes travel lowered by 128
-    tvm_v4i lo, hi;
-    lo[0] = (int)(u32)st[0];
-    hi[0] = (int)(u32)(st[0] >> 32);
-#pragma unroll
-    for (int t = 1; t < 4; t++) {
-        lo[t] = (int)((u32)st[t] ^ pad);
-        hi[t] = (int)((u32)(st[t] >> 32) ^ pad);
-    }
-#pragma unroll
-    for (int s = 0; s < TIP5_MFMA_SHIFTS; s++) d[s] = TVM_MFMA_I8(m.a[s], lo, d[s]);
-#pragma unroll
-    for (int s = 0; s < TIP5_MFMA_SHIFTS; s++) d[s + 4] = TVM_MFMA_I8(m.a[s], hi, d[s + 4]);
-#if TVM_TIP5_PAIRED_TAIL
-    // the tail as two pairs of words, the first of them optional (one instruction stream up to the branch, nothing but the pair
-    // behind it: as two alternative tails the kernel spilled)
-    tip5_mfma_recombine_pair<2>(d, st);
-    if (!lean) tip5_mfma_recombine_pair<0>(d, st);
-#else
-    (void)lean;
-    tip5_mfma_recombine(d, st);
-#endif
-}
+// Round 6, measured and NOT adopted (the code is in the history; profiles/r06_b_*, r06_c_*, r06_d_*):
+//  * commit 71bc48c -- the split-and-lookup S-box two bytes at a time from a 65536-entry table in LDS: 250 instead of 260 VALU
+//    instructions per round, but 128 KB of LDS mean one workgroup of sixteen wavefronts per CU, and at four wavefronts per SIMD instead
+//    of six the wait states of the carry chains are no longer hidden: 52.8 against 44.3 ms for the main table's rows.  (The d16 loads
+//    that would assemble the result for free zero the other half of their register under SRAM-ECC: hipcc never selects them.)
+//  * commit 77412a9 -- tools/ubench/tip5_floor.hip puts the product's row hashing 6.5-7 % above its own permutations run on registers
+//    alone.  (a) The next block of a row requested a whole permutation ahead through LDS-DMA loads (no register holds it): no scratch
+//    at all, and no gain (43.9-44.1 against 43.7-44.0 ms) -- the gap is NOT the latency of the absorb's loads.  (b) A LEAN last round
+//    that does not recombine the rate words the next block overwrites (34 of a permutation's 1300 VALU instructions): as a branch
+//    between two tails it spills one matrix operand per round, as two pairs of words it loses the four-chain interleave: 44.3-44.7 ms.
+//    What the 6.5-7 % are, by count: the absorb's own instructions 1.7 %, workgroup set-up and relaunch ~1.2 %, the launch's last
+//    wave of workgroups (85.3 rounds of them: one in 86) ~1.2 %; the rest (~2.5 %) moves with the memory traffic, not with the code.
+//
+// st[t] = word g + 4t of the state of permutation n; every lane of the wavefront must take part.  `lut` is the S-box table
+// LOWERED by 128 (tip5_stage_lut_lowered): the looked-up word goes to the matrix cores only, where bytes travel that way.
 TVM_D void tip5_permute_mfma(u64 (&st)[4], const Tip5MfmaOperands& m, int g, const unsigned char* lut, const int* ctab) {
-    for (int r = 0; r < TIP5_ROUNDS; r++) tip5_round_mfma(st, m, g, lut, ctab, r, false);
+    for (int r = 0; r < TIP5_ROUNDS; r++) {
+        // accumulator inputs first: their LDS latency hides behind the S-box layer
+        tvm_v4i d[TIP5_MFMA_POSITIONS];
+#pragma unroll
+        for (int c = 0; c < TIP5_MFMA_POSITIONS; c++) {
+            const int* cp = ctab + ((r * TIP5_MFMA_POSITIONS + c) * 4 + g) * 4;
+#pragma unroll
+            for (int v = 0; v < 4; v++) d[c][v] = cp[v];
+        }
+        st[0] = tip5_sbox_lookup(st[0], lut);
+#pragma unroll
+        for (int t = 1; t < 4; t++) st[t] = tip5_pow7(st[t]);
+        const u32 pad = 0x80808080u;  // bytes travel lowered by 128
+        tvm_v4i lo, hi;
+        lo[0] = (int)(u32)st[0];
+        hi[0] = (int)(u32)(st[0] >> 32);
+#pragma unroll
+        for (int t = 1; t < 4; t++) {
+            lo[t] = (int)((u32)st[t] ^ pad);
+            hi[t] = (int)((u32)(st[t] >> 32) ^ pad);
+        }
+#pragma unroll
+        for (int s = 0; s < TIP5_MFMA_SHIFTS; s++) d[s] = TVM_MFMA_I8(m.a[s], lo, d[s]);
+#pragma unroll
+        for (int s = 0; s < TIP5_MFMA_SHIFTS; s++) d[s + 4] = TVM_MFMA_I8(m.a[s], hi, d[s + 4]);
+        tip5_mfma_recombine(d, st);
+    }
 }

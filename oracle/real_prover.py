@@ -228,7 +228,82 @@ def xfe_scale(x, b_mont):
 
 
 # ---- the prover ----------------------------------------------------------------------------------------------------------------
-def prove(program, public_input, secret_input=(), secret_digests=(), ram=None, seed_u64=None, variant=None, security_level=160):
+def stir_prove(ps, codeword, ldt, stir, variant):
+    """Stir::prove (low_degree_test/stir.rs:885-993), statement by statement, on polynomials in COEFFICIENT form with the arithmetic of
+    oracle/stir_oracle.py -- Lagrange interpolation, an explicit zerofier, long division, schoolbook multiplication: none of what
+    csrc/stir.hip does (which works on evaluations over a coset and never divides polynomials).  `stir`: the instance's numbers
+    (folding_factor, round_queries [(in_domain, out_of_domain)], final_num_in_domain_queries) -- the parameter derivation is host
+    arithmetic pinned by the reference's own constants (tests/test_stir_parameters.py), not part of what is compared here.
+    Returns the first round's queried indices (the rows the STARK prover opens)."""
+    from . import stir_oracle as so
+
+    ff = stir["folding_factor"]
+    domain = ldt
+    stacks, nodes = so.stack_tree(codeword, ff)
+    ps.enqueue("MerkleRoot", enc_bfe_words(values_of(nodes[1])))
+    poly = orc.coset_interpolate(codeword, domain, 3).reshape(-1, 3)
+    first_round_queried_indices = None
+
+    def next_round_domain(d):   # stir.rs:1149-1155: the squares of the domain's points, shifted by the domain's offset
+        nxt = orc.domain_pow(d, 2)
+        nxt.offset = int(orc.lib().orc_bfe_mul(nxt.offset, d.offset))
+        return nxt
+
+    def unique(seq):
+        return list(dict.fromkeys(seq))
+
+    def respond(stacks, nodes, n_leaves, folded_indices):
+        # StirMerkleTree::inclusion_proof (stir.rs:1421-1440) -> StirResponse {queried_leafs: Vec<Vec<XFE>>, auth_structure}
+        leafs = [enc_vec_static(enc_xfes(list(stacks[i])), len(stacks[i])) for i in folded_indices]
+        auth = authentication_structure(nodes, n_leaves, folded_indices, variant)
+        ps.enqueue("StirResponse", enc_struct([enc_vec_dynamic(leafs, variant), enc_digests_vec(auth)], variant))
+
+    for in_domain, out_of_domain in stir["round_queries"]:
+        folding_randomness = ps.sample_scalars(1)[0]
+        folded = so.fold_polynomial(poly, ff, folding_randomness)
+        nxt_domain = next_round_domain(domain)
+        folded_evaluations = orc.coset_evaluate(folded, nxt_domain, 3).reshape(-1, 3)
+        nxt_stacks, nxt_nodes = so.stack_tree(folded_evaluations, ff)
+        ps.enqueue("MerkleRoot", enc_bfe_words(values_of(nxt_nodes[1])))
+
+        ood_queries = ps.sample_scalars(out_of_domain)
+        ood_values = [orc.poly_eval_xfe(folded, x) for x in ood_queries]
+        ps.enqueue("StirOutOfDomainValues", enc_vec_static(enc_xfes(ood_values), len(ood_values)))
+
+        queried_indices = ps.sample_indices(domain.length, in_domain)
+        folded_domain = orc.domain_pow(domain, ff)
+        folded_queried = unique(i % folded_domain.length for i in queried_indices)
+        respond(stacks, nodes, domain.length // ff, folded_queried)
+
+        # the witness polynomial of the next round
+        values = orc.domain_values(folded_domain)
+        queried_domain_values = [np.array([values[i], 0, 0], np.uint64) for i in folded_queried]
+        answers = [orc.poly_eval_xfe(folded, x) for x in queried_domain_values] + ood_values
+        quotient_set = queried_domain_values + list(ood_queries)
+        degree_correction_randomness = ps.sample_scalars(1)[0]
+        poly = np.array(so.next_polynomial(folded, quotient_set, answers, degree_correction_randomness,
+                                           interpolate=so.lagrange_interpolate_from_zerofier), np.uint64).reshape(-1, 3)
+        domain, stacks, nodes = nxt_domain, nxt_stacks, nxt_nodes
+        if first_round_queried_indices is None:
+            first_round_queried_indices = queried_indices
+
+    # the final round: no quotienting
+    folding_randomness = ps.sample_scalars(1)[0]
+    final = so.fold_polynomial(poly, ff, folding_randomness)
+    coeffs = [values_of(c) for c in final]
+    if variant.normalize_polynomial:
+        while coeffs and coeffs[-1] == [0, 0, 0]:
+            coeffs.pop()
+    ps.enqueue("Polynomial", enc_struct([enc_vec_static(list(itertools.chain.from_iterable(coeffs)), len(coeffs))], variant))
+    folded_domain = orc.domain_pow(domain, ff)
+    queried_indices = ps.sample_indices(domain.length, stir["final_num_in_domain_queries"])
+    respond(stacks, nodes, domain.length // ff, unique(i % folded_domain.length for i in queried_indices))
+    return first_round_queried_indices if first_round_queried_indices is not None else queried_indices
+
+
+def prove(program, public_input, secret_input=(), secret_digests=(), ram=None, seed_u64=None, variant=None, security_level=160, stir=None):
+    """`stir`: None = LdtChoice::Fri (what the reference's snapshots use: FRI-sized programs), or the numbers of the STIR instance
+    (dict: initial_domain_length, num_trace_randomizers, folding_factor, round_queries, final_num_in_domain_queries) = LdtChoice::Stir"""
     variant = variant or Variant()
     aet, output = vm.trace_execution(program, public_input, secret_input, secret_digests, ram)
     program_digest = vm.hash_varlen(program.to_bwords())
@@ -246,7 +321,7 @@ def prove(program, public_input, secret_input=(), secret_digests=(), ram=None, s
     import math
 
     num_checks = fri_num_collinearity_checks(security_level, 2)
-    h = num_checks + 4 * 3 * 2 + 1
+    h = num_checks + 4 * 3 * 2 + 1 if stir is None else stir["num_trace_randomizers"]
     padded_height = aet.padded_height()
     rtl = 1 << (max(padded_height + h, 2 * h + 1, (h + 1) * 5) - 1).bit_length()
     n = rtl // 2
@@ -256,6 +331,8 @@ def prove(program, public_input, secret_input=(), secret_digests=(), ram=None, s
         ldt_len = 1 << (log2_hdb + 2)
         if ldt_len >= rtl * 4:
             break
+    if stir is not None:
+        ldt_len = stir["initial_domain_length"]   # Stark::stir (stark.rs:1972-2032) sizes the domain itself
     quot_len = 4 * rtl          # max_degree = 4 * rtl - 1 for every padded height (stark.rs:1905-1916)
     assert quot_len == ldt_len, "only the shape quotient domain == LDT domain is restated here"
     g = orc.lib().orc_bfe_generator()
@@ -339,40 +416,43 @@ def prove(program, public_input, secret_input=(), secret_digests=(), ram=None, s
              orc.deep_codeword(r_cw, ldt, za4, orc.poly_eval_xfe(r_poly, za4))]
     codeword = np.array([xsum([orc.xfe_mul(parts[k][i], wd[k]) for k in range(4)]) for i in range(ldt_len)], np.uint64)
 
-    # FRI (fri.rs:130-345, 757-775)
-    rounds = []
-    dom, cw = ldt, codeword
-    for r in range(fri_rounds + 1):
-        if r:
-            challenge = ps.sample_scalars(1)[0]
-            cw = orc.fri_split_and_fold(cw, dom, challenge)
-            dom = orc.domain_pow(dom, 2)
-        nodes = orc.merkle_tree(orc.xfe_to_digest(cw))
-        ps.enqueue("MerkleRoot", enc_bfe_words(values_of(nodes[1])))
-        rounds.append((dom, cw, nodes))
-    last_cw = rounds[-1][1]
-    ps.enqueue("FriCodeword", enc_vec_static(enc_xfes(last_cw), len(last_cw)))
-    last_poly = orc.coset_interpolate(last_cw, orc.domain_of_length(len(last_cw)), 3).reshape(-1, 3)
-    coeffs = [values_of(c) for c in last_poly]
-    if variant.normalize_polynomial:
-        while coeffs and coeffs[-1] == [0, 0, 0]:
-            coeffs.pop()
-    poly_enc = enc_struct([enc_vec_static(list(itertools.chain.from_iterable(coeffs)), len(coeffs))], variant)
-    ps.enqueue("Polynomial", poly_enc)
-    a_indices = ps.sample_indices(ldt_len, num_checks)
+    if stir is not None:
+        a_indices = stir_prove(ps, codeword, ldt, stir, variant)
+    else:
+        # FRI (fri.rs:130-345, 757-775)
+        rounds = []
+        dom, cw = ldt, codeword
+        for r in range(fri_rounds + 1):
+            if r:
+                challenge = ps.sample_scalars(1)[0]
+                cw = orc.fri_split_and_fold(cw, dom, challenge)
+                dom = orc.domain_pow(dom, 2)
+            nodes = orc.merkle_tree(orc.xfe_to_digest(cw))
+            ps.enqueue("MerkleRoot", enc_bfe_words(values_of(nodes[1])))
+            rounds.append((dom, cw, nodes))
+        last_cw = rounds[-1][1]
+        ps.enqueue("FriCodeword", enc_vec_static(enc_xfes(last_cw), len(last_cw)))
+        last_poly = orc.coset_interpolate(last_cw, orc.domain_of_length(len(last_cw)), 3).reshape(-1, 3)
+        coeffs = [values_of(c) for c in last_poly]
+        if variant.normalize_polynomial:
+            while coeffs and coeffs[-1] == [0, 0, 0]:
+                coeffs.pop()
+        poly_enc = enc_struct([enc_vec_static(list(itertools.chain.from_iterable(coeffs)), len(coeffs))], variant)
+        ps.enqueue("Polynomial", poly_enc)
+        a_indices = ps.sample_indices(ldt_len, num_checks)
 
-    def respond(r, indices):
-        d, c, nodes = rounds[r]
-        leaves = [c[i] for i in indices]
-        auth = authentication_structure(nodes, d.length, indices, variant)
-        fields = [enc_vec_static(enc_xfes(leaves), len(leaves)), enc_digests_vec(auth)]   # queried_leaves, auth_structure
-        ps.enqueue("FriResponse", enc_struct(fields, variant))
+        def respond(r, indices):
+            d, c, nodes = rounds[r]
+            leaves = [c[i] for i in indices]
+            auth = authentication_structure(nodes, d.length, indices, variant)
+            fields = [enc_vec_static(enc_xfes(leaves), len(leaves)), enc_digests_vec(auth)]   # queried_leaves, auth_structure
+            ps.enqueue("FriResponse", enc_struct(fields, variant))
 
-    respond(0, a_indices)
-    for r in range(len(rounds) - 1):
-        n_r = rounds[r][0].length
-        respond(r, [(i + n_r // 2) % n_r for i in a_indices])
-    ps.sample_scalars(1)
+        respond(0, a_indices)
+        for r in range(len(rounds) - 1):
+            n_r = rounds[r][0].length
+            respond(r, [(i + n_r // 2) % n_r for i in a_indices])
+        ps.sample_scalars(1)
 
     # open the trace leafs (stark.rs:665-716)
     for name, lde, nodes, width in (("MasterMainTableRows", main_lde, main_nodes, NUM_MAIN),

@@ -90,6 +90,31 @@ def lagrange_interpolate(points, values):
     return total
 
 
+def divide_by_linear(poly, root):
+    """poly / (X - root) for a root of poly: synthetic division (the quotient's coefficients, lowest first)"""
+    out = [ZERO.copy() for _ in range(len(poly) - 1)]
+    carry = ZERO.copy()
+    for i in range(len(poly) - 1, 0, -1):
+        carry = orc.xfe_add(poly[i], orc.xfe_mul(carry, root))
+        out[i - 1] = carry
+    return out
+
+
+def lagrange_interpolate_from_zerofier(points, values):
+    """the same polynomial as lagrange_interpolate, in O(k^2): the basis polynomial of point i is Z / (X - p_i) over its own value at
+    p_i, with Z the zerofier of all points (what lets the oracle prover handle the ~200 points of a STIR round in seconds; the cubic
+    form above stays for the small cases, and the two are compared in tests/test_stir.py)"""
+    k = len(points)
+    z = zerofier(points)
+    total = [ZERO.copy() for _ in range(k)]
+    for i in range(k):
+        basis = divide_by_linear(z, points[i])
+        at_point = orc.poly_eval_xfe(np.array(basis, np.uint64), points[i])
+        scale = orc.xfe_mul(values[i], orc.xfe_inv(at_point))
+        total = poly_add(total, [orc.xfe_mul(c, scale) for c in basis])
+    return total
+
+
 def fold_polynomial(coeffs, folding_factor, randomness):
     """stir.rs:1132-1147: every chunk of `folding_factor` coefficients evaluated at the randomness"""
     coeffs = np.asarray(coeffs, np.uint64).reshape(-1, 3)
@@ -110,12 +135,12 @@ def stir_merkle_root(codeword, stack_height):
     return orc.merkle_tree(digests)[1]
 
 
-def next_polynomial(folded, quotient_set, quotient_answers, degree_correction_randomness):
+def next_polynomial(folded, quotient_set, quotient_answers, degree_correction_randomness, interpolate=None):
     """stir.rs:945-966: ((folded - Ans) / Zerofier) * (1 + r X + ... + r^k X^k), coefficients"""
     folded = [c for c in np.asarray(folded, np.uint64).reshape(-1, 3)]
     points = [p for p in np.asarray(quotient_set, np.uint64).reshape(-1, 3)]
     answers = [v for v in np.asarray(quotient_answers, np.uint64).reshape(-1, 3)]
-    ans = lagrange_interpolate(points, answers)
+    ans = (interpolate or lagrange_interpolate)(points, answers)
     quotient, remainder = poly_divmod(poly_sub(folded, ans), zerofier(points))
     assert not remainder, "folded - Ans must vanish on the quotient set"
     correction, power = [], one()
@@ -123,3 +148,10 @@ def next_polynomial(folded, quotient_set, quotient_answers, degree_correction_ra
         correction.append(power)
         power = orc.xfe_mul(power, degree_correction_randomness)
     return poly_mul(quotient, correction)
+
+
+def stack_tree(codeword, stack_height):
+    """StirMerkleTree::new (stir.rs:1380-1400) -> (the stacks, the node array of the tree over their digests)"""
+    stacks = stack(codeword, stack_height)
+    digests = np.array([orc.hash_varlen(np.ascontiguousarray(s).reshape(-1)) for s in stacks], np.uint64)
+    return stacks, orc.merkle_tree(digests)

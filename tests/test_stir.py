@@ -57,6 +57,19 @@ def test_host_interpolation_matches_lagrange(ctx, orc):
     assert ctx.lib.tvm_host_xfe_interpolate(pts.ctypes.data, pts.ctypes.data, 2, np.empty((2, 3), np.uint64).ctypes.data) != 0
 
 
+def test_the_two_lagrange_forms_of_the_oracle_agree(orc):
+    """oracle/stir_oracle.py: the O(k^2) form the oracle prover uses (basis polynomial = zerofier / (X - p_i)) against the cubic textbook
+    form, base-field points lifted and extension-field points mixed as in a STIR quotient set"""
+    rng = np.random.default_rng(11)
+    for k in (1, 2, 5, 12):
+        pts, vals = orc.random_elements(rng, (k, 3)), orc.random_elements(rng, (k, 3))
+        pts[: k // 2, 1:] = 0
+        a, b = so.lagrange_interpolate(list(pts), list(vals)), so.lagrange_interpolate_from_zerofier(list(pts), list(vals))
+        assert len(so.poly_trim(a)) == len(so.poly_trim(b)) and all((x == y).all() for x, y in zip(so.poly_trim(a), so.poly_trim(b)))
+        for p_, v_ in zip(pts, vals):
+            assert (orc.poly_eval_xfe(np.array(b, np.uint64), p_) == v_).all()
+
+
 @pytest.mark.parametrize("log2_bound,queries", [(6, [(3, 1), (2, 0)]), (8, [(5, 2), (3, 1), (4, 0)])])
 def test_prover_rounds_match_the_coefficient_form_restatement(ctx, orc, log2_bound, queries):
     rng = np.random.default_rng(log2_bound)

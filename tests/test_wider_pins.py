@@ -5,8 +5,9 @@
     it IS the reference's prover as far as the repository can know) at padded heights 2^12 and 2^14: larger domains, more FRI
     rounds, 1024- and 4096-point transform axes, multi-chunk tables;
   * STIR regression digests: `Tip5::hash(proof)` of the two snapshot programs with `LdtChoice::Stir` forced.  The reference holds
-    no STIR vector (its snapshots are FRI-sized), so these are NOT parity pins -- they freeze today's STIR proofs, which both
-    restated verifiers accept (tests/test_stir.py, tests/test_ldt_verifiers.py), against drift.
+    no STIR vector (its snapshots are FRI-sized), so these are NOT reference pins -- but since round 6 they are not the product's own
+    word either: the oracle prover's coefficient-form STIR (oracle/real_prover.py `stir=`, oracle/stir_oracle.py) arrives at the same
+    digests, and at 2^12 / 2^14 rows the device's STIR proofs equal the oracle prover's word for word.
 """
 import numpy as np
 import pytest
@@ -21,6 +22,33 @@ def _golden():
 
     with open(os.path.join(os.path.dirname(__file__), "golden", "stir_regression_digests.json")) as f:
         return json.load(f)
+
+
+def stir_numbers(padded_height, security_level):
+    """the STIR instance the reference's Stark::stir picks (host arithmetic, pinned by tests/test_stir_parameters.py), as plain numbers
+    for the oracle prover"""
+    from triton_vm_amd.low_degree_test import stark_stir
+
+    st = stark_stir(padded_height, security_level=security_level)
+    return dict(initial_domain_length=st.initial_domain.length, num_trace_randomizers=st.num_trace_randomizers(), folding_factor=st.folding_factor,
+                round_queries=list(st.round_queries), final_num_in_domain_queries=st.final_num_in_domain_queries)
+
+
+@pytest.mark.parametrize("which,seed,security_level", [("tiny", snap.SEED_U64, 160), ("every", snap.SEED_U64_EVERY, 32)])
+def test_oracle_stir_prover_reproduces_the_frozen_stir_digests(which, seed, security_level):
+    """Round 6: the frozen STIR digests are no longer the product's word alone.  oracle/real_prover.py with `stir=` runs Stir::prove
+    (stir.rs:885-993) statement by statement on polynomials in COEFFICIENT form -- Lagrange interpolation, an explicit zerofier, long
+    division, schoolbook multiplication (oracle/stir_oracle.py): nothing of csrc/stir.hip's evaluation-form round -- and arrives at
+    the very digests the device proofs were frozen with ("every": two full rounds + the final one; "tiny": the final round only).
+    Still no reference-held STIR vector (that needs cargo): what the digests freeze is now an ORACLE-EQUAL proof."""
+    from oracle import real_prover
+
+    program, aet, public_input, _ = vf.run(which)
+    extra = vf.non_determinism(which) if which == "every" else ()
+    proof = real_prover.prove(program, public_input, *extra, seed_u64=seed, security_level=security_level,
+                              stir=stir_numbers(aet.padded_height(), security_level))
+    assert proof["digest"] == _golden()[which]["digest"]
+    assert len(proof["proof"]) == _golden()[which]["proof_words"]
 
 
 def test_stir_proof_of_the_first_snapshot_program_has_not_drifted(ctx, orc):
@@ -42,6 +70,30 @@ def test_stir_proof_of_the_second_snapshot_program_has_not_drifted(orc):
     try:
         proof = snap.device_proof(ctx, orc, "every", snap.SEED_U64_EVERY, 32, ldt="stir")
         assert [int(w) for w in proof.digest(ctx.lib)] == _golden()["every"]["digest"]
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log2_rows", [12, 14])
+def test_device_stir_proof_equals_the_oracle_provers_at_larger_heights(orc, log2_rows):
+    """LdtChoice::Stir on prove_fib at 2^12 rows (one full STIR round of 246 + 1 queries) and 2^14 rows (three): every word of the
+    device proof (Python host and C++ host) equals the oracle prover's coefficient-form STIR (see the test above)."""
+    from oracle import real_prover
+    from oracle.vm import workload
+    from triton_vm_amd import Context, native_host
+    from triton_vm_amd.prover import Claim, Prover
+
+    e = workload.execution("fib", log2_rows)
+    want = real_prover.prove(e["program"], [e["index"]], seed_u64=snap.SEED_U64, stir=stir_numbers(e["padded_height"], 160))
+    seed = snap.prover_seed(snap.SEED_U64)
+    claim = Claim(e["program_digest"], e["public_input"], e["public_output"])
+    ctx = Context(device=0)
+    try:
+        words = Prover.from_execution(ctx, e["aet"], e["padded_height"], claim, seed, ldt="stir").prove().proof().words
+        assert [int(v) for v in orc.from_mont(words)] == want["proof"]
+        native = native_host.prove_execution(ctx, native_host.load_host_library(), e["aet"], e["padded_height"], claim, seed, ldt="stir")
+        assert native.size == words.size and (native == words).all()
     finally:
         ctx.close()
 

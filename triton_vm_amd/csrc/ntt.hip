@@ -721,7 +721,7 @@ __global__ void __launch_bounds__(64 * WAVES, LOGN <= 10 ? 4 : 2) k_lde_pass3_ro
         row_ntt<true, MAXK, LOGN, 1>(row, tw_lds, lane);
         const u64 j1 = rho >> log_x, k = rho & (X - 1);
         const u64 blk = (k * a.pitch + (j1 << LOGN)) >> TVM_RB_LOG;   // the row's first 16-row block of the table
-#pragma unroll (E < 4 ? E : 4)
+#pragma unroll 4
         for (int e = 0; e < E; e++)   // j2 = lane + 64 e: consecutive lanes = consecutive storage rows, 4 full lines per store
             TVM_STORE_STREAM(&out_l[((blk + 4 * e) * W) << TVM_RB_LOG], rowl[68 * e]);
         tvm_wave_sync();   // (the next tile overwrites the row)
@@ -917,7 +917,8 @@ __global__ void __launch_bounds__((1 << (LOGN - 4)) * ROWS, 4) k_lde_pass1_rows(
 // per row, TWO / FOUR rows per wavefront (everything between two butterfly groups of a row stays inside its wavefront, as at 1024
 // points), the last group radix 2 / nothing but the inter-pass factors; 256 / 128 work-items, 42 / 23 KB of LDS.
 template <int LOGN>
-__global__ void __launch_bounds__(8 << (LOGN - 4), 4) k_lde_pass2_fused(LdePass2Args a) {
+// (below 1024 points the LDS leaves room for three wavefronts per SIMD: the register budget is set for three, and nothing spills)
+__global__ void __launch_bounds__(8 << (LOGN - 4), LOGN >= 10 ? 4 : 3) k_lde_pass2_fused(LdePass2Args a) {
     constexpr int n2 = 1 << LOGN, ROWS = 8, LPR = n2 / 16, WPR = LPR / 64, NT = ROWS * LPR, RLOG = 3;
     constexpr int ROWW = TVM_P2F_ROWW(LOGN), K3 = LOGN - 8, R3 = 1 << K3, ITS = 16 / R3, LSTEP = LPR + LPR / 16;
     constexpr int FE = LOGN == 11 ? TVM_P2F_FT_EARLY_11 : TVM_P2F_FT_EARLY;   // 16-byte loads of the last group's factors requested early

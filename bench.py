@@ -911,7 +911,7 @@ def main():
             out["workload_generation"] = {"vm_seconds": round(vm_s, 2), "cycles": e["cycles"], "table_heights": e["table_heights"],
                                           "note": "oracle-side VM (oracle/vm), outside the timed region; the product path starts at Prover::prove(claim, aet)"}
         if stage_ms.get("AIR quotients", 0.0) > (80.0 if args.log2_rows == 20 and world == 1 else 1e9):
-            # the unexplained slow mode of the AIR kernels seen on 2 of ~40 boxes in round 2: leave evidence
+            # the unexplained slow mode of the AIR kernels seen on 2 of ~40 boxes in round 2 (HISTORY.md 5.1): leave evidence
             out["air_slow_mode"] = {"stage_ms": stage_ms["AIR quotients"], "smi": smi_snapshot()}
         extras = world == 1 and not sharded and not coset_wise and not args.no_extras
         if extras and args.data == "real":

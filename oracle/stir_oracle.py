@@ -2,8 +2,9 @@
 (/root/reference/triton-vm/src/low_degree_test/stir.rs:885-993), written the way the reference writes it: with
 polynomials in coefficient form, Lagrange interpolation, an explicit zerofier, polynomial long division and
 schoolbook multiplication (twenty-first's Polynomial::{interpolate, zerofier, /, *}).  Pure-Python loops over the C
-oracle's field arithmetic: small cases only.  The product never imports this file; PARITY UNPINNED in the sense of
-DESIGN.md section 7 (no golden vectors for STIR exist in the reference tree; its own tests are prove-then-verify).
+oracle's field arithmetic.  The product never imports this file.  PARITY: no reference-held STIR vector exists (its own tests are
+prove-then-verify); since round 6 oracle/real_prover.py builds whole STIR proofs from this file and the device proofs equal them --
+DESIGN.md section 7.
 """
 import numpy as np
 

@@ -6,7 +6,7 @@
 //   MasterTable::{randomized_column_interpolant, maybe_low_degree_extend_all_columns}
 //       /root/reference/triton-vm/src/table/master_table.rs:258-322, 392-403
 //
-// Design (DESIGN.md section 3): a length-N transform (N up to 2^24) is split N = N1 x N2 and done in
+// Design (DESIGN.md 4.1): a length-N transform (N up to 2^24) is split N = N1 x N2 and done in
 // two HBM passes whose tiles live in LDS: a "strided" pass (all i1 for a batch of 16 adjacent i2,
 // 128-byte coalesced runs) and a "row" pass (whole contiguous rows).  No bit-reversal pass exists
 // anywhere: inverse sub-transforms are decimation-in-frequency (natural in, bit-reversed out),

@@ -193,8 +193,16 @@ TVM_D void lds_ntt_fixed(u64* s, const u64* __restrict__ tw, int tid, int nt) {
 // `lane` is the lane number within the pair, and the groups are separated by workgroup barriers: every wavefront of the workgroup runs
 // the same sequence), or 32 / 16 (round 6: rows of 512 / 256 points, two / four of them per wavefront, `lane` the number within the
 // row's lanes; still wavefront-private: tvm_wave_sync)
-template <bool DIT, int K, int L, int LOGN, int ROOT, int TWB = TVM_TW_BATCH, int LPR = 64>
-TVM_D void row_ntt_group(u64* row, const u64* __restrict__ tw, int lane) {
+// what separates two butterfly groups of a row by default: see LPR below
+template <int LPR>
+struct RowSync {
+    TVM_D void operator()() const {
+        if constexpr (LPR <= 64) tvm_wave_sync();
+        else tvm_lds_barrier();
+    }
+};
+template <bool DIT, int K, int L, int LOGN, int ROOT, int TWB = TVM_TW_BATCH, int LPR = 64, class Sync = RowSync<LPR>>
+TVM_D void row_ntt_group(u64* row, const u64* __restrict__ tw, int lane, Sync& sync) {
     static_assert(ROOT == 1 || ROOT == 2, "the domains' own roots of unity only");
     constexpr int R = 1 << K, NG = 1 << (LOGN - K);
 #pragma unroll 1
@@ -233,17 +241,28 @@ TVM_D void row_ntt_group(u64* row, const u64* __restrict__ tw, int lane) {
 #pragma unroll
         for (int e = 0; e < R; e++) p[TVM_ROW_SKEW(e << L)] = x[e];
     }
-    if constexpr (LPR <= 64) tvm_wave_sync();
-    else tvm_lds_barrier();
+    sync();
 }
-template <bool DIT, int MAXK, int LOGN, int ROOT, int DONE = 0, int LPR = 64>
-TVM_D void row_ntt(u64* row, const u64* __restrict__ tw, int lane) {
+template <bool DIT, int K, int L, int LOGN, int ROOT, int TWB = TVM_TW_BATCH, int LPR = 64>
+TVM_D void row_ntt_group(u64* row, const u64* __restrict__ tw, int lane) {
+    RowSync<LPR> sync;
+    row_ntt_group<DIT, K, L, LOGN, ROOT, TWB, LPR, RowSync<LPR>>(row, tw, lane, sync);
+}
+// (`sync`: called after every group; the default is the wavefront-level wait for rows of <= 64 lanes and the workgroup barrier for
+// rows of 128 -- the kernels with two wavefronts per row pass their pair synchronisation instead)
+template <bool DIT, int MAXK, int LOGN, int ROOT, int DONE = 0, int LPR = 64, class Sync = RowSync<LPR>>
+TVM_D void row_ntt(u64* row, const u64* __restrict__ tw, int lane, Sync& sync) {
     if constexpr (DONE < LOGN) {
         constexpr int k = (LOGN - DONE) >= MAXK ? MAXK : (LOGN - DONE);
         constexpr int l = DIT ? DONE : (LOGN - DONE - k);
-        row_ntt_group<DIT, k, l, LOGN, ROOT, TVM_TW_BATCH, LPR>(row, tw, lane);
-        row_ntt<DIT, MAXK, LOGN, ROOT, DONE + k, LPR>(row, tw, lane);
+        row_ntt_group<DIT, k, l, LOGN, ROOT, TVM_TW_BATCH, LPR, Sync>(row, tw, lane, sync);
+        row_ntt<DIT, MAXK, LOGN, ROOT, DONE + k, LPR, Sync>(row, tw, lane, sync);
     }
+}
+template <bool DIT, int MAXK, int LOGN, int ROOT, int DONE = 0, int LPR = 64>
+TVM_D void row_ntt(u64* row, const u64* __restrict__ tw, int lane) {
+    RowSync<LPR> sync;
+    row_ntt<DIT, MAXK, LOGN, ROOT, DONE, LPR, RowSync<LPR>>(row, tw, lane, sync);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -843,7 +862,8 @@ __global__ void __launch_bounds__((1 << (LOGN - 4)) * ROWS, 4) k_lde_pass1_rows(
     // LOGN = 9 / 8 (round 6; 2^16 .. 2^19-row traces): 32 / 16 lanes per row, two / four rows per wavefront, 16 rows.
     constexpr int n1 = 1 << LOGN, ROWW = TVM_ROW_WORDS(n1), LPR = n1 / 16, NT = LPR * ROWS, RLOG = ROWS == 16 ? 4 : 3;
     static_assert((LOGN >= 8 && LOGN <= 10 && (ROWS == 16 || ROWS == 8)) || (LOGN == 11 && ROWS == 8), "16 .. 128 lanes per row of 256 .. 2048 points");
-    TVM_DYN_SMEM(u64, s);
+    TVM_DYN_SMEM(u64, s_all);
+    u64* const s = s_all + (LPR > 64 ? 512 : 0);   // (two wavefronts per row: sixteen blocks of 64 pair flags first, tvm_pair_sync)
     const int tid = threadIdx.x;
     const u64 n2 = 1ull << a.log_n2;
     const int vl = blockIdx.y, v = a.col0 + vl;
@@ -857,8 +877,19 @@ __global__ void __launch_bounds__((1 << (LOGN - 4)) * ROWS, 4) k_lde_pass1_rows(
     }
     u64* tw_lds = s + ROWS * ROWW;
     for (int i = tid; i < n1; i += NT) tw_lds[i] = a.tw1[i];   // all n1 powers of the inverse root
-    tvm_lds_barrier();
-    row_ntt<false, 4, LOGN, 2, 0, LPR>(s + (tid / LPR) * ROWW, tw_lds, tid % LPR);
+    if constexpr (LPR > 64) {   // two wavefronts per row: the pair meets between the butterfly groups (tvm_pair_sync), not the workgroup
+        unsigned* const pair_flags = (unsigned*)s_all;
+        pair_flags[tid] = 0;   // (NT = 16 x 64)
+        tvm_lds_barrier();
+        unsigned pair_epoch = 0;
+        const int wave = tvm_uniform(tid >> 6);
+        int row_lane = tid % LPR;   // (tvm_pair_sync borrows its register: 64 * (wave % 2) + lane)
+        auto pair = [&] { tvm_pair_sync(pair_flags, wave, wave ^ 1, ++pair_epoch, row_lane, (wave & 1) * 64); };
+        row_ntt<false, 4, LOGN, 2, 0, LPR>(s + (tid / LPR) * ROWW, tw_lds, row_lane, pair);
+    } else {
+        tvm_lds_barrier();
+        row_ntt<false, 4, LOGN, 2, 0, LPR>(s + (tid / LPR) * ROWW, tw_lds, tid % LPR);
+    }
     tvm_lds_barrier();
     // position p = q0 + LPR * brev4(c) holds index k1 = brev(p) = brev(q0) * 16 + c
     const u64 i2 = i2_0 + b;
@@ -897,7 +928,9 @@ __global__ void __launch_bounds__((1 << (LOGN - 4)) * ROWS, 4) k_lde_pass1_rows(
 // 8 rows, 512 work-items, 78 KB of LDS: two workgroups per CU.
 #define TVM_P2F_ROWW(logn) ((logn) == 8 ? 296 : (logn) == 9 ? 552 : (logn) == 10 ? 1096 : 2184)   // >= TVM_ROW_WORDS, = 8 (mod 32)
 #define TVM_P2F_TW2_WORDS 272   // 16 x 17: the middle group's twiddles
-#define TVM_P2F_LDS_WORDS(logn) (8 * TVM_P2F_ROWW(logn) + TVM_P2F_TW2_WORDS + TVM_ROW_WORDS(1 << (logn)) + 8)   // tile + twiddles + one coset's factors + a randomizer word per row: 79.2 / 159.4 KB
+#define TVM_P2F_LDS_WORDS(logn) (8 * TVM_P2F_ROWW(logn) + TVM_P2F_TW2_WORDS + TVM_ROW_WORDS(1 << (logn)) + 8)
+#define TVM_P2F_FLAG_WORDS 512   // u64 words in front of the tile at 2048 points: sixteen blocks of 64 pair flags (tvm_pair_sync)
+#define TVM_P2F_LDS_BYTES(logn) ((size_t)(TVM_P2F_LDS_WORDS(logn) + ((logn) == 11 ? TVM_P2F_FLAG_WORDS : 0)) * sizeof(u64))   // tile + twiddles + one coset's factors + a randomizer word per row: 79.2 / 159.4 KB
 #ifndef TVM_P2F_FT_EARLY_11
 #define TVM_P2F_FT_EARLY_11 0   // (2048-point rows: the radix-8 last group leaves no registers for them)
 #endif
@@ -923,14 +956,16 @@ __global__ void __launch_bounds__(8 << (LOGN - 4), LOGN >= 10 ? 4 : 3) k_lde_pas
     constexpr int ROWW = TVM_P2F_ROWW(LOGN), K3 = LOGN - 8, R3 = 1 << K3, ITS = 16 / R3, LSTEP = LPR + LPR / 16;
     constexpr int FE = LOGN == 11 ? TVM_P2F_FT_EARLY_11 : TVM_P2F_FT_EARLY;   // 16-byte loads of the last group's factors requested early
     static_assert(LOGN >= 8 && LOGN <= 11 && ROWW >= TVM_ROW_WORDS(n2) && ROWW % 32 == 8, "256 .. 2048 points, bank-spread row pitch");
-    TVM_DYN_SMEM(u64, s);
+    TVM_DYN_SMEM(u64, s_all);
+    // (two wavefronts per row: the pair flags of tvm_pair_sync come FIRST -- they must lie in the first 64 KB of LDS)
+    u64* const s = s_all + (WPR > 1 ? TVM_P2F_FLAG_WORDS : 0);
     const int tid = threadIdx.x;
     // this lane's row of the tile and its number within the row's lanes (a row per wavefront, per pair of wavefronts, or -- below
     // 1024 points -- per 32 / 16 lanes; with whole wavefronts per row the row number is uniform, and told so)
     int r;
     if constexpr (WPR >= 1) r = tvm_uniform(tid >> 6) / WPR;
     else r = tid / LPR;
-    const int rl = tid % LPR;
+    int rl = tid % LPR;   // (not const: with two wavefronts per row tvm_pair_sync borrows its register and puts the value back)
     const u64 n1 = 1ull << a.log_n1, n = n1 << LOGN;
     const int vl = blockIdx.y, v = a.col0 + vl;
     const u64 p0 = (u64)blockIdx.x * ROWS, p = p0 + (u64)r;
@@ -939,10 +974,17 @@ __global__ void __launch_bounds__(8 << (LOGN - 4), LOGN >= 10 ? 4 : 3) k_lde_pas
     // profiles/r05_j_pmc_lde_hash_2p22.txt -- the kernel takes the same time at 2^22 rows (20.75 against 20.92 ms) and 1 % longer at
     // 2^20: the Infinity Cache serves the table, the fetches were never what the kernel waited for; profiles/r05_k_*.)
     u64* const row = s + r * ROWW;
-    auto row_sync = [] {   // between two butterfly groups of a row: its lanes exchange data through the row's LDS words
+    // between two butterfly groups of a row: its lanes exchange data through the row's LDS words.  One wavefront (or less) per row:
+    // a wait on the wavefront's own LDS traffic; two wavefronts per row (2048 points): the PAIR meets (tvm_pair_sync, round 6 -- a
+    // workgroup barrier here stopped all sixteen wavefronts of the CU's one workgroup five times per coset)
+    unsigned* const pair_flags = (unsigned*)s_all;   // a block of 64 words per wavefront
+    unsigned pair_epoch = 0;   // (uniform, like the wavefront's number: scalar registers)
+    const int wave = tvm_uniform(tid >> 6);
+    auto row_sync = [&] {
         if constexpr (WPR <= 1) tvm_wave_sync();
-        else tvm_lds_barrier();
+        else tvm_pair_sync(pair_flags, wave, wave ^ 1, pair_epoch = (unsigned)tvm_uniform((int)pair_epoch + 1), rl, (wave & 1) * 64);
     };
+    if constexpr (WPR > 1) pair_flags[tid] = 0;   // (NT = 16 x 64 words; visible after the workgroup barrier below, before the first meeting)
     // behind the tile: the 15 x 16 twiddles the middle butterfly group uses, tw2[17 j0 + e] = w_n2^((j0 brev4(e)) << (LOGN - 8)) (pitch
     // 17: sixteen j0 in sixteen banks), and the coset factors of the current coset at their positions, skewed like a row
     u64* const tw2 = s + ROWS * ROWW;
@@ -956,9 +998,10 @@ __global__ void __launch_bounds__(8 << (LOGN - 4), LOGN >= 10 ? 4 : 3) k_lde_pas
     for (int i = tid; i < 256; i += NT) tw2[17 * (i >> 4) + (i & 15)] = a.tw_b1[((i >> 4) * brev_bits((u32)(i & 15), 4)) << (LOGN - 8)];
 #pragma unroll
     for (int hh = 0; hh < n2 / NT; hh++) ghl[TVM_ROW_SKEW(tid + hh * NT)] = a.g_hi_pos[tid + hh * NT];
-    row_sync();
+    if constexpr (WPR <= 1) tvm_wave_sync();
+    else tvm_lds_barrier();   // (the row is loaded, the pair flags are zero)
     // inverse rows step: position q of the row then holds N * t[m1*n1 + m2], m1 = brev(q), m2 = brev(p)
-    if (a.mode != TVM_LDE_FORWARD_ONLY) row_ntt<false, 4, LOGN, 2, 0, LPR>(row, a.tw_a2, rl);
+    if (a.mode != TVM_LDE_FORWARD_ONLY) row_ntt<false, 4, LOGN, 2, 0, LPR>(row, a.tw_a2, rl, row_sync);
     if (a.mode == TVM_LDE_INVERSE_ONLY) {
         u64* yw = const_cast<u64*>(a.y) + (u64)vl * n + p * n2 + rl;
         const u64* const rowl = row + TVM_ROW_SKEW(rl);
@@ -1552,7 +1595,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
                 const size_t lds_r = (size_t)(16 * TVM_ROW_WORDS(n1) + n1) * sizeof(u64);
                 TVM_LAUNCH((k_lde_pass1_rows<10, 16>), dim3((unsigned)(n2 / 16), (unsigned)nc), dim3(1024), lds_r, c->stream, a);
             } else if (std_roots && sp.log_n1 == 11 && n2 % 8 == 0 && c->lde_pass2_tiles == 0) {   // 2048-point axis: two wavefronts per row
-                const size_t lds_r = (size_t)(8 * TVM_ROW_WORDS(n1) + n1) * sizeof(u64);
+                const size_t lds_r = (size_t)(8 * TVM_ROW_WORDS(n1) + n1 + 512) * sizeof(u64);   // (+ sixteen blocks of 64 pair flags)
                 TVM_LAUNCH((k_lde_pass1_rows<11, 8>), dim3((unsigned)(n2 / 8), (unsigned)nc), dim3(1024), lds_r, c->stream, a);
             } else
                 TVM_LAUNCH(k_ntt2_pass1, grid, dim3(threads_for_tile(tile)), (size_t)tile * sizeof(u64), c->stream, a);
@@ -1573,7 +1616,7 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
             if (fused) {
                 // 1024- / 2048-point axis: every wavefront (pair of wavefronts) keeps its row across the coset loop (k_lde_pass2_fused);
                 // more trace randomizers than n1 (never the case for a STARK's parameters) take the kernels below
-                const size_t lds_r = (size_t)TVM_P2F_LDS_WORDS(sp.log_n2) * sizeof(u64);
+                const size_t lds_r = TVM_P2F_LDS_BYTES(sp.log_n2);
                 if (sp.log_n2 == 8) TVM_LAUNCH((k_lde_pass2_fused<8>), dim3((unsigned)(n1 / 8), (unsigned)nc), dim3(128), lds_r, c->stream, a);
                 else if (sp.log_n2 == 9) TVM_LAUNCH((k_lde_pass2_fused<9>), dim3((unsigned)(n1 / 8), (unsigned)nc), dim3(256), lds_r, c->stream, a);
                 else if (sp.log_n2 == 10) TVM_LAUNCH((k_lde_pass2_fused<10>), dim3((unsigned)(n1 / 8), (unsigned)nc), dim3(512), lds_r, c->stream, a);

@@ -1212,8 +1212,12 @@ extern "C" int32_t tvmh_local_comms_create(uint32_t world, uint32_t lockstep, tv
     g->comms.resize(world);
     for (uint32_t r = 0; r < world; r++) {
         g->members[r] = {g, r};
+        // The asynchronous exchange is offered by the FREE-RUNNING group only (the tests of the ordering logic).  A lockstep group is a
+        // measurement of per-rank compute: its exchanges are real copies whose time is charged to no stage, and copies in flight on the
+        // one shared GPU under a rank's kernels would be charged to them (4.9 GB per rank and proof: the column split measured 80 ms
+        // that way against 48 with the exchange outside the turn, profiles/r06_e_*) -- so there the caller takes the synchronous path.
         g->comms[r] = tvmh_comm{&g->members[r], r, world, local_all_gather, local_all_to_all, local_begin, local_mark, local_end, local_abort, local_share,
-                                local_all_gather_async, local_wait};
+                                lockstep ? nullptr : local_all_gather_async, lockstep ? nullptr : local_wait};
         out[r] = &g->comms[r];
     }
     return TVM_OK;

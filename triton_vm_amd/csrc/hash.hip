@@ -69,7 +69,10 @@ __global__ void __launch_bounds__(256, 6) k_merkle_level(u64* __restrict__ nodes
     const int lane = tid & 63, n = lane & 15, g = lane >> 4;
     const Tip5MfmaOperands a = tip5_mfma_matrix_operands(lane);
     // `reps` groups of 64 parents per workgroup, one after the other: the tables above and the matrix operands are set up once
-    // (a wide level is ONE permutation per lane quadruple: the set-up was a fifth of the kernel)
+    // (a wide level is ONE permutation per lane quadruple: the set-up was a fifth of the kernel).  (Round 6, measured and not adopted:
+    // the children of parent rep + 1 requested before the permutation of parent rep through LDS-DMA staging words -- every
+    // permutation here starts from cold loads -- changed nothing: 130.7 against 127.8 us per launch on average,
+    // profiles/r06_j_kernels_merkle_level_children_staged.txt.  The kernel is not waiting for its loads.)
     for (int rep = 0; rep < reps; rep++) {
         u64 j = (((u64)blockIdx.x * reps + rep) * 4 + (tid >> 6)) * 16 + n;
         const bool live = j < count;  // every lane of a wavefront takes part in the matrix instructions

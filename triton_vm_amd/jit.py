@@ -1,5 +1,9 @@
 """The memory-lean formulation of the hot path: extended tables evaluated coset by coset, never all at once.
 
+ROLE (round 6): the PRODUCTION host is the C++ one (triton_vm_amd/host/: what bench.py times and what a Rust binding would call);
+this Python module is its mirror for the parity tests -- test scaffolding above the C ABI, kept word-for-word equal to the C++ host by
+tests/test_native_host.py and tests/test_sharded_host.py.  No algorithm lives here.
+
 Mirrors the reference's "just in time" branches -- Prover::compute_quotient_segments_with_jit_lde
 (/root/reference/triton-vm/src/stark.rs:805-1006), the JIT branch of hash_all_ldt_domain_rows
 (master_table.rs:470-503) and of reveal_rows (master_table.rs:556-609) -- which it takes when the cached

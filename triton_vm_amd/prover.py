@@ -2,6 +2,10 @@
 step for step, over the C ABI.  Everything bulky stays in HBM; the host only sees Merkle roots,
 out-of-domain rows, the last FRI codeword and the opened rows.
 
+ROLE (round 6): the PRODUCTION host is the C++ one (triton_vm_amd/host/: what bench.py times and what a Rust binding would call);
+this Python module is its mirror for the parity tests -- test scaffolding above the C ABI, kept word-for-word equal to the C++ host by
+tests/test_native_host.py and tests/test_sharded_host.py.  No algorithm lives here.
+
 The Fiat-Shamir transcript is the reference's (triton_vm_amd/proof_stream.py: ProofItem encoding, Claim, sampling), the
 prover's randomness is the reference's when a 32-byte seed is given (triton_vm_amd/randomness.py): `Prover.from_execution`
 on the reference's own snapshot program yields the reference's proof, word for word (tests/test_proof_snapshot.py).

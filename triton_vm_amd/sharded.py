@@ -1,5 +1,9 @@
 """One proof across the GPUs of a node: coset (row) sharding of the extended master tables.
 
+ROLE (round 6): the PRODUCTION host is the C++ one (triton_vm_amd/host/: what bench.py times and what a Rust binding would call);
+this Python module is its mirror for the parity tests -- test scaffolding above the C ABI, kept word-for-word equal to the C++ host by
+tests/test_native_host.py and tests/test_sharded_host.py.  No algorithm lives here.
+
 SURVEY.md section 8(e): the LDT / quotient domain g*<w_L> is X = L/N cosets of the trace domain; rank r of R
 owns the cosets k = r (mod R), i.e. the extended rows i = r (mod R).  Those rows are themselves an arithmetic
 domain -- offset g*w_L^r, generator w_L^R, length L/R -- so a rank's share of

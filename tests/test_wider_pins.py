@@ -124,3 +124,42 @@ def test_device_proof_equals_the_oracle_provers_at_larger_heights(orc, kind, log
         assert native.size == words.size and (native == words).all()
     finally:
         ctx.close()
+
+
+def _oracle_digests():
+    import json
+    import os
+
+    path = os.path.join(os.path.dirname(__file__), "golden", "oracle_proof_digests.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return json.load(f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(_oracle_digests()) or ["none"])
+def test_device_proof_hashes_to_the_oracle_provers_digest_at_2p16_to_2p18(orc, case):
+    """Whole-proof parity where the oracle prover takes minutes (tests/golden/make_oracle_proof_digests.py ran it on the CPU and
+    committed `Tip5::hash(proof)` + the proof's length): prove_fib at 2^16, 2^17 and 2^18 rows with FRI and at 2^16 rows with STIR (the
+    reference's default from there on).  The device proof of the same (program, input, prover seed) -- C++ host -- must hash to the
+    same digest: every word of the proof, at the heights whose extension runs the 256-, 512- and 1024-point row kernels of round 6."""
+    if case == "none":
+        pytest.skip("tests/golden/oracle_proof_digests.json has not been generated")
+    from oracle.vm import workload
+    from triton_vm_amd import Context, native_host
+    from triton_vm_amd.proof_stream import Proof
+    from triton_vm_amd.prover import Claim
+
+    want = _oracle_digests()[case]
+    e = workload.execution(want["program"], want["log2_padded_height"])
+    assert [int(v) for v in orc.from_mont(e["public_input"])] == want["public_input"]
+    claim = Claim(e["program_digest"], e["public_input"], e["public_output"])
+    ctx = Context(device=0)
+    try:
+        words = native_host.prove_execution(ctx, native_host.load_host_library(), e["aet"], e["padded_height"], claim,
+                                            snap.prover_seed(want["seed_u64"]), ldt=want["ldt"])
+        assert words.size == want["proof_words"]
+        assert [int(w) for w in Proof(words).digest(ctx.lib)] == want["digest"]
+    finally:
+        ctx.close()

@@ -179,13 +179,16 @@ def randomized_column_interpolant(column, randomizer, fk=1):
     return out
 
 
-def lde_table(trace, randomizers, eval_domain, fk=1):
-    """trace [n_cols, n_rows(, 3)] column-major; randomizers [n_cols, h(, 3)] -> [L, n_cols(, 3)]."""
+def lde_table(trace, randomizers, eval_domain, fk=1, out=None):
+    """trace [n_cols, n_rows(, 3)] column-major; randomizers [n_cols, h(, 3)] -> [L, n_cols(, 3)].  `out`: an array of that shape to
+    fill instead of a new one (a file-backed np.memmap for the heights whose tables do not fit the host's memory)."""
     trace, randomizers = _arr(trace), _arr(randomizers)
     n_cols, n_rows = trace.shape[0], trace.shape[1]
     h = randomizers.shape[1]
     shape = (eval_domain.length, n_cols) + ((3,) if fk == 3 else ())
-    out = np.zeros(shape, np.uint64)
+    if out is None:
+        out = np.zeros(shape, np.uint64)
+    assert out.shape == shape and out.dtype == np.uint64 and out.flags.c_contiguous
     lib().orc_lde_table(fk, _p(trace), C.c_uint64(n_rows), C.c_uint64(n_cols), _p(randomizers),
                         C.c_uint64(h), eval_domain, _p(out))
     return out

@@ -301,9 +301,20 @@ def stir_prove(ps, codeword, ldt, stir, variant):
     return first_round_queried_indices if first_round_queried_indices is not None else queried_indices
 
 
-def prove(program, public_input, secret_input=(), secret_digests=(), ram=None, seed_u64=None, variant=None, security_level=160, stir=None):
+def prove(program, public_input, secret_input=(), secret_digests=(), ram=None, seed_u64=None, variant=None, security_level=160, stir=None,
+          spill_dir=None):
     """`stir`: None = LdtChoice::Fri (what the reference's snapshots use: FRI-sized programs), or the numbers of the STIR instance
-    (dict: initial_domain_length, num_trace_randomizers, folding_factor, round_queries, final_num_in_domain_queries) = LdtChoice::Stir"""
+    (dict: initial_domain_length, num_trace_randomizers, folding_factor, round_queries, final_num_in_domain_queries) = LdtChoice::Stir.
+    `spill_dir`: a directory for the two extended tables as file-backed arrays (2^19 rows and more: 22 / 44 GB of tables next to the
+    Python-integer trace tables do not fit a 64 GB host); same results."""
+
+    def table_array(name, shape):
+        if spill_dir is None:
+            return None
+        import os
+
+        return np.lib.format.open_memmap(os.path.join(spill_dir, name + ".npy"), mode="w+", dtype=np.uint64, shape=shape)
+
     variant = variant or Variant()
     aet, output = vm.trace_execution(program, public_input, secret_input, secret_digests, ram)
     program_digest = vm.hash_varlen(program.to_bwords())
@@ -348,7 +359,7 @@ def prove(program, public_input, secret_input=(), secret_digests=(), ram=None, s
     main[:T.NUM_MAIN] = orc.to_mont(np.array(mt.columns(), dtype=object))
     main, _ = dlo.fill(main)
     main_rnd = np.stack([random_elements(offset_rng_seed(seed, c), h, 1) for c in range(NUM_MAIN)])
-    main_lde = orc.lde_table(main, main_rnd, ldt, 1)
+    main_lde = orc.lde_table(main, main_rnd, ldt, 1, out=table_array("main_lde", (ldt_len, NUM_MAIN)))
     main_nodes = orc.merkle_tree(orc.hash_rows(main_lde))
     ps.enqueue("MerkleRoot", enc_bfe_words(values_of(main_nodes[1])))
     sampled = ps.sample_scalars(59)
@@ -362,7 +373,7 @@ def prove(program, public_input, secret_input=(), secret_digests=(), ram=None, s
     aux[NUM_AUX - 1] = random_elements(offset_rng_seed(aux_seed, NUM_AUX), n, 3)
     _, aux = dlo.fill(main, aux, ch)
     aux_rnd = np.stack([random_elements(offset_rng_seed(aux_seed, c), h, 3) for c in range(NUM_AUX)])
-    aux_lde = orc.lde_table(aux, aux_rnd, ldt, 3)
+    aux_lde = orc.lde_table(aux, aux_rnd, ldt, 3, out=table_array("aux_lde", (ldt_len, NUM_AUX, 3)))
     aux_nodes = orc.merkle_tree(orc.hash_rows(aux_lde.reshape(ldt_len, -1)))
     ps.enqueue("MerkleRoot", enc_bfe_words(values_of(aux_nodes[1])))
     w0 = ps.sample_scalars(1)[0]

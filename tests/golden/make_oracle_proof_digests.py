@@ -36,7 +36,16 @@ def main(cases):
         t0 = time.time()
         e = workload.execution(kind, int(log2_rows))
         stir = stir_numbers(e["padded_height"], 160) if ldt == "stir" else None
-        proof = real_prover.prove(e["program"], [e["index"]], seed_u64=snap.SEED_U64, stir=stir)
+        spill = None
+        if int(log2_rows) >= 19:   # the extended tables as files (oracle/real_prover.py: spill_dir)
+            import tempfile
+
+            spill = tempfile.mkdtemp(prefix="oracle_tables_", dir=os.environ.get("TVM_ORACLE_SPILL_DIR", "/tmp"))
+        proof = real_prover.prove(e["program"], [e["index"]], seed_u64=snap.SEED_U64, stir=stir, spill_dir=spill)
+        if spill:
+            import shutil
+
+            shutil.rmtree(spill, ignore_errors=True)
         rec[case] = {"program": kind, "log2_padded_height": int(log2_rows), "ldt": ldt, "public_input": [int(e["index"])],
                      "seed_u64": snap.SEED_U64, "security_level": 160, "digest": [int(v) for v in proof["digest"]],
                      "proof_words": len(proof["proof"]), "oracle_seconds": round(time.time() - t0, 1)}

@@ -71,3 +71,44 @@ def test_malformed_calls_are_refused_and_the_context_survives(ctx, orc):
 def test_the_python_wrapper_raises_with_the_message(ctx):
     with pytest.raises(TritonHipError, match="invalid argument"):
         ctx._check(ctx.lib.tvm_ntt(ctx.handle, 1, None, 8, field.ONE), "tvm_ntt")
+
+
+def test_the_split_extension_refuses_foreign_handles_other_domains_and_incomplete_tables(ctx, orc):
+    """tvm_lde_table_begin / _add_columns / _end (the column split, include/triton_hip.h): add_columns and end take only a table that
+    begin made and end has not closed, only with begin's domains and randomizer count, only columns inside the table (no wrap-around
+    in first + count), and end refuses a table with a column that was never written (round-5 advice)."""
+    lib, h = ctx.lib, ctx.handle
+    n, n_cols, hr = 64, 5, 3
+    dom = ArithmeticDomain.of_length(n)
+    ev = ArithmeticDomain.of_length(4 * n).with_offset(field.generator())
+    rng = np.random.default_rng(9)
+    trace, rnd = orc.random_elements(rng, (n_cols, n)), orc.random_elements(rng, (n_cols, hr))
+    d_trace, d_rnd = ctx.to_device(trace), ctx.to_device(rnd)
+    coeffs = ctx.alloc(n_cols * n)
+    ctx._check(lib.tvm_lde_column_coefficients(h, 1, d_trace.ptr, n, n_cols, dom.c(), 0, n_cols, coeffs.ptr), "coefficients")
+    refused(ctx, lib.tvm_lde_column_coefficients(h, 1, d_trace.ptr, n, n_cols, dom.c(), 2, 2 ** 64 - 1, coeffs.ptr), "first + count wraps")
+
+    whole = C.c_void_p()
+    ctx._check(lib.tvm_lde_table(h, 1, d_trace.ptr, n, n_cols, d_rnd.ptr, hr, dom.c(), ev.c(), C.byref(whole)), "tvm_lde_table")
+    refused(ctx, lib.tvm_lde_table_add_columns(h, whole, coeffs.ptr, 0, n_cols, d_rnd.ptr, hr, dom.c(), ev.c()), "add_columns on a finished table")
+    refused(ctx, lib.tvm_lde_table_end(h, whole), "end on a table that begin did not make")
+
+    t = C.c_void_p()
+    ctx._check(lib.tvm_lde_table_begin(h, 1, n, n_cols, hr, dom.c(), ev.c(), C.byref(t)), "begin")
+    other_ev = ArithmeticDomain.of_length(4 * n).with_offset(field.mont_mul(field.generator(), field.generator()))
+    refused(ctx, lib.tvm_lde_table_add_columns(h, t, coeffs.ptr, 0, n_cols, d_rnd.ptr, hr, dom.c(), other_ev.c()), "another evaluation domain")
+    refused(ctx, lib.tvm_lde_table_add_columns(h, t, coeffs.ptr, 0, n_cols, d_rnd.ptr, hr + 1, dom.c(), ev.c()), "another randomizer count")
+    refused(ctx, lib.tvm_lde_table_add_columns(h, t, coeffs.ptr, 3, 2 ** 64 - 2, d_rnd.ptr, hr, dom.c(), ev.c()), "first + count wraps")
+    refused(ctx, lib.tvm_lde_table_add_columns(h, t, coeffs.ptr, 4, 2, d_rnd.ptr, hr, dom.c(), ev.c()), "columns beyond the table")
+    ctx._check(lib.tvm_lde_table_add_columns(h, t, coeffs.ptr, 0, 3, d_rnd.ptr, hr, dom.c(), ev.c()), "columns 0..2")
+    refused(ctx, lib.tvm_lde_table_end(h, t), "end with columns 3, 4 never written")
+    ctx._check(lib.tvm_lde_table_add_columns(h, t, coeffs.ptr + 8 * 3 * n, 3, 2, d_rnd.ptr, hr, dom.c(), ev.c()), "columns 3, 4")
+    ctx._check(lib.tvm_lde_table_end(h, t), "end")
+    refused(ctx, lib.tvm_lde_table_end(h, t), "end twice")
+    # ... and the assembled table is the whole one
+    out_a, out_b = ctx.alloc(4 * n * n_cols), ctx.alloc(4 * n * n_cols)
+    ctx._check(lib.tvm_table_export_row_major(h, t, out_a.ptr), "export")
+    ctx._check(lib.tvm_table_export_row_major(h, whole, out_b.ptr), "export")
+    assert (out_a.download() == out_b.download()).all()
+    lib.tvm_table_free(h, t)
+    lib.tvm_table_free(h, whole)

@@ -140,9 +140,10 @@ def _oracle_digests():
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", sorted(_oracle_digests()) or ["none"])
 def test_device_proof_hashes_to_the_oracle_provers_digest_at_2p16_to_2p18(orc, case):
-    """Whole-proof parity where the oracle prover takes minutes (tests/golden/make_oracle_proof_digests.py ran it on the CPU and
-    committed `Tip5::hash(proof)` + the proof's length): prove_fib at 2^16, 2^17 and 2^18 rows with FRI and at 2^16 rows with STIR (the
-    reference's default from there on).  The device proof of the same (program, input, prover seed) -- C++ host -- must hash to the
+    """Whole-proof parity where the oracle prover takes minutes to hours (tests/golden/make_oracle_proof_digests.py ran it on the CPU and
+    committed `Tip5::hash(proof)` + the proof's length): prove_fib at 2^16 ... 2^20 rows with FRI -- 2^20 is BASELINE configs[1], the
+    headline workload at full size: 1 h 53 min of oracle prover -- and at 2^16 rows with STIR (the reference's default from there on);
+    the u32, ram and sponge loops at 2^16 rows.  The device proof of the same (program, input, prover seed) -- C++ host -- must hash to the
     same digest: every word of the proof, at the heights whose extension runs the 256-, 512- and 1024-point row kernels of round 6."""
     if case == "none":
         pytest.skip("tests/golden/oracle_proof_digests.json has not been generated")

@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(TVM_HASH_BLOCK, 6) k_hash_rows_mfma(const u64*
             const int wi = perm * TIP5_RATE + q;
             if (q < TIP5_RATE) st[t3] = wi < W ? TVM_LOAD_STREAM(&base[(u64)wi * TVM_RB]) : (wi == W ? TVM_ONE : 0);  // padding: 1 then 0s
         }
-        tip5_permute_mfma(st, a, g, lut, ctab);
+        tip5_permute_mfma(st, a, g, lut, ctab, perm + 1 < n_perms);
     }
     if (live) {
         digests[r * 5 + g] = st[0];

@@ -289,7 +289,13 @@ TVM_D Tip5MfmaOperands tip5_mfma_matrix_operands(int lane) {
 //   z = s + EPS carries (c2):  result = (c | c2) ? z : s  -- the shape of bfe_add's tail.
 // The tail of the four words is one instruction stream, chain by chain (carries in VCC and seven SGPR pairs), so that
 // every carry consumer has at least two instructions between it and its producer (field.h: TVM_VCC_WAIT).
-TVM_D void tip5_mfma_recombine(const tvm_v4i (&d)[TIP5_MFMA_POSITIONS], u64 (&st)[4]) {
+// `lean` (uniform over the wavefront): the words v = 0, 1 are NOT owed -- the caller overwrites them (tip5_permute_mfma with rate_is_overwritten) --
+// so their multiply-add chains are skipped (18 instructions); the carry tail below stays the one four-chain block and turns
+// whatever it is given for them into values nobody reads.
+#ifndef TVM_TIP5_LEAN_ROUND
+#define TVM_TIP5_LEAN_ROUND 1   // 0: the last round recombines the rate words all the same (A/B: profiles/r06_n_*, 43.0-43.3 against 43.4-43.6 ms)
+#endif
+TVM_D void tip5_mfma_recombine(const tvm_v4i (&d)[TIP5_MFMA_POSITIONS], u64 (&st)[4], bool lean = false) {
     u64 t[4];
     u32 pl[4];
     // the shifts as multiplications by values the compiler cannot see through (it would widen every term into a register
@@ -300,6 +306,11 @@ TVM_D void tip5_mfma_recombine(const tvm_v4i (&d)[TIP5_MFMA_POSITIONS], u64 (&st
 #endif
 #pragma unroll
     for (int v = 0; v < 4; v++) {
+        if (v < 2 && lean) {   // (any defined value will do)
+            t[v] = (u64)(u32)d[0][v];
+            pl[v] = (u32)d[4][v];
+            continue;
+        }
         u64 p0 = (u64)(u32)d[1][v] * w8;
         p0 += (u64)(u32)d[2][v] * w16;
         p0 += (u64)(u32)d[3][v] * w24;
@@ -368,7 +379,10 @@ TVM_D void tip5_mfma_recombine(const tvm_v4i (&d)[TIP5_MFMA_POSITIONS], u64 (&st
 //
 // st[t] = word g + 4t of the state of permutation n; every lane of the wavefront must take part.  `lut` is the S-box table
 // LOWERED by 128 (tip5_stage_lut_lowered): the looked-up word goes to the matrix cores only, where bytes travel that way.
-TVM_D void tip5_permute_mfma(u64 (&st)[4], const Tip5MfmaOperands& m, int g, const unsigned char* lut, const int* ctab) {
+// `rate_is_overwritten` (uniform): the caller absorbs the next block in overwrite mode right after this permutation, i.e. replaces the
+// words 0 .. 9 -- st[0], st[1] of every lane and st[2] of the lanes g < 2 -- so the last round need not produce st[0], st[1].
+TVM_D void tip5_permute_mfma(u64 (&st)[4], const Tip5MfmaOperands& m, int g, const unsigned char* lut, const int* ctab,
+                             bool rate_is_overwritten = false) {
     for (int r = 0; r < TIP5_ROUNDS; r++) {
         // accumulator inputs first: their LDS latency hides behind the S-box layer
         tvm_v4i d[TIP5_MFMA_POSITIONS];
@@ -394,6 +408,6 @@ TVM_D void tip5_permute_mfma(u64 (&st)[4], const Tip5MfmaOperands& m, int g, con
         for (int s = 0; s < TIP5_MFMA_SHIFTS; s++) d[s] = TVM_MFMA_I8(m.a[s], lo, d[s]);
 #pragma unroll
         for (int s = 0; s < TIP5_MFMA_SHIFTS; s++) d[s + 4] = TVM_MFMA_I8(m.a[s], hi, d[s + 4]);
-        tip5_mfma_recombine(d, st);
+        tip5_mfma_recombine(d, st, TVM_TIP5_LEAN_ROUND && rate_is_overwritten && r + 1 == TIP5_ROUNDS);
     }
 }

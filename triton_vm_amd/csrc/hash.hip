@@ -20,6 +20,9 @@ namespace tvm {
 #ifndef TVM_HASH_BLOCK
 #define TVM_HASH_BLOCK 256
 #endif
+#ifndef TVM_HASH_SPLIT_ABSORB
+#define TVM_HASH_SPLIT_ABSORB 1   // 0: one loop over all blocks with the padding logic in every one (A/B, profiles/r06_o_*: proof 182.3 -> 180.1-180.5 ms on one box)
+#endif
 
 // digests[r] = Tip5::hash_varlen(domain row r*stride of the table), W words per row, with the permutation's MDS layer on
 // the matrix cores (tip5_permute_mfma): four lanes per row, sixteen rows per wavefront.  Lane (n, g) absorbs the
@@ -42,6 +45,26 @@ __global__ void __launch_bounds__(TVM_HASH_BLOCK, 6) k_hash_rows_mfma(const u64*
     const u64* base = table + (row >> TVM_RB_LOG) * (u64)W * TVM_RB + (row & (TVM_RB - 1));
     const Tip5MfmaOperands a = tip5_mfma_matrix_operands(lane);
     u64 st[4] = {0, 0, 0, 0};
+#if TVM_HASH_SPLIT_ABSORB
+    // The W / 10 FULL blocks of a row need no padding logic: the lane's words g, g + 4 (, g + 8) at fixed offsets from a pointer that
+    // advances by a block (round 6: the compares and selects of the general form were 18 of the 22 VALU instructions a permutation
+    // spends outside its rounds); the last block -- W % 10 words, then the padding 1, 0, ... -- keeps the general form.
+    const int n_full = W / TIP5_RATE;
+    const u64* p = base + (u64)g * TVM_RB;
+    for (int perm = 0; perm < n_full; perm++) {
+        st[0] = TVM_LOAD_STREAM(p);
+        st[1] = TVM_LOAD_STREAM(p + 4 * TVM_RB);
+        if (g < 2) st[2] = TVM_LOAD_STREAM(p + 8 * TVM_RB);
+        p += TIP5_RATE * TVM_RB;
+        tip5_permute_mfma(st, a, g, lut, ctab, true);   // (a block always follows: the one with the padding)
+    }
+#pragma unroll
+    for (int t3 = 0; t3 < 3; t3++) {
+        const int q = g + 4 * t3, wi = n_full * TIP5_RATE + q;
+        if (q < TIP5_RATE) st[t3] = wi < W ? TVM_LOAD_STREAM(&base[(u64)wi * TVM_RB]) : (wi == W ? TVM_ONE : 0);  // padding: 1 then 0s
+    }
+    tip5_permute_mfma(st, a, g, lut, ctab, false);
+#else
     const int n_perms = W / TIP5_RATE + 1;
     for (int perm = 0; perm < n_perms; perm++) {
 #pragma unroll
@@ -52,6 +75,7 @@ __global__ void __launch_bounds__(TVM_HASH_BLOCK, 6) k_hash_rows_mfma(const u64*
         }
         tip5_permute_mfma(st, a, g, lut, ctab, perm + 1 < n_perms);
     }
+#endif
     if (live) {
         digests[r * 5 + g] = st[0];
         if (g == 0) digests[r * 5 + 4] = st[1];

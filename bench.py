@@ -642,6 +642,8 @@ def main():
     ap.add_argument("--column-split", type=int, default=0, help="sharded proof (--gpus N > 1, --simulate-gpus N): split the inverse transforms of the "
                     "table extensions by columns over the ranks and exchange the coefficients in this many chunks per table "
                     "(TVMH_OPTION_COLUMN_SPLIT; north_star's column sharding where it applies) instead of replicating them")
+    ap.add_argument("--air-fork", type=int, default=-1, help="TVM_OPTION_AIR_FORK_MAX_WORKGROUPS for the run (A/B; -1: the library's default, 256; "
+                    "0: the parts of the AIR never run side by side)")
     ap.add_argument("--host", choices=["cpp", "python"], default="cpp",
                     help="host side that sequences the C-ABI calls of the timed step: the C++ mirror of Prover::prove "
                          "(triton_vm_amd/host/, the default where it applies: cached tables, one proof per GPU) or the "
@@ -673,6 +675,8 @@ def main():
     from triton_vm_amd.prover import Prover, StarkParameters, stark_parameters
 
     ctx = make_context(local_rank)
+    if args.air_fork >= 0:
+        ctx.air_fork_max_workgroups(args.air_fork)
     sharded = (world > 1 or args.sharded) and not args.replicas
     coset_wise = bool(args.jit_passes or args.memory_policy)   # the C++ host's sharded entry with no communicator
     ldt = None if args.ldt == "auto" else args.ldt

@@ -78,6 +78,10 @@ int32_t tvm_ctx_trim(tvm_ctx* ctx);
 /* TVM_OPTION_LDE_PASS2_TILES = 1: the middle pass of tvm_lde_table on 2048-point axes (2^21 / 2^22 rows) runs the position-major tile
  * kernel (k_lde_pass2_v3) instead of k_lde_pass2_fused (and the generic kernel on 1024-point axes): the A/B switch of profiles/r05_*. */
 #define TVM_OPTION_LDE_PASS2_TILES 4
+/* TVM_OPTION_AIR_FORK_MAX_WORKGROUPS (default 256; 0 = never): tvm_all_quotients_combined / tvm_air_class_values on a quotient domain of at
+ * most this many workgroups of 256 rows launch the parts of the AIR on four streams side by side (the context's and three of its
+ * own, joined before the call returns to the context's stream), and on such a domain valid-trace mode evaluates row by row. */
+#define TVM_OPTION_AIR_FORK_MAX_WORKGROUPS 5
 int32_t tvm_ctx_set_option(tvm_ctx* ctx, int32_t option, uint64_t value);
 /* Cap on the bytes this context may hold through tvm_malloc / table handles (0 = no cap).  Requests beyond it fail
  * with TVM_ERR_OUT_OF_MEMORY exactly like a full device: the knob a host uses to share a GPU, and what the tests use to
@@ -430,6 +434,11 @@ void tvm_host_stdrng_elements(const uint8_t seed[32], uint64_t n, uint64_t* out)
 /* the same n elements into device memory, generated on the device (one ChaCha block per work-item); when a draw takes the
  * range sampler's rare short path the stream is regenerated sequentially on the host -- the result is always the host's */
 int32_t tvm_stdrng_elements(tvm_ctx* ctx, const uint8_t seed[32], uint64_t n, uint64_t* d_out);
+/* n_streams generators at once: stream s is `StdRng::from_seed(seed + s)` (the 256-bit little-endian sum: rng_from_offset_seed,
+ * master_table.rs:630-662 -- a table's trace randomizers, one stream per column, master_table.rs:423-434), per_stream draws
+ * each, d_out[s * per_stream + i].  One launch; the same rare-short-path rule as tvm_stdrng_elements (then every stream is drawn
+ * on the host).  Replaces 1.3 ms of sequential ChaCha on the host per proof (470 streams at 198 randomizers). */
+int32_t tvm_stdrng_streams(tvm_ctx* ctx, const uint8_t seed[32], uint64_t n_streams, uint64_t per_stream, uint64_t* d_out);
 
 /* The RAM table's Bezout coefficient polynomials: bezout_coefficient_polynomials_coefficients (table/ram.rs:152-207) for n
  * pairwise distinct roots (the unique RAM pointers, device array): a and b with a * rp + b * rp' = 1, rp = prod (X - r_i),

@@ -128,7 +128,9 @@ def test_sampled_quotient_rows_small(ctx, orc, log_n, log_ldt_expansion):
     check_sampled_quotient_rows(ctx, orc, log_n, log_ldt_expansion, 3, synthetic=False, n_random=64)
 
 
-def _quotient(ctx, orc, main_trace, aux_trace, h, seed, ch=None, valid_mode=False):
+def _quotient(ctx, orc, main_trace, aux_trace, h, seed, ch=None, valid_mode=False, fork=0):
+    """fork: TVM_OPTION_AIR_FORK_MAX_WORKGROUPS for the call -- 0 keeps the parts on one stream and lets valid-trace mode split
+    these short domains (the library's default, 256, would evaluate them row by row on the fork lanes)"""
     rng = np.random.default_rng(seed)
     n = main_trace.shape[1]
     g = field.generator()
@@ -141,10 +143,12 @@ def _quotient(ctx, orc, main_trace, aux_trace, h, seed, ch=None, valid_mode=Fals
     challenges = orc.random_elements(rng, (63, 3)) if ch is None else ch
     weights = orc.random_elements(rng, (604, 3))
     ctx.assume_valid_trace(valid_mode)
+    ctx.air_fork_max_workgroups(fork)
     try:
         got = stark.all_quotients_combined(ctx, main, aux, trace_dom, quot, challenges, weights).download((len(quot), 3))
     finally:
         ctx.assume_valid_trace(False)
+        ctx.air_fork_max_workgroups(256)
     want = orc.quotients_combined(main.low_degree_extended_table(), aux.low_degree_extended_table(), odom(orc, trace_dom),
                                   odom(orc, quot), challenges, weights)
     return got, want, quot
@@ -162,6 +166,33 @@ def test_valid_trace_mode_is_exact_on_a_valid_trace(ctx, orc):
     assert (got == want).all()
     coeffs = quot.interpolate(ctx, ctx.to_device(got), 3).download((len(quot), 3))
     assert not coeffs[4 * (256 + h):].any() and coeffs[:4 * 256].any()
+
+
+def test_forked_parts_give_the_same_words(ctx, orc):
+    """The parts of the AIR on four streams, one accumulator per lane, summed by the scatter (the default on short quotient domains)
+    against the parts one behind another on the context's stream: the same codeword, and the oracle's.  In valid-trace mode a
+    domain short enough to fork is evaluated row by row: exact on ANY trace, so the random tables below come out as the oracle's."""
+    rng = np.random.default_rng(21)
+    n, h = 16, 3
+    main_trace, aux_trace = orc.random_elements(rng, (379, n)), orc.random_elements(rng, (91, n, 3))
+    serial, want, _ = _quotient(ctx, orc, main_trace, aux_trace, h, 5, fork=0)
+    forked, _, _ = _quotient(ctx, orc, main_trace, aux_trace, h, 5, fork=256)
+    assert (serial == want).all() and (forked == want).all()
+    forked_valid, _, _ = _quotient(ctx, orc, main_trace, aux_trace, h, 5, valid_mode=True, fork=256)
+    assert (forked_valid == want).all()
+
+
+@pytest.mark.gpu
+def test_valid_trace_classes_on_the_fork_lanes(ctx, orc):
+    """Valid-trace mode whose class evaluations fork: the quotient domain of the 256-row trace is 8 workgroups -- above a limit of 4
+    it is split into the classes, whose half / quarter / single-coset domains (4 / 2 / 1 workgroups) run their parts side by side."""
+    if ctx.kind != "gpu":
+        pytest.skip("several 256-row workgroups: runs on the MI355X")
+    from tests import vm_fixture as vf
+
+    main_trace, aux_trace, ch, _ = vf.valid_tables("tiny")
+    got, want, _ = _quotient(ctx, orc, main_trace, aux_trace, 5, 3, ch=ch, valid_mode=True, fork=4)
+    assert (got == want).all()
 
 
 def test_valid_trace_mode_changes_only_interpolated_rows_of_an_invalid_trace(ctx, orc):

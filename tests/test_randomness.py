@@ -22,6 +22,23 @@ def test_stdrng_elements_host_and_device_equal_the_oracle_stream(ctx, orc, n):
     assert (got[1:n + 1] == want).all() and got[0] == 77 and got[n + 1] == 77     # nothing outside the n elements
 
 
+@pytest.mark.parametrize("n_streams,per_stream,seed", [
+    (1, 5, bytes(range(32))), (7, 198, bytes(range(32))), (3, 594, bytes(range(50, 82))),
+    (5, 9, bytes([255]) * 8 + bytes(24)),      # the stream number carries out of the first 64 bits of the seed
+    (4, 4, bytes([254]) + bytes([255]) * 31)])  # ... and wraps around 2^256 (offset_rng_seed: wrapping)
+def test_stdrng_streams_are_the_offset_seed_streams(ctx, n_streams, per_stream, seed):
+    """tvm_stdrng_streams: stream s = StdRng::from_seed(seed + s), i.e. a table's trace randomizers column by column
+    (master_table.rs:423-434 with rng_from_offset_seed, master_table.rs:630-662), in one launch"""
+    d = ctx.alloc(n_streams * per_stream + 2)
+    d.upload(np.full(n_streams * per_stream + 2, 77, np.uint64))
+    ctx._check(ctx.lib.tvm_stdrng_streams(ctx.handle, seed, n_streams, per_stream, d.ptr + 8), "tvm_stdrng_streams")
+    got = d.download()
+    assert got[0] == 77 and got[-1] == 77
+    for s in range(n_streams):
+        want = R.random_elements(ctx.lib, R.offset_rng_seed(seed, s), per_stream)
+        assert (got[1 + s * per_stream:1 + (s + 1) * per_stream] == want).all()
+
+
 def test_offset_rng_seed_carries_across_the_whole_seed():
     from oracle import real_prover
 

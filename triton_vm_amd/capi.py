@@ -142,6 +142,7 @@ _SIGNATURES = {
     "tvm_host_xfe_poly_eval": (None, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p]),
     "tvm_host_stdrng_elements": (None, [C.c_char_p, C.c_uint64, C.c_void_p]),
     "tvm_stdrng_elements": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p]),
+    "tvm_stdrng_streams": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_void_p]),
     "tvm_bezout_coefficients": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "tvm_host_air_constraints": (C.c_int32, [C.c_void_p] * 6),
 }
@@ -256,6 +257,11 @@ class Context:
         """TVM_OPTION_AIR_VALID_TRACE: the tables come from a valid execution -- the quotient evaluation may use the
         degree bounds of the constraint quotients (half the rows + interpolation; identical on valid traces)"""
         self._check(self.lib.tvm_ctx_set_option(self.handle, 1, 1 if on else 0), "tvm_ctx_set_option")
+
+    def air_fork_max_workgroups(self, n=256):
+        """TVM_OPTION_AIR_FORK_MAX_WORKGROUPS: quotient domains of at most n workgroups of 256 rows run the parts of the AIR on
+        four streams side by side, and valid-trace mode evaluates them row by row (0: never; the library's default is 256)"""
+        self._check(self.lib.tvm_ctx_set_option(self.handle, 5, n), "tvm_ctx_set_option")
 
     def trim(self):
         """give the cached device blocks back to the driver"""

@@ -84,7 +84,9 @@ __global__ void __launch_bounds__(256) k_zerofier_inverses(ZerofierArgs a) {
 }
 
 // the quotient values from the work order of the parts into the order of the domain: out[index(t)] (+)= acc[t]
-__global__ void __launch_bounds__(256) k_air_scatter(AirArgs a, const u64* __restrict__ acc, u64* __restrict__ out, int accumulate) {
+// (n_acc accumulators 3 * q_len words apart: the parts of a forked evaluation -- all_quotients_combined below -- add into one
+// accumulator per lane; field addition is exact, the sum does not depend on how the parts were grouped)
+__global__ void __launch_bounds__(256) k_air_scatter(AirArgs a, const u64* __restrict__ acc, int n_acc, u64* __restrict__ out, int accumulate) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.q_len) return;
     bool active;
@@ -93,14 +95,19 @@ __global__ void __launch_bounds__(256) k_air_scatter(AirArgs a, const u64* __res
     air_locate(a, t / AIR_BLOCK, (int)(t % AIR_BLOCK), tt, active, s_base, rel, index);
     u64* o = out + 3 * index;
     const u64* v = acc + 3 * t;
+    u64 v0 = v[0], v1 = v[1], v2 = v[2];
+    for (int k = 1; k < n_acc; k++) {
+        v += 3 * a.q_len;
+        v0 = bfe_add(v0, v[0]), v1 = bfe_add(v1, v[1]), v2 = bfe_add(v2, v[2]);
+    }
     if (accumulate) {
-        o[0] = bfe_add(o[0], v[0]);
-        o[1] = bfe_add(o[1], v[1]);
-        o[2] = bfe_add(o[2], v[2]);
+        o[0] = bfe_add(o[0], v0);
+        o[1] = bfe_add(o[1], v1);
+        o[2] = bfe_add(o[2], v2);
     } else {
-        o[0] = v[0];
-        o[1] = v[1];
-        o[2] = v[2];
+        o[0] = v0;
+        o[1] = v1;
+        o[2] = v2;
     }
 }
 
@@ -109,7 +116,7 @@ __global__ void __launch_bounds__(256) k_air_scatter(AirArgs a, const u64* __res
 // (block j1, coset kq) pairs -- in the work order 16 consecutive values per pair, 384 bytes -- and writes, for each j2, the 128
 // pairs as 128 CONSECUTIVE domain rows (runs of eight when the quotient domain has more than eight cosets).
 #define AIR_SCATTER_PAIRS 128
-__global__ void __launch_bounds__(256) k_air_scatter_tiles(AirArgs a, const u64* __restrict__ acc, u64* __restrict__ out, int accumulate) {
+__global__ void __launch_bounds__(256) k_air_scatter_tiles(AirArgs a, const u64* __restrict__ acc, int n_acc, u64* __restrict__ out, int accumulate) {
     constexpr int WPB_LOG = TVM_AIR_BLOCK_LOG - 6;
     constexpr int RS = 3 * AIR_SCATTER_PAIRS + 1;
     __shared__ u64 so[16 * RS];
@@ -128,7 +135,13 @@ __global__ void __launch_bounds__(256) k_air_scatter_tiles(AirArgs a, const u64*
         const u64 block = (kq << log_tiles) + ((j2 >> 6) << log_groups) + (j1 >> WPB_LOG);   // air_locate, inverted
         const u64 t = block * AIR_BLOCK + ((j1 & ((1 << WPB_LOG) - 1)) << 6) + (j2 & 63);
         u64* d = so + p * RS + 3 * pair;
-        d[0] = acc[3 * t], d[1] = acc[3 * t + 1], d[2] = acc[3 * t + 2];
+        const u64* v = acc + 3 * t;
+        u64 v0 = v[0], v1 = v[1], v2 = v[2];
+        for (int k = 1; k < n_acc; k++) {
+            v += 3 * a.q_len;
+            v0 = bfe_add(v0, v[0]), v1 = bfe_add(v1, v[1]), v2 = bfe_add(v2, v[2]);
+        }
+        d[0] = v0, d[1] = v1, d[2] = v2;
     }
     __syncthreads();
     for (int e = tid; e < 16 * 3 * AIR_SCATTER_PAIRS; e += 256) {
@@ -138,6 +151,29 @@ __global__ void __launch_bounds__(256) k_air_scatter_tiles(AirArgs a, const u64*
         u64* o = out + 3 * i + comp;
         *o = accumulate ? bfe_add(*o, so[pp * RS + word]) : so[pp * RS + word];
     }
+}
+
+bool air_parts_fork(const tvm_ctx* c, u64 q_len) { return (q_len + AIR_BLOCK - 1) / AIR_BLOCK <= c->air_fork_max_workgroups; }
+
+bool fork_lanes(tvm_ctx* c) {
+    if (c->fork_ready) return true;
+    int cur = -1;   // streams belong to the device that is current when they are created
+    if ((hipGetDevice(&cur) != hipSuccess || cur != c->device) && hipSetDevice(c->device) != hipSuccess) return false;
+    hipStream_t s[3] = {};
+    hipEvent_t e[4] = {};
+    bool ok = true;
+    for (int k = 0; k < 3 && ok; k++) ok = hipStreamCreateWithFlags(&s[k], hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < 4 && ok; k++) ok = hipEventCreateWithFlags(&e[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        for (hipStream_t x : s)
+            if (x) hipStreamDestroy(x);
+        for (hipEvent_t x : e)
+            if (x) hipEventDestroy(x);
+        return false;
+    }
+    for (int k = 0; k < 3; k++) c->fork[k] = s[k], c->fork_done[k] = e[k];
+    c->fork_ready = e[3];
+    return true;
 }
 
 int all_quotients_combined(tvm_ctx* c, const u64* main_table, const TabLayout& layout, u64 main_w, const u64* aux_table,
@@ -171,8 +207,20 @@ int all_quotients_combined(tvm_ctx* c, const u64* main_table, const TabLayout& l
     const u64 reach = a.tiled ? (WPB + 1) * layout.n1 + TVM_RB : layout.storage_rows() + layout.n1 + TVM_RB;  // rows a 32-bit lane offset must span
     if (reach * wider * 8 >= (1ull << 32))
         return set_error(c, TVM_ERR_UNSUPPORTED, "quotients: table shape beyond the 32-bit lane offsets of the AIR kernels");
+    // Fork: a part on a short quotient domain is a few workgroups that run for the latency of its ~1000 dependent multiplications
+    // (80-130 us) whatever their number; ten of them one behind the other are a millisecond of a proof that takes eight.  While one
+    // part leaves most of the chip empty (grid <= air_fork_max_workgroups) the selected parts go out on the context's stream and its
+    // three fork lanes, each lane adding into an accumulator of its own (longest part first, each to the lane with the least work so
+    // far: the multiplications per row of air_gen.h), and the scatter adds the accumulators.  Exact arithmetic: the same words.
+    static const int PART_COST[TVM_AIR_NUM_PARTS] = {126, 886, 1129, 1373, 1243, 1170, 834, 1434, 1452, 1211};
+    const dim3 grid((unsigned)((q_len + AIR_BLOCK - 1) / AIR_BLOCK));
+    int selected[TVM_AIR_NUM_PARTS], n_selected = 0;
+    for (int p = 0; p < TVM_AIR_NUM_PARTS; p++)
+        if (!part_select || (part_select >> TVM_AIR_PART_CLASS[p] & 1)) selected[n_selected++] = p;
+    int n_lanes = 1;
+    if (n_selected > 1 && air_parts_fork(c, q_len) && fork_lanes(c)) n_lanes = n_selected < 4 ? n_selected : 4;
     u64* zinv = (u64*)scratch(c, 14, (size_t)4 * q_len * sizeof(u64));
-    u64* acc = (u64*)scratch(c, 23, (size_t)3 * q_len * sizeof(u64));
+    u64* acc = (u64*)scratch(c, 23, (size_t)n_lanes * 3 * q_len * sizeof(u64));
     if (!zinv || !acc) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "zerofier inverses");
     a.challenges = d_challenges;
     a.weights = d_weights;
@@ -191,22 +239,45 @@ int all_quotients_combined(tvm_ctx* c, const u64* main_table, const TabLayout& l
         const u64 n_threads = (q_len + AIR_ZB - 1) / AIR_ZB;
         TVM_LAUNCH(k_zerofier_inverses, dim3((unsigned)((n_threads + 255) / 256)), dim3(256), 0, c->stream, z);
     }
-    const dim3 grid((unsigned)((q_len + AIR_BLOCK - 1) / AIR_BLOCK));
-    a.accumulate = 0;
-    bool any = false;
-    for (int p = 0; p < TVM_AIR_NUM_PARTS; p++) {
-        if (part_select && !(part_select >> TVM_AIR_PART_CLASS[p] & 1)) continue;
-        TVM_LAUNCH(TVM_AIR_PARTS[p], grid, dim3(AIR_BLOCK), 0, c->stream, a);
-        a.accumulate = 1;
-        any = true;
+    if (n_lanes == 1) {
+        a.accumulate = 0;
+        for (int s = 0; s < n_selected; s++) {
+            TVM_LAUNCH(TVM_AIR_PARTS[selected[s]], grid, dim3(AIR_BLOCK), 0, c->stream, a);
+            a.accumulate = 1;
+        }
+        if (!n_selected) TVM_HIP_CHECK(c, hipMemsetAsync(acc, 0, (size_t)3 * q_len * sizeof(u64), c->stream));
+    } else {
+        for (int i = 1; i < n_selected; i++)   // by cost, descending (insertion sort of at most ten)
+            for (int j = i; j > 0 && PART_COST[selected[j]] > PART_COST[selected[j - 1]]; j--) {
+                const int t = selected[j];
+                selected[j] = selected[j - 1];
+                selected[j - 1] = t;
+            }
+        int load[4] = {0, 0, 0, 0}, started[4] = {0, 0, 0, 0};
+        TVM_HIP_CHECK(c, hipEventRecord(c->fork_ready, c->stream));   // the tables, the challenges, the zerofier inverses
+        for (int l = 1; l < n_lanes; l++) TVM_HIP_CHECK(c, hipStreamWaitEvent(c->fork[l - 1], c->fork_ready, 0));
+        for (int s = 0; s < n_selected; s++) {
+            int l = 0;
+            for (int k = 1; k < n_lanes; k++)
+                if (load[k] < load[l]) l = k;
+            load[l] += PART_COST[selected[s]];
+            a.out = acc + (u64)l * 3 * q_len;
+            a.accumulate = started[l];
+            started[l] = 1;
+            TVM_LAUNCH(TVM_AIR_PARTS[selected[s]], grid, dim3(AIR_BLOCK), 0, l ? c->fork[l - 1] : c->stream, a);
+        }
+        a.out = acc;
+        for (int l = 1; l < n_lanes; l++) {
+            TVM_HIP_CHECK(c, hipEventRecord(c->fork_done[l - 1], c->fork[l - 1]));
+            TVM_HIP_CHECK(c, hipStreamWaitEvent(c->stream, c->fork_done[l - 1], 0));
+        }
     }
-    if (!any) TVM_HIP_CHECK(c, hipMemsetAsync(acc, 0, (size_t)3 * q_len * sizeof(u64), c->stream));
     const u64 cosets = q_len / trace_len;
     if (a.tiled && (1ull << a.log_n2) >= AIR_SCATTER_PAIRS / (cosets < 8 ? cosets : 8))
         TVM_LAUNCH(k_air_scatter_tiles, dim3((unsigned)(q_len / (16 * AIR_SCATTER_PAIRS))), dim3(256), 0, c->stream, a, (const u64*)acc,
-                   d_out, accumulate);
+                   n_lanes, d_out, accumulate);
     else
-        TVM_LAUNCH(k_air_scatter, dim3((unsigned)((q_len + 255) / 256)), dim3(256), 0, c->stream, a, (const u64*)acc, d_out, accumulate);
+        TVM_LAUNCH(k_air_scatter, dim3((unsigned)((q_len + 255) / 256)), dim3(256), 0, c->stream, a, (const u64*)acc, n_lanes, d_out, accumulate);
     TVM_HIP_CHECK(c, hipGetLastError());
     return TVM_OK;
 }

@@ -66,6 +66,14 @@ void tvm_ctx_destroy(tvm_ctx* c) {
         hipStreamDestroy(c->side);
     }
     if (c->side_ready) hipEventDestroy(c->side_ready);
+    for (hipStream_t s : c->fork)
+        if (s) {
+            hipStreamSynchronize(s);
+            hipStreamDestroy(s);
+        }
+    if (c->fork_ready) hipEventDestroy(c->fork_ready);
+    for (hipEvent_t e : c->fork_done)
+        if (e) hipEventDestroy(e);
     for (hipEvent_t e : c->side_done)
         if (e) hipEventDestroy(e);
     if (c->owns_stream) hipStreamDestroy(c->stream);
@@ -125,6 +133,10 @@ int32_t tvm_ctx_set_option(tvm_ctx* c, int32_t option, uint64_t value) {
     }
     if (option == TVM_OPTION_LDE_PASS2_TILES) {
         c->lde_pass2_tiles = value ? 1 : 0;
+        return TVM_OK;
+    }
+    if (option == TVM_OPTION_AIR_FORK_MAX_WORKGROUPS) {
+        c->air_fork_max_workgroups = value;
         return TVM_OK;
     }
     if (option == TVM_OPTION_MERKLE_MIN_WORKGROUPS) {
@@ -947,7 +959,8 @@ int32_t tvm_all_quotients_combined(tvm_ctx* c, const tvm_table* mt, const tvm_ta
     // there, and their coefficients added to the half-domain interpolant before the one evaluation on all points.
     const u64 m = mt->interpolant_len > at->interpolant_len ? mt->interpolant_len : at->interpolant_len;
     const u64 half = qd.length / 2, quarter = qd.length / 4;
-    const bool split = c->air_valid_trace && mt->interpolant_len && at->interpolant_len && half >= 2 * td.length && half % td.length == 0 &&
+    // (a quotient domain short enough for the parts to run side by side is evaluated row by row: air.hip, fork lanes)
+    const bool split = c->air_valid_trace && !tvm::air_parts_fork(c, qd.length) && mt->interpolant_len && at->interpolant_len && half >= 2 * td.length && half % td.length == 0 &&
                        4 * (m - 1) + 2 <= half + td.length && 3 * (m - 1) <= half && mt->rows % half == 0;
     if (!split)
         return all_quotients_combined(c, mt->data, mt->layout, (u64)mt->W, at->data, (u64)at->W, td.length, td.generator,
@@ -1454,9 +1467,19 @@ struct StdRngKey {
 // elements 4t .. 4t+3.  That is the host stream as long as every draw takes its second u64 -- it does unless the low
 // half of x * p is below 2^32 (probability 2^-32 per element); such a draw is reported in *short_draws and the caller
 // regenerates on the host, where the stream is consumed sequentially.
+// (streams: blockIdx.y = the stream; its key is the launch's key plus the stream number as 256-bit little-endian integers)
 __global__ void k_stdrng_elements(StdRngKey key, u64 n, u64* __restrict__ out, unsigned* __restrict__ short_draws) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (4 * t >= n) return;
+    if (blockIdx.y) {
+        u64 carry = blockIdx.y;
+        for (int i = 0; i < 8 && carry; i++) {
+            carry += key.w[i];
+            key.w[i] = (uint32_t)carry;
+            carry >>= 32;
+        }
+        out += (u64)blockIdx.y * n;
+    }
     uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
     for (int i = 0; i < 8; i++) s[4 + i] = key.w[i];
     s[12] = (uint32_t)t; s[13] = (uint32_t)(t >> 32); s[14] = 0; s[15] = 0;
@@ -1513,6 +1536,40 @@ int32_t tvm_stdrng_elements(tvm_ctx* c, const uint8_t seed[32], uint64_t n, uint
             rc = set_error(c, TVM_ERR_DEVICE, "stdrng elements (host path)");
     }
     return rc;
+}
+
+int32_t tvm_stdrng_streams(tvm_ctx* c, const uint8_t seed[32], uint64_t n_streams, uint64_t per_stream, uint64_t* d_out) {
+    if (!c || !seed || n_streams > 65535 || (n_streams && per_stream && !d_out))
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_stdrng_streams arguments");
+    if (!n_streams || !per_stream) return TVM_OK;
+    tvm::StdRngKey key;
+    for (int i = 0; i < 8; i++)
+        key.w[i] = (uint32_t)seed[4 * i] | ((uint32_t)seed[4 * i + 1] << 8) | ((uint32_t)seed[4 * i + 2] << 16) | ((uint32_t)seed[4 * i + 3] << 24);
+    tvm::PoolBlock flag(c, sizeof(unsigned));
+    unsigned* d_flag = (unsigned*)flag.p;
+    if (!d_flag) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "stdrng flag");
+    unsigned short_draws = 0;
+    TVM_HIP_CHECK(c, hipMemsetAsync(d_flag, 0, sizeof(unsigned), c->stream));
+    const u64 blocks = (per_stream + 3) / 4;
+    TVM_LAUNCH(tvm::k_stdrng_elements, dim3((unsigned)((blocks + 255) / 256), (unsigned)n_streams), dim3(256), 0, c->stream, key, per_stream, d_out, d_flag);
+    TVM_HIP_CHECK(c, hipMemcpyAsync(&short_draws, d_flag, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (short_draws) {  // a draw that took one u64 shifts the rest of its stream: every stream sequentially on the host
+        std::vector<uint64_t> host(n_streams * per_stream);
+        for (uint64_t st = 0; st < n_streams; st++) {
+            uint8_t sd[32];
+            uint64_t carry = st;
+            for (int k = 0; k < 32; k++) {
+                carry += seed[k];
+                sd[k] = (uint8_t)carry;
+                carry >>= 8;
+            }
+            tvm_host_stdrng_elements(sd, per_stream, host.data() + st * per_stream);
+        }
+        TVM_HIP_CHECK(c, hipMemcpyAsync(d_out, host.data(), host.size() * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+        TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    }
+    return TVM_OK;
 }
 }  // extern "C"
 

@@ -114,6 +114,12 @@ struct tvm_ctx {
     // the side lane (include/triton_hip.h: tvm_side_*): created on first use
     hipStream_t side = nullptr;
     hipEvent_t side_ready = nullptr, side_done[16] = {};
+    // the fork lanes (air.hip: all_quotients_combined): launches that are independent of one another and too small to fill the
+    // chip each -- the parts of the AIR on a short quotient domain -- go out on these streams beside the context's own and meet
+    // it again before the next dependent launch.  Created on first use.
+    hipStream_t fork[3] = {};
+    hipEvent_t fork_ready = nullptr, fork_done[3] = {};
+    u64 air_fork_max_workgroups = 256;                  // TVM_OPTION_AIR_FORK_MAX_WORKGROUPS (0 after set_option(…, 0): never fork)
 };
 
 namespace tvm {
@@ -134,7 +140,9 @@ int set_error(tvm_ctx* c, int code, const char* what);
 void* pool_alloc(tvm_ctx* c, size_t bytes);
 void pool_release(tvm_ctx* c, void* p);   // back to the cache (stream-ordered reuse)
 void pool_trim(tvm_ctx* c);               // cached blocks back to the driver (synchronises the stream)
-size_t pool_available(tvm_ctx* c, size_t* device_total);   // device free + own cache, capped by the context's limit
+size_t pool_available(tvm_ctx* c, size_t* device_total);
+// the context's fork lanes (three more streams and their events), created on first use; false if the driver refuses
+bool fork_lanes(tvm_ctx* c);   // device free + own cache, capped by the context's limit
 // a pool block that goes back to the cache on every exit path of the function that holds it
 struct PoolBlock {
     tvm_ctx* c;

@@ -59,6 +59,9 @@ int verifier_deep_values(tvm_ctx* c, const u64* d_main_rows, int n_main, const u
 int all_quotients_combined(tvm_ctx* c, const u64* main_table, const TabLayout& layout, u64 main_w, const u64* aux_table,
                            u64 aux_w, u64 trace_len, u64 trace_gen, u64 q_offset, u64 q_gen, u64 q_len, const u64* d_challenges,
                            const u64* d_weights, u64* d_out, int part_select = 0, int accumulate = 0);
+// a quotient domain this short leaves the chip to the parts side by side (the fork lanes): the row-by-row evaluation of all ten
+// parts then costs what its longest lane does, less than valid-trace mode's six evaluations and five transforms one behind another
+bool air_parts_fork(const tvm_ctx* c, u64 q_len);
 }  // namespace tvm
 
 struct tvm_table {

@@ -917,19 +917,21 @@ std::vector<u64> Stir::prove(const Context& c, const u64* d_codeword, ProofStrea
 
 // ------------------------------------------------------------------------------------------------ from an execution trace
 namespace {
-// TVMH_OPTION_TRACE: wall time of the steps of prove_execution on stderr (each step drains the stream first)
+// TVMH_OPTION_TRACE: wall time of the steps of prove_execution on stderr (1: each step drains the stream first; 2: it does not --
+// the host's own time per step, what a proof of a short trace is made of)
 struct Stopwatch {
     const Context& c;
-    const bool on = tvmh_get_option(TVMH_OPTION_TRACE) != 0;
+    const uint64_t mode = tvmh_get_option(TVMH_OPTION_TRACE);
+    const bool on = mode != 0;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), start = t0;
     ~Stopwatch() {
         if (on) std::fprintf(stderr, "[tvmh] %-28s %8.2f ms\n", "total", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - start).count());
     }
     void lap(const char* what) {
         if (!on) return;
-        (void)tvm_sync(c.raw());
+        if (mode == 1) (void)tvm_sync(c.raw());
         const auto t1 = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[tvmh] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        std::fprintf(stderr, "[tvmh] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
         t0 = t1;
     }
 };
@@ -975,30 +977,20 @@ DeviceBuffer upload(const Context& c, const std::vector<u64>& host) {
 ExecutionTables::ExecutionTables(const Context& c, const StarkParameters& p, const tvm_aet& aet, const uint8_t seed[32],
                                  const std::function<void(const char*)>& lap) {
     const u64 n = p.trace.length;
-    // the seeded randomness: offsets as in the table of master_table.rs:618-628.  The 470 trace-randomizer streams are
-    // sequential ChaCha streams (0.7 ms of host time at 198 randomizers): a helper thread draws them while the device fills
-    // and pads the main table.
+    // the seeded randomness: offsets as in the table of master_table.rs:618-628.  The 470 trace-randomizer streams are drawn on the
+    // device, one launch per table (tvm_stdrng_streams; round 6: they were 1.3 ms of sequential ChaCha on a helper thread, hidden
+    // behind fill + pad at 2^20 rows and the largest idle gap of a proof of a short trace)
     uint8_t aux_seed[32], batch_seed[32], quotient_seed[32];
     offset_rng_seed(seed, NUM_MAIN, aux_seed);
     offset_rng_seed(aux_seed, NUM_AUX, batch_seed);
     offset_rng_seed(seed, NUM_MAIN + NUM_AUX + 1, quotient_seed);
-    std::vector<u64> main_rnd_host, aux_rnd_host;
     quotient_randomizer.resize(p.num_quotient_randomizers);
-    std::exception_ptr draw_error;  // an exception on the helper thread (bad_alloc) is rethrown on this one
-    std::thread draws([&] {
-        try {
-            main_rnd_host = trace_randomizers_host(seed, NUM_MAIN, p.h, 1);
-            aux_rnd_host = trace_randomizers_host(aux_seed, NUM_AUX, p.h, 3);
-            if (!quotient_randomizer.empty())
-                tvm_host_stdrng_elements(quotient_seed, 3 * quotient_randomizer.size(), quotient_randomizer.data()->c);
-        } catch (...) {
-            draw_error = std::current_exception();
-        }
-    });
-    struct Join {
-        std::thread& t;
-        ~Join() { if (t.joinable()) t.join(); }
-    } join{draws};
+    if (!quotient_randomizer.empty()) tvm_host_stdrng_elements(quotient_seed, 3 * quotient_randomizer.size(), quotient_randomizer.data()->c);
+    main_rnd = DeviceBuffer(c, NUM_MAIN * p.h);
+    aux_rnd = DeviceBuffer(c, NUM_AUX * p.h * 3);
+    c.check(tvm_stdrng_streams(c.raw(), seed, NUM_MAIN, p.h, main_rnd.ptr()), "tvm_stdrng_streams");
+    c.check(tvm_stdrng_streams(c.raw(), aux_seed, NUM_AUX, 3 * p.h, aux_rnd.ptr()), "tvm_stdrng_streams");
+    lap("trace randomizers");
     // MasterMainTable::new + pad (master_table.rs:881-983)
     main_trace = DeviceBuffer(c, NUM_MAIN * n);
     u64 lengths[9];
@@ -1009,11 +1001,6 @@ ExecutionTables::ExecutionTables(const Context& c, const StarkParameters& p, con
     c.check(tvm_pad_main_table(c.raw(), main_trace.ptr(), n, lengths), "tvm_pad_main_table");
     c.check(tvm_fill_derived_main_columns(c.raw(), main_trace.ptr(), n), "tvm_fill_derived_main_columns");
     lap("pad + derived main columns");
-    draws.join();
-    if (draw_error) std::rethrow_exception(draw_error);
-    main_rnd = upload(c, main_rnd_host);
-    aux_rnd = upload(c, aux_rnd_host);
-    lap("trace randomizers");
     // MasterMainTable::extend (master_table.rs:1006-1075): the batch-randomizer column now, the rest once the challenges exist
     aux_trace = DeviceBuffer(c, NUM_AUX * n * 3);
     c.check(tvm_stdrng_elements(c.raw(), batch_seed, 3 * n, aux_trace.ptr() + (NUM_AUX - 1) * n * 3), "tvm_stdrng_elements");

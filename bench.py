@@ -644,6 +644,8 @@ def main():
                     "(TVMH_OPTION_COLUMN_SPLIT; north_star's column sharding where it applies) instead of replicating them")
     ap.add_argument("--air-fork", type=int, default=-1, help="TVM_OPTION_AIR_FORK_MAX_WORKGROUPS for the run (A/B; -1: the library's default, 256; "
                     "0: the parts of the AIR never run side by side)")
+    ap.add_argument("--host-trace", type=int, default=0, help="TVMH_OPTION_TRACE for the run: the C++ host's wall time per step of prove_execution on "
+                    "stderr (1: the stream drained at every step; 2: not drained -- the host's own time)")
     ap.add_argument("--host", choices=["cpp", "python"], default="cpp",
                     help="host side that sequences the C-ABI calls of the timed step: the C++ mirror of Prover::prove "
                          "(triton_vm_amd/host/, the default where it applies: cached tables, one proof per GPU) or the "
@@ -689,6 +691,8 @@ def main():
             host_lib = load_host_library()
         except Exception as e:  # no g++ on this machine: the Python mirror sequences the same C-ABI calls
             print(f"bench.py: C++ host library unavailable ({e}); timing the Python host", file=sys.stderr)
+    if host_lib is not None and args.host_trace:
+        host_lib.tvmh_set_option(native_host.OPTION_TRACE, args.host_trace)
     if sharded and host_lib is not None:
         host_lib.tvmh_set_option(native_host.OPTION_COLUMN_SPLIT, args.column_split)
         try:

@@ -220,6 +220,11 @@ int32_t tvm_xfe_linear_combination(tvm_ctx* ctx, const uint64_t* d_vectors, uint
 /* Polynomial::evaluate at XFE points (stark.rs:480,491,568,579,590,600): d_coeffs n XFE -> h_out n_points XFE */
 int32_t tvm_evaluate_at_points(tvm_ctx* ctx, const uint64_t* d_coeffs, uint64_t n, const uint64_t* h_points,
                                uint32_t n_points, uint64_t* h_out);
+/* The same for n_polys polynomials of n coefficients each, `stride` XFE apart in d_coeffs, at the same points, in ONE round trip:
+ * h_out[(p * n_points + j) * 3 ..] = polynomial p at point j (the five quotient-segment polynomials at the two out-of-domain
+ * points, stark.rs:474-495). */
+int32_t tvm_evaluate_polys_at_points(tvm_ctx* ctx, const uint64_t* d_coeffs, uint64_t n, uint64_t stride, uint32_t n_polys,
+                                     const uint64_t* h_points, uint32_t n_points, uint64_t* h_out);
 
 /* ---- degree-lowering fill (second half) ---------------------------------------
  * The generated DegreeLoweringTable::fill_derived_main_columns / fill_derived_aux_columns

@@ -107,6 +107,8 @@ static inline hipError_t hipMalloc(void** p, size_t n) {
     return *p ? hipSuccess : hipErrorOutOfMemory;
 }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }

@@ -50,6 +50,23 @@ def test_evaluate_at_points(ctx, orc, n):
         assert (got[p] == orc.poly_eval_xfe(co, pts[p])).all()
 
 
+@pytest.mark.parametrize("n,stride,n_polys", [(1, 1, 1), (5, 5, 5), (64, 70, 3), (1000, 1000, 5)])
+def test_evaluate_polys_at_points(ctx, orc, n, stride, n_polys):
+    """tvm_evaluate_polys_at_points: several polynomials (stride XFE apart) at the same points in one round trip -- the five
+    quotient-segment polynomials at the two out-of-domain points (stark.rs:474-495)"""
+    rng = np.random.default_rng(n + stride)
+    co = orc.random_elements(rng, (n_polys * stride, 3))
+    pts = orc.random_elements(rng, (2, 3))
+    d = ctx.to_device(co)
+    out = np.full((n_polys * 2 + 1, 3), 77, np.uint64)
+    ctx._check(ctx.lib.tvm_evaluate_polys_at_points(ctx.handle, d.ptr, n, stride, n_polys, pts.ctypes.data, 2, out.ctypes.data),
+               "tvm_evaluate_polys_at_points")
+    assert (out[-1] == 77).all()
+    for k in range(n_polys):
+        for j in range(2):
+            assert (out[2 * k + j] == orc.poly_eval_xfe(co[k * stride:k * stride + n], pts[j])).all()
+
+
 @pytest.mark.parametrize("log_q,log_ldt,n_rand", [(4, 4, 3), (5, 5, 8), (5, 7, 5), (6, 6, 16), (9, 11, 7), (8, 9, 100), (7, 5, 32)])
 def test_quotient_segments(ctx, orc, log_q, log_ldt, n_rand):
     rng = np.random.default_rng(log_q * 7 + log_ldt + n_rand)

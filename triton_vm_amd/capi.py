@@ -104,6 +104,7 @@ _SIGNATURES = {
     "tvm_xfe_add_assign": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "tvm_xfe_linear_combination": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "tvm_evaluate_at_points": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "tvm_evaluate_polys_at_points": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]),
     "tvm_fill_derived_main_columns": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "tvm_fill_derived_aux_columns": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "tvm_fill_main_table": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),

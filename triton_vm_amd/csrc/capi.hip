@@ -76,6 +76,7 @@ void tvm_ctx_destroy(tvm_ctx* c) {
         if (e) hipEventDestroy(e);
     for (hipEvent_t e : c->side_done)
         if (e) hipEventDestroy(e);
+    if (c->pin) hipHostFree(c->pin);
     if (c->owns_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -565,8 +566,7 @@ int32_t tvm_table_reveal_rows(tvm_ctx* c, const tvm_table* t, uint64_t ldt_lengt
     u64* d_idx = (u64*)scratch(c, 4, n * sizeof(u64));
     u64* d_out = (u64*)scratch(c, 5, n * t->W * sizeof(u64));
     if (!d_idx || !d_out) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "reveal scratch");
-    TVM_HIP_CHECK(c, hipMemcpyAsync(d_idx, idx.data(), n * sizeof(u64), hipMemcpyHostToDevice, c->stream));
-    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));  // idx is a local
+    TVM_TRY(h2d_small(c, d_idx, idx.data(), n * sizeof(u64)));   // (idx is a local)
     TVM_TRY(gather_rows(c, t->data, t->layout, t->W, d_idx, n, d_out));
     TVM_HIP_CHECK(c, hipMemcpyAsync(h_out, d_out, n * t->W * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
@@ -616,8 +616,7 @@ namespace tvm {
 static const u64* stage_small(tvm_ctx* c, int slot, const u64* h, size_t words) {
     u64* d = (u64*)scratch(c, slot, (words ? words : 1) * sizeof(u64));
     if (!d) return nullptr;
-    if (hipMemcpyAsync(d, h, words * sizeof(u64), hipMemcpyHostToDevice, c->stream) != hipSuccess) return nullptr;
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return nullptr;  // h may be a caller temporary
+    if (h2d_small(c, d, h, words * sizeof(u64)) != TVM_OK) return nullptr;   // (h may be a caller temporary)
     return d;
 }
 // coeffs[i + N * r] += sum_k w[3 * r + k] * q[k][i]  (r, k < 3; i < N; XFE vectors q, base-field weights w): the polynomial
@@ -747,6 +746,21 @@ int32_t tvm_evaluate_at_points(tvm_ctx* c, const uint64_t* d_coeffs, uint64_t n,
     return TVM_OK;
 }
 
+int32_t tvm_evaluate_polys_at_points(tvm_ctx* c, const uint64_t* d_coeffs, uint64_t n, uint64_t stride, uint32_t n_polys,
+                                     const uint64_t* h_points, uint32_t n_points, uint64_t* h_out) {
+    if (!c || (n && !d_coeffs) || !h_points || !h_out || !n_points || !n_polys || n_polys > 64 || stride < n)
+        return set_error(c, TVM_ERR_INVALID_ARGUMENT, "evaluate_polys_at_points arguments");
+    const u64* d_points = stage_small(c, 9, h_points, 3 * (size_t)n_points);
+    u64* d_out = (u64*)scratch(c, 10, (size_t)n_polys * n_points * 3 * sizeof(u64));
+    if (!d_points || !d_out) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "points staging");
+    // (the partial sums of poly_eval share one scratch slot: the evaluations follow one another on the stream)
+    for (uint32_t p = 0; p < n_polys; p++)
+        TVM_TRY(poly_eval(c, n ? d_coeffs + (u64)p * stride * 3 : d_coeffs, n, d_points, (int)n_points, d_out + (size_t)p * n_points * 3));
+    TVM_HIP_CHECK(c, hipMemcpyAsync(h_out, d_out, (size_t)n_polys * n_points * 3 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return TVM_OK;
+}
+
 int32_t tvm_quotient_segments(tvm_ctx* c, const uint64_t* d_cw, tvm_domain qd, tvm_domain ldt, const uint64_t* h_rnd,
                               uint64_t n_rand, uint64_t zeta, tvm_table** out_table, uint64_t* d_polys, uint64_t poly_len) {
     if (!c || !out_table) return TVM_ERR_INVALID_ARGUMENT;
@@ -853,8 +867,7 @@ int32_t tvm_fri_commit_phase(tvm_ctx* c, const uint64_t* d_cw, tvm_domain dom, u
     u64* d = (u64*)scratch(c, 24, n_words * sizeof(u64));
     if (!d) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "fri_commit_phase scratch");
     u64 *d_state = d, *d_roots = d + 16, *d_ch = d_roots + (size_t)(n_rounds + 1) * 5;
-    TVM_HIP_CHECK(c, hipMemcpyAsync(d_state, h_state, 16 * sizeof(u64), hipMemcpyHostToDevice, c->stream));
-    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));  // h_state may be a caller temporary
+    TVM_TRY(tvm::h2d_small(c, d_state, h_state, 16 * sizeof(u64)));   // (h_state may be a caller temporary)
     const u64* cw = d_cw;
     u64 offset = dom.offset, gen = dom.generator, n = dom.length;
     for (uint32_t r = 0; r <= n_rounds; r++) {
@@ -894,8 +907,7 @@ int32_t tvm_fill_derived_aux_columns(tvm_ctx* c, const uint64_t* d_main_trace, u
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_fill_derived_aux_columns arguments");
     u64* staged = (u64*)scratch(c, 20, (size_t)3 * TVM_NUM_CHALLENGES * sizeof(u64));
     if (!staged) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "challenge staging");
-    TVM_HIP_CHECK(c, hipMemcpyAsync(staged, h_challenges, 3 * TVM_NUM_CHALLENGES * sizeof(u64), hipMemcpyHostToDevice, c->stream));
-    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));  // h_challenges may be a caller temporary
+    TVM_TRY(tvm::h2d_small(c, staged, h_challenges, 3 * TVM_NUM_CHALLENGES * sizeof(u64)));   // (h_challenges may be a caller temporary)
     return fill_degree_lowering(c, 1, const_cast<u64*>(d_main_trace), d_aux_trace, staged, n_rows);
 }
 
@@ -921,8 +933,7 @@ int32_t tvm_extend_aux_table(tvm_ctx* c, const uint64_t* d_main_trace, uint64_t*
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "tvm_extend_aux_table arguments");
     u64* staged = (u64*)scratch(c, 21, (size_t)3 * TVM_NUM_CHALLENGES * sizeof(u64));
     if (!staged) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "challenge staging");
-    TVM_HIP_CHECK(c, hipMemcpyAsync(staged, h_challenges, 3 * TVM_NUM_CHALLENGES * sizeof(u64), hipMemcpyHostToDevice, c->stream));
-    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));  // h_challenges may be a caller temporary
+    TVM_TRY(tvm::h2d_small(c, staged, h_challenges, 3 * TVM_NUM_CHALLENGES * sizeof(u64)));   // (h_challenges may be a caller temporary)
     return extend_aux_table(c, d_main_trace, d_aux_trace, staged, n_rows);
 }
 
@@ -937,10 +948,8 @@ int32_t tvm_all_quotients_combined(tvm_ctx* c, const tvm_table* mt, const tvm_ta
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "all_quotients_combined: tables must be 379 BFE / 91 XFE columns wide, made by tvm_lde_table over one domain");
     u64* staged = (u64*)scratch(c, 13, (size_t)3 * (TVM_NUM_CHALLENGES + TVM_NUM_QUOTIENT_WEIGHTS) * sizeof(u64));
     if (!staged) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "challenge staging");
-    TVM_HIP_CHECK(c, hipMemcpyAsync(staged, h_challenges, 3 * TVM_NUM_CHALLENGES * sizeof(u64), hipMemcpyHostToDevice, c->stream));
-    TVM_HIP_CHECK(c, hipMemcpyAsync(staged + 3 * TVM_NUM_CHALLENGES, h_weights, 3 * TVM_NUM_QUOTIENT_WEIGHTS * sizeof(u64),
-                                    hipMemcpyHostToDevice, c->stream));
-    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    TVM_TRY(tvm::h2d_small(c, staged, h_challenges, 3 * TVM_NUM_CHALLENGES * sizeof(u64)));
+    TVM_TRY(tvm::h2d_small(c, staged + 3 * TVM_NUM_CHALLENGES, h_weights, 3 * TVM_NUM_QUOTIENT_WEIGHTS * sizeof(u64)));
     const u64* d_ch = staged;
     const u64* d_w = staged + 3 * TVM_NUM_CHALLENGES;
     // Valid-trace mode (tvm_ctx_set_option TVM_OPTION_AIR_VALID_TRACE; off by default).  Every column is a polynomial with at most m = interpolant_len coefficients, every constraint has degree
@@ -1076,10 +1085,8 @@ int32_t tvm_air_class_values(tvm_ctx* c, const tvm_table* mt, const tvm_table* a
         return set_error(c, TVM_ERR_INVALID_ARGUMENT, "air_class_values: tables made by tvm_lde_table over table_domain, one coset of them");
     u64* staged = (u64*)scratch(c, 13, (size_t)3 * (TVM_NUM_CHALLENGES + TVM_NUM_QUOTIENT_WEIGHTS) * sizeof(u64));
     if (!staged) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "challenge staging");
-    TVM_HIP_CHECK(c, hipMemcpyAsync(staged, h_challenges, 3 * TVM_NUM_CHALLENGES * sizeof(u64), hipMemcpyHostToDevice, c->stream));
-    TVM_HIP_CHECK(c, hipMemcpyAsync(staged + 3 * TVM_NUM_CHALLENGES, h_weights, 3 * TVM_NUM_QUOTIENT_WEIGHTS * sizeof(u64),
-                                    hipMemcpyHostToDevice, c->stream));
-    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    TVM_TRY(tvm::h2d_small(c, staged, h_challenges, 3 * TVM_NUM_CHALLENGES * sizeof(u64)));
+    TVM_TRY(tvm::h2d_small(c, staged + 3 * TVM_NUM_CHALLENGES, h_weights, 3 * TVM_NUM_QUOTIENT_WEIGHTS * sizeof(u64)));
     const u64 X = table_dom.length / N;
     const u64 gamma = bfe_mul(table_dom.offset, bfe_pow(table_dom.generator, coset));
     TabLayout lm = mt->layout;   // the one coset of the tables: a table of its own (the layout is coset-major, context.h)
@@ -1163,10 +1170,8 @@ int32_t tvm_stir_next_polynomial(tvm_ctx* c, const uint64_t* d_folded_poly, uint
     u64* staged = (u64*)scratch(c, 16, (size_t)(k ? k : 1) * 6 * sizeof(u64));
     if (!vals || !staged) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "stir scratch");
     if (k) {
-        TVM_HIP_CHECK(c, hipMemcpyAsync(staged, h_quotient_set, (size_t)k * 3 * sizeof(u64), hipMemcpyHostToDevice, c->stream));
-        TVM_HIP_CHECK(c, hipMemcpyAsync(staged + 3 * (size_t)k, h_answer_poly, (size_t)k * 3 * sizeof(u64), hipMemcpyHostToDevice,
-                                        c->stream));
-        TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+        TVM_TRY(tvm::h2d_small(c, staged, h_quotient_set, (size_t)k * 3 * sizeof(u64)));
+        TVM_TRY(tvm::h2d_small(c, staged + 3 * (size_t)k, h_answer_poly, (size_t)k * 3 * sizeof(u64)));
     }
     TVM_TRY(tvm_evaluate(c, 3, d_folded_poly, n_coeffs, work_domain, vals));
     // Ans on the work domain by one zero-padded transform where that is cheaper than Horner at every point (k multiplications
@@ -1292,8 +1297,7 @@ int32_t tvm_gather_elements(tvm_ctx* c, const uint64_t* d_src, uint32_t elem_wor
     u64* d_idx = (u64*)scratch(c, 4, n * sizeof(u64));
     u64* d_out = (u64*)scratch(c, 5, n * elem_words * sizeof(u64));
     if (!d_idx || !d_out) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "gather scratch");
-    TVM_HIP_CHECK(c, hipMemcpyAsync(d_idx, h_idx, n * sizeof(u64), hipMemcpyHostToDevice, c->stream));
-    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    TVM_TRY(tvm::h2d_small(c, d_idx, h_idx, n * sizeof(u64)));
     const u64 total = n * elem_words;
     TVM_LAUNCH(tvm::k_gather_elements, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_src, elem_words,
                d_idx, n, d_out);
@@ -1323,8 +1327,7 @@ int32_t tvm_gather_elements_batch(tvm_ctx* c, uint32_t n_jobs, const uint64_t* c
     u64* d_idx = (u64*)scratch(c, 4, n_idx * sizeof(u64));
     u64* d_out = (u64*)scratch(c, 5, n_words * sizeof(u64));
     if (!d_idx || !d_out) return set_error(c, TVM_ERR_OUT_OF_MEMORY, "gather scratch");
-    TVM_HIP_CHECK(c, hipMemcpyAsync(d_idx, idx.data(), n_idx * sizeof(u64), hipMemcpyHostToDevice, c->stream));
-    TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    TVM_TRY(tvm::h2d_small(c, d_idx, idx.data(), n_idx * sizeof(u64)));
     u64 i0 = 0, w0 = 0;
     for (uint32_t j = 0; j < n_jobs; j++) {
         const u64 total = n[j] * elem_words[j];

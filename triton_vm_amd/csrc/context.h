@@ -114,6 +114,10 @@ struct tvm_ctx {
     // the side lane (include/triton_hip.h: tvm_side_*): created on first use
     hipStream_t side = nullptr;
     hipEvent_t side_ready = nullptr, side_done[16] = {};
+    // the staging ring (h2d_small): pinned host memory that small host arrays (points, weights, challenges, index lists) pass through
+    // on their way to the device, so that the copy is asynchronous AND the caller's array is free when the entry point returns
+    char* pin = nullptr;
+    size_t pin_bytes = 0, pin_head = 0;
     // the fork lanes (air.hip: all_quotients_combined): launches that are independent of one another and too small to fill the
     // chip each -- the parts of the AIR on a short quotient domain -- go out on these streams beside the context's own and meet
     // it again before the next dependent launch.  Created on first use.
@@ -141,6 +145,11 @@ void* pool_alloc(tvm_ctx* c, size_t bytes);
 void pool_release(tvm_ctx* c, void* p);   // back to the cache (stream-ordered reuse)
 void pool_trim(tvm_ctx* c);               // cached blocks back to the driver (synchronises the stream)
 size_t pool_available(tvm_ctx* c, size_t* device_total);
+// Host array -> device, stream-ordered, WITHOUT draining the stream: the bytes are copied into the context's pinned staging ring and
+// go from there (the caller's array may be a temporary: it is free on return).  The ring wraps after a stream synchronisation -- once
+// in some tens of proofs; arrays above a quarter of the ring take the plain path (copy, then wait).  Before round 6 every such hand-over
+// was hipMemcpyAsync + hipStreamSynchronize: some twenty drained streams per proof, a fifth of a proof of a 2^10-row trace.
+int h2d_small(tvm_ctx* c, void* d, const void* h, size_t bytes);
 // the context's fork lanes (three more streams and their events), created on first use; false if the driver refuses
 bool fork_lanes(tvm_ctx* c);   // device free + own cache, capped by the context's limit
 // a pool block that goes back to the cache on every exit path of the function that holds it

@@ -28,6 +28,7 @@
 // (field.h) keeps one more register pair live per product and measured 3-7 % slower in the three passes.
 #define TVM_MUL_CARRY_FORM 0
 #include <cstdlib>
+#include <cstring>
 
 #include "context.h"
 #include "ntt_shift.h"
@@ -1227,6 +1228,35 @@ void pool_trim(tvm_ctx* c) {
 }
 
 // what a pool_alloc could still obtain: the device's free memory plus this context's cached blocks, capped by the limit
+int h2d_small(tvm_ctx* c, void* d, const void* h, size_t bytes) {
+    if (!bytes) return TVM_OK;
+    constexpr size_t RING = (size_t)4 << 20;
+    if (!c->pin && c->pin_bytes == 0) {
+        void* p = nullptr;
+        if (bind_device(c) && hipHostMalloc(&p, RING, 0) == hipSuccess) {
+            c->pin = (char*)p;
+            c->pin_bytes = RING;
+        } else {
+            (void)hipGetLastError();
+            c->pin_bytes = 1;   // no pinned memory on this machine: the plain path from now on
+        }
+    }
+    if (!c->pin || bytes > c->pin_bytes / 4) {
+        TVM_HIP_CHECK(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+        TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+        return TVM_OK;
+    }
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (c->pin_head + need > c->pin_bytes) {   // wrap: every copy out of the ring so far has been issued on this stream
+        TVM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+        c->pin_head = 0;
+    }
+    char* slot = c->pin + c->pin_head;
+    c->pin_head += need;
+    std::memcpy(slot, h, bytes);
+    TVM_HIP_CHECK(c, hipMemcpyAsync(d, slot, bytes, hipMemcpyHostToDevice, c->stream));
+    return TVM_OK;
+}
 size_t pool_available(tvm_ctx* c, size_t* device_total) {
     size_t free_b = 0, total_b = 0;
     if (!bind_device(c) || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
@@ -1628,8 +1658,20 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
                 else if (sp.log_n2 == 7) TVM_LAUNCH((k_lde_pass2_v3<7, 6>), g2, dim3(64), lds_v3, c->stream, a);
                 else TVM_LAUNCH((k_lde_pass2_v3<8, 6>), g2, dim3(64), lds_v3, c->stream, a);
             }
-            else
-                TVM_LAUNCH(k_lde_pass2, grid, dim3(threads_for_tile(tile)), lds, c->stream, a);
+            else {
+                // Short axes (traces below 2^13 rows): a 16-row tile is ONE wavefront that walks its 16 coefficients per lane through
+                // nine transforms, and the grid is n1 / 16 x columns of them -- 384 wavefronts for 96 columns of a 2^12-row trace, 200 us
+                // of latency.  Fewer rows per tile until the grid has ~2048 wavefronts (or a tile is two rows): the same kernel, the
+                // same words (the tile height is a launch shape: every row is transformed on its own), 200 -> 60 us.
+                int bl = a.batch_log;
+                const auto waves = [&](int b) { return (u64)((n1 + (1u << b) - 1) >> b) * (u64)nc * (u64)(threads_for_tile((int)n2 << b) / 64); };
+                while (bl > 1 && waves(bl) < 2048) bl--;
+                a.batch_log = bl;
+                const int tile_s = (int)n2 << bl;
+                const dim3 grid_s((unsigned)((n1 + (1u << bl) - 1) >> bl), (unsigned)nc);
+                const size_t lds_s = ((size_t)(n2 + TVM_ROW_PAD) << bl) * sizeof(u64);
+                TVM_LAUNCH(k_lde_pass2, grid_s, dim3(threads_for_tile(tile_s)), lds_s, c->stream, a);
+            }
         }
         if (mode != TVM_LDE_INVERSE_ONLY) {
             LdePass3Args a = p3;

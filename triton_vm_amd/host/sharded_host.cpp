@@ -680,10 +680,10 @@ struct ShardedRun {
         const Xfe a4 = xfe_powers(alpha, 4, 1)[0];
         const Xfe za4 = xfe_powers(xfe_scale(alpha, zeta), 4, 1)[0];
         Xfe seg_ood[5][2];
-        for (int k = 0; k < 5; k++) {
-            const Xfe pts[2] = {a4, za4};
-            c.check(tvm_evaluate_at_points(c.raw(), polys.ptr() + (u64)k * poly_len * 3, poly_len, pts[0].c, 2, seg_ood[k][0].c),
-                    "tvm_evaluate_at_points");
+        {
+            const Xfe pts[2] = {a4, za4};   // the five segment polynomials at both points: one round trip
+            c.check(tvm_evaluate_polys_at_points(c.raw(), polys.ptr(), poly_len, poly_len, 5, pts[0].c, 2, seg_ood[0][0].c),
+                    "tvm_evaluate_polys_at_points");
         }
         ps.enqueue("ood main", ood_main.data(), NUM_MAIN * 3);
         ps.enqueue("ood aux", ood_aux.data(), NUM_AUX * 3);

@@ -181,6 +181,27 @@ __global__ void k_weighted_row_sum(const u64* __restrict__ trace, int fk, u64 n,
     if (accumulate) r = xfe_add(r, ld_xfe(out + 3 * j));
     st_xfe(out + 3 * j, r);
 }
+// The same for short traces: with a work-item per row, 1024 rows are four workgroups whose lanes walk the 379 columns one after
+// another (88 us at 2^10 rows, twice per proof).  Here a workgroup is 64 rows x 16 column groups -- a wavefront reads 64 consecutive
+// rows of its columns c = q mod 16 (coalesced) -- and the sixteen partial sums of a row meet in LDS.  Exact sums: the same words.
+#define TVM_WRS_GROUPS 16
+__global__ void __launch_bounds__(64 * TVM_WRS_GROUPS) k_weighted_row_sum_split(const u64* __restrict__ trace, int fk, u64 n, u64 n_cols,
+                                                                                const u64* __restrict__ w, int accumulate, u64* __restrict__ out) {
+    __shared__ u64 smem[TVM_WRS_GROUPS][3][64];
+    const int r = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const u64 j = (u64)blockIdx.x * 64 + r;
+    xfe acc = xfe_zero();
+    if (j < n)
+        for (u64 c = q; c < n_cols; c += TVM_WRS_GROUPS) acc = xfe_add(acc, cell_times(trace, fk, n, c, j, ld_xfe(w + 3 * c)));
+    smem[q][0][r] = acc.c0;
+    smem[q][1][r] = acc.c1;
+    smem[q][2][r] = acc.c2;
+    __syncthreads();
+    if (q || j >= n) return;
+    for (int g = 1; g < TVM_WRS_GROUPS; g++) acc = xfe_add(acc, xfe_make(smem[g][0][r], smem[g][1][r], smem[g][2][r]));
+    if (accumulate) acc = xfe_add(acc, ld_xfe(out + 3 * j));
+    st_xfe(out + 3 * j, acc);
+}
 // R[j] = sum_c w_c r_c[j], j < h; poly[j] -= R[j]; poly[n + j] += R[j]   (mul_zerofier_with, offset 1)
 // (one WAVEFRONT per coefficient j, the columns over its lanes: a work-item per coefficient walked the 379 columns serially in
 // four workgroups, 0.21 + 0.09 ms per proof)
@@ -481,7 +502,10 @@ int out_of_domain_rows(tvm_ctx* c, int fk, const u64* trace, u64 n, u64 n_cols, 
 
 // d_values: n XFE sums over the trace rows (+ accumulate); no transform here
 int weighted_row_sum(tvm_ctx* c, int fk, const u64* trace, u64 n, u64 n_cols, const u64* d_w, int accumulate, u64* d_values) {
-    TVM_LAUNCH(k_weighted_row_sum, TVM_GRID(n, 256), dim3(256), 0, c->stream, trace, fk, n, n_cols, d_w, accumulate, d_values);
+    if (n <= 16384)   // fewer than 64 workgroups of a work-item per row: split the columns too
+        TVM_LAUNCH(k_weighted_row_sum_split, TVM_GRID(n, 64), dim3(64 * TVM_WRS_GROUPS), 0, c->stream, trace, fk, n, n_cols, d_w, accumulate, d_values);
+    else
+        TVM_LAUNCH(k_weighted_row_sum, TVM_GRID(n, 256), dim3(256), 0, c->stream, trace, fk, n, n_cols, d_w, accumulate, d_values);
     TVM_HIP_CHECK(c, hipGetLastError());
     return TVM_OK;
 }

@@ -2,12 +2,12 @@
 """Host side of one proof from a rocprofv3 --kernel-trace --hip-trace (rocpd sqlite) run: for the LAST proof of the run (from its
 k_pad_main_table back to the fill kernels before it, to the last kernel), the HIP API calls that took longest, the totals per API,
 and for every device-idle gap above a threshold the API calls the host was inside meanwhile.
-Usage: python tools/rocprof_host_timeline.py <results.db> [gap_us]"""
+Usage: python tools/rocprof_host_timeline.py <results.db> [gap_us] [file for the merged kernel / API timeline of that proof]"""
 import sqlite3
 import sys
 
 
-def main(path, gap_us="40"):
+def main(path, gap_us="40", dump=""):
     gap_ns = float(gap_us) * 1e3
     con = sqlite3.connect(path)
     cur = con.cursor()
@@ -36,6 +36,11 @@ def main(path, gap_us="40"):
     print("## host API totals inside the proof")
     for n, (k, ns) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:14]:
         print(f"{n:40s} {k:6d} calls {ns / 1e6:9.3f} ms")
+    if dump:   # the merged timeline of the proof: kernels (K) and host API regions (A) by start time, microseconds from the first kernel
+        merged = [(s0, "K", n, e0 - s0) for n, s0, e0 in seg] + [(s0, "A", n, e0 - s0) for n, s0, e0 in api if s0 >= t0]
+        with open(dump, "w") as f:
+            for s0, kind, n, d in sorted(merged):
+                f.write(f"{(s0 - t0) / 1e3:10.1f} {kind} {d / 1e3:8.1f} {n[:70]}\n")
     print(f"## device-idle gaps > {gap_us} us and what the host was in")
     for k in range(len(seg) - 1):
         g0, g1 = seg[k][2], seg[k + 1][1]

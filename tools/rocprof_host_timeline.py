@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Host side of one proof from a rocprofv3 --kernel-trace --hip-trace (rocpd sqlite) run: for the LAST proof of the run (from its
-k_pad_main_table back to the fill kernels before it, to the last kernel), the HIP API calls that took longest, the totals per API,
+"""Host side of one proof from a rocprofv3 --kernel-trace --hip-trace (rocpd sqlite) run: for a proof from the MIDDLE of the run (one of bench.py's timed steps; from
+its first fill kernel to the next proof's), the HIP API calls that took longest, the totals per API,
 and for every device-idle gap above a threshold the API calls the host was inside meanwhile.
 Usage: python tools/rocprof_host_timeline.py <results.db> [gap_us] [file for the merged kernel / API timeline of that proof]"""
 import sqlite3
@@ -17,9 +17,10 @@ def main(path, gap_us="40", dump=""):
     if not marks:
         print("no k_fill_main_init kernel in the trace")
         return
-    # (bench.py's LAST proof is the one with the stage timers: an event synchronisation per stage; take the one before it)
-    which = -2 if len(marks) >= 3 else -1
-    seg = kernels[marks[which]:marks[which + 1]] if which != -1 else kernels[marks[-1]:]
+    # (bench.py's last proofs are the ones with the stage timers -- an event synchronisation per stage -- and the Python mirror
+    # host's; a proof from the middle of the run is one of the timed steps of the C++ host)
+    which = len(marks) // 2 if len(marks) >= 3 else len(marks) - 1
+    seg = kernels[marks[which]:marks[which + 1]] if which + 1 < len(marks) else kernels[marks[which]:]
     t0, t1 = seg[0][1], seg[-1][2]
     view = "regions" if "regions" in names else None
     if view is None:

@@ -211,8 +211,7 @@ int all_quotients_combined(tvm_ctx* c, const u64* main_table, const TabLayout& l
     // (80-130 us) whatever their number; ten of them one behind the other are a millisecond of a proof that takes eight.  While one
     // part leaves most of the chip empty (grid <= air_fork_max_workgroups) the selected parts go out on the context's stream and its
     // three fork lanes, each lane adding into an accumulator of its own (longest part first, each to the lane with the least work so
-    // far: the multiplications per row of air_gen.h), and the scatter adds the accumulators.  Exact arithmetic: the same words.
-    static const int PART_COST[TVM_AIR_NUM_PARTS] = {126, 886, 1129, 1373, 1243, 1170, 834, 1434, 1452, 1211};
+    // far: TVM_AIR_PART_COST of air_gen.h), and the scatter adds the accumulators.  Exact arithmetic: the same words.
     const dim3 grid((unsigned)((q_len + AIR_BLOCK - 1) / AIR_BLOCK));
     int selected[TVM_AIR_NUM_PARTS], n_selected = 0;
     for (int p = 0; p < TVM_AIR_NUM_PARTS; p++)
@@ -248,7 +247,7 @@ int all_quotients_combined(tvm_ctx* c, const u64* main_table, const TabLayout& l
         if (!n_selected) TVM_HIP_CHECK(c, hipMemsetAsync(acc, 0, (size_t)3 * q_len * sizeof(u64), c->stream));
     } else {
         for (int i = 1; i < n_selected; i++)   // by cost, descending (insertion sort of at most ten)
-            for (int j = i; j > 0 && PART_COST[selected[j]] > PART_COST[selected[j - 1]]; j--) {
+            for (int j = i; j > 0 && TVM_AIR_PART_COST[selected[j]] > TVM_AIR_PART_COST[selected[j - 1]]; j--) {
                 const int t = selected[j];
                 selected[j] = selected[j - 1];
                 selected[j - 1] = t;
@@ -260,7 +259,7 @@ int all_quotients_combined(tvm_ctx* c, const u64* main_table, const TabLayout& l
             int l = 0;
             for (int k = 1; k < n_lanes; k++)
                 if (load[k] < load[l]) l = k;
-            load[l] += PART_COST[selected[s]];
+            load[l] += TVM_AIR_PART_COST[selected[s]];
             a.out = acc + (u64)l * 3 * q_len;
             a.accumulate = started[l];
             started[l] = 1;

@@ -118,6 +118,7 @@ struct tvm_ctx {
     // on their way to the device, so that the copy is asynchronous AND the caller's array is free when the entry point returns
     char* pin = nullptr;
     size_t pin_bytes = 0, pin_head = 0;
+    bool pin_unavailable = false;   // hipHostMalloc refused once: the plain path (copy, then wait) from then on
     // the fork lanes (air.hip: all_quotients_combined): launches that are independent of one another and too small to fill the
     // chip each -- the parts of the AIR on a short quotient domain -- go out on these streams beside the context's own and meet
     // it again before the next dependent launch.  Created on first use.

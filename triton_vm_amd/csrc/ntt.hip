@@ -1231,14 +1231,14 @@ void pool_trim(tvm_ctx* c) {
 int h2d_small(tvm_ctx* c, void* d, const void* h, size_t bytes) {
     if (!bytes) return TVM_OK;
     constexpr size_t RING = (size_t)4 << 20;
-    if (!c->pin && c->pin_bytes == 0) {
+    if (!c->pin && !c->pin_unavailable) {
         void* p = nullptr;
         if (bind_device(c) && hipHostMalloc(&p, RING, 0) == hipSuccess) {
             c->pin = (char*)p;
             c->pin_bytes = RING;
         } else {
             (void)hipGetLastError();
-            c->pin_bytes = 1;   // no pinned memory on this machine: the plain path from now on
+            c->pin_unavailable = true;
         }
     }
     if (!c->pin || bytes > c->pin_bytes / 4) {

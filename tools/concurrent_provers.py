@@ -3,7 +3,9 @@
 (DESIGN.md 4.5).  The backend's contract is one context per proving thread (triton_vm::prove may run on several threads,
 /root/reference/triton-vm/src/lib.rs:522-532): this measures what K threads, each with its own context and its own device-resident
 trace, prove per second on ONE GPU -- the same prove_fib instance and seed everywhere, every proof compared with the first one.
-Usage: python tools/concurrent_provers.py [log2_rows=10] [proofs_per_thread=40] [threads=1,2,4,8,16]  -> one JSON line"""
+Usage: python tools/concurrent_provers.py [log2_rows=10] [proofs_per_thread=40] [threads=1,2,4,8,16] [start_at]  -> one JSON line
+start_at (epoch seconds): every run's timed loop starts no earlier than that -- several PROCESSES of this script started together
+(each with ONE thread count) measure what P processes x K threads prove at once (tools/r06_job21.sh adds their lines up)."""
 import json
 import os
 import sys
@@ -13,7 +15,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main(log2_rows=10, per_thread=40, thread_counts="1,2,4,8,16"):
+def main(log2_rows=10, per_thread=40, thread_counts="1,2,4,8,16", start_at="0"):
     import numpy as np
     import torch  # noqa: F401  (first: the ROCm runtime torch ships)
 
@@ -56,6 +58,8 @@ def main(log2_rows=10, per_thread=40, thread_counts="1,2,4,8,16"):
         threads = [threading.Thread(target=work, args=(k,)) for k in range(K)]
         for t in threads:
             t.start()
+        while time.time() < float(start_at):
+            time.sleep(0.001)
         start.wait()
         t0 = time.perf_counter()
         for t in threads:
@@ -63,7 +67,7 @@ def main(log2_rows=10, per_thread=40, thread_counts="1,2,4,8,16"):
         dt = time.perf_counter() - t0
         if errors:
             raise SystemExit(f"{K} threads: {errors[0]}")
-        out["runs"].append({"threads": K, "proofs_per_s": round(K * per_thread / dt, 1), "ms_per_proof_per_thread": round(1e3 * dt / per_thread, 3),
+        out["runs"].append({"threads": K, "window": [round(time.time() - dt, 3), round(time.time(), 3)], "proofs_per_s": round(K * per_thread / dt, 1), "ms_per_proof_per_thread": round(1e3 * dt / per_thread, 3),
                             "trace_cells_per_s": round(K * per_thread * e["padded_height"] * 652 / dt, 1)})
     print(json.dumps(out))
 

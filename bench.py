@@ -644,6 +644,8 @@ def main():
                     "(TVMH_OPTION_COLUMN_SPLIT; north_star's column sharding where it applies) instead of replicating them")
     ap.add_argument("--air-fork", type=int, default=-1, help="TVM_OPTION_AIR_FORK_MAX_WORKGROUPS for the run (A/B; -1: the library's default, 256; "
                     "0: the parts of the AIR never run side by side)")
+    ap.add_argument("--ctx-option", action="append", default=[], metavar="K=V", help="tvm_ctx_set_option(K, V) on the context before the run (A/B of "
+                    "tuning options, include/triton_hip.h: e.g. 6=0 builds the narrow Merkle levels one launch per level)")
     ap.add_argument("--host-trace", type=int, default=0, help="TVMH_OPTION_TRACE for the run: the C++ host's wall time per step of prove_execution on "
                     "stderr (1: the stream drained at every step; 2: not drained -- the host's own time)")
     ap.add_argument("--host", choices=["cpp", "python"], default="cpp",
@@ -679,6 +681,9 @@ def main():
     ctx = make_context(local_rank)
     if args.air_fork >= 0:
         ctx.air_fork_max_workgroups(args.air_fork)
+    for kv in args.ctx_option:
+        k, v = kv.split("=")
+        ctx._check(ctx.lib.tvm_ctx_set_option(ctx.handle, int(k), int(v)), "tvm_ctx_set_option")
     sharded = (world > 1 or args.sharded) and not args.replicas
     coset_wise = bool(args.jit_passes or args.memory_policy)   # the C++ host's sharded entry with no communicator
     ldt = None if args.ldt == "auto" else args.ldt

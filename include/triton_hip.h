@@ -82,6 +82,9 @@ int32_t tvm_ctx_trim(tvm_ctx* ctx);
  * most this many workgroups of 256 rows launch the parts of the AIR on four streams side by side (the context's and three of its
  * own, joined before the call returns to the context's stream), and on such a domain valid-trace mode evaluates row by row. */
 #define TVM_OPTION_AIR_FORK_MAX_WORKGROUPS 5
+/* TVM_OPTION_MERKLE_SUBTREES (default 1): the levels of a Merkle tree between 32768 and 64 parents are built up to seven to a launch
+ * (a workgroup per subtree of 64 parents); 0: one launch per level (A/B). */
+#define TVM_OPTION_MERKLE_SUBTREES 6
 int32_t tvm_ctx_set_option(tvm_ctx* ctx, int32_t option, uint64_t value);
 /* Cap on the bytes this context may hold through tvm_malloc / table handles (0 = no cap).  Requests beyond it fail
  * with TVM_ERR_OUT_OF_MEMORY exactly like a full device: the knob a host uses to share a GPU, and what the tests use to

@@ -55,11 +55,16 @@ def test_ldt_view_is_strided_subset(ctx, orc):
     assert (mt.reveal_rows([1, 15]) == table[[4, 60]]).all()
 
 
-# 12: 16-lanes-per-parent levels, 17: all three level kernels, -17: the same with several groups of parents per workgroup
-@pytest.mark.parametrize("log_n", [0, 1, 4, 10, 12, 17, -17])
-def test_merkle_tree_sizes_and_codeword_tree(ctx, orc, log_n, request):
+# 8 / 9 / 10 / 12: 16-lanes-per-parent levels, two / three / four / six of them to a launch (k_merkle_subtrees; 14 and 17: seven, and two
+# launches of them); 17: all three level kernels, -17: the same with several groups of parents per workgroup; "one": TVM_OPTION_MERKLE_SUBTREES
+# = 0, a launch per level (k_merkle_level_lanes)
+@pytest.mark.parametrize("log_n,subtrees", [(0, 1), (1, 1), (4, 1), (8, 1), (9, 1), (10, 1), (12, 1), (12, 0), (14, 1), (17, 1), (17, 0), (-17, 1)])
+def test_merkle_tree_sizes_and_codeword_tree(ctx, orc, log_n, subtrees, request):
     if abs(log_n) > 12 and ctx.kind == "emu":
-        pytest.skip("2^17 leaves take minutes on the fiber emulation; the size runs on the GPU")
+        pytest.skip("2^14 / 2^17 leaves take minutes on the fiber emulation; the sizes run on the GPU")
+    if not subtrees:
+        ctx._check(ctx.lib.tvm_ctx_set_option(ctx.handle, 6, 0), "tvm_ctx_set_option")
+        request.addfinalizer(lambda: ctx.lib.tvm_ctx_set_option(ctx.handle, 6, 1))
     if log_n < 0:
         # TVM_OPTION_MERKLE_MIN_WORKGROUPS = 3: 1024 groups of 64 parents on the widest level -> 8 per workgroup
         ctx._check(ctx.lib.tvm_ctx_set_option(ctx.handle, 3, 64), "tvm_ctx_set_option")

@@ -136,6 +136,10 @@ int32_t tvm_ctx_set_option(tvm_ctx* c, int32_t option, uint64_t value) {
         c->lde_pass2_tiles = value ? 1 : 0;
         return TVM_OK;
     }
+    if (option == TVM_OPTION_MERKLE_SUBTREES) {
+        c->merkle_subtrees = value != 0;
+        return TVM_OK;
+    }
     if (option == TVM_OPTION_AIR_FORK_MAX_WORKGROUPS) {
         c->air_fork_max_workgroups = value;
         return TVM_OK;

@@ -109,6 +109,7 @@ struct tvm_ctx {
     int lde_chunk_columns = 0;                          // TVM_OPTION_LDE_CHUNK_COLUMNS: 0 = chosen by lde_table (ntt.hip)
     int lde_pass2_tiles = 0;                            // TVM_OPTION_LDE_PASS2_TILES: 1 = the tile kernels instead of k_lde_pass2_fused (A/B)
     u64 merkle_min_workgroups = 4096;                   // TVM_OPTION_MERKLE_MIN_WORKGROUPS (hash.hip: merkle_tree_from_leaves)
+    bool merkle_subtrees = true;                        // TVM_OPTION_MERKLE_SUBTREES: narrow levels seven to a launch (k_merkle_subtrees)
     std::string last_error;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     // the side lane (include/triton_hip.h: tvm_side_*): created on first use

@@ -1516,6 +1516,9 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
     // c->lde_chunk_columns (TVM_OPTION_LDE_CHUNK_COLUMNS) overrides.
     const auto intermediates = [&](int cols) { return (size_t)cols * (1 + X) * n_rows * sizeof(u64); };
     if (chunk_cols <= 0) chunk_cols = c->lde_chunk_columns;
+    // (short traces: every column in ONE chunk while its intermediates stay below 512 MB -- traces of up to 2^14 rows: three launches per
+    // table instead of twelve, and grids four times as wide on a chip they do not fill)
+    if (chunk_cols <= 0 && !split && intermediates(W) <= ((size_t)512 << 20)) chunk_cols = W > 96 ? W : 96;
     if (chunk_cols <= 0) chunk_cols = (intermediates(96) <= ((size_t)36 << 30) && intermediates(96) <= pool_available(c, nullptr) / 3) ? 96 : 32;
     // (a chunk wider than the columns there are buys nothing; not below 96, so that narrow tables keep sharing the blocks of the wide ones)
     if (chunk_cols > 96 && chunk_cols > last - first) chunk_cols = last - first > 96 ? last - first : 96;

@@ -133,32 +133,6 @@ __global__ void __launch_bounds__(256) k_merkle_level_lanes(u64* __restrict__ no
     if (live && pos < 5) nodes[5 * i + pos] = x;
 }
 
-// Several narrow levels in ONE launch: a workgroup owns 64 consecutive parents of the widest level and everything above them that only
-// they feed -- 64, 32, ..., 1 parents on up to seven consecutive levels, sixteen lanes per parent as above.  A workgroup's subtree depends
-// on nothing outside it, so the levels are separated by workgroup barriers instead of launches: what a tree costs between its wide levels
-// and its top is the latency of its permutations either way, but a proof of a short trace is bounded by the NUMBER of dependent
-// dispatches (36 of these levels per proof at 2^10 rows).
-__global__ void __launch_bounds__(1024) k_merkle_subtrees(u64* __restrict__ nodes, u64 widest, int levels) {
-    __shared__ unsigned char lut[256];
-    tip5_stage_lut(lut, threadIdx.x, blockDim.x);
-    const int pos = (int)(threadIdx.x & 15), lane = (int)(threadIdx.x & 63);
-    u64 lvl = widest;
-    int per = 64;   // this workgroup's parents on the current level
-    for (int t = 0; t < levels; t++, lvl >>= 1, per >>= 1) {
-        // (a wavefront without a parent sits the level out; one with fewer than four clamps the rest: every lane joins the rotations)
-        if ((int)((threadIdx.x & ~63u) >> 4) < per) {
-            int jl = (int)(threadIdx.x >> 4);
-            const bool live = jl < per;
-            if (!live) jl = per - 1;
-            const u64 i = lvl + (u64)blockIdx.x * (u64)per + (u64)jl;
-            u64 x = pos < 10 ? nodes[10 * i + pos] : TVM_ONE;  // fixed-length domain: capacity all ones (tip-0005.md:82)
-            x = tip5_permute_lanes(x, pos, lane, lut);
-            if (live && pos < 5) nodes[5 * i + pos] = x;
-        }
-        __syncthreads();  // the same workgroup wrote the children of the next level: workgroup-scope visibility suffices
-    }
-}
-
 // the last levels of a tree (<= 64 parents on the widest: one pass per level) inside one workgroup, 16 lanes per parent
 __global__ void __launch_bounds__(1024) k_merkle_top(u64* __restrict__ nodes, u64 widest) {
     __shared__ unsigned char lut[256];
@@ -274,6 +248,8 @@ int hash_rows(tvm_ctx* c, const u64* table, const TabLayout& layout, int W, u64 
 }
 
 // nodes: [2*n_leaves][5], leaves already at nodes[n_leaves..2*n_leaves)
+int merkle_subtrees(tvm_ctx* c, u64* nodes, u64 widest, int levels);   // merkle_subtrees.hip
+
 int merkle_tree_from_leaves(tvm_ctx* c, u64* nodes, u64 n_leaves) {
     if (!is_pow2(n_leaves)) return set_error(c, TVM_ERR_INVALID_ARGUMENT, "merkle: leaf count must be a power of two");
     u64 lvl = n_leaves >> 1;
@@ -288,7 +264,7 @@ int merkle_tree_from_leaves(tvm_ctx* c, u64* nodes, u64 n_leaves) {
         // narrow levels, 16 lanes per parent (latency form), up to seven levels per launch, down to the level of 64 parents
         while (lvl > 64) {
             const int levels = ilog2(lvl) - 5 < 7 ? ilog2(lvl) - 5 : 7;
-            TVM_LAUNCH(k_merkle_subtrees, dim3((unsigned)(lvl / 64)), dim3(1024), 0, c->stream, nodes, lvl, levels);
+            TVM_TRY(merkle_subtrees(c, nodes, lvl, levels));   // merkle_subtrees.hip
             lvl >>= levels;
         }
     } else

@@ -14,6 +14,8 @@ int lde_table(tvm_ctx* c, int fk, const u64* trace, u64 n_rows, u64 n_cols, cons
 // hash.hip
 int hash_rows(tvm_ctx* c, const u64* table, const TabLayout& layout, int W, u64 stride, u64* digests);
 int merkle_tree_from_leaves(tvm_ctx* c, u64* nodes, u64 n_leaves);
+// merkle_subtrees.hip: `levels` (<= 7) consecutive levels from the one of `widest` parents (a multiple of 64) upwards, in one launch
+int merkle_subtrees(tvm_ctx* c, u64* nodes, u64 widest, int levels);
 int xfe_leaves(tvm_ctx* c, const u64* cw, u64 plane, u64 n, u64* leaves);
 int gather_rows(tvm_ctx* c, const u64* table, const TabLayout& layout, int W, const u64* d_idx, u64 n, u64* d_out);   // d_idx: domain rows
 int table_to_row_major(tvm_ctx* c, const u64* table, const TabLayout& layout, int W, u64* d_out);

@@ -253,9 +253,11 @@ int all_quotients_combined(tvm_ctx* c, const u64* main_table, const TabLayout& l
                 selected[j - 1] = t;
             }
         int load[4] = {0, 0, 0, 0}, started[4] = {0, 0, 0, 0};
-        TVM_HIP_CHECK(c, hipEventRecord(c->fork_ready, c->stream));   // the tables, the challenges, the zerofier inverses
-        for (int l = 1; l < n_lanes; l++) TVM_HIP_CHECK(c, hipStreamWaitEvent(c->fork[l - 1], c->fork_ready, 0));
-        for (int s = 0; s < n_selected; s++) {
+        // (a failure between fork and join must not leave a lane running over tables the caller is about to release: the lanes are
+        // drained before the error goes up)
+        hipError_t fe = hipEventRecord(c->fork_ready, c->stream);   // the tables, the challenges, the zerofier inverses
+        for (int l = 1; l < n_lanes && fe == hipSuccess; l++) fe = hipStreamWaitEvent(c->fork[l - 1], c->fork_ready, 0);
+        for (int s = 0; s < n_selected && fe == hipSuccess; s++) {
             int l = 0;
             for (int k = 1; k < n_lanes; k++)
                 if (load[k] < load[l]) l = k;
@@ -264,11 +266,16 @@ int all_quotients_combined(tvm_ctx* c, const u64* main_table, const TabLayout& l
             a.accumulate = started[l];
             started[l] = 1;
             TVM_LAUNCH(TVM_AIR_PARTS[selected[s]], grid, dim3(AIR_BLOCK), 0, l ? c->fork[l - 1] : c->stream, a);
+            fe = hipGetLastError();
         }
         a.out = acc;
-        for (int l = 1; l < n_lanes; l++) {
-            TVM_HIP_CHECK(c, hipEventRecord(c->fork_done[l - 1], c->fork[l - 1]));
-            TVM_HIP_CHECK(c, hipStreamWaitEvent(c->stream, c->fork_done[l - 1], 0));
+        for (int l = 1; l < n_lanes && fe == hipSuccess; l++) {
+            fe = hipEventRecord(c->fork_done[l - 1], c->fork[l - 1]);
+            if (fe == hipSuccess) fe = hipStreamWaitEvent(c->stream, c->fork_done[l - 1], 0);
+        }
+        if (fe != hipSuccess) {
+            for (int l = 1; l < n_lanes; l++) (void)hipStreamSynchronize(c->fork[l - 1]);
+            return set_error(c, fe == hipErrorOutOfMemory ? TVM_ERR_OUT_OF_MEMORY : TVM_ERR_DEVICE, "quotients: fork lanes");
         }
     }
     const u64 cosets = q_len / trace_len;
